@@ -1,0 +1,858 @@
+// mundy_oracle.hpp -- CPU restatement of MuNDy's contact hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing in the product path (mundy_amd/, include/) may include, link or call this
+// file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker / CPU baseline.
+//
+// Every function restates, in plain scalar C++ and with the reference's operation order, one function of the
+// reference (cited as path:line relative to /root/reference).  No reference source is copied: the reference is
+// Kokkos-templated C++20 over accessor/ownership types; this is flat structs and loops.
+//
+// Parity pinning: the reference cannot be built in this image (it needs Kokkos, KokkosKernels, STK, OpenRAND, GTest,
+// none of which exist here, and hand-written stand-ins for them are not allowed), so this oracle is pinned by the
+// reference's own known-answer tests and analytic/manufactured test cases, restated in tests/test_oracle_*.py:
+//   mundy/geom/tests/unit_tests/UnitTestSegmentSegment.cpp:417-472 (two 17-digit KATs) and :74-350 (generators)
+//   mundy/geom/tests/unit_tests/UnitTestComputeAABB.cpp:137-262, UnitTestComputeBoundingRadius.cpp:120-242
+//   mundy/math/tests/unit_tests/UnitTestConvex.cpp:46-143,608-625
+//   mundy/math/tests/unit_tests/UnitTestZMorton.cpp:217-380, UnitTestHilbert.cpp:48-387
+//   mundy/geom/tests/unit_tests/UnitTestPeriodicity.cpp:623-948 (properties)
+// The neighbour-search predicate is third-party in the reference (stk::search / ArborX, absent): "parity unpinned"
+// for pair sets; the predicate is defined here from MuNDy's own geom::intersects / bounding-sphere code.
+//
+// Build with -ffp-contract=off so that a*b+c is two roundings, as in the device code.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace moracle {
+
+// ---------------------------------------------------------------------------------------------------------------
+// mundy::math -- Vector3 / Quaternion subset
+// ---------------------------------------------------------------------------------------------------------------
+struct V3 {
+  double x, y, z;
+  double& operator[](int i) { return (&x)[i]; }
+  const double& operator[](int i) const { return (&x)[i]; }
+};
+struct Quat {
+  double w, x, y, z;
+};
+
+inline V3 operator+(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, const V3& a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator*(const V3& a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+
+// mundy/math/src/mundy_math/impl/VectorImpl.hpp:339-344: unary right fold, a0*b0 + (a1*b1 + a2*b2).
+inline double dot(const V3& a, const V3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+// mundy/math/src/mundy_math/Vector.hpp:1150-1156: two_norm = std::sqrt(dot(v, v)).
+inline double norm(const V3& a) { return std::sqrt(dot(a, a)); }
+// mundy/math/src/mundy_math/Vector3.hpp:93-105.
+inline V3 cross(const V3& a, const V3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// mundy/math/src/mundy_math/impl/QuaternionImpl.hpp:142-164.
+inline Quat qmul(const Quat& q, const Quat& o) {
+  Quat r;
+  r.w = q.w * o.w - q.x * o.x - q.y * o.y - q.z * o.z;
+  r.x = q.w * o.x + q.x * o.w + q.y * o.z - q.z * o.y;
+  r.y = q.w * o.y - q.x * o.z + q.y * o.w + q.z * o.x;
+  r.z = q.w * o.z + q.x * o.y - q.y * o.x + q.z * o.w;
+  return r;
+}
+// mundy/math/src/mundy_math/Quaternion.hpp:1208-1219.
+inline Quat conjugate(const Quat& q) { return {q.w, -q.x, -q.y, -q.z}; }
+// mundy/math/src/mundy_math/Quaternion.hpp:1221-1229: conjugate(q) * (1 / |q|^2), plain left-to-right sum.
+inline Quat inverse(const Quat& q) {
+  const double inv_norm_squared = 1.0 / (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  const Quat c = conjugate(q);
+  return {c.w * inv_norm_squared, c.x * inv_norm_squared, c.y * inv_norm_squared, c.z * inv_norm_squared};
+}
+// mundy/math/src/mundy_math/impl/QuaternionImpl.hpp:184-202: (q * (0, v)) * inverse(q).
+inline V3 qrot(const Quat& q, const V3& v) {
+  const Quat vq{0.0, v.x, v.y, v.z};
+  const Quat qi = inverse(q);
+  const Quat r = qmul(qmul(q, vq), qi);
+  return {r.x, r.y, r.z};
+}
+// mundy/math/src/mundy_math/Quaternion.hpp:1489-1505.
+inline Quat quat_from_parallel_transport(const V3& from, const V3& to) {
+  const double dp = dot(from, to);
+  const V3 cp = cross(from, to);
+  const double sqrt_term = std::sqrt(0.5 * (1.0 + dp));
+  // vec = 0.5 * cross / sqrt_term  ==  (0.5 * cross) / sqrt_term
+  const V3 half_cp = 0.5 * cp;
+  return {sqrt_term, half_cp.x / sqrt_term, half_cp.y / sqrt_term, half_cp.z / sqrt_term};
+}
+
+// mundy/math/src/mundy_math/Tolerance.hpp:38-70.
+constexpr double kZeroTol = 1e-15;
+constexpr double kRelaxedZeroTol = 1e-8;
+
+// ---------------------------------------------------------------------------------------------------------------
+// mundy::geom -- AABB / bounding radius
+// ---------------------------------------------------------------------------------------------------------------
+struct AABB {
+  double lo[3], hi[3];
+};
+
+// mundy/geom/src/mundy_geom/compute_aabb.hpp:72-80 (center -/+ ones * radius).
+inline AABB compute_aabb_sphere(const V3& c, double r) {
+  AABB b;
+  for (int k = 0; k < 3; ++k) {
+    b.lo[k] = c[k] - 1.0 * r;
+    b.hi[k] = c[k] + 1.0 * r;
+  }
+  return b;
+}
+// The centreline half vector shared by compute_aabb(Spherocylinder) (compute_aabb.hpp:115-117) and the rod contact
+// assembly:  scaled_dir = 0.5 * length * (orientation * z_axis).
+inline V3 spherocylinder_half_axis(const Quat& q, double length) {
+  const V3 zaxis{0.0, 0.0, 1.0};
+  return (0.5 * length) * qrot(q, zaxis);
+}
+// mundy/geom/src/mundy_geom/compute_aabb.hpp:105-127.
+inline AABB compute_aabb_spherocylinder(const V3& c, const Quat& q, double r, double length) {
+  const V3 d = spherocylinder_half_axis(q, length);
+  const V3 p0 = c - d, p1 = c + d;
+  AABB b;
+  for (int k = 0; k < 3; ++k) {
+    b.lo[k] = std::min(p0[k], p1[k]) - r;
+    b.hi[k] = std::max(p0[k], p1[k]) + r;
+  }
+  return b;
+}
+// mundy/geom/src/mundy_geom/compute_aabb.hpp:82-103 (exact only for axis-aligned rotations -- quirk kept).
+inline AABB compute_aabb_ellipsoid(const V3& c, const Quat& q, const V3& radii) {
+  const V3 rr = qrot(q, radii);
+  const V3 p0 = c - rr, p1 = c + rr;
+  AABB b;
+  for (int k = 0; k < 3; ++k) {
+    b.lo[k] = std::min(p0[k], p1[k]);
+    b.hi[k] = std::max(p0[k], p1[k]);
+  }
+  return b;
+}
+// mundy/geom/src/mundy_geom/compute_aabb.hpp:129-143 (SpherocylinderSegment).
+inline AABB compute_aabb_segment(const V3& p0, const V3& p1, double r) {
+  AABB b;
+  for (int k = 0; k < 3; ++k) {
+    b.lo[k] = std::min(p0[k], p1[k]) - r;
+    b.hi[k] = std::max(p0[k], p1[k]) + r;
+  }
+  return b;
+}
+// mundy/geom/src/mundy_geom/primitives/AABB.hpp:420-431 (closed test: touching boxes intersect).
+inline bool intersects(const AABB& a, const AABB& b) {
+  if (a.hi[0] < b.lo[0] || a.hi[1] < b.lo[1] || a.hi[2] < b.lo[2]) return false;
+  const bool disjoint2 = b.hi[0] < a.lo[0] || b.hi[1] < a.lo[1] || b.hi[2] < a.lo[2];
+  return !disjoint2;
+}
+// mundy/geom/src/mundy_geom/compute_bounding_radius.hpp:61-81.
+inline double bounding_radius_sphere(double r) { return r; }
+inline double bounding_radius_ellipsoid(const V3& radii) { return std::max(radii.x, std::max(radii.y, radii.z)); }
+inline double bounding_radius_spherocylinder(double r, double length) { return 0.5 * length + r; }
+inline double bounding_radius_segment(const V3& p0, const V3& p1, double r) { return 0.5 * norm(p1 - p0) + r; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// mundy::geom -- periodicity (PeriodicScaledMetric only)
+// ---------------------------------------------------------------------------------------------------------------
+struct PeriodicScaledMetric {
+  V3 scale, scale_inv;
+  // mundy/geom/src/mundy_geom/periodicity.hpp:756-759.
+  explicit PeriodicScaledMetric(const V3& cell) : scale(cell), scale_inv{1.0 / cell.x, 1.0 / cell.y, 1.0 / cell.z} {}
+  // :785-788 / :793-796 (elementwise_mul(scale_inv, p)).
+  V3 to_fractional(const V3& p) const { return {scale_inv.x * p.x, scale_inv.y * p.y, scale_inv.z * p.z}; }
+  V3 from_fractional(const V3& f) const { return {scale.x * f.x, scale.y * f.y, scale.z * f.z}; }
+  // :798-803: x - (double)(int64)round(x).
+  static double min_image1(double x) { return x - static_cast<double>(static_cast<int64_t>(std::round(x))); }
+  // :140-150 impl::safe_unit_mod1<int64_t>.
+  static double unit_mod1(double s) {
+    const double k = static_cast<double>(static_cast<int64_t>(std::floor(s)));
+    double t = s - k;
+    if (std::fabs(t - 1.0) < kZeroTol) t = 0.0;
+    return t;
+  }
+  // :812-816.
+  V3 sep(const V3& p1, const V3& p2) const {
+    const V3 f = to_fractional(p2 - p1);
+    return from_fractional({min_image1(f.x), min_image1(f.y), min_image1(f.z)});
+  }
+  // :818-823.
+  V3 wrap(const V3& p) const {
+    const V3 f = to_fractional(p);
+    return from_fractional({unit_mod1(f.x), unit_mod1(f.y), unit_mod1(f.z)});
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// mundy::geom -- distances
+// ---------------------------------------------------------------------------------------------------------------
+// mundy/geom/src/mundy_geom/distance/PointPoint.hpp:43-62.
+inline double distance_point_point(const V3& p1, const V3& p2, V3* sep = nullptr) {
+  const V3 s = p2 - p1;
+  if (sep) *sep = s;
+  return norm(s);
+}
+// mundy/geom/src/mundy_geom/distance/SphereSphere.hpp:54-59.
+inline double distance_sphere_sphere(const V3& c1, double r1, const V3& c2, double r2) {
+  return distance_point_point(c1, c2) - r1 - r2;
+}
+// mundy/geom/src/mundy_geom/distance/SphereSphere.hpp:66-76 (sep rescaled to surface-to-surface; NaN if coincident).
+inline double distance_sphere_sphere(const V3& c1, double r1, const V3& c2, double r2, V3& sep) {
+  const double cc = distance_point_point(c1, c2, &sep);
+  const double surface_distance = cc - r1 - r2;
+  const double f = surface_distance / cc;
+  sep = sep * f;
+  return surface_distance;
+}
+
+// mundy/geom/src/mundy_geom/distance/PointLineSegment.hpp:128-172.  Note arch_length is left unclamped in
+// cases 3.1/3.2 (:158-163).
+inline double distance_point_segment(const V3& point, const V3& p1, const V3& p2, V3& closest, double& t, V3& sep) {
+  const V3 p21 = p2 - p1;
+  const double num = dot(p21, point - p1);
+  if ((num < kZeroTol) & (num > -kZeroTol)) {
+    closest = p1;
+    t = 0.0;
+  } else {
+    const double denom = dot(p21, p21);
+    if (denom < kZeroTol) {
+      closest = p1;
+      t = 0.0;
+    } else {
+      t = num / denom;
+      if (t < 0.0) {
+        closest = p1;
+      } else if (t > 1.0) {
+        closest = p2;
+      } else {
+        closest = p1 + t * p21;
+      }
+    }
+  }
+  return distance_point_point(point, closest, &sep);
+}
+
+// mundy/geom/src/mundy_geom/distance/LineSegmentLineSegment.hpp:189-318.
+inline double distance_segment_segment(const V3& l0, const V3& l1, const V3& m0, const V3& m1, V3& cp1, V3& cp2,
+                                       double& s, double& t, V3& sep) {
+  const V3 u = l1 - l0;
+  const V3 v = m1 - m0;
+  const V3 w = l0 - m0;
+  const double a = dot(u, u);
+  const double b = dot(u, v);
+  const double c = dot(v, v);
+  const double d = dot(u, w);
+  const double e = dot(v, w);
+  const double D = a * c - b * b;
+
+  if (D < std::sqrt(kZeroTol)) {
+    // colinear: 4 point-segment distances, first exact match of the minimum wins (:236-265)
+    V3 c1, c2, c3, c4, s1, s2, s3, s4;
+    double t1, t2, t3, t4;
+    const double dist1 = distance_point_segment(l0, m0, m1, c1, t1, s1);
+    const double dist2 = distance_point_segment(l1, m0, m1, c2, t2, s2);
+    const double dist3 = distance_point_segment(m0, l0, l1, c3, t3, s3);
+    const double dist4 = distance_point_segment(m1, l0, l1, c4, t4, s4);
+    const double min_distance = std::min(std::min(dist1, dist2), std::min(dist3, dist4));
+    if (min_distance == dist1) {
+      s = 0.0; t = t1; cp1 = l0; cp2 = c1; sep = s1;
+    } else if (min_distance == dist2) {
+      s = 1.0; t = t2; cp1 = l1; cp2 = c2; sep = s2;
+    } else if (min_distance == dist3) {
+      s = t3; t = 0.0; cp1 = c3; cp2 = m0; sep = s3;
+    } else {
+      s = t4; t = 1.0; cp1 = c4; cp2 = m1; sep = s4;
+    }
+    return min_distance;
+  }
+
+  double sN = b * e - c * d;
+  double tN = a * e - b * d;
+  double sD = D;
+  double tD = D;
+  if (sN < 0.0) {
+    sN = 0.0; tN = e; tD = c;
+  } else if (sN > sD) {
+    sN = sD; tN = e + b; tD = c;
+  }
+  if (tN < 0.0) {
+    tN = 0.0;
+    if (-d < 0.0) {
+      sN = 0.0;
+    } else if (-d > a) {
+      sN = sD;
+    } else {
+      sN = -d; sD = a;
+    }
+  } else if (tN > tD) {
+    tN = tD;
+    if ((-d + b) < 0.0) {
+      sN = 0.0;
+    } else if ((-d + b) > a) {
+      sN = sD;
+    } else {
+      sN = (-d + b); sD = a;
+    }
+  }
+  s = (std::fabs(sN) < kZeroTol) ? 0.0 : sN / sD;
+  t = (std::fabs(tN) < kZeroTol) ? 0.0 : tN / tD;
+  cp1 = l0 + s * u;
+  cp2 = m0 + t * v;
+  return distance_point_point(cp1, cp2, &sep);
+}
+
+// Spherocylinder-spherocylinder contact.  Not a reference function: assembled as the deprecated linker
+// kernel does (scrap/parameter_interface/linkers/.../SpherocylinderSpherocylinderLinker.cpp:207-247) but with the
+// live tree's z reference axis (compute_aabb.hpp:115-117):
+//   endpoints = c -/+ 0.5*L*(q*zhat); dist = seg-seg; sep = dist - (r1 + r2); n = (cp2 - cp1) * (1/dist);
+//   contact points = the centreline closest points.
+struct RodContact {
+  double sep;
+  V3 normal, cp1, cp2;
+  double s, t;
+};
+inline RodContact contact_segments(const V3& a0, const V3& a1, double ra, const V3& b0, const V3& b1, double rb) {
+  RodContact out;
+  V3 sepv;
+  const double dist = distance_segment_segment(a0, a1, b0, b1, out.cp1, out.cp2, out.s, out.t, sepv);
+  const double radius_sum = ra + rb;
+  out.sep = dist - radius_sum;
+  const double inv = 1.0 / dist;
+  // the scrap linker takes left_to_right = cp2 - cp1, NOT the distance function's `sep` output: in the colinear
+  // cases 1.3/1.4 (LineSegmentLineSegment.hpp:251-264) `sep` is the point->segment vector of m0/m1 onto segment 1,
+  // i.e. it points from segment 2 to segment 1 (reference quirk, reproduced by distance_segment_segment above).
+  (void)sepv;
+  out.normal = (out.cp2 - out.cp1) * inv;
+  return out;
+}
+
+// Sphere-sphere contact = distance(Sphere,Sphere) (SphereSphere.hpp:54-59) for the signed separation and the scrap
+// app's normal  n = (xj - xi) * (1/|xj - xi|)  (scrap/lcp_spheres/NgpLcp.cpp:360-372).
+inline double contact_spheres(const V3& c1, double r1, const V3& c2, double r2, V3& normal) {
+  V3 s;
+  const double cc = distance_point_point(c1, c2, &s);
+  const double inv = 1.0 / cc;
+  normal = s * inv;
+  return cc - r1 - r2;
+}
+// Periodic variant: the centre separation comes from PeriodicScaledMetric::sep (periodicity.hpp:812-816).
+inline double contact_spheres_periodic(const PeriodicScaledMetric& m, const V3& c1, double r1, const V3& c2,
+                                       double r2, V3& normal) {
+  const V3 s = m.sep(c1, c2);
+  const double cc = norm(s);
+  const double inv = 1.0 / cc;
+  normal = s * inv;
+  return cc - r1 - r2;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mundy::math::convex -- spaces, residual policies, BB step, BBPGD (convex.hpp)
+// ---------------------------------------------------------------------------------------------------------------
+enum SpaceKind : int { kUnconstrained = 0, kLowerBound = 1, kUpperBound = 2, kBounded = 3 };
+// mundy/math/src/mundy_math/convex.hpp:46-115.
+struct Space {
+  int kind;
+  double lo, hi;
+  double project(double x) const {
+    switch (kind) {
+      case kLowerBound: return std::max(x, lo);
+      case kUpperBound: return std::min(x, hi);
+      case kBounded: return std::min(std::max(x, lo), hi);
+      default: return x;
+    }
+  }
+};
+enum ResidualKind : int { kProjectedDiff = 0, kProjectedGradient = 1 };
+
+// KokkosBackend vector kernels, serial order (convex.hpp:201-284).
+inline void axpby(double alpha, const double* x, double beta, double* y, size_t n) {
+  const bool az = std::fabs(alpha) < kZeroTol, bz = std::fabs(beta) < kZeroTol;
+  if (!az && !bz) {
+    for (size_t i = 0; i < n; ++i) y[i] = alpha * x[i] + beta * y[i];
+  } else if (az && !bz) {
+    for (size_t i = 0; i < n; ++i) y[i] *= beta;
+  } else if (!az && bz) {
+    for (size_t i = 0; i < n; ++i) y[i] = alpha * x[i];
+  } else {
+    for (size_t i = 0; i < n; ++i) y[i] = 0.0;
+  }
+}
+inline void wrapped_axpbyz(double alpha, const double* x, double beta, const double* y, double* z, size_t n,
+                           const Space& sp) {
+  const bool az = std::fabs(alpha) < kZeroTol, bz = std::fabs(beta) < kZeroTol;
+  if (!az && !bz) {
+    for (size_t i = 0; i < n; ++i) z[i] = sp.project(alpha * x[i] + beta * y[i]);
+  } else if (az && !bz) {
+    for (size_t i = 0; i < n; ++i) z[i] = sp.project(beta * y[i]);
+  } else if (!az && bz) {
+    for (size_t i = 0; i < n; ++i) z[i] = sp.project(alpha * x[i]);
+  } else {
+    for (size_t i = 0; i < n; ++i) z[i] = sp.project(0.0);
+  }
+}
+inline double diff_dot(const double* x, const double* y, size_t n) {
+  double sum = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double diff = x[i] - y[i];
+    sum += diff * diff;
+  }
+  return sum;
+}
+inline double diff_dot(const double* x1, const double* x2, const double* y1, const double* y2, size_t n) {
+  double sum = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const double xd = x1[i] - x2[i];
+    const double yd = y1[i] - y2[i];
+    sum += xd * yd;
+  }
+  return sum;
+}
+// convex.hpp:434-496.  Kokkos::Max<double> starts from the lowest finite double.
+inline double residual(int kind, const double* x, const double* g, size_t n, const Space& sp) {
+  double mx = std::numeric_limits<double>::lowest();
+  if (kind == kProjectedGradient) {
+    for (size_t i = 0; i < n; ++i) {
+      const double v = (x[i] < kZeroTol) ? std::max(0.0, g[i]) : std::fabs(g[i]);
+      if (v > mx) mx = v;
+    }
+    return mx;
+  }
+  constexpr double small_step_size = 1e-6;
+  for (size_t i = 0; i < n; ++i) {
+    const double xp = sp.project(x[i] - small_step_size * g[i]);
+    const double v = std::fabs(x[i] - xp);
+    if (v > mx) mx = v;
+  }
+  return mx / small_step_size;
+}
+// convex.hpp:498-516.
+inline double bb_step(const double* x_old, const double* g_old, const double* x, const double* g, size_t n) {
+  const double num = diff_dot(x, x_old, n);
+  double denom = diff_dot(x, x_old, g, g_old, n);
+  constexpr double eps = kZeroTol * 10;
+  denom += eps * (std::fabs(denom) < eps);
+  return num / denom;
+}
+
+struct SolveResult {
+  unsigned num_iters;
+  double residual;
+  int converged;
+};
+
+// convex.hpp:614-666, 789-797.  Op is any callable  void(const double* x, double* y).
+template <class Op>
+SolveResult solve_cqpp(const Op& A, const double* q, const Space& sp, int resid_kind, unsigned max_iters, double tol,
+                       size_t n, double* x, double* g, double* x_tmp, double* g_tmp) {
+  // initialize
+  std::copy(x, x + n, x_tmp);
+  A(x_tmp, g_tmp);
+  axpby(1.0, q, 1.0, g_tmp, n);
+  double res = residual(resid_kind, x_tmp, g_tmp, n, sp);
+  double step = 1.0 / res;
+  unsigned iter = 0;
+  bool converged = (res <= tol);
+  if (converged) std::copy(g_tmp, g_tmp + n, g);
+  // iterate
+  while (!(converged || iter >= max_iters)) {
+    wrapped_axpbyz(1.0, x_tmp, -step, g_tmp, x, n, sp);
+    A(x, g);
+    axpby(1.0, q, 1.0, g, n);
+    res = residual(resid_kind, x, g, n, sp);
+    if (res <= tol) {
+      converged = true;
+      break;
+    }
+    step = bb_step(x_tmp, g_tmp, x, g, n);
+    std::copy(x, x + n, x_tmp);
+    std::copy(g, g + n, g_tmp);
+    ++iter;
+  }
+  return {iter, res, converged ? 1 : 0};
+}
+
+// Dense operator, row-major n x n (KokkosBlas::gemv "N", convex.hpp:168-174).
+struct DenseOp {
+  const double* A;
+  size_t n;
+  void operator()(const double* x, double* y) const {
+    for (size_t i = 0; i < n; ++i) {
+      double acc = 0;
+      for (size_t j = 0; j < n; ++j) acc += A[i * n + j] * x[j];
+      y[i] = acc;
+    }
+  }
+};
+
+// Matrix-free contact operator  y = dt * D^T M D x  (scrap/lcp_spheres/NgpLcp.cpp:442-548: K21 scatter, K22 dry
+// mobility, K23 gather).  Rigid bodies: force f and torque tq per body, diagonal mobilities mt (translation) and
+// mr (rotation; 0 for the translation-only sphere app).  Lever arms ra, rb = contact point - body centre; pass
+// nullptr for spheres (no torque).  Scrap sign conventions: F_src += -lam*n, F_tgt += +lam*n (:467-472);
+// sdot = -n.(U_src - U_tgt) (:526-528).  Body sums are taken in constraint order (Kokkos-Serial order).
+struct ContactOp {
+  const int32_t* pairs;  // [C][2]
+  const double* normal;  // [C][3]
+  const double* ra;      // [C][3] or null
+  const double* rb;      // [C][3] or null
+  const double* mt;      // [N]
+  const double* mr;      // [N] or null
+  double dt;
+  size_t C, N;
+  mutable std::vector<double> F, T, U, W;
+  void operator()(const double* x, double* y) const {
+    F.assign(3 * N, 0.0);
+    U.resize(3 * N);
+    const bool rot = (ra && rb && mr);
+    if (rot) {
+      T.assign(3 * N, 0.0);
+      W.resize(3 * N);
+    }
+    for (size_t c = 0; c < C; ++c) {
+      const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
+      const double lam = x[c];
+      const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
+      const V3 f{lam * n.x, lam * n.y, lam * n.z};
+      for (int k = 0; k < 3; ++k) {
+        F[3 * i + k] += -f[k];
+        F[3 * j + k] += f[k];
+      }
+      if (rot) {
+        const V3 a{ra[3 * c], ra[3 * c + 1], ra[3 * c + 2]}, b{rb[3 * c], rb[3 * c + 1], rb[3 * c + 2]};
+        const V3 ta = cross(a, f), tb = cross(b, f);
+        for (int k = 0; k < 3; ++k) {
+          T[3 * i + k] += -ta[k];
+          T[3 * j + k] += tb[k];
+        }
+      }
+    }
+    for (size_t b = 0; b < N; ++b)
+      for (int k = 0; k < 3; ++k) {
+        U[3 * b + k] = mt[b] * F[3 * b + k];
+        if (rot) W[3 * b + k] = mr[b] * T[3 * b + k];
+      }
+    for (size_t c = 0; c < C; ++c) {
+      const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
+      const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
+      V3 vi{U[3 * i], U[3 * i + 1], U[3 * i + 2]}, vj{U[3 * j], U[3 * j + 1], U[3 * j + 2]};
+      if (rot) {
+        const V3 a{ra[3 * c], ra[3 * c + 1], ra[3 * c + 2]}, b{rb[3 * c], rb[3 * c + 1], rb[3 * c + 2]};
+        const V3 wi{W[3 * i], W[3 * i + 1], W[3 * i + 2]}, wj{W[3 * j], W[3 * j + 1], W[3 * j + 2]};
+        vi = vi + cross(wi, a);
+        vj = vj + cross(wj, b);
+      }
+      const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
+      y[c] = dt * sdot;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Neighbour search oracle.  The reference's search is stk::search::coarse_search (Trilinos 16.0.0, absent) at
+// mundy/mesh/src/mundy_mesh/GenNeighborLinkers.hpp:658 -- PARITY UNPINNED; predicate defined from MuNDy's own code:
+//   kSearchSpheres: bounding spheres (c, R + buffer) as built at GenNeighborLinkers.hpp:579-583, closed test
+//                   |c_j - c_i|^2 <= ((R_i + buffer) + (R_j + buffer))^2
+//   kSearchAABB:    compute_aabb(body) grown by buffer on every face, geom::intersects (AABB.hpp:420-431, closed).
+// Output: pairs (i, j) sorted by (i, j); unique i<j (scrap/lcp_spheres/NgpLcp.cpp:287-295) or symmetric i!=j
+// (GenNeighborLinkers.hpp:655 + ExcludeSelfInteractions :185-200).
+// Periodic boxes use the minimum image of the centre separation (PeriodicScaledMetric::sep).
+// ---------------------------------------------------------------------------------------------------------------
+enum SearchKind : int { kSearchSpheres = 0, kSearchAABB = 1 };
+
+inline bool search_overlap(int kind, const double* lo_i, const double* hi_i, const double* lo_j, const double* hi_j,
+                           const V3& ci, double Ri, const V3& cj, double Rj, const PeriodicScaledMetric* pm) {
+  if (kind == kSearchSpheres) {
+    const V3 s = pm ? pm->sep(ci, cj) : (cj - ci);
+    const double d2 = dot(s, s);
+    const double rs = Ri + Rj;
+    return d2 <= rs * rs;
+  }
+  if (!pm) {
+    AABB a, b;
+    for (int k = 0; k < 3; ++k) {
+      a.lo[k] = lo_i[k]; a.hi[k] = hi_i[k]; b.lo[k] = lo_j[k]; b.hi[k] = hi_j[k];
+    }
+    return intersects(a, b);
+  }
+  // periodic AABB test: shift box j by the lattice image that brings its centre closest to box i's centre
+  // (centres = box midpoints), then the closed interval test.
+  V3 mi, mj;
+  for (int k = 0; k < 3; ++k) {
+    mi[k] = 0.5 * (lo_i[k] + hi_i[k]);
+    mj[k] = 0.5 * (lo_j[k] + hi_j[k]);
+  }
+  const V3 s = pm->sep(mi, mj);
+  for (int k = 0; k < 3; ++k) {
+    const double shift = (mi[k] + s[k]) - mj[k];
+    const double blo = lo_j[k] + shift, bhi = hi_j[k] + shift;
+    if (hi_i[k] < blo || bhi < lo_i[k]) return false;
+  }
+  return true;
+}
+
+// O(N^2) reference search over grown boxes [lo, hi] ([N][3] each), centres c ([N][3]) and grown radii R ([N]).
+inline void search_bruteforce(int kind, size_t n, const double* lo, const double* hi, const double* c,
+                              const double* R, const double* box /*null or [3]*/, bool symmetric,
+                              std::vector<int32_t>& pairs) {
+  pairs.clear();
+  PeriodicScaledMetric pmv(box ? V3{box[0], box[1], box[2]} : V3{1, 1, 1});
+  const PeriodicScaledMetric* pm = box ? &pmv : nullptr;
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t j = symmetric ? 0 : i + 1; j < n; ++j) {
+      if (j == i) continue;
+      // the predicate is always evaluated with the lower index first, so (i,j) and (j,i) agree bit for bit
+      const size_t a = std::min(i, j), b = std::max(i, j);
+      const V3 ca{c[3 * a], c[3 * a + 1], c[3 * a + 2]}, cb{c[3 * b], c[3 * b + 1], c[3 * b + 2]};
+      if (search_overlap(kind, lo + 3 * a, hi + 3 * a, lo + 3 * b, hi + 3 * b, ca, R[a], cb, R[b], pm)) {
+        pairs.push_back(static_cast<int32_t>(i));
+        pairs.push_back(static_cast<int32_t>(j));
+      }
+    }
+  }
+}
+
+// Cell-list search with the same predicate (evaluated with the lower index first, so it is orientation
+// independent and identical to the brute-force result).  This is also the CPU-baseline broad phase.
+inline void search_celllist(int kind, size_t n, const double* lo, const double* hi, const double* c, const double* R,
+                            const double* box, bool symmetric, std::vector<int32_t>& pairs) {
+  pairs.clear();
+  if (n == 0) return;
+  PeriodicScaledMetric pmv(box ? V3{box[0], box[1], box[2]} : V3{1, 1, 1});
+  const PeriodicScaledMetric* pm = box ? &pmv : nullptr;
+  // binning point = box midpoint (AABB mode) or centre (sphere mode); reach = max half extent / radius
+  std::vector<double> p(3 * n);
+  double reach = 0;
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      if (kind == kSearchAABB) {
+        p[3 * i + k] = 0.5 * (lo[3 * i + k] + hi[3 * i + k]);
+        reach = std::max(reach, 0.5 * (hi[3 * i + k] - lo[3 * i + k]));
+      } else {
+        p[3 * i + k] = c[3 * i + k];
+        reach = std::max(reach, R[i]);
+      }
+    }
+  double h = 2.0 * reach * (1.0 + 1e-12);
+  if (!(h > 0)) h = 1.0;
+  double origin[3], ext[3];
+  int nc[3];
+  for (int k = 0; k < 3; ++k) {
+    if (pm) {
+      origin[k] = 0.0;
+      ext[k] = box[k];
+    } else {
+      double mn = p[k], mx = p[k];
+      for (size_t i = 1; i < n; ++i) {
+        mn = std::min(mn, p[3 * i + k]);
+        mx = std::max(mx, p[3 * i + k]);
+      }
+      origin[k] = mn;
+      ext[k] = mx - mn;
+    }
+    nc[k] = std::max(1, std::min(1024, static_cast<int>(std::floor(ext[k] / h))));
+  }
+  if (pm)
+    for (size_t i = 0; i < n; ++i) {
+      const V3 w = pm->wrap({p[3 * i], p[3 * i + 1], p[3 * i + 2]});
+      p[3 * i] = w.x; p[3 * i + 1] = w.y; p[3 * i + 2] = w.z;
+    }
+  auto cell_of = [&](size_t i, int k) {
+    if (ext[k] <= 0) return 0;
+    const int ci = static_cast<int>(std::floor((p[3 * i + k] - origin[k]) / ext[k] * nc[k]));
+    return std::max(0, std::min(nc[k] - 1, ci));
+  };
+  const size_t ncell = static_cast<size_t>(nc[0]) * nc[1] * nc[2];
+  std::vector<int32_t> head(ncell + 1, 0), cellid(n), order(n);
+  for (size_t i = 0; i < n; ++i) {
+    cellid[i] = (cell_of(i, 2) * nc[1] + cell_of(i, 1)) * nc[0] + cell_of(i, 0);
+    head[cellid[i] + 1]++;
+  }
+  for (size_t k = 0; k < ncell; ++k) head[k + 1] += head[k];
+  {
+    std::vector<int32_t> cur(head.begin(), head.end() - 1);
+    for (size_t i = 0; i < n; ++i) order[cur[cellid[i]]++] = static_cast<int32_t>(i);
+  }
+  std::vector<int32_t> row;
+  for (size_t i = 0; i < n; ++i) {
+    row.clear();
+    const int cx = cellid[i] % nc[0], cy = (cellid[i] / nc[0]) % nc[1], cz = cellid[i] / (nc[0] * nc[1]);
+    int seen[27];
+    int nseen = 0;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          int x = cx + dx, y = cy + dy, z = cz + dz;
+          if (pm) {
+            x = (x + nc[0]) % nc[0]; y = (y + nc[1]) % nc[1]; z = (z + nc[2]) % nc[2];
+          } else if (x < 0 || y < 0 || z < 0 || x >= nc[0] || y >= nc[1] || z >= nc[2]) {
+            continue;
+          }
+          const int cid = (z * nc[1] + y) * nc[0] + x;
+          bool dup = false;
+          for (int q = 0; q < nseen; ++q) dup |= (seen[q] == cid);
+          if (dup) continue;
+          seen[nseen++] = cid;
+          for (int32_t s = head[cid]; s < head[cid + 1]; ++s) {
+            const size_t j = order[s];
+            if (j == i || (!symmetric && j < i)) continue;
+            const size_t a = std::min(i, j), b2 = std::max(i, j);
+            const V3 ca{c[3 * a], c[3 * a + 1], c[3 * a + 2]}, cb{c[3 * b2], c[3 * b2 + 1], c[3 * b2 + 2]};
+            if (search_overlap(kind, lo + 3 * a, hi + 3 * a, lo + 3 * b2, hi + 3 * b2, ca, R[a], cb, R[b2], pm))
+              row.push_back(static_cast<int32_t>(j));
+          }
+        }
+    std::sort(row.begin(), row.end());
+    for (int32_t j : row) {
+      pairs.push_back(static_cast<int32_t>(i));
+      pairs.push_back(j);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// zorder_knn / zmorton_less (mundy/math/src/mundy_math/zmort.hpp)
+// ---------------------------------------------------------------------------------------------------------------
+// zmort.hpp:95-107.
+inline int float_exp(uint64_t xi) {
+  uint64_t uxi = xi & 0x7fffffffffffffffull;
+  if (uxi == 0 || uxi >= 0x7ff0000000000000ull) return 0;
+  uxi >>= 52;
+  return (uxi == 0) ? -1022 : static_cast<int>(uxi) - 1023;
+}
+inline int float_exp(uint32_t xi) {
+  uint32_t uxi = xi & 0x7fffffffu;
+  if (uxi == 0 || uxi >= 0x7f800000u) return 0;
+  uxi >>= 23;
+  return (uxi == 0) ? -126 : static_cast<int>(uxi) - 127;
+}
+// zmort.hpp:109-115.
+inline uint64_t float_sig(uint64_t xi) { return xi & 0x000fffffffffffffull; }
+inline uint32_t float_sig(uint32_t xi) { return xi & 0x007fffffu; }
+// zmort.hpp:129-151 (table lookup there; the value is floor(log2 x)).
+inline int uint_log_base2(uint64_t x) {
+  int l = -1;
+  while (x) {
+    x >>= 1;
+    ++l;
+  }
+  return l;
+}
+inline uint64_t to_uint(double x) {
+  uint64_t u;
+  std::memcpy(&u, &x, 8);
+  return u;
+}
+inline uint32_t to_uint(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  return u;
+}
+// zmort.hpp:166-188.
+template <class S>
+inline int float_xor_msb(S p, S q) {
+  constexpr int nbits = sizeof(S) == 8 ? 52 : 23;
+  if (p == q || p == -q) return std::numeric_limits<int>::min();
+  const auto pui = to_uint(p), qui = to_uint(q);
+  const int pe = float_exp(pui), qe = float_exp(qui);
+  if (pe == qe) {
+    const auto x = float_sig(pui) ^ float_sig(qui);
+    if (x > 0) return pe + uint_log_base2(static_cast<uint64_t>(x)) - nbits;
+    return pe;
+  }
+  return std::max(pe, qe);
+}
+// zmort.hpp:195-220 (zorder_knn::Less<Point, d>): axes scanned d-1 .. 0, strict <, sign mismatch decides at once.
+template <class S>
+inline bool zorder_less(const S* p, const S* q, int d) {
+  int x = std::numeric_limits<int>::min();
+  int k = 0;
+  for (int j = d; j-- > 0;) {
+    if ((p[j] < S(0)) != (q[j] < S(0))) return p[j] < q[j];
+    const int y = float_xor_msb(p[j], q[j]);
+    if (x < y) {
+      x = y;
+      k = j;
+    }
+  }
+  return p[k] < q[k];
+}
+// zmort.hpp:228-265 (mundy::math::zmorton_less): axes scanned 0,1,2; sign mismatches resolved z, y, x.
+inline bool zmorton_less(const double* p, const double* q) {
+  int sl[3];
+  for (int k = 0; k < 3; ++k) sl[k] = ((p[k] < 0.0) != (q[k] < 0.0)) ? (p[k] < q[k]) : -1;
+  int x = std::numeric_limits<int>::min();
+  int k = 0;
+  for (int j = 0; j < 3; ++j) {
+    const int y = float_xor_msb(p[j], q[j]);
+    if (x < y) {
+      x = y;
+      k = j;
+    }
+  }
+  return (sl[2] != -1) ? sl[2] : ((sl[1] != -1) ? sl[1] : ((sl[0] != -1) ? sl[0] : (p[k] < q[k])));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hilbert curve generator (mundy/math/src/mundy_math/Hilbert.hpp:48-128)
+// ---------------------------------------------------------------------------------------------------------------
+inline size_t hilbert_3d(size_t s, size_t i, std::vector<V3>& pos, V3 cur, V3 dr1, V3 dr2, V3 dr3) {
+  if (s == 1) {
+    pos[i] = cur;
+    return i + 1;
+  }
+  const size_t snew = s / 2;
+  const double sn = static_cast<double>(snew);
+  V3 cn = cur;
+  for (const V3& dr : {dr1, dr2, dr3}) {
+    const V3 st{dr.x < 0.0 ? 1.0 : 0.0, dr.y < 0.0 ? 1.0 : 0.0, dr.z < 0.0 ? 1.0 : 0.0};
+    cn = cn - sn * V3{st.x * dr.x, st.y * dr.y, st.z * dr.z};
+  }
+  const V3 m1 = -1.0 * dr1, m2 = -1.0 * dr2, m3 = -1.0 * dr3;
+  i = hilbert_3d(snew, i, pos, cn, dr2, dr3, dr1);
+  i = hilbert_3d(snew, i, pos, cn + sn * dr1, dr3, dr1, dr2);
+  i = hilbert_3d(snew, i, pos, cn + sn * (dr1 + dr2), dr3, dr1, dr2);
+  i = hilbert_3d(snew, i, pos, cn + sn * dr2, m1, m2, dr3);
+  i = hilbert_3d(snew, i, pos, cn + sn * (dr2 + dr3), m1, m2, dr3);
+  i = hilbert_3d(snew, i, pos, cn + sn * ((dr1 + dr2) + dr3), m3, dr1, m2);
+  i = hilbert_3d(snew, i, pos, cn + sn * (dr1 + dr3), m3, dr1, m2);
+  i = hilbert_3d(snew, i, pos, cn + sn * dr3, dr2, m3, m1);
+  return i;
+}
+// Hilbert.hpp:86-128.
+inline void create_hilbert_positions_and_directors(size_t num_points, V3 orientation, double side_length,
+                                                   std::vector<V3>& positions, std::vector<V3>& directors) {
+  size_t ns = 2;
+  while (ns * ns * ns < num_points) ns *= 2;
+  positions.assign(ns * ns * ns, V3{0, 0, 0});
+  const V3 zhat{0, 0, 1};
+  V3 d1 = orientation;
+  d1 = d1 * (1.0 / 1.0);
+  {
+    const double nn = norm(d1);
+    d1 = {d1.x / nn, d1.y / nn, d1.z / nn};
+  }
+  V3 d2 = cross(zhat, d1);
+  {
+    const double nn = norm(d2);
+    d2 = {d2.x / nn, d2.y / nn, d2.z / nn};
+  }
+  V3 d3 = cross(d1, d2);
+  {
+    const double nn = norm(d3);
+    d3 = {d3.x / nn, d3.y / nn, d3.z / nn};
+  }
+  hilbert_3d(ns, 0, positions, V3{0, 0, 0}, side_length * d1, side_length * d2, side_length * d3);
+  directors.resize(positions.size() - 1);
+  for (size_t i = 0; i < directors.size(); ++i) {
+    V3 d = positions[(i + 1) % positions.size()] - positions[i];
+    const double nn = norm(d);
+    directors[i] = {d.x / nn, d.y / nn, d.z / nn};
+  }
+}
+
+}  // namespace moracle
