@@ -1,0 +1,242 @@
+/* mundy_hip.h -- C ABI of the MI355X (gfx950) implementation of MuNDy's contact hot path.
+ *
+ * One shared library, libmundy_hip.so, hand-written HIP underneath.  Every entry point returns an int status
+ * (MHIP_SUCCESS == 0) and records a message retrievable with mhip_last_error() (thread local).  Unless a parameter is
+ * marked [host], every pointer is a DEVICE pointer (hipMalloc / torch.cuda memory); `stream` is a hipStream_t passed
+ * as void* (NULL = the null stream).  Entry points that return host scalars synchronise `stream`, exactly where the
+ * reference's Kokkos parallel_reduce / deep_copy-to-host calls block; everything else is asynchronous.
+ * Handles are not thread safe; use one handle per host thread / stream.
+ *
+ * All floating point is fp64; the device code is built with -ffp-contract=off and follows the reference's operation
+ * order (right-fold dot, q*(0,v)*inverse(q), tolerance constants, branch structure), so per-element results are
+ * bit-identical to a scalar evaluation of the reference formulas.
+ *
+ * "Replaces" lines cite the reference interface (path:line under the MuNDy tree) that a maintainer would route
+ * through each entry point; INTEGRATION.md shows the C++ binding.  Layouts: centre [n][3], quaternion [n][4] as
+ * (w,x,y,z), AABB [n][6] as (min xyz, max xyz), pairs [c][2] int32 (source, target).
+ */
+#ifndef MUNDY_HIP_H_
+#define MUNDY_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mhip_stream_t;
+
+/* Status codes.  The C++ adapter (include/mundy_hip/adapter.hpp) maps them back to the exception types the reference
+ * throws through MUNDY_THROW_REQUIRE (mundy/core/src/mundy_core/throw_assert.hpp:135-203). */
+enum {
+  MHIP_SUCCESS = 0,
+  MHIP_ERR_INVALID_ARGUMENT = 1, /* std::invalid_argument: size mismatch, null pointer, bad enum */
+  MHIP_ERR_LOGIC = 2,            /* std::logic_error */
+  MHIP_ERR_RUNTIME = 3,          /* std::runtime_error: builder misuse, capacity */
+  MHIP_ERR_HIP = 4,              /* a HIP runtime call failed (message carries hipGetErrorString) */
+  MHIP_ERR_NO_DEVICE = 5         /* no gfx950 device visible: the library never falls back to the CPU */
+};
+
+const char* mhip_last_error(void);
+int mhip_version(void);
+/* Fails with MHIP_ERR_NO_DEVICE when no GPU is visible. [host] out pointers. */
+int mhip_device_info(int* device_count, char* arch_name, size_t arch_name_len);
+
+/* Plain device memory for hosts that do not bring their own allocator. */
+int mhip_malloc(void** ptr, size_t bytes);
+int mhip_free(void* ptr);
+int mhip_memcpy_h2d(void* dst, const void* src_host, size_t bytes, mhip_stream_t stream);
+int mhip_memcpy_d2h(void* dst_host, const void* src, size_t bytes, mhip_stream_t stream); /* synchronises */
+int mhip_stream_synchronize(mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-body geometry (seam S4).
+ * Replaces: compute_aabb(Sphere/Spherocylinder/Ellipsoid/SpherocylinderSegment)
+ *           mundy/geom/src/mundy_geom/compute_aabb.hpp:72-143
+ *           compute_bounding_radius(...) mundy/geom/src/mundy_geom/compute_bounding_radius.hpp:61-93
+ * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_compute_aabb_spheres(size_t n, const double* center, const double* radius, double* aabb, mhip_stream_t stream);
+int mhip_compute_aabb_spherocylinders(size_t n, const double* center, const double* quat, const double* radius,
+                                      const double* length, double* aabb, mhip_stream_t stream);
+int mhip_compute_aabb_ellipsoids(size_t n, const double* center, const double* quat, const double* radii,
+                                 double* aabb, mhip_stream_t stream);
+/* segment records seg[n][8] = (p0 xyz, p1 xyz, radius, 0) */
+int mhip_compute_aabb_segments(size_t n, const double* seg, double* aabb, mhip_stream_t stream);
+int mhip_bounding_radius_spherocylinders(size_t n, const double* radius, const double* length, double* out,
+                                         mhip_stream_t stream);
+int mhip_bounding_radius_ellipsoids(size_t n, const double* radii, double* out, mhip_stream_t stream);
+/* Spherocylinder -> SpherocylinderSegment records: endpoints c -/+ 0.5*L*(q*zhat) (compute_aabb.hpp:115-117),
+ * one 64-byte record per body so the pair kernels gather a single line per body. */
+int mhip_spherocylinder_segments(size_t n, const double* center, const double* quat, const double* radius,
+                                 const double* length, double* seg, mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Narrow phase (seam S4).
+ * Replaces: distance(SharedNormalSigned, Sphere, Sphere[, sep])     mundy/geom/src/mundy_geom/distance/SphereSphere.hpp:54-76
+ *           distance(Point, LineSegment, cp, t, sep)                .../distance/PointLineSegment.hpp:128-172
+ *           distance(LineSegment, LineSegment, cp1, cp2, s, t, sep) .../distance/LineSegmentLineSegment.hpp:189-318
+ *           the per-linker contact kernels of the (deprecated) operator
+ *           ComputeSignedSeparationDistanceAndContactNormal: scrap/lcp_spheres/NgpLcp.cpp:332-374 (spheres) and
+ *           scrap/parameter_interface/linkers/.../SpherocylinderSpherocylinderLinker.cpp:207-247 (rods).
+ * Any output pointer may be NULL to skip that output.
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* element-wise batches over n independent object pairs (test / adapter entry points) */
+int mhip_distance_sphere_sphere(size_t n, const double* c1, const double* r1, const double* c2, const double* r2,
+                                double* dist, double* sep, mhip_stream_t stream);
+int mhip_distance_point_segment(size_t n, const double* p, const double* a0, const double* a1, double* dist,
+                                double* cp, double* t, double* sep, mhip_stream_t stream);
+int mhip_distance_segment_segment(size_t n, const double* a0, const double* a1, const double* b0, const double* b1,
+                                  double* dist, double* cp1, double* cp2, double* s, double* t, double* sep,
+                                  mhip_stream_t stream);
+/* contact generation over a neighbour list: sep = |c_j - c_i| - r_i - r_j, normal = (c_j - c_i)/|c_j - c_i|.
+ * box [host] = NULL (free space) or 3 doubles: PeriodicScaledMetric::sep (periodicity.hpp:812-816) minimum image. */
+int mhip_contact_spheres(size_t c, const int32_t* pairs, const double* center, const double* radius,
+                         const double* box, double* sep, double* normal, mhip_stream_t stream);
+/* rods: seg from mhip_spherocylinder_segments; sep = dist(seg_i, seg_j) - (r_i + r_j); normal = (cp2 - cp1)/dist;
+ * cp1/cp2 centreline closest points; ra/rb = cp - body centre (lever arms); s/t arclength parameters. */
+int mhip_contact_spherocylinders(size_t c, const int32_t* pairs, const double* seg, const double* center, double* sep,
+                                 double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
+                                 double* t, mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Broad phase (seam S3).
+ * Replaces: stk::search::coarse_search(domain, range, MORTON_LBVH, comm, results, exec, symmetry) +
+ *           SearchFilter::apply / filter_view compaction     mundy/mesh/src/mundy_mesh/GenNeighborLinkers.hpp:650-664,
+ *           :141-183; the rebuild rule :603-615; scrap: ArborX BVH query scrap/lcp_spheres/NgpLcp.cpp:297-330.
+ * Predicate (defined here; the reference's is third party): MHIP_SEARCH_SPHERES = bounding spheres
+ * (centre, bounding_radius + buffer), closed test d^2 <= (Ri + Rj)^2; MHIP_SEARCH_AABB = aabb grown by buffer on every
+ * face, closed interval test of geom::intersects (AABB.hpp:420-431).  Results are canonical: sorted by (i, j);
+ * symmetric = 0 gives unique i < j pairs, 1 gives both orientations, never i == j.
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { MHIP_SEARCH_SPHERES = 0, MHIP_SEARCH_AABB = 1 };
+
+typedef struct mhip_broadphase* mhip_broadphase_t;
+
+typedef struct {
+  int search_kind; /* MHIP_SEARCH_* */
+  int symmetric;   /* 0: i<j ; 1: i!=j both orders */
+  double buffer;   /* search buffer added to every volume */
+  int periodic;    /* 0 free space, 1 orthorhombic periodic box [0,box) */
+  double box[3];
+} mhip_broadphase_config;
+
+int mhip_broadphase_create(mhip_broadphase_t* handle);
+int mhip_broadphase_destroy(mhip_broadphase_t handle);
+/* Builds the neighbour list of n bodies; *num_pairs [host] receives the pair count (synchronises, as filter_view's
+ * deep_copy of the scan total does, GenNeighborLinkers.hpp:155-156).  Also snapshots the centres for
+ * mhip_broadphase_needs_rebuild. */
+int mhip_broadphase_build(mhip_broadphase_t handle, const mhip_broadphase_config* config /*[host]*/, size_t n,
+                          const double* aabb, const double* center, const double* bounding_radius,
+                          size_t* num_pairs /*[host]*/, mhip_stream_t stream);
+/* Copies the pair list ([num_pairs][2] int32) and/or the CSR form (row_ptr[n+1], col[num_pairs]); NULL skips. */
+int mhip_broadphase_get_pairs(mhip_broadphase_t handle, int32_t* pairs, int32_t* row_ptr, int32_t* col,
+                              mhip_stream_t stream);
+/* Rebuild rule: *flag [host] = 1 iff any centre moved more than 0.5*buffer since the last build (synchronises). */
+int mhip_broadphase_needs_rebuild(mhip_broadphase_t handle, size_t n, const double* center, int* flag /*[host]*/,
+                                  mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Convex solver backend (seam S1) -- the static interface of convex::KokkosBackend as a C ABI.
+ * Replaces: mundy/math/src/mundy_math/convex.hpp:141-285 (deep_copy, apply/gemv, axpby, wrapped_axpbyz, diff_dot x2,
+ *           reduce_max), residual policies :434-496, BBStepStrategy :498-516.  Functors cannot cross a C ABI, so the
+ *           four convex spaces (:46-115) and the two residual policies are enums + scalars.
+ * ---------------------------------------------------------------------------------------------------------------- */
+enum { MHIP_SPACE_UNCONSTRAINED = 0, MHIP_SPACE_LOWER_BOUND = 1, MHIP_SPACE_UPPER_BOUND = 2, MHIP_SPACE_BOUNDED = 3 };
+enum { MHIP_RESIDUAL_PROJECTED_DIFF = 0, MHIP_RESIDUAL_PROJECTED_GRADIENT = 1 };
+
+typedef struct {
+  int kind; /* MHIP_SPACE_* */
+  double lower_bound, upper_bound;
+} mhip_space;
+
+typedef struct {
+  unsigned max_iters; /* PGDConfig::max_iters, default 1000 (convex.hpp:523) */
+  double tol;         /* PGDConfig::tol, default 1e-8 (convex.hpp:524) */
+  int residual_kind;  /* MHIP_RESIDUAL_*; default policy is PROJECTED_DIFF (convex.hpp:762-768) */
+} mhip_pgd_config;
+
+typedef struct {
+  unsigned num_iters; /* completed non-terminal iterations (convex.hpp:664) */
+  double residual;
+  int converged; /* non-convergence is not an error (convex.hpp:673-675) */
+} mhip_solve_result;
+
+int mhip_deep_copy(size_t n, double* dst, const double* src, mhip_stream_t stream);
+int mhip_fill(size_t n, double* dst, double value, mhip_stream_t stream);
+int mhip_axpby(size_t n, double alpha, const double* x, double beta, double* y, mhip_stream_t stream);
+int mhip_wrapped_axpbyz(size_t n, double alpha, const double* x, double beta, const double* y, double* z,
+                        const mhip_space* space /*[host]*/, mhip_stream_t stream);
+int mhip_diff_dot2(size_t n, const double* x, const double* y, double* result /*[host]*/, mhip_stream_t stream);
+int mhip_diff_dot4(size_t n, const double* x1, const double* x2, const double* y1, const double* y2,
+                   double* result /*[host]*/, mhip_stream_t stream);
+int mhip_residual(size_t n, int residual_kind, const double* x, const double* grad, const mhip_space* space /*[host]*/,
+                  double* result /*[host]*/, mhip_stream_t stream);
+int mhip_bb_step(size_t n, const double* x_old, const double* g_old, const double* x, const double* g,
+                 double* result /*[host]*/, mhip_stream_t stream);
+/* y = A x, A row-major n x n (KokkosBlas::gemv "N", convex.hpp:168-174) */
+int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Matrix-free contact operator (seam S2):  y = dt * D^T M D x  over a neighbour list.
+ * Replaces: sum_collision_force / compute_the_mobility_problem (dry) / compute_rate_of_change_of_sep,
+ *           scrap/lcp_spheres/NgpLcp.cpp:442-530; rigid-body torque terms follow the dry local-drag mobility of
+ *           scrap/parameter_interface/alens/tests/performance_tests/Bacteria.cpp:808-848 (U = F/(6 pi mu r),
+ *           W = T/(8 pi mu r^3)), passed in as per-body scalars.
+ * ra, rb, mob_rot may all be NULL (translation only, the sphere app).  The handle keeps views of the caller's
+ * arrays (they must outlive it) and owns a body->constraint incidence index, so sums run in a fixed order (bitwise
+ * reproducible, no atomics).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mhip_contact_op* mhip_contact_op_t;
+
+int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
+                           const double* normal, const double* ra, const double* rb, const double* mob_trans,
+                           const double* mob_rot, double dt, mhip_stream_t stream);
+int mhip_contact_op_destroy(mhip_contact_op_t handle);
+int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, mhip_stream_t stream);
+/* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate */
+int mhip_contact_op_body_velocity(mhip_contact_op_t handle, const double** velocity /*[host] out: device pointer*/);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * BBPGD drivers (seam S1): solve_cqpp / solve_lcp with PGDStrategy<BBStepStrategy, residual policy>.
+ * Replaces: mundy/math/src/mundy_math/convex.hpp:592-681 (PGDStrategy::initialize/iterate/done/result), :789-845.
+ * State vectors x, g, x_tmp, g_tmp are caller-owned (PGDState holds references, convex.hpp:551-585); on return they
+ * hold what the reference leaves in them.  x is the initial guess.
+ *   _dense   : A is a row-major n x n device matrix (the KokkosBlas::gemv path)
+ *   _contact : A is a contact operator handle; the iteration is fused into 3 kernels per iteration with a
+ *              device-resident step size and residual (no host round trip per reduction).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_bbpgd_solve_dense(size_t n, const double* A, const double* q, const mhip_space* space /*[host]*/,
+                           const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
+                           double* g_tmp, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
+                             const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
+                             double* g_tmp, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+/* Same algorithm driven kernel-by-kernel through the S1 vector entry points above (what the C++ adapter's
+ * HipBackend does): the unfused reference structure, kept as an in-library cross-check of the fused path. */
+int mhip_bbpgd_solve_contact_unfused(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
+                                     const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
+                                     double* g_tmp, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Time integration either side of the solve: x += dt * U (scrap/lcp_spheres/NgpLcp.cpp:898) and, for
+ * rods, q <- rotate_quaternion(q, W, dt) (mundy/math/src/mundy_math/Quaternion.hpp:1366-1390).
+ * velocity is [n][6] as produced by the contact operator.  quat may be NULL (spheres).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_integrate_euler(size_t n, double dt, const double* velocity, double* center, double* quat,
+                         mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Body reordering: Z-order (Morton) permutation of bodies by centre, z most significant as
+ * zorder_knn::Less (mundy/math/src/mundy_math/zmort.hpp:195-220) orders non-negative lattice coordinates.
+ * perm[k] = index of the body that goes to position k.  Deterministic (ties broken by index).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_morton_order(size_t n, const double* center, const double* lo /*[host] 3*/, double cell_size, int32_t* perm,
+                      mhip_stream_t stream);
+/* dst[k][0..width) = src[perm[k]][0..width)  for rows of `width` doubles */
+int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst, mhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUNDY_HIP_H_ */

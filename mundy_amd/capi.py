@@ -1,0 +1,125 @@
+"""ctypes binding of libmundy_hip.so (include/mundy_hip.h).  Plumbing only: torch supplies device memory and the
+current HIP stream; every computation happens in the hand-written HIP library.  There is no CPU fallback: if the
+library is missing `load()` raises, and on a box without a GPU every compute entry point fails in HIP.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmundy_hip.so")
+
+SUCCESS, ERR_INVALID_ARGUMENT, ERR_LOGIC, ERR_RUNTIME, ERR_HIP, ERR_NO_DEVICE = range(6)
+SEARCH_SPHERES, SEARCH_AABB = 0, 1
+SPACE_UNCONSTRAINED, SPACE_LOWER_BOUND, SPACE_UPPER_BOUND, SPACE_BOUNDED = 0, 1, 2, 3
+RESIDUAL_PROJECTED_DIFF, RESIDUAL_PROJECTED_GRADIENT = 0, 1
+
+
+class MhipError(RuntimeError):
+    """HIP runtime failure or missing device (MHIP_ERR_HIP / MHIP_ERR_NO_DEVICE)."""
+
+
+class BroadphaseConfig(C.Structure):
+    _fields_ = [("search_kind", C.c_int), ("symmetric", C.c_int), ("buffer", C.c_double), ("periodic", C.c_int),
+                ("box", C.c_double * 3)]
+
+
+class Space(C.Structure):
+    _fields_ = [("kind", C.c_int), ("lower_bound", C.c_double), ("upper_bound", C.c_double)]
+
+
+class PgdConfig(C.Structure):
+    _fields_ = [("max_iters", C.c_uint), ("tol", C.c_double), ("residual_kind", C.c_int)]
+
+
+class SolveResult(C.Structure):
+    _fields_ = [("num_iters", C.c_uint), ("residual", C.c_double), ("converged", C.c_int)]
+
+
+_vp, _sz, _d, _i = C.c_void_p, C.c_size_t, C.c_double, C.c_int
+
+# name -> argtypes; every function returns int status.  Must list every symbol include/mundy_hip.h declares
+# (tests/test_capi_symbols.py checks the header against this table and against the built library).
+SIGNATURES = {
+    "mhip_device_info": [C.POINTER(C.c_int), C.c_char_p, _sz],
+    "mhip_malloc": [C.POINTER(_vp), _sz],
+    "mhip_free": [_vp],
+    "mhip_memcpy_h2d": [_vp, _vp, _sz, _vp],
+    "mhip_memcpy_d2h": [_vp, _vp, _sz, _vp],
+    "mhip_stream_synchronize": [_vp],
+    "mhip_compute_aabb_spheres": [_sz, _vp, _vp, _vp, _vp],
+    "mhip_compute_aabb_spherocylinders": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_compute_aabb_ellipsoids": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "mhip_compute_aabb_segments": [_sz, _vp, _vp, _vp],
+    "mhip_bounding_radius_spherocylinders": [_sz, _vp, _vp, _vp, _vp],
+    "mhip_bounding_radius_ellipsoids": [_sz, _vp, _vp, _vp],
+    "mhip_spherocylinder_segments": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_distance_sphere_sphere": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_distance_point_segment": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_distance_segment_segment": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_contact_spheres": [_sz, _vp, _vp, _vp, C.POINTER(_d), _vp, _vp, _vp],
+    "mhip_contact_spherocylinders": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_broadphase_create": [C.POINTER(_vp)],
+    "mhip_broadphase_destroy": [_vp],
+    "mhip_broadphase_build": [_vp, C.POINTER(BroadphaseConfig), _sz, _vp, _vp, _vp, C.POINTER(_sz), _vp],
+    "mhip_broadphase_get_pairs": [_vp, _vp, _vp, _vp, _vp],
+    "mhip_broadphase_needs_rebuild": [_vp, _sz, _vp, C.POINTER(_i), _vp],
+    "mhip_deep_copy": [_sz, _vp, _vp, _vp],
+    "mhip_fill": [_sz, _vp, _d, _vp],
+    "mhip_axpby": [_sz, _d, _vp, _d, _vp, _vp],
+    "mhip_wrapped_axpbyz": [_sz, _d, _vp, _d, _vp, _vp, C.POINTER(Space), _vp],
+    "mhip_diff_dot2": [_sz, _vp, _vp, C.POINTER(_d), _vp],
+    "mhip_diff_dot4": [_sz, _vp, _vp, _vp, _vp, C.POINTER(_d), _vp],
+    "mhip_residual": [_sz, _i, _vp, _vp, C.POINTER(Space), C.POINTER(_d), _vp],
+    "mhip_bb_step": [_sz, _vp, _vp, _vp, _vp, C.POINTER(_d), _vp],
+    "mhip_gemv": [_sz, _vp, _vp, _vp, _vp],
+    "mhip_contact_op_create": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp],
+    "mhip_contact_op_destroy": [_vp],
+    "mhip_contact_op_apply": [_vp, _vp, _vp, _vp],
+    "mhip_contact_op_body_velocity": [_vp, C.POINTER(_vp)],
+    "mhip_bbpgd_solve_dense": [_sz, _vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
+                               C.POINTER(SolveResult), _vp],
+    "mhip_bbpgd_solve_contact": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
+                                 C.POINTER(SolveResult), _vp],
+    "mhip_bbpgd_solve_contact_unfused": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
+                                         C.POINTER(SolveResult), _vp],
+    "mhip_integrate_euler": [_sz, _d, _vp, _vp, _vp, _vp],
+    "mhip_morton_order": [_sz, _vp, C.POINTER(_d), _d, _vp, _vp],
+    "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],
+}
+OTHER_SYMBOLS = {"mhip_last_error": ([], C.c_char_p), "mhip_version": ([], C.c_int)}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MhipError("%s is missing: run `python -m mundy_amd.build` (or __graft_entry__.build()); "
+                            "mundy_amd has no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        for name, (argtypes, restype) in OTHER_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    """status -> the exception type the reference throws for that class of error (throw_assert.hpp:135-203)."""
+    if status == SUCCESS:
+        return
+    msg = load().mhip_last_error().decode()
+    if status == ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)  # std::invalid_argument
+    if status == ERR_LOGIC:
+        raise AssertionError(msg)  # std::logic_error
+    if status == ERR_RUNTIME:
+        raise RuntimeError(msg)  # std::runtime_error
+    raise MhipError(msg)

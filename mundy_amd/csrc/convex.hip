@@ -1,0 +1,759 @@
+// convex.hip -- the BBPGD solver backend (convex.hpp restated for gfx950): S1 vector kernels, the matrix-free contact
+// operator (S2) and the fused BBPGD driver.
+//
+// Everything here is HBM-bandwidth bound (SpMV-like gathers and streaming vector passes): no MFMA.
+//
+// Fused iteration (mhip_bbpgd_solve_contact), 3 launches, no host round trip:
+//   k_body        per body:       x_c = Proj(xt_c - step*gt_c) for the incident constraints (fixed order),
+//                                 F = sum -/+ x_c n_c, T = sum -/+ r x (x_c n_c), (U, W) = (mt F, mr T)   [K24+K21+K22]
+//   k_constraint  per constraint: x_c again (bitwise the same), g_c = dt * sdot(U, W) + q_c, store x, g;
+//                                 block partials of max residual, sum dx^2, sum dx dg                       [K23+K14+K17+K16]
+//   k_finalize    one workgroup:  ordered reduction of the partials, residual test, BB1 step, iteration count,
+//                                 all kept in a device-resident state block                                  [a26/a27]
+// x/x_tmp and g/g_tmp ping-pong by iteration parity instead of being copied (K20); mhip_bbpgd_solve_* restores the
+// reference's post-conditions (which array holds what) once, at the end.
+#include <vector>
+
+#include "mhip_internal.hpp"
+
+namespace mhip {
+
+constexpr double kSmallStep = 1e-6;            // convex.hpp:479
+constexpr double kBBEps = 1e-15 * 10;          // convex.hpp:511
+constexpr double kLowest = -1.7976931348623157e308;  // Kokkos::Max<double> identity
+
+// ------------------------------------------------------------------------------------------------------------------
+// S1 vector kernels (KokkosBackend, convex.hpp:201-284).  The |alpha|,|beta| < 1e-15 branches are resolved on the
+// host exactly as the reference does and select the kernel variant.
+// ------------------------------------------------------------------------------------------------------------------
+template <int MODE>  // 0: a*x+b*y   1: b*y   2: a*x   3: 0
+__global__ void __launch_bounds__(kBlock) k_axpby(size_t n, double alpha, const double* __restrict__ x, double beta,
+                                                 double* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (MODE == 0) y[i] = alpha * x[i] + beta * y[i];
+    if (MODE == 1) y[i] *= beta;
+    if (MODE == 2) y[i] = alpha * x[i];
+    if (MODE == 3) y[i] = 0.0;
+  }
+}
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_wrapped_axpbyz(size_t n, double alpha, const double* __restrict__ x,
+                                                          double beta, const double* __restrict__ y,
+                                                          double* __restrict__ z, Space sp) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double v;
+    if (MODE == 0) v = alpha * x[i] + beta * y[i];
+    if (MODE == 1) v = beta * y[i];
+    if (MODE == 2) v = alpha * x[i];
+    if (MODE == 3) v = 0.0;
+    z[i] = sp.project(v);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_copy(size_t n, double* __restrict__ dst, const double* __restrict__ src) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+__global__ void __launch_bounds__(kBlock) k_fill(size_t n, double* __restrict__ dst, double v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = v;
+}
+
+// residual term of one unknown (policies convex.hpp:434-496)
+__device__ inline double residual_term(int kind, double x, double g, const Space& sp) {
+  if (kind == MHIP_RESIDUAL_PROJECTED_GRADIENT) return (x < kZeroTol) ? ((0.0 < g) ? g : 0.0) : fabs(g);
+  return fabs(x - sp.project(x - kSmallStep * g));
+}
+
+// reductions: partials[block] then an ordered final pass.  OP: 0 = sum (x-y)^2, 1 = sum (x1-x2)(y1-y2), 2 = max resid
+template <int OP>
+__global__ void __launch_bounds__(kBlock)
+    k_reduce_partials(size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                      const double* __restrict__ c, const double* __restrict__ d, int resid_kind, Space sp,
+                      double* __restrict__ partials) {
+  __shared__ double scratch[kBlock / 64];
+  double acc = (OP == 2) ? kLowest : 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (OP == 0) {
+      const double df = a[i] - b[i];
+      acc += df * df;
+    } else if (OP == 1) {
+      acc += (a[i] - b[i]) * (c[i] - d[i]);
+    } else {
+      const double v = residual_term(resid_kind, a[i], b[i], sp);
+      if (v > acc) acc = v;
+    }
+  }
+  const double r = (OP == 2) ? block_max(acc, scratch) : block_sum(acc, scratch);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+template <int OP>
+__global__ void __launch_bounds__(kBlock) k_reduce_final(int nparts, const double* __restrict__ partials,
+                                                        double* __restrict__ out) {
+  __shared__ double scratch[kBlock / 64];
+  double acc = (OP == 2) ? kLowest : 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    if (OP == 2) {
+      if (partials[i] > acc) acc = partials[i];
+    } else {
+      acc += partials[i];
+    }
+  }
+  const double r = (OP == 2) ? block_max(acc, scratch) : block_sum(acc, scratch);
+  if (threadIdx.x == 0) *out = r;
+}
+
+// y = A x, row-major n x n: one wavefront per row (KokkosBlas::gemv "N")
+__global__ void __launch_bounds__(kBlock) k_gemv(size_t n, const double* __restrict__ A, const double* __restrict__ x,
+                                                double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t row = wave; row < n; row += nwaves) {
+    const double* Ar = A + row * n;
+    double acc = 0.0;
+    for (size_t j = lane; j < n; j += 64) acc += Ar[j] * x[j];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc;
+  }
+}
+
+// thread-local scratch for the blocking S1 reductions (the stream is synchronised before they return)
+struct ReduceScratch {
+  DeviceBuffer dev;  // kMaxGrid partials + 1 result
+  double* host = nullptr;
+  int ensure() {
+    if (int e = dev.reserve((kMaxGrid + 8) * sizeof(double))) return e;
+    if (!host) MHIP_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), 8 * sizeof(double)));
+    return MHIP_SUCCESS;
+  }
+};
+ReduceScratch& reduce_scratch() {
+  thread_local ReduceScratch s;
+  return s;
+}
+
+template <int OP>
+int reduce_to_host(size_t n, const double* a, const double* b, const double* c, const double* d, int resid_kind,
+                   Space sp, double* result, hipStream_t stream) {
+  ReduceScratch& rs = reduce_scratch();
+  if (int e = rs.ensure()) return e;
+  double* partials = rs.dev.as<double>();
+  double* out = partials + kMaxGrid;
+  const unsigned grid = grid_for(n);
+  k_reduce_partials<OP><<<grid, kBlock, 0, stream>>>(n, a, b, c, d, resid_kind, sp, partials);
+  MHIP_LAUNCH_CHECK();
+  k_reduce_final<OP><<<1, kBlock, 0, stream>>>(n == 0 ? 0 : static_cast<int>(grid), partials, out);
+  MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipMemcpyAsync(rs.host, out, sizeof(double), hipMemcpyDeviceToHost, stream));
+  MHIP_HIP(hipStreamSynchronize(stream));
+  *result = rs.host[0];
+  return MHIP_SUCCESS;
+}
+
+int launch_axpby(size_t n, double alpha, const double* x, double beta, double* y, hipStream_t s) {
+  if (n == 0) return MHIP_SUCCESS;
+  const bool az = fabs(alpha) < kZeroTol, bz = fabs(beta) < kZeroTol;
+  const unsigned g = grid_for(n);
+  if (!az && !bz) k_axpby<0><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
+  else if (az && !bz) k_axpby<1><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
+  else if (!az && bz) k_axpby<2><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
+  else k_axpby<3><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+int launch_wrapped_axpbyz(size_t n, double alpha, const double* x, double beta, const double* y, double* z, Space sp,
+                          hipStream_t s) {
+  if (n == 0) return MHIP_SUCCESS;
+  const bool az = fabs(alpha) < kZeroTol, bz = fabs(beta) < kZeroTol;
+  const unsigned g = grid_for(n);
+  if (!az && !bz) k_wrapped_axpbyz<0><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
+  else if (az && !bz) k_wrapped_axpbyz<1><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
+  else if (!az && bz) k_wrapped_axpbyz<2><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
+  else k_wrapped_axpbyz<3><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+int launch_copy(size_t n, double* dst, const double* src, hipStream_t s) {
+  if (n == 0 || dst == src) return MHIP_SUCCESS;
+  k_copy<<<grid_for(n), kBlock, 0, s>>>(n, dst, src);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// contact operator
+// ------------------------------------------------------------------------------------------------------------------
+struct SolverState {  // device resident
+  double step, residual, num, den;
+  unsigned iter;
+  int converged, done, converged_at_init;
+};
+
+enum XMode { X_APPLY = 0, X_INIT = 1, X_SOLVE = 2 };
+
+struct OpView {
+  size_t C, N;
+  const int2* pairs;
+  const double *normal, *ra, *rb, *mt, *mr;
+  const int32_t *inc_ptr, *inc;  // body -> incident constraints, entry = (c << 1) | side, ascending
+  double* vel;                   // [N][6]
+  double dt;
+};
+
+// the iterate a constraint carries in a given mode; bitwise identical wherever it is evaluated
+template <int MODE>
+__device__ inline double iterate_x(size_t c, const double* __restrict__ xt, const double* __restrict__ gt,
+                                   double step, bool step_is_zero, const Space& sp) {
+  if (MODE == X_SOLVE) {
+    // wrapped_axpbyz(1, x_tmp, -step, g_tmp, x, space) with its beta ~ 0 branch (convex.hpp:228-247, :647)
+    const double v = step_is_zero ? 1.0 * xt[c] : 1.0 * xt[c] + (-step) * gt[c];
+    return sp.project(v);
+  }
+  return xt[c];
+}
+
+template <int MODE, bool ROT>
+__global__ void __launch_bounds__(kBlock)
+    k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
+           const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
+  const double* xt = X0;
+  const double* gt = G0;
+  double step = 0.0;
+  if (MODE == X_SOLVE) {
+    if (st->done) return;
+    if (st->iter & 1u) {
+      xt = X1;
+      gt = G1;
+    }
+    step = st->step;
+  }
+  const bool step_is_zero = fabs(-step) < kZeroTol;
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b >= op.N) return;
+  V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
+  const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
+  for (int32_t k = beg; k < end; ++k) {
+    const int32_t e = op.inc[k];
+    const size_t c = static_cast<size_t>(e >> 1);
+    const bool target = e & 1;
+    const double lam = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
+    const V3 n = load3(op.normal, c);
+    const V3 f{lam * n.x, lam * n.y, lam * n.z};
+    if (target) {
+      F = F + f;  // F_tgt += +lam n  (NgpLcp.cpp:470-472)
+      if (ROT) T = T + cross(load3(op.rb, c), f);
+    } else {
+      F = F + V3{-f.x, -f.y, -f.z};  // F_src += -lam n  (NgpLcp.cpp:467-469)
+      if (ROT) {
+        const V3 ta = cross(load3(op.ra, c), f);
+        T = T + V3{-ta.x, -ta.y, -ta.z};
+      }
+    }
+  }
+  const double mt = op.mt[b];
+  double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
+  V3 W{0.0, 0.0, 0.0};
+  if (ROT) {
+    const double mr = op.mr[b];
+    W = V3{mr * T.x, mr * T.y, mr * T.z};
+  }
+  v[0] = make_double2(mt * F.x, mt * F.y);  // U = F / (6 pi r mu)  (NgpLcp.cpp:484-486)
+  v[1] = make_double2(mt * F.z, W.x);
+  v[2] = make_double2(W.y, W.z);
+}
+
+template <int MODE, bool ROT>
+__global__ void __launch_bounds__(kBlock)
+    k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
+                 double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
+                 int resid_kind, double* __restrict__ partials) {
+  __shared__ double scratch[kBlock / 64];
+  const double* xt = X0;
+  const double* gt = G0;
+  double* xn = X1;
+  double* gn = G1;
+  double step = 0.0;
+  if (MODE == X_SOLVE) {
+    if (st->done) return;
+    if (st->iter & 1u) {
+      xt = X1; gt = G1; xn = X0; gn = G0;
+    }
+    step = st->step;
+  }
+  if (MODE == X_INIT) gn = G0;  // g_tmp = A x_tmp + q
+  const bool step_is_zero = fabs(-step) < kZeroTol;
+  double rmax = kLowest, num = 0.0, den = 0.0;
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = op.pairs[c];
+    const double xc = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
+    const V3 n = load3(op.normal, c);
+    const double2* vi2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.x);
+    const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
+    const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
+    V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
+    if (ROT) {
+      const double2 a2 = vi2[2], b2 = vj2[2];
+      vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
+      vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    }
+    // sdot = -n . (v_src - v_tgt)  (NgpLcp.cpp:526-528)
+    const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
+    const double y = op.dt * sdot;
+    if (MODE == X_APPLY) {
+      gn[c] = y;
+    } else {
+      const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
+      gn[c] = g;
+      if (MODE == X_SOLVE) xn[c] = xc;
+      const double r = residual_term(resid_kind, xc, g, sp);
+      if (r > rmax) rmax = r;
+      if (MODE == X_SOLVE) {
+        const double dx = xc - xt[c];
+        num += dx * dx;            // diff_dot(x, x_old)              (convex.hpp:507)
+        den += dx * (g - gt[c]);   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+      }
+    }
+  }
+  if (MODE != X_APPLY) {
+    const double m = block_max(rmax, scratch);
+    const double s1 = block_sum(num, scratch);
+    const double s2 = block_sum(den, scratch);
+    if (threadIdx.x == 0) {
+      partials[3 * blockIdx.x] = m;
+      partials[3 * blockIdx.x + 1] = s1;
+      partials[3 * blockIdx.x + 2] = s2;
+    }
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_finalize(int nparts, const double* __restrict__ partials,
+                                                    SolverState* __restrict__ st, int resid_kind, double tol,
+                                                    unsigned max_iters) {
+  __shared__ double scratch[kBlock / 64];
+  if (MODE == X_SOLVE && st->done) return;
+  double rmax = kLowest, num = 0.0, den = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    const double m = partials[3 * i];
+    if (m > rmax) rmax = m;
+    num += partials[3 * i + 1];
+    den += partials[3 * i + 2];
+  }
+  rmax = block_max(rmax, scratch);
+  num = block_sum(num, scratch);
+  den = block_sum(den, scratch);
+  if (threadIdx.x != 0) return;
+  const double res = (resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF) ? rmax / kSmallStep : rmax;
+  st->residual = res;
+  if (MODE == X_INIT) {
+    st->step = 1.0 / res;  // Dai-Fletcher initial step (convex.hpp:626-627)
+    st->iter = 0;
+    st->converged = (res <= tol) ? 1 : 0;
+    st->converged_at_init = st->converged;
+    st->done = (st->converged || max_iters == 0) ? 1 : 0;
+    st->num = 0.0;
+    st->den = 0.0;
+  } else {
+    if (res <= tol) {
+      st->converged = 1;
+      st->done = 1;
+      return;
+    }
+    den += kBBEps * (fabs(den) < kBBEps ? 1.0 : 0.0);  // convex.hpp:511-512
+    st->num = num;
+    st->den = den;
+    st->step = num / den;
+    st->iter += 1;
+    if (st->iter >= max_iters) st->done = 1;
+  }
+}
+
+// restores the reference's post-conditions (see file header)
+__global__ void __launch_bounds__(kBlock) k_finish(size_t n, const SolverState* __restrict__ st,
+                                                  double* __restrict__ X0, double* __restrict__ X1,
+                                                  double* __restrict__ G0, double* __restrict__ G1) {
+  const bool p = st->iter & 1u;
+  const int mode = st->converged_at_init ? 0 : (st->converged ? (p ? 1 : 3) : 2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (mode == 0) {
+      G1[i] = G0[i];  // grad <- grad_tmp (convex.hpp:632-635)
+    } else if (mode == 1) {
+      const double x0 = X0[i], x1 = X1[i], g0 = G0[i], g1 = G1[i];  // final iterate sits in the *_tmp arrays: swap
+      X0[i] = x1; X1[i] = x0; G0[i] = g1; G1[i] = g0;
+    } else if (mode == 2) {
+      if (p) {  // x == x_tmp == latest iterate after the roll-forward copies (convex.hpp:662-663)
+        X0[i] = X1[i]; G0[i] = G1[i];
+      } else {
+        X1[i] = X0[i]; G1[i] = G0[i];
+      }
+    }
+  }
+}
+
+// ---- incidence index build --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_inc_count(size_t C, size_t N, const int2* __restrict__ pairs,
+                                                     int32_t* __restrict__ deg, int* __restrict__ bad) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    if (ij.x < 0 || ij.y < 0 || (size_t)ij.x >= N || (size_t)ij.y >= N || ij.x == ij.y) {
+      *bad = 1;  // checked on the host before any gather runs: out-of-range indices never reach a kernel
+      continue;
+    }
+    atomicAdd(&deg[ij.x], 1);
+    atomicAdd(&deg[ij.y], 1);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_inc_fill(size_t C, const int2* __restrict__ pairs,
+                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ inc) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    inc[atomicAdd(&cursor[ij.x], 1)] = static_cast<int32_t>(c << 1);
+    inc[atomicAdd(&cursor[ij.y], 1)] = static_cast<int32_t>((c << 1) | 1);
+  }
+}
+// each body's list sorted ascending => sums run in constraint order whatever order the atomics arrived in
+__global__ void __launch_bounds__(kBlock) k_inc_sort(size_t N, const int32_t* __restrict__ inc_ptr,
+                                                    int32_t* __restrict__ inc) {
+  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const int32_t beg = inc_ptr[b], end = inc_ptr[b + 1];
+  for (int32_t i = beg + 1; i < end; ++i) {
+    const int32_t v = inc[i];
+    int32_t j = i - 1;
+    while (j >= beg && inc[j] > v) {
+      inc[j + 1] = inc[j];
+      --j;
+    }
+    inc[j + 1] = v;
+  }
+}
+
+}  // namespace mhip
+
+using namespace mhip;
+
+struct mhip_contact_op {
+  OpView view{};
+  bool rot = false;
+  DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws;
+  SolverState* host_state = nullptr;  // pinned
+};
+
+namespace {
+
+int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double* X1, const double* G0,
+                   const double* G1, Space sp, hipStream_t s) {
+  if (op->view.N == 0) return MHIP_SUCCESS;
+  const unsigned grid = grid_exact(op->view.N);
+  const SolverState* st = op->state.as<SolverState>();
+#define BODY(M, R) k_body<M, R><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
+  if (op->rot) {
+    if (mode == X_APPLY) BODY(X_APPLY, true); else if (mode == X_INIT) BODY(X_INIT, true); else BODY(X_SOLVE, true);
+  } else {
+    if (mode == X_APPLY) BODY(X_APPLY, false); else if (mode == X_INIT) BODY(X_INIT, false); else BODY(X_SOLVE, false);
+  }
+#undef BODY
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, double* G0, double* G1,
+                         const double* q, Space sp, int resid_kind, unsigned grid, hipStream_t s) {
+  if (op->view.C == 0) return MHIP_SUCCESS;
+  const SolverState* st = op->state.as<SolverState>();
+  double* parts = op->partials.as<double>();
+#define CON(M, R) k_constraint<M, R><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts)
+  if (op->rot) {
+    if (mode == X_APPLY) CON(X_APPLY, true); else if (mode == X_INIT) CON(X_INIT, true); else CON(X_SOLVE, true);
+  } else {
+    if (mode == X_APPLY) CON(X_APPLY, false); else if (mode == X_INIT) CON(X_INIT, false); else CON(X_SOLVE, false);
+  }
+#undef CON
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int check_config(const mhip_pgd_config* cfg) {
+  MHIP_REQUIRE(cfg != nullptr, MHIP_ERR_INVALID_ARGUMENT, "config must not be null");
+  MHIP_REQUIRE(cfg->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF ||
+                   cfg->residual_kind == MHIP_RESIDUAL_PROJECTED_GRADIENT,
+               MHIP_ERR_INVALID_ARGUMENT, "unknown residual kind %d", cfg->residual_kind);
+  return MHIP_SUCCESS;
+}
+
+// The reference's driver, kernel by kernel (PGDStrategy::initialize / iterate, convex.hpp:614-666): used for the
+// dense operator and as the unfused cross-check of the contact operator.
+template <class Apply>
+int solve_generic(size_t n, const Apply& apply, const double* q, Space sp, const mhip_pgd_config* cfg, double* x,
+                  double* g, double* x_tmp, double* g_tmp, mhip_solve_result* result, hipStream_t s) {
+  double res = 0.0;
+  if (int e = launch_copy(n, x_tmp, x, s)) return e;
+  if (int e = apply(x_tmp, g_tmp)) return e;
+  if (int e = launch_axpby(n, 1.0, q, 1.0, g_tmp, s)) return e;
+  if (int e = reduce_to_host<2>(n, x_tmp, g_tmp, nullptr, nullptr, cfg->residual_kind, sp, &res, s)) return e;
+  if (cfg->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF) res = res / kSmallStep;
+  double step = 1.0 / res;
+  unsigned iter = 0;
+  bool converged = (res <= cfg->tol);
+  if (converged)
+    if (int e = launch_copy(n, g, g_tmp, s)) return e;
+  while (!(converged || iter >= cfg->max_iters)) {
+    if (int e = launch_wrapped_axpbyz(n, 1.0, x_tmp, -step, g_tmp, x, sp, s)) return e;
+    if (int e = apply(x, g)) return e;
+    if (int e = launch_axpby(n, 1.0, q, 1.0, g, s)) return e;
+    if (int e = reduce_to_host<2>(n, x, g, nullptr, nullptr, cfg->residual_kind, sp, &res, s)) return e;
+    if (cfg->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF) res = res / kSmallStep;
+    if (res <= cfg->tol) {
+      converged = true;
+      break;
+    }
+    double num = 0.0, den = 0.0;
+    if (int e = reduce_to_host<0>(n, x, x_tmp, nullptr, nullptr, 0, sp, &num, s)) return e;
+    if (int e = reduce_to_host<1>(n, x, x_tmp, g, g_tmp, 0, sp, &den, s)) return e;
+    den += kBBEps * (fabs(den) < kBBEps);
+    step = num / den;
+    if (int e = launch_copy(n, x_tmp, x, s)) return e;
+    if (int e = launch_copy(n, g_tmp, g, s)) return e;
+    ++iter;
+  }
+  MHIP_HIP(hipStreamSynchronize(s));
+  result->num_iters = iter;
+  result->residual = res;
+  result->converged = converged ? 1 : 0;
+  return MHIP_SUCCESS;
+}
+
+}  // namespace
+
+#define REQ(p) MHIP_REQUIRE((p) != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT, "%s: %s is null", __func__, #p)
+
+extern "C" {
+
+int mhip_deep_copy(size_t n, double* dst, const double* src, mhip_stream_t stream) {
+  REQ(dst); REQ(src);
+  return launch_copy(n, dst, src, as_stream(stream));
+}
+int mhip_fill(size_t n, double* dst, double value, mhip_stream_t stream) {
+  REQ(dst);
+  if (n == 0) return MHIP_SUCCESS;
+  k_fill<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, dst, value);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+int mhip_axpby(size_t n, double alpha, const double* x, double beta, double* y, mhip_stream_t stream) {
+  REQ(x); REQ(y);
+  return launch_axpby(n, alpha, x, beta, y, as_stream(stream));
+}
+int mhip_wrapped_axpbyz(size_t n, double alpha, const double* x, double beta, const double* y, double* z,
+                        const mhip_space* space, mhip_stream_t stream) {
+  REQ(x); REQ(y); REQ(z);
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  return launch_wrapped_axpbyz(n, alpha, x, beta, y, z, sp, as_stream(stream));
+}
+int mhip_diff_dot2(size_t n, const double* x, const double* y, double* result, mhip_stream_t stream) {
+  REQ(x); REQ(y);
+  MHIP_REQUIRE(result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "result is null");
+  return reduce_to_host<0>(n, x, y, nullptr, nullptr, 0, Space{0, 0, 0}, result, as_stream(stream));
+}
+int mhip_diff_dot4(size_t n, const double* x1, const double* x2, const double* y1, const double* y2, double* result,
+                   mhip_stream_t stream) {
+  REQ(x1); REQ(x2); REQ(y1); REQ(y2);
+  MHIP_REQUIRE(result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "result is null");
+  return reduce_to_host<1>(n, x1, x2, y1, y2, 0, Space{0, 0, 0}, result, as_stream(stream));
+}
+int mhip_residual(size_t n, int residual_kind, const double* x, const double* grad, const mhip_space* space,
+                  double* result, mhip_stream_t stream) {
+  REQ(x); REQ(grad);
+  MHIP_REQUIRE(result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "result is null");
+  MHIP_REQUIRE(residual_kind == 0 || residual_kind == 1, MHIP_ERR_INVALID_ARGUMENT, "unknown residual kind");
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  double r;
+  if (int e = reduce_to_host<2>(n, x, grad, nullptr, nullptr, residual_kind, sp, &r, as_stream(stream))) return e;
+  *result = (residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF) ? r / kSmallStep : r;
+  return MHIP_SUCCESS;
+}
+int mhip_bb_step(size_t n, const double* x_old, const double* g_old, const double* x, const double* g, double* result,
+                 mhip_stream_t stream) {
+  REQ(x_old); REQ(g_old); REQ(x); REQ(g);
+  MHIP_REQUIRE(result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "result is null");
+  double num, den;
+  if (int e = reduce_to_host<0>(n, x, x_old, nullptr, nullptr, 0, Space{0, 0, 0}, &num, as_stream(stream))) return e;
+  if (int e = reduce_to_host<1>(n, x, x_old, g, g_old, 0, Space{0, 0, 0}, &den, as_stream(stream))) return e;
+  den += kBBEps * (fabs(den) < kBBEps);
+  *result = num / den;
+  return MHIP_SUCCESS;
+}
+int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream_t stream) {
+  REQ(A); REQ(x); REQ(y);
+  if (n == 0) return MHIP_SUCCESS;
+  k_gemv<<<grid_for(n * 64), kBlock, 0, as_stream(stream)>>>(n, A, x, y);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
+                           const double* normal, const double* ra, const double* rb, const double* mob_trans,
+                           const double* mob_rot, double dt, mhip_stream_t stream) {
+  MHIP_REQUIRE(handle != nullptr, MHIP_ERR_INVALID_ARGUMENT, "handle is null");
+  *handle = nullptr;
+  const size_t C = num_constraints, N = num_bodies;
+  MHIP_REQUIRE(C == 0 || (pairs && normal), MHIP_ERR_INVALID_ARGUMENT, "pairs / normal must not be null");
+  MHIP_REQUIRE(N == 0 || mob_trans, MHIP_ERR_INVALID_ARGUMENT, "mob_trans must not be null");
+  const int nrot = (ra != nullptr) + (rb != nullptr) + (mob_rot != nullptr);
+  MHIP_REQUIRE(nrot == 0 || nrot == 3, MHIP_ERR_INVALID_ARGUMENT,
+               "ra, rb and mob_rot must be given together (rigid bodies) or all be null (translation only)");
+  MHIP_REQUIRE(C < (1u << 30) && N < (1u << 31), MHIP_ERR_RUNTIME, "problem too large for 32-bit incidence entries");
+  hipStream_t s = as_stream(stream);
+  mhip_contact_op* op = new mhip_contact_op();
+  auto bail = [&](int e) {
+    mhip_contact_op_destroy(op);
+    return e;
+  };
+  op->rot = (nrot == 3);
+  if (int e = op->inc_ptr.reserve((N + 2) * sizeof(int32_t))) return bail(e);
+  if (int e = op->cursor.reserve((N + 2) * sizeof(int32_t))) return bail(e);
+  if (int e = op->inc.reserve((2 * C + 2) * sizeof(int32_t))) return bail(e);
+  if (int e = op->vel.reserve((6 * N + 2) * sizeof(double))) return bail(e);
+  if (int e = op->partials.reserve((3 * kMaxGrid + 8) * sizeof(double))) return bail(e);
+  if (int e = op->state.reserve(sizeof(SolverState) + 64)) return bail(e);
+  if (int e = op->scanws.reserve(scan_workspace_bytes(N + 1) + 64)) return bail(e);
+  {
+    hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&op->host_state), sizeof(SolverState) + 64);
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(he)));
+  }
+  int32_t* deg = op->cursor.as<int32_t>();
+  int* bad = reinterpret_cast<int*>(op->state.as<char>() + sizeof(SolverState));
+  hipError_t he = hipMemsetAsync(deg, 0, (N + 1) * sizeof(int32_t), s);
+  if (he == hipSuccess) he = hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState) + 64, s);
+  if (he == hipSuccess) he = hipMemsetAsync(op->vel.ptr, 0, (6 * N + 2) * sizeof(double), s);
+  if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
+  const int2* p2 = reinterpret_cast<const int2*>(pairs);
+  if (C > 0) {
+    k_inc_count<<<grid_for(C), kBlock, 0, s>>>(C, N, p2, deg, bad);
+    int hbad = 0;
+    he = hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (he == hipSuccess) he = hipStreamSynchronize(s);
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "pair validation failed: %s", hipGetErrorString(he)));
+    if (hbad)
+      return bail(fail(MHIP_ERR_INVALID_ARGUMENT, "pairs contain an index outside [0, %zu) or a self pair", N));
+  }
+  if (int e = exclusive_scan_i32(deg, op->inc_ptr.as<int32_t>(), N, op->scanws.ptr, s)) return bail(e);
+  he = hipMemcpyAsync(deg, op->inc_ptr.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
+  if (C > 0) {
+    k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>());
+    k_inc_sort<<<grid_exact(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>());
+  }
+  he = hipGetLastError();
+  if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "incidence build failed: %s", hipGetErrorString(he)));
+  op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
+                    op->vel.as<double>(), dt};
+  *handle = op;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_destroy(mhip_contact_op_t op) {
+  if (!op) return MHIP_SUCCESS;
+  op->inc_ptr.release(); op->inc.release(); op->cursor.release(); op->vel.release();
+  op->partials.release(); op->state.release(); op->scanws.release();
+  if (op->host_state) (void)hipHostFree(op->host_state);
+  delete op;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_apply(mhip_contact_op_t op, const double* x, double* y, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(op->view.C == 0 || (x && y), MHIP_ERR_INVALID_ARGUMENT, "x / y must not be null");
+  hipStream_t s = as_stream(stream);
+  const Space none{MHIP_SPACE_UNCONSTRAINED, 0, 0};
+  if (int e = op_launch_body(op, X_APPLY, x, x, nullptr, nullptr, none, s)) return e;
+  // APPLY reads the iterate from X0 and writes y through G1
+  return op_launch_constraint(op, X_APPLY, const_cast<double*>(x), nullptr, nullptr, y, nullptr, none, 0,
+                              grid_for(op->view.C), s);
+}
+
+int mhip_contact_op_body_velocity(mhip_contact_op_t op, const double** velocity) {
+  MHIP_REQUIRE(op != nullptr && velocity != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  *velocity = op->vel.as<double>();
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_space* space,
+                             const mhip_pgd_config* config, double* x, double* g, double* x_tmp, double* g_tmp,
+                             mhip_solve_result* result, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
+  if (int e = check_config(config)) return e;
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  const size_t C = op->view.C;
+  hipStream_t s = as_stream(stream);
+  if (C == 0) {  // empty reduce_max: the identity survives (Kokkos::Max), residual = lowest / 1e-6
+    result->num_iters = 0;
+    result->residual = config->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF ? kLowest / kSmallStep : kLowest;
+    result->converged = 1;
+    return MHIP_SUCCESS;
+  }
+  MHIP_REQUIRE(q && x && g && x_tmp && g_tmp, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not be null");
+  MHIP_REQUIRE(x != x_tmp && g != g_tmp && x != g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not alias");
+  SolverState* st = op->state.as<SolverState>();
+  double* parts = op->partials.as<double>();
+  const unsigned cgrid = grid_for(C);
+  const int rk = config->residual_kind;
+  // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res
+  if (int e = launch_copy(C, x_tmp, x, s)) return e;
+  if (int e = op_launch_body(op, X_INIT, x_tmp, x, g_tmp, g, sp, s)) return e;
+  if (int e = op_launch_constraint(op, X_INIT, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
+  k_finalize<X_INIT><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
+  MHIP_LAUNCH_CHECK();
+  unsigned enqueued = 0, chunk = 8;
+  for (;;) {
+    MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    if (op->host_state->done || enqueued >= config->max_iters) break;
+    const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
+    for (unsigned k = 0; k < todo; ++k) {
+      if (int e = op_launch_body(op, X_SOLVE, x_tmp, x, g_tmp, g, sp, s)) return e;
+      if (int e = op_launch_constraint(op, X_SOLVE, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
+      k_finalize<X_SOLVE><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
+      MHIP_LAUNCH_CHECK();
+    }
+    enqueued += todo;
+    if (chunk < 64) chunk *= 2;
+  }
+  k_finish<<<grid_for(C), kBlock, 0, s>>>(C, st, x_tmp, x, g_tmp, g);
+  MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipStreamSynchronize(s));
+  result->num_iters = op->host_state->iter;
+  result->residual = op->host_state->residual;
+  result->converged = op->host_state->converged;
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_solve_contact_unfused(mhip_contact_op_t op, const double* q, const mhip_space* space,
+                                     const mhip_pgd_config* config, double* x, double* g, double* x_tmp,
+                                     double* g_tmp, mhip_solve_result* result, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
+  if (int e = check_config(config)) return e;
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  const size_t n = op->view.C;
+  REQ(q); REQ(x); REQ(g); REQ(x_tmp); REQ(g_tmp);
+  auto apply = [&](const double* in, double* out) { return mhip_contact_op_apply(op, in, out, stream); };
+  return solve_generic(n, apply, q, sp, config, x, g, x_tmp, g_tmp, result, as_stream(stream));
+}
+
+int mhip_bbpgd_solve_dense(size_t n, const double* A, const double* q, const mhip_space* space,
+                           const mhip_pgd_config* config, double* x, double* g, double* x_tmp, double* g_tmp,
+                           mhip_solve_result* result, mhip_stream_t stream) {
+  MHIP_REQUIRE(result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "result is null");
+  if (int e = check_config(config)) return e;
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  REQ(A); REQ(q); REQ(x); REQ(g); REQ(x_tmp); REQ(g_tmp);
+  auto apply = [&](const double* in, double* out) { return mhip_gemv(n, A, in, out, stream); };
+  return solve_generic(n, apply, q, sp, config, x, g, x_tmp, g_tmp, result, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// mhip_internal.hpp -- shared host/device helpers of libmundy_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/mundy_hip.h"
+
+namespace mhip {
+
+// ------------------------------------------------------------------------------------------------------------------
+// error plumbing: status code + thread-local message (mundy_core/throw_assert.hpp conventions mapped onto a C ABI)
+// ------------------------------------------------------------------------------------------------------------------
+std::string& last_error_storage();
+int fail(int code, const char* fmt, ...);
+
+#define MHIP_REQUIRE(cond, code, ...)                      \
+  do {                                                     \
+    if (!(cond)) return ::mhip::fail((code), __VA_ARGS__); \
+  } while (0)
+
+#define MHIP_HIP(call)                                                                                  \
+  do {                                                                                                  \
+    hipError_t e_ = (call);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return ::mhip::fail(MHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                          __LINE__);                                                                    \
+  } while (0)
+
+#define MHIP_LAUNCH_CHECK() MHIP_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(mhip_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kBlock = 256;     // 4 waves per workgroup
+constexpr int kMaxGrid = 2048;  // grid-stride cap: 256 CUs x 8 workgroups (guide, Guideline 11)
+
+inline unsigned grid_for(size_t n, int block = kBlock) {
+  const size_t g = (n + block - 1) / block;
+  return static_cast<unsigned>(g == 0 ? 1 : (g > static_cast<size_t>(kMaxGrid) ? kMaxGrid : g));
+}
+inline unsigned grid_exact(size_t n, int block = kBlock) {
+  const size_t g = (n + block - 1) / block;
+  return static_cast<unsigned>(g == 0 ? 1 : g);
+}
+
+// A device buffer that only ever grows (workspace owned by a handle; never allocated inside a timed loop once warm).
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need) {
+    if (need <= bytes) return MHIP_SUCCESS;
+    if (ptr) MHIP_HIP(hipFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+    const size_t want = need + need / 4 + 256;
+    MHIP_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+    return MHIP_SUCCESS;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(ptr);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// device math: the mundy::math subset the path needs, same operation order as the reference
+// ------------------------------------------------------------------------------------------------------------------
+struct V3 {
+  double x, y, z;
+};
+struct Quat {
+  double w, x, y, z;
+};
+
+__host__ __device__ inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__host__ __device__ inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__host__ __device__ inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__host__ __device__ inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+// right fold: a0*b0 + (a1*b1 + a2*b2)   (mundy_math/impl/VectorImpl.hpp:339-344)
+__host__ __device__ inline double dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__host__ __device__ inline double norm(V3 a) { return sqrt(dot(a, a)); }
+__host__ __device__ inline V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__host__ __device__ inline double comp(V3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+__host__ __device__ inline Quat qmul(Quat q, Quat o) {
+  Quat r;
+  r.w = q.w * o.w - q.x * o.x - q.y * o.y - q.z * o.z;
+  r.x = q.w * o.x + q.x * o.w + q.y * o.z - q.z * o.y;
+  r.y = q.w * o.y - q.x * o.z + q.y * o.w + q.z * o.x;
+  r.z = q.w * o.z + q.x * o.y - q.y * o.x + q.z * o.w;
+  return r;
+}
+// q * v = (q (0,v)) inverse(q), inverse = conjugate * (1/|q|^2)  (impl/QuaternionImpl.hpp:184-202)
+__host__ __device__ inline V3 qrot(Quat q, V3 v) {
+  const double inv_n2 = 1.0 / (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  const Quat qi{q.w * inv_n2, -q.x * inv_n2, -q.y * inv_n2, -q.z * inv_n2};
+  const Quat vq{0.0, v.x, v.y, v.z};
+  const Quat r = qmul(qmul(q, vq), qi);
+  return {r.x, r.y, r.z};
+}
+
+constexpr double kZeroTol = 1e-15;  // get_zero_tolerance<double>() (mundy_math/Tolerance.hpp:38-50)
+
+__device__ inline V3 load3(const double* p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+__device__ inline void store3(double* p, size_t i, V3 v) {
+  p[3 * i] = v.x;
+  p[3 * i + 1] = v.y;
+  p[3 * i + 2] = v.z;
+}
+__device__ inline Quat load4q(const double* p, size_t i) {
+  const double2 a = *reinterpret_cast<const double2*>(p + 4 * i);
+  const double2 b = *reinterpret_cast<const double2*>(p + 4 * i + 2);
+  return {a.x, a.y, b.x, b.y};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// wave / block reductions (64-lane wavefronts)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ inline double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+__device__ inline int wave_or(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v |= __shfl_down(v, off, 64);
+  return v;
+}
+// Block reductions for kBlock threads; result valid in thread 0.  `scratch` holds kBlock/64 doubles.
+__device__ inline double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += scratch[i];
+  }
+  __syncthreads();
+  return r;
+}
+__device__ inline double block_max(double v, double* scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) scratch[w] = v;
+  __syncthreads();
+  double r = -1.7976931348623157e308;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r = fmax(r, scratch[i]);
+  }
+  __syncthreads();
+  return r;
+}
+
+// projection onto the separable 1-D convex spaces of convex.hpp:46-115
+struct Space {
+  int kind;
+  double lo, hi;
+  __host__ __device__ inline double project(double x) const {
+    // max(a,b) = a<b ? b : a ; min(a,b) = b<a ? b : a  (explicit, so -0.0 / ties behave as on the host)
+    switch (kind) {
+      case MHIP_SPACE_LOWER_BOUND: return (x < lo) ? lo : x;
+      case MHIP_SPACE_UPPER_BOUND: return (hi < x) ? hi : x;
+      case MHIP_SPACE_BOUNDED: {
+        const double m = (x < lo) ? lo : x;
+        return (hi < m) ? hi : m;
+      }
+      default: return x;
+    }
+  }
+};
+inline int to_space(const mhip_space* s, Space* out) {
+  MHIP_REQUIRE(s != nullptr, MHIP_ERR_INVALID_ARGUMENT, "space must not be null");
+  MHIP_REQUIRE(s->kind >= MHIP_SPACE_UNCONSTRAINED && s->kind <= MHIP_SPACE_BOUNDED, MHIP_ERR_INVALID_ARGUMENT,
+               "unknown convex space kind %d", s->kind);
+  *out = Space{s->kind, s->lower_bound, s->upper_bound};
+  return MHIP_SUCCESS;
+}
+
+// exclusive scan of n int32 counts into out[0..n] (out[n] = total); workspace >= scan_workspace_bytes(n)
+size_t scan_workspace_bytes(size_t n);
+int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, void* workspace, hipStream_t stream);
+
+}  // namespace mhip

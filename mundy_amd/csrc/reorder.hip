@@ -1,0 +1,170 @@
+// reorder.hip -- Z-order (Morton) body reordering, row gathers and the explicit Euler update either side of the solve.
+//
+// Bodies are binned on a lattice of edge `cell_size` anchored at `lo`; the Morton code interleaves the lattice
+// coordinates with z most significant, which is the order zorder_knn::Less (mundy_math/zmort.hpp:195-220) gives to
+// non-negative lattice points.  The sort is a counting sort over codes (histogram, scan, scatter) followed by a
+// per-code tie-break by body index, so the permutation is deterministic.  Integer work: HBM/atomic bound.
+#include "geom_device.hpp"
+
+namespace mhip {
+
+__device__ inline unsigned spread3(unsigned v) {  // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__device__ inline unsigned morton_code(const double* __restrict__ center, size_t i, V3 lo, double inv_cell, int bits) {
+  const V3 c = load3(center, i);
+  const int maxc = (1 << bits) - 1;
+  int ix = static_cast<int>(floor((c.x - lo.x) * inv_cell));
+  int iy = static_cast<int>(floor((c.y - lo.y) * inv_cell));
+  int iz = static_cast<int>(floor((c.z - lo.z) * inv_cell));
+  ix = ix < 0 ? 0 : (ix > maxc ? maxc : ix);
+  iy = iy < 0 ? 0 : (iy > maxc ? maxc : iy);
+  iz = iz < 0 ? 0 : (iz > maxc ? maxc : iz);
+  return spread3((unsigned)ix) | (spread3((unsigned)iy) << 1) | (spread3((unsigned)iz) << 2);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_morton_count(size_t n, const double* __restrict__ center, V3 lo, double inv_cell, int bits,
+                   unsigned* __restrict__ code, int32_t* __restrict__ hist) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned m = morton_code(center, i, lo, inv_cell, bits);
+    code[i] = m;
+    atomicAdd(&hist[m], 1);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_morton_scatter(size_t n, const unsigned* __restrict__ code,
+                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    perm[atomicAdd(&cursor[code[i]], 1)] = static_cast<int32_t>(i);
+}
+__global__ void __launch_bounds__(kBlock) k_segment_sort(size_t ncodes, const int32_t* __restrict__ ptr,
+                                                        int32_t* __restrict__ perm) {
+  for (size_t m = blockIdx.x * (size_t)blockDim.x + threadIdx.x; m < ncodes; m += (size_t)gridDim.x * blockDim.x) {
+    const int32_t beg = ptr[m], end = ptr[m + 1];
+    for (int32_t a = beg + 1; a < end; ++a) {
+      const int32_t v = perm[a];
+      int32_t b = a - 1;
+      while (b >= beg && perm[b] > v) {
+        perm[b + 1] = perm[b];
+        --b;
+      }
+      perm[b + 1] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_gather_rows(size_t n, size_t width, const int32_t* __restrict__ perm, const double* __restrict__ src,
+                  double* __restrict__ dst) {
+  const size_t total = n * width;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = e / width, w = e - k * width;
+    dst[e] = src[(size_t)perm[k] * width + w];
+  }
+}
+
+// x += dt*U (NgpLcp.cpp:898); q <- rotate_quaternion(q, W, dt) (mundy_math/Quaternion.hpp:1366-1390)
+__global__ void __launch_bounds__(kBlock)
+    k_integrate(size_t n, double dt, const double* __restrict__ vel, double* __restrict__ center,
+                double* __restrict__ quat) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double* v = vel + 6 * i;
+    center[3 * i] = dt * v[0] + 1.0 * center[3 * i];  // axpby(dt, U, 1, x)
+    center[3 * i + 1] = dt * v[1] + 1.0 * center[3 * i + 1];
+    center[3 * i + 2] = dt * v[2] + 1.0 * center[3 * i + 2];
+    if (quat) {
+      const V3 om{v[3], v[4], v[5]};
+      const double w = norm(om);
+      if (w < kZeroTol) continue;
+      const double winv = 1.0 / w;
+      const double sw = sin(0.5 * w * dt), cw = cos(0.5 * w * dt);
+      const Quat q = load4q(quat, i);
+      const double s = q.w;
+      const V3 p{q.x, q.y, q.z};
+      const V3 cr = cross(om, p);
+      // xyz = s*sw*omega*winv + cw*p + sw*winv*cross(omega, p), left to right
+      const double a = s * sw, b = sw * winv;
+      const V3 xyz{a * om.x * winv + cw * p.x + b * cr.x, a * om.y * winv + cw * p.y + b * cr.y,
+                   a * om.z * winv + cw * p.z + b * cr.z};
+      const double qw = s * cw - dot(om, p) * sw * winv;
+      const double inv = 1.0 / sqrt(qw * qw + xyz.x * xyz.x + xyz.y * xyz.y + xyz.z * xyz.z);
+      quat[4 * i] = qw * inv;
+      quat[4 * i + 1] = xyz.x * inv;
+      quat[4 * i + 2] = xyz.y * inv;
+      quat[4 * i + 3] = xyz.z * inv;
+    }
+  }
+}
+
+struct ReorderScratch {
+  DeviceBuffer code, hist, ptr, scanws;
+};
+ReorderScratch& reorder_scratch() {
+  thread_local ReorderScratch s;
+  return s;
+}
+
+}  // namespace mhip
+
+using namespace mhip;
+
+extern "C" {
+
+int mhip_morton_order(size_t n, const double* center, const double* lo, double cell_size, int32_t* perm,
+                      mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (center && perm), MHIP_ERR_INVALID_ARGUMENT, "center / perm is null");
+  MHIP_REQUIRE(lo != nullptr, MHIP_ERR_INVALID_ARGUMENT, "lo is null");
+  MHIP_REQUIRE(cell_size > 0.0, MHIP_ERR_INVALID_ARGUMENT, "cell_size must be positive");
+  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
+  if (n == 0) return MHIP_SUCCESS;
+  hipStream_t s = as_stream(stream);
+  // lattice resolution: the finest of 2^bits per axis whose code space stays within 8 codes per body (>= 2^12)
+  int bits = 4;
+  while (bits < 8 && (size_t(1) << (3 * (bits + 1))) <= 8 * n) ++bits;
+  const size_t ncodes = size_t(1) << (3 * bits);
+  ReorderScratch& rs = reorder_scratch();
+  if (int e = rs.code.reserve(n * sizeof(unsigned))) return e;
+  if (int e = rs.hist.reserve((ncodes + 2) * sizeof(int32_t))) return e;
+  if (int e = rs.ptr.reserve((ncodes + 2) * sizeof(int32_t))) return e;
+  if (int e = rs.scanws.reserve(scan_workspace_bytes(ncodes + 2) + 64)) return e;
+  MHIP_HIP(hipMemsetAsync(rs.hist.ptr, 0, (ncodes + 1) * sizeof(int32_t), s));
+  const V3 l{lo[0], lo[1], lo[2]};
+  k_morton_count<<<grid_for(n), kBlock, 0, s>>>(n, center, l, 1.0 / cell_size, bits, rs.code.as<unsigned>(),
+                                               rs.hist.as<int32_t>());
+  MHIP_LAUNCH_CHECK();
+  if (int e = exclusive_scan_i32(rs.hist.as<int32_t>(), rs.ptr.as<int32_t>(), ncodes, rs.scanws.ptr, s)) return e;
+  MHIP_HIP(hipMemcpyAsync(rs.hist.ptr, rs.ptr.ptr, (ncodes + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  k_morton_scatter<<<grid_for(n), kBlock, 0, s>>>(n, rs.code.as<unsigned>(), rs.hist.as<int32_t>(), perm);
+  MHIP_LAUNCH_CHECK();
+  k_segment_sort<<<grid_for(ncodes), kBlock, 0, s>>>(ncodes, rs.ptr.as<int32_t>(), perm);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst,
+                     mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (perm && src && dst), MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(width > 0, MHIP_ERR_INVALID_ARGUMENT, "width must be positive");
+  MHIP_REQUIRE(src != dst, MHIP_ERR_INVALID_ARGUMENT, "gather cannot run in place");
+  if (n == 0) return MHIP_SUCCESS;
+  k_gather_rows<<<grid_for(n * width), kBlock, 0, as_stream(stream)>>>(n, width, perm, src, dst);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_integrate_euler(size_t n, double dt, const double* velocity, double* center, double* quat,
+                         mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (velocity && center), MHIP_ERR_INVALID_ARGUMENT, "velocity / center is null");
+  if (n == 0) return MHIP_SUCCESS;
+  k_integrate<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, dt, velocity, center, quat);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+}  // extern "C"

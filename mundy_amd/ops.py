@@ -1,0 +1,400 @@
+"""Host-side mirror of the reference's hot-path interface over libmundy_hip.so, on torch CUDA(HIP) tensors.
+
+Names follow the reference: compute_aabb / distance / GenNeighborLinks (mundy_mesh/GenNeighborLinkers.hpp) /
+solve_cqpp, solve_lcp, PGDConfig, SolveResult (mundy_math/convex.hpp).  torch is plumbing (device memory + the
+current stream); all arithmetic runs in the HIP library.  float64 everywhere; pairs are int32 [C, 2].
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import capi
+from .capi import (RESIDUAL_PROJECTED_DIFF, RESIDUAL_PROJECTED_GRADIENT, SEARCH_AABB, SEARCH_SPHERES,  # noqa: F401
+                   SPACE_BOUNDED, SPACE_LOWER_BOUND, SPACE_UNCONSTRAINED, SPACE_UPPER_BOUND)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=torch.float64, cols=None, name="tensor", allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("%s must not be None" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (mundy_amd has no CPU path)" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if cols is not None and (t.dim() != 2 or t.shape[1] != cols):
+        raise ValueError("%s must have shape [n, %d], got %s" % (name, cols, tuple(t.shape)))
+    return C.c_void_p(t.data_ptr())
+
+
+def _new(ref, *shape, dtype=torch.float64):
+    return torch.empty(shape, dtype=dtype, device=ref.device)
+
+
+def device_info():
+    n = C.c_int(0)
+    name = C.create_string_buffer(256)
+    capi.check(capi.load().mhip_device_info(C.byref(n), name, 256))
+    return n.value, name.value.decode()
+
+
+# ---- per-body geometry (compute_aabb.hpp / compute_bounding_radius.hpp) --------------------------------------------
+def compute_aabb_spheres(center, radius):
+    n = radius.shape[0]
+    out = _new(center, n, 6)
+    capi.check(capi.load().mhip_compute_aabb_spheres(n, _ptr(center, cols=3), _ptr(radius), _ptr(out), _stream()))
+    return out
+
+
+def compute_aabb_spherocylinders(center, quat, radius, length):
+    n = radius.shape[0]
+    out = _new(center, n, 6)
+    capi.check(capi.load().mhip_compute_aabb_spherocylinders(n, _ptr(center, cols=3), _ptr(quat, cols=4),
+                                                             _ptr(radius), _ptr(length), _ptr(out), _stream()))
+    return out
+
+
+def compute_aabb_ellipsoids(center, quat, radii):
+    n = center.shape[0]
+    out = _new(center, n, 6)
+    capi.check(capi.load().mhip_compute_aabb_ellipsoids(n, _ptr(center, cols=3), _ptr(quat, cols=4),
+                                                        _ptr(radii, cols=3), _ptr(out), _stream()))
+    return out
+
+
+def compute_aabb_segments(seg):
+    n = seg.shape[0]
+    out = _new(seg, n, 6)
+    capi.check(capi.load().mhip_compute_aabb_segments(n, _ptr(seg, cols=8), _ptr(out), _stream()))
+    return out
+
+
+def bounding_radius_spherocylinders(radius, length):
+    out = torch.empty_like(radius)
+    capi.check(capi.load().mhip_bounding_radius_spherocylinders(radius.shape[0], _ptr(radius), _ptr(length),
+                                                                _ptr(out), _stream()))
+    return out
+
+
+def bounding_radius_ellipsoids(radii):
+    out = _new(radii, radii.shape[0])
+    capi.check(capi.load().mhip_bounding_radius_ellipsoids(radii.shape[0], _ptr(radii, cols=3), _ptr(out), _stream()))
+    return out
+
+
+def spherocylinder_segments(center, quat, radius, length, out=None):
+    n = radius.shape[0]
+    seg = _new(center, n, 8) if out is None else out
+    capi.check(capi.load().mhip_spherocylinder_segments(n, _ptr(center, cols=3), _ptr(quat, cols=4), _ptr(radius),
+                                                        _ptr(length), _ptr(seg, cols=8), _stream()))
+    return seg
+
+
+# ---- distances (mundy_geom/distance/*.hpp) ----------------------------------------------------------------------------
+def distance_sphere_sphere(c1, r1, c2, r2):
+    n = r1.shape[0]
+    dist, sep = _new(c1, n), _new(c1, n, 3)
+    capi.check(capi.load().mhip_distance_sphere_sphere(n, _ptr(c1, cols=3), _ptr(r1), _ptr(c2, cols=3), _ptr(r2),
+                                                       _ptr(dist), _ptr(sep), _stream()))
+    return dist, sep
+
+
+def distance_point_segment(p, a0, a1):
+    n = p.shape[0]
+    dist, cp, t, sep = _new(p, n), _new(p, n, 3), _new(p, n), _new(p, n, 3)
+    capi.check(capi.load().mhip_distance_point_segment(n, _ptr(p, cols=3), _ptr(a0, cols=3), _ptr(a1, cols=3),
+                                                       _ptr(dist), _ptr(cp), _ptr(t), _ptr(sep), _stream()))
+    return dist, cp, t, sep
+
+
+def distance_segment_segment(a0, a1, b0, b1):
+    n = a0.shape[0]
+    dist, cp1, cp2 = _new(a0, n), _new(a0, n, 3), _new(a0, n, 3)
+    s, t, sep = _new(a0, n), _new(a0, n), _new(a0, n, 3)
+    capi.check(capi.load().mhip_distance_segment_segment(n, _ptr(a0, cols=3), _ptr(a1, cols=3), _ptr(b0, cols=3),
+                                                         _ptr(b1, cols=3), _ptr(dist), _ptr(cp1), _ptr(cp2), _ptr(s),
+                                                         _ptr(t), _ptr(sep), _stream()))
+    return dist, cp1, cp2, s, t, sep
+
+
+def contact_spheres(pairs, center, radius, box=None, out=None):
+    c = pairs.shape[0]
+    sep, normal = (_new(center, c), _new(center, c, 3)) if out is None else out
+    boxp = None if box is None else (C.c_double * 3)(*[float(b) for b in box])
+    capi.check(capi.load().mhip_contact_spheres(c, _ptr(pairs, torch.int32, 2), _ptr(center, cols=3), _ptr(radius),
+                                                boxp, _ptr(sep), _ptr(normal), _stream()))
+    return sep, normal
+
+
+def contact_spherocylinders(pairs, seg, center, want_points=True, out=None):
+    c = pairs.shape[0]
+    if out is None:
+        out = dict(sep=_new(seg, c), normal=_new(seg, c, 3), ra=_new(seg, c, 3), rb=_new(seg, c, 3))
+        if want_points:
+            out.update(cp1=_new(seg, c, 3), cp2=_new(seg, c, 3), s=_new(seg, c), t=_new(seg, c))
+    g = lambda k: _ptr(out.get(k), allow_none=True, name=k)  # noqa: E731
+    capi.check(capi.load().mhip_contact_spherocylinders(c, _ptr(pairs, torch.int32, 2), _ptr(seg, cols=8),
+                                                        _ptr(center, cols=3), g("sep"), g("normal"), g("cp1"),
+                                                        g("cp2"), g("ra"), g("rb"), g("s"), g("t"), _stream()))
+    return out
+
+
+# ---- broad phase (GenNeighborLinks, mundy_mesh/GenNeighborLinkers.hpp:294-866) ---------------------------------------
+class GenNeighborLinks:
+    """Builder-style mirror of mundy::mesh::GenNeighborLinks: set_* -> concretize() -> generate().
+
+    generate(aabb, center, bounding_radius) returns True when a search was performed (first call, or some centre moved
+    more than half the search buffer, :510-543, :603-615); the links are then available as .pairs ([P, 2] int32,
+    sorted by (source, target)), .row_ptr / .col (CSR).
+    """
+
+    def __init__(self):
+        h = C.c_void_p()
+        capi.check(capi.load().mhip_broadphase_create(C.byref(h)))
+        self._h = h
+        self._cfg = capi.BroadphaseConfig(SEARCH_SPHERES, 0, 0.0, 0, (C.c_double * 3)(0, 0, 0))
+        self._concretized = False
+        self._generated = False
+        self.pairs = self.row_ptr = self.col = None
+        self.num_pairs = 0
+
+    def _setter_guard(self, what):
+        if self._concretized:
+            raise RuntimeError("Cannot set %s after concretization." % what)  # :402-462
+
+    def set_search_buffer(self, search_buffer):
+        self._setter_guard("search buffer")
+        self._cfg.buffer = float(search_buffer)
+        return self
+
+    def set_search_kind(self, kind):
+        self._setter_guard("search kind")
+        self._cfg.search_kind = int(kind)
+        return self
+
+    def set_enforce_source_target_symmetry(self, value):
+        self._setter_guard("enforce source-target symmetry")
+        self._cfg.symmetric = 1 if value else 0
+        return self
+
+    def set_periodic_box(self, box):
+        self._setter_guard("periodic box")
+        if box is None:
+            self._cfg.periodic = 0
+        else:
+            self._cfg.periodic = 1
+            self._cfg.box = (C.c_double * 3)(*[float(b) for b in box])
+        return self
+
+    def concretize(self):
+        if self._concretized:
+            raise RuntimeError("Cannot concretize more than once.")  # :494
+        self._concretized = True
+        return self
+
+    def needs_rebuild(self, center):
+        flag = C.c_int(0)
+        capi.check(capi.load().mhip_broadphase_needs_rebuild(self._h, center.shape[0], _ptr(center, cols=3),
+                                                             C.byref(flag), _stream()))
+        return bool(flag.value)
+
+    def generate(self, aabb, center, bounding_radius, force=False):
+        if not self._concretized:
+            raise RuntimeError("Cannot generate links before concretization.")  # :511
+        if self._generated and not force and not self.needs_rebuild(center):
+            return False
+        n = center.shape[0]
+        cnt = C.c_size_t(0)
+        capi.check(capi.load().mhip_broadphase_build(
+            self._h, C.byref(self._cfg), n, _ptr(aabb, cols=6, allow_none=True, name="aabb"), _ptr(center, cols=3),
+            _ptr(bounding_radius, allow_none=True, name="bounding_radius"), C.byref(cnt), _stream()))
+        self.num_pairs = int(cnt.value)
+        self.pairs = torch.empty((self.num_pairs, 2), dtype=torch.int32, device=center.device)
+        self.row_ptr = torch.empty(n + 1, dtype=torch.int32, device=center.device)
+        self.col = torch.empty(self.num_pairs, dtype=torch.int32, device=center.device)
+        capi.check(capi.load().mhip_broadphase_get_pairs(self._h, _ptr(self.pairs, torch.int32),
+                                                         _ptr(self.row_ptr, torch.int32), _ptr(self.col, torch.int32),
+                                                         _stream()))
+        self._generated = True
+        return True
+
+    def close(self):
+        if self._h:
+            capi.load().mhip_broadphase_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- convex (mundy_math/convex.hpp) ----------------------------------------------------------------------------------
+@dataclass
+class PGDConfig:  # convex.hpp:519-525
+    max_iters: int = 1000
+    tol: float = 1e-8
+    residual_kind: int = RESIDUAL_PROJECTED_DIFF
+
+
+@dataclass
+class SolveResult:  # convex.hpp:527-541
+    num_iters: int = 0
+    residual: float = 0.0
+    converged: bool = False
+
+
+def _space(space):
+    kind, lo, hi = space
+    return capi.Space(int(kind), float(lo), float(hi))
+
+
+def _cfg(cfg):
+    return capi.PgdConfig(int(cfg.max_iters), float(cfg.tol), int(cfg.residual_kind))
+
+
+LCP_SPACE = (SPACE_LOWER_BOUND, 0.0, 0.0)  # to_cqpp: LowerBound{0} (convex.hpp:424-428)
+
+
+def axpby(alpha, x, beta, y):
+    capi.check(capi.load().mhip_axpby(x.shape[0], alpha, _ptr(x), beta, _ptr(y), _stream()))
+
+
+def wrapped_axpbyz(alpha, x, beta, y, z, space):
+    sp = _space(space)
+    capi.check(capi.load().mhip_wrapped_axpbyz(x.shape[0], alpha, _ptr(x), beta, _ptr(y), _ptr(z), C.byref(sp),
+                                               _stream()))
+
+
+def diff_dot(x, y, x2=None, y2=None):
+    r = C.c_double()
+    if x2 is None:
+        capi.check(capi.load().mhip_diff_dot2(x.shape[0], _ptr(x), _ptr(y), C.byref(r), _stream()))
+    else:  # diff_dot(x1, x2, y1, y2) = sum (x1-x2)(y1-y2)
+        capi.check(capi.load().mhip_diff_dot4(x.shape[0], _ptr(x), _ptr(y), _ptr(x2), _ptr(y2), C.byref(r), _stream()))
+    return r.value
+
+
+def residual(kind, x, grad, space):
+    r = C.c_double()
+    sp = _space(space)
+    capi.check(capi.load().mhip_residual(x.shape[0], kind, _ptr(x), _ptr(grad), C.byref(sp), C.byref(r), _stream()))
+    return r.value
+
+
+def bb_step(x_old, g_old, x, g):
+    r = C.c_double()
+    capi.check(capi.load().mhip_bb_step(x.shape[0], _ptr(x_old), _ptr(g_old), _ptr(x), _ptr(g), C.byref(r), _stream()))
+    return r.value
+
+
+def gemv(A, x):
+    y = torch.empty_like(x)
+    capi.check(capi.load().mhip_gemv(x.shape[0], _ptr(A), _ptr(x), _ptr(y), _stream()))
+    return y
+
+
+class ContactOperator:
+    """Matrix-free A = dt D^T M D over a neighbour list (the LinearOp of seam S2; apply(x, y) as convex.hpp:133-136)."""
+
+    def __init__(self, pairs, normal, mob_trans, dt, ra=None, rb=None, mob_rot=None):
+        self.num_constraints = pairs.shape[0]
+        self.num_bodies = mob_trans.shape[0]
+        self._keep = (pairs, normal, ra, rb, mob_trans, mob_rot)  # the handle holds views of these
+        h = C.c_void_p()
+        capi.check(capi.load().mhip_contact_op_create(
+            C.byref(h), self.num_constraints, self.num_bodies, _ptr(pairs, torch.int32, 2), _ptr(normal, cols=3),
+            _ptr(ra, allow_none=True, name="ra"), _ptr(rb, allow_none=True, name="rb"), _ptr(mob_trans),
+            _ptr(mob_rot, allow_none=True, name="mob_rot"), float(dt), _stream()))
+        self._h = h
+        self._device = normal.device
+
+    def apply(self, x, y=None):
+        y = torch.empty_like(x) if y is None else y
+        capi.check(capi.load().mhip_contact_op_apply(self._h, _ptr(x), _ptr(y), _stream()))
+        return y
+
+    def body_velocity(self):
+        """[N, 6] (U, W) of the last evaluated iterate -- a view of handle-owned memory; clone to keep."""
+        p = C.c_void_p()
+        capi.check(capi.load().mhip_contact_op_body_velocity(self._h, C.byref(p)))
+        n = self.num_bodies
+        if n == 0:
+            return torch.empty((0, 6), dtype=torch.float64, device=self._device)
+        out = torch.empty((n, 6), dtype=torch.float64, device=self._device)
+        capi.check(capi.load().mhip_deep_copy(6 * n, _ptr(out), p, _stream()))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.load().mhip_contact_op_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _state(x0, state):
+    if state is not None:
+        return state
+    x = x0.clone()
+    return x, torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+
+
+def solve_cqpp(A, q, space, x0, cfg=None, state=None, fused=True):
+    """solve_cqpp (convex.hpp:789-797).  A is a ContactOperator (matrix free) or a dense [n, n] tensor.
+    Returns (x, grad, SolveResult); `state` = caller-owned (x, grad, x_tmp, grad_tmp) as PGDState holds them."""
+    cfg = cfg or PGDConfig()
+    x, g, x_tmp, g_tmp = _state(x0, state)
+    res, sp, pc = capi.SolveResult(), _space(space), _cfg(cfg)
+    lib = capi.load()
+    if isinstance(A, ContactOperator):
+        fn = lib.mhip_bbpgd_solve_contact if fused else lib.mhip_bbpgd_solve_contact_unfused
+        capi.check(fn(A._h, _ptr(q), C.byref(sp), C.byref(pc), _ptr(x), _ptr(g), _ptr(x_tmp), _ptr(g_tmp),
+                      C.byref(res), _stream()))
+    else:
+        n = q.shape[0]
+        if A.dim() != 2 or A.shape[0] != n or A.shape[1] != n:
+            raise ValueError("gemv: dimension mismatch A vs x")  # convex.hpp:171-172
+        capi.check(lib.mhip_bbpgd_solve_dense(n, _ptr(A), _ptr(q), C.byref(sp), C.byref(pc), _ptr(x), _ptr(g),
+                                              _ptr(x_tmp), _ptr(g_tmp), C.byref(res), _stream()))
+    return x, g, SolveResult(int(res.num_iters), float(res.residual), bool(res.converged))
+
+
+def solve_lcp(A, q, x0, cfg=None, state=None, fused=True):
+    """solve_lcp (convex.hpp:839-845): 0 <= A x + q  _|_  x >= 0."""
+    return solve_cqpp(A, q, LCP_SPACE, x0, cfg, state, fused)
+
+
+# ---- reordering / integration -----------------------------------------------------------------------------------------
+def morton_order(center, lo, cell_size):
+    n = center.shape[0]
+    perm = torch.empty(n, dtype=torch.int32, device=center.device)
+    lop = (C.c_double * 3)(*[float(v) for v in lo])
+    capi.check(capi.load().mhip_morton_order(n, _ptr(center, cols=3), lop, float(cell_size), _ptr(perm, torch.int32),
+                                             _stream()))
+    return perm
+
+
+def gather_rows(perm, src):
+    src2 = src if src.dim() == 2 else src.unsqueeze(1)
+    dst = torch.empty_like(src2)
+    capi.check(capi.load().mhip_gather_rows(src2.shape[0], src2.shape[1], _ptr(perm, torch.int32), _ptr(src2),
+                                            _ptr(dst), _stream()))
+    return dst if src.dim() == 2 else dst.squeeze(1)
+
+
+def integrate_euler(dt, velocity, center, quat=None):
+    capi.check(capi.load().mhip_integrate_euler(center.shape[0], float(dt), _ptr(velocity, cols=6),
+                                                _ptr(center, cols=3), _ptr(quat, cols=4, allow_none=True), _stream()))

@@ -1,0 +1,136 @@
+"""The timestep composition of the hot path -- what the reference's step loops call, in their order
+(scrap/lcp_spheres/NgpLcp.cpp:835-920; operator pipeline of
+scrap/parameter_interface/alens/tests/performance_tests/Bacteria.cpp:755-805):
+
+    compute_aabb -> GenNeighborLinks.generate (rebuild only when the search buffer is violated)
+                 -> signed separation + contact normal (+ lever arms) per link
+                 -> resolve_collisions: BBPGD on the LCP  0 <= dt D^T M D lambda + sep  _|_  lambda >= 0
+                 -> Euler update x += dt U (and q <- rotate(q, W dt) for rods)
+
+Everything is device resident; host logic here only sequences library calls.
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops, synth
+
+
+@dataclass
+class StepStats:
+    num_bodies: int = 0
+    num_contacts: int = 0
+    rebuilt: bool = False
+    num_iters: int = 0
+    residual: float = 0.0
+    converged: bool = False
+    timings_ms: dict = field(default_factory=dict)
+
+
+class ContactStepper:
+    """One rank's bodies (spheres or spherocylinders) and the per-timestep contact resolution."""
+
+    def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
+                 search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
+                 mob_rot=None):
+        if kind not in ("sphere", "spherocylinder"):
+            raise ValueError("kind must be 'sphere' or 'spherocylinder'")
+        if kind == "spherocylinder" and (quat is None or length is None):
+            raise ValueError("spherocylinders need quat and length")
+        if kind == "spherocylinder" and periodic_box is not None:
+            raise ValueError("periodic boxes are supported for spheres only")
+        self.kind = kind
+        self.center, self.radius, self.quat, self.length = center, radius, quat, length
+        self.dt, self.viscosity = float(dt), float(viscosity)
+        self.box = periodic_box
+        self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)  # NgpLcp.cpp:851-852
+        self.warm_start = warm_start
+        self.links = (ops.GenNeighborLinks().set_search_buffer(search_buffer).set_search_kind(search_kind)
+                      .set_periodic_box(periodic_box).concretize())
+        n = center.shape[0]
+        # dry local drag U = F/(6 pi mu r), W = T/(8 pi mu r^3) (NgpLcp.cpp:484-486, Bacteria.cpp:810-848); the
+        # per-body coefficients are set-up data computed once on the host (same numbers feed the CPU oracle)
+        if kind == "sphere":
+            self.bounding_radius = radius
+            eff = radius
+        else:
+            self.bounding_radius = ops.bounding_radius_spherocylinders(radius, length)
+            eff = self.bounding_radius
+            self.seg = torch.empty((n, 8), dtype=torch.float64, device=center.device)
+        if mob_trans is None:
+            mt, mr = synth.dry_mobility(eff.cpu().numpy(), viscosity=self.viscosity)
+            mob_trans = torch.from_numpy(mt).to(center.device)
+            mob_rot = torch.from_numpy(mr).to(center.device) if kind == "spherocylinder" else None
+        self.mob_trans, self.mob_rot = mob_trans, (mob_rot if kind == "spherocylinder" else None)
+        self.op = None
+        self.lam = None
+        self.contacts = None
+
+    # -- stages -----------------------------------------------------------------------------------------------------
+    def compute_aabb(self):
+        if self.kind == "sphere":
+            self.aabb = ops.compute_aabb_spheres(self.center, self.radius)
+        else:
+            self.aabb = ops.compute_aabb_spherocylinders(self.center, self.quat, self.radius, self.length)
+        return self.aabb
+
+    def generate_neighbor_links(self, force=False):
+        return self.links.generate(self.aabb, self.center, self.bounding_radius, force=force)
+
+    def compute_contacts(self):
+        pairs = self.links.pairs
+        if self.kind == "sphere":
+            sep, normal = ops.contact_spheres(pairs, self.center, self.radius, box=self.box)
+            self.contacts = dict(sep=sep, normal=normal, ra=None, rb=None)
+        else:
+            ops.spherocylinder_segments(self.center, self.quat, self.radius, self.length, out=self.seg)
+            self.contacts = ops.contact_spherocylinders(pairs, self.seg, self.center, want_points=False)
+        return self.contacts
+
+    def resolve_collisions(self, rebuilt):
+        c = self.contacts
+        if self.op is not None:
+            self.op.close()
+        self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c["ra"], rb=c["rb"],
+                                      mob_rot=self.mob_rot)
+        nc = self.links.num_pairs
+        if rebuilt or self.lam is None or not self.warm_start or self.lam.shape[0] != nc:
+            self.lam = torch.zeros(nc, dtype=torch.float64, device=self.center.device)  # NgpLcp.cpp:890-891
+        x, g, res = ops.solve_lcp(self.op, c["sep"], self.lam, self.cfg)
+        self.lam = x
+        return res
+
+    def integrate(self):
+        vel = self.op.body_velocity()
+        ops.integrate_euler(self.dt, vel, self.center, self.quat)
+
+    # -- one timestep -------------------------------------------------------------------------------------------------
+    def step(self, integrate=True, force_rebuild=False, timed=False):
+        st = StepStats(num_bodies=self.center.shape[0])
+        ev = []
+
+        def mark(name):
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+
+        mark("start")
+        self.compute_aabb()
+        mark("aabb")
+        st.rebuilt = self.generate_neighbor_links(force=force_rebuild)
+        mark("broadphase")
+        self.compute_contacts()
+        mark("narrowphase")
+        res = self.resolve_collisions(st.rebuilt)
+        mark("solve")
+        if integrate:
+            self.integrate()
+        mark("integrate")
+        st.num_contacts = self.links.num_pairs
+        st.num_iters, st.residual, st.converged = res.num_iters, res.residual, res.converged
+        if timed:
+            torch.cuda.synchronize()
+            for (_, a), (name, b) in zip(ev[:-1], ev[1:]):
+                st.timings_ms[name] = a.elapsed_time(b)
+        return st

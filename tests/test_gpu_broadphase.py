@@ -1,0 +1,171 @@
+"""GPU parity, neighbour lists: pair sets from libmundy_hip.so are BIT-EXACT (same pairs, same (i,j)-sorted order)
+against the CPU oracle's brute-force / cell-list search with the same predicate.  The reference's own search is third
+party (stk::search, GenNeighborLinkers.hpp:658): parity unpinned at that boundary (see oracle header)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+    assert torch.cuda.is_available()
+    from mundy_amd import ops as o
+    return o
+
+
+def _links(ops, kind, buffer, symmetric=False, box=None):
+    return (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(buffer)
+            .set_enforce_source_target_symmetry(symmetric).set_periodic_box(box).concretize())
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("periodic", [False, True])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_pairs_bit_exact_vs_bruteforce(ops, oracle, kind, periodic, symmetric):
+    from gpu_util import dev, host, random_rods
+    rng = np.random.default_rng(100 + 10 * kind + 2 * periodic + symmetric)
+    box = np.array([9.0, 11.0, 13.0])
+    c, q, r, L = random_rods(rng, 3000, box)
+    if periodic:
+        c += rng.integers(-2, 3, c.shape) * box  # unwrapped images must not matter
+    aabb = oracle.compute_aabb_spherocylinders(c, q, r, L)
+    brad = oracle.bounding_radius_spherocylinders(r, L)
+    lo, hi, R = oracle.grow(aabb, brad, 0.15)
+    b = box if periodic else None
+    exp = oracle.search(kind, lo, hi, c, R, box=b, symmetric=symmetric, method="brute")
+    g = _links(ops, kind, 0.15, symmetric, b)
+    assert g.generate(dev(aabb), dev(c), dev(brad)) is True
+    got = host(g.pairs)
+    assert len(exp) > 5000
+    np.testing.assert_array_equal(got, exp)
+    # CSR view is the same list
+    rp, col = host(g.row_ptr), host(g.col)
+    assert rp[0] == 0 and rp[-1] == len(exp) and np.all(np.diff(rp) >= 0)
+    np.testing.assert_array_equal(col, exp[:, 1])
+    np.testing.assert_array_equal(np.repeat(np.arange(len(c)), np.diff(rp)), exp[:, 0])
+    g.close()
+
+
+def test_config1_10k_spheres_periodic(ops, oracle):
+    # BASELINE.json configs[0]: 10k spheres, periodic box, pairwise distance + neighbour list only
+    from gpu_util import assert_bits_equal, dev, host
+    from mundy_amd import synth
+    s = synth.spheres(10_000)
+    box = np.full(3, s["box"])
+    c, r = s["center"], s["radius"]
+    aabb = oracle.compute_aabb_spheres(c, r)
+    for buffer in (0.0, 1.0):
+        lo, hi, R = oracle.grow(aabb, r, buffer)
+        for kind in (0, 1):
+            exp = oracle.search(kind, lo, hi, c, R, box=box, method="cell")
+            g = _links(ops, kind, buffer, False, box)
+            g.generate(ops.compute_aabb_spheres(dev(c), dev(r)), dev(c), dev(r))
+            np.testing.assert_array_equal(host(g.pairs), exp)
+            sep, nrm = ops.contact_spheres(g.pairs, dev(c), dev(r), box=box)
+            osep, onrm = oracle.contact_spheres(exp, c, r, box=box)
+            assert_bits_equal(host(sep), osep, "sep")
+            assert_bits_equal(host(nrm), onrm, "normal")
+            if kind == 0 and buffer == 0.0:  # bounding spheres with no buffer: every pair overlaps or touches
+                assert osep.max() <= 1e-12
+            g.close()
+
+
+def test_edge_cases(ops, oracle):
+    from gpu_util import dev, host
+    import torch
+    z3 = torch.zeros((0, 3), dtype=torch.float64, device="cuda")
+    z6 = torch.zeros((0, 6), dtype=torch.float64, device="cuda")
+    z1 = torch.zeros(0, dtype=torch.float64, device="cuda")
+    for kind in (0, 1):
+        g = _links(ops, kind, 0.1)
+        g.generate(z6, z3, z1)
+        assert g.num_pairs == 0 and host(g.row_ptr).tolist() == [0]
+        c = np.zeros((1, 3))
+        g.generate(dev(np.array([[-1.0, -1, -1, 1, 1, 1]])), dev(c), dev(np.ones(1)), force=True)
+        assert g.num_pairs == 0 and host(g.row_ptr).tolist() == [0, 0]
+        g.close()
+        # UnitTestGenNeighborLinks.cpp:73-152: two coincident spheres -> one link (two when symmetric)
+        c2, r2 = np.zeros((2, 3)), np.ones(2)
+        a2 = oracle.compute_aabb_spheres(c2, r2)
+        for sym, exp in ((False, [[0, 1]]), (True, [[0, 1], [1, 0]])):
+            g = _links(ops, kind, 0.0, sym)
+            g.generate(dev(a2), dev(c2), dev(r2))
+            assert host(g.pairs).tolist() == exp
+            g.close()
+        # touching volumes are a hit (closed predicate), separated ones are not
+        c3 = np.array([[0.0, 0, 0], [2.0, 0, 0], [4.5, 0, 0]])
+        g = _links(ops, kind, 0.0)
+        g.generate(dev(oracle.compute_aabb_spheres(c3, np.ones(3))), dev(c3), dev(np.ones(3)))
+        assert host(g.pairs).tolist() == [[0, 1]]
+        g.close()
+
+
+def test_all_bodies_in_one_cell_and_clusters(ops, oracle):
+    # degenerate grids: everything coincident-ish (one cell) and two distant clusters (sparse grid)
+    from gpu_util import dev, host
+    rng = np.random.default_rng(3)
+    for c in (rng.uniform(0, 0.5, (300, 3)),
+              np.concatenate([rng.uniform(0, 3, (200, 3)), 1e4 + rng.uniform(0, 3, (200, 3))])):
+        r = np.full(len(c), 0.4)
+        aabb = oracle.compute_aabb_spheres(c, r)
+        lo, hi, R = oracle.grow(aabb, r, 0.05)
+        for kind in (0, 1):
+            exp = oracle.search(kind, lo, hi, c, R, method="brute")
+            g = _links(ops, kind, 0.05)
+            g.generate(dev(aabb), dev(c), dev(r))
+            np.testing.assert_array_equal(host(g.pairs), exp)
+            g.close()
+
+
+def test_rebuild_rule(ops):
+    # GenNeighborLinkers.hpp:510-543, :603-615: generate() returns False until a centre moves > buffer/2
+    from gpu_util import dev
+    rng = np.random.default_rng(1)
+    c = rng.uniform(0, 10, (500, 3))
+    r = np.full(500, 0.5)
+    g = _links(ops, 0, 1.0)
+    dc, dr = dev(c), dev(r)
+    aabb = ops.compute_aabb_spheres(dc, dr)
+    assert g.generate(aabb, dc, dr) is True
+    assert g.generate(aabb, dc, dr) is False
+    dc[7, 1] += 0.5
+    assert g.generate(aabb, dc, dr) is False       # exactly half the buffer: not "more than"
+    dc[7, 1] += 1e-6
+    assert g.generate(aabb, dc, dr) is True
+    assert g.generate(aabb, dc, dr) is False       # snapshot was refreshed by the rebuild
+    g.close()
+
+
+def test_full_size_properties_1M_rods(ops):
+    # BASELINE.json configs[2] size: properties that do not need the oracle -- sorted unique rows, i<j, symmetric
+    # list = both orientations of the unique list, every listed pair passes the predicate, determinism
+    import torch
+    from gpu_util import dev
+    from mundy_amd import synth
+    b = synth.spherocylinders(1_000_000)
+    c, q, r, L = dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"])
+    aabb = ops.compute_aabb_spherocylinders(c, q, r, L)
+    brad = ops.bounding_radius_spherocylinders(r, L)
+    g = _links(ops, 1, 0.25)
+    g.generate(aabb, c, brad)
+    p = g.pairs.to(torch.int64)
+    assert g.num_pairs > 5_000_000
+    assert bool((p[:, 0] < p[:, 1]).all())
+    key = p[:, 0] * 1_000_000 + p[:, 1]
+    assert bool((key[1:] > key[:-1]).all())          # strictly increasing: sorted and duplicate free
+    lo, hi = aabb[:, :3] - 0.25, aabb[:, 3:] + 0.25
+    ok = ((hi[p[:, 0]] >= lo[p[:, 1]]) & (hi[p[:, 1]] >= lo[p[:, 0]])).all()
+    assert bool(ok)
+    g2 = _links(ops, 1, 0.25, symmetric=True)
+    g2.generate(aabb, c, brad)
+    assert g2.num_pairs == 2 * g.num_pairs
+    p2 = g2.pairs.to(torch.int64)
+    fwd = p2[p2[:, 0] < p2[:, 1]]
+    assert torch.equal(fwd, p)
+    g3 = _links(ops, 1, 0.25)
+    g3.generate(aabb, c, brad)
+    assert torch.equal(g3.pairs, g.pairs)           # atomics inside, deterministic outside
+    for x in (g, g2, g3):
+        x.close()
