@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- timesteps/s and contact-pairs/s of the contact hot path on 10^6 spherocylinders per GPU.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run, one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a barrier +
+torch.cuda.synchronize() on both sides, MAX over ranks; rank 0 prints ONE JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input, i.e. the whole body of the reference's
+single-device app (scrap/lcp_spheres/NgpLcp.cpp:835-920) on BASELINE.json configs[2]: 10^6 spherocylinders (r = 0.5,
+L = 2) at 40 % volume fraction, random positions/orientations (overlaps allowed, the LCP resolves them):
+    compute_aabb -> neighbour list (AABB + buffer, rebuilt every step) -> signed separations / normals / lever arms ->
+    BBPGD solve of the frictionless LCP (tol 1e-5, dt 5e-3, mu 1e-3, dry mobility) -> Euler update.
+Every step starts from the same pristine input (restored by a device copy inside the timed region), so all steps do
+identical work.  Inputs are resident in HBM before the timed region starts.
+
+N > 1: each rank advances its own 10^6-body shard of the synthetic system (weak scaling, no data-path collective in
+this round: shards are independent boxes -- "replicas" of the path; the RCCL ghost halo is the next row of SURVEY 8e).
+`value` = timesteps of 10^6-spherocylinder shards completed per second over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--bodies", type=int, default=1_000_000, help="spherocylinders per GPU (default: configs[2])")
+    p.add_argument("--buffer", type=float, default=0.1, help="search buffer added to every AABB")
+    p.add_argument("--tol", type=float, default=1e-5)
+    p.add_argument("--max-iters", type=int, default=10000)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-reorder", dest="reorder", action="store_false", help="skip the per-step Z-order reordering")
+    p.add_argument("--reorder-cell", type=float, default=3.0, help="lattice edge of the Morton keys")
+    p.add_argument("--cpu-iters", type=int, default=12, help="BBPGD iterations timed on the host cores")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: mundy_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from mundy_amd import build as hip_build
+    if rank == 0:
+        hip_build.build()
+    if dist is not None:
+        dist.barrier()
+    from mundy_amd import ops, pipeline, synth
+
+    n = args.bodies
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    # each rank's shard: its own index range of the counter-based generator (first = rank * n)
+    b = synth.spherocylinders(n, seed=1234, first=rank * n)
+    center, quat = dev(b["center"]), dev(b["quat"])
+    radius, length = dev(b["radius"]), dev(b["length"])
+    cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
+    stepper = pipeline.ContactStepper("spherocylinder", center, radius, quat, length, dt=5e-3, viscosity=1e-3,
+                                      search_buffer=args.buffer, search_kind=ops.SEARCH_AABB, cfg=cfg)
+    pristine = stepper.snapshot()
+    prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
+
+    def one_step(timed_kernels, timed_stages=False):
+        stepper.restore(pristine)
+        if args.reorder:
+            # the synthetic input is in random order; the Z-order body reordering operator is part of the step
+            stepper.reorder_bodies(cell_size=args.reorder_cell, lo=[0.0, 0.0, 0.0])
+        stepper.profile_next = timed_kernels
+        st = stepper.step(integrate=True, force_rebuild=True, timed=timed_stages)
+        if timed_kernels:
+            a, c, k = stepper.op.get_profile()
+            prof["body_ms"] += a
+            prof["con_ms"] += c
+            prof["iters"] += k
+        return st
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    sync()
+    t0 = time.perf_counter()
+    stats = [one_step(True) for _ in range(args.steps)]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stage_ms = one_step(False, timed_stages=True).timings_ms  # one extra, untimed step for the stage breakdown
+    contacts = stats[-1].num_contacts
+    iters = [s.num_iters for s in stats]
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (k_constraint of the fused BBPGD iteration) -------------------------------
+    # algorithmic bytes per constraint: pair 8 + normal 24 + lever arms 48 + 2 x 48 gathered body
+    # velocities + x_tmp, g_tmp, q 24 read; x, g 16 written = 216 B;  k_body: 2 x (x_tmp, g_tmp 16 + normal 24 +
+    # arm 24 + incidence entry 4) = 136 B per constraint + 68 B per body (row pointer 4, mobilities 16, velocity 48)
+    con_bytes = 216.0 * contacts
+    body_bytes = 136.0 * contacts + 68.0 * n
+    roof, extra = None, {}
+    if prof["iters"] > 0:
+        con_ms = prof["con_ms"] / prof["iters"]
+        body_ms = prof["body_ms"] / prof["iters"]
+        achieved = con_bytes / (con_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_constraint<X_SOLVE,rot>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(con_ms, 4), "launches": prof["iters"], "bytes_per_launch": con_bytes}
+        extra = {"k_body": {"avg_launch_ms": round(body_ms, 4),
+                            "achieved_GBs": round(body_bytes / (body_ms * 1e-3) / 1e9, 1)}}
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (scripts/profile_bench.sh:
+        # separate FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE + WRITE_SIZE as the gfx950 guide prescribes)
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and n == 1_000_000 and args.buffer == 0.1:
+            tj = json.load(open(tpath))
+            roof["traffic"] = tj.get("k_constraint", {}).get("hbm_bytes_per_launch")
+            extra["k_body"]["traffic"] = tj.get("k_body", {}).get("hbm_bytes_per_launch")
+
+    # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this box's host cores, rank 0 ---------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(b, stepper, args, int(np.mean(iters)))
+
+    if rank == 0:
+        out = {
+            "metric": "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",
+            "value": round(value, 4), "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: 1M spherocylinders r=0.5 L=2 at 40%% volume fraction, random packing, "
+                                   "AABB+%.2g neighbour list, frictionless LCP tol %.0e" % (args.buffer, args.tol),
+                       "bodies_per_gpu": n, "contacts_per_gpu": contacts, "bbpgd_iters_per_step": iters,
+                       "converged": [bool(s.converged) for s in stats],
+                       "parallelism": "1 shard per GPU, independent shards (no halo collective yet)"},
+            "contact_pairs_per_sec": round(world * contacts * args.steps / elapsed, 1),
+            "bbpgd_iterations_per_sec": round(world * sum(iters) / elapsed, 1),
+            "roofline": roof, "cpu_baseline": cpu,
+            "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(b, stepper, args, gpu_iters):
+    """Times the CPU oracle (kind "port") on a bounded sample of the same workload: the full AABB / neighbour search /
+    narrow phase once at full size, and `--cpu-iters` BBPGD iterations of the full-size LCP on all host threads; the
+    solve is extrapolated to the iteration count the GPU needed.  Reported, never the target."""
+    import oracle
+    oracle.build()
+    threads = oracle.num_threads()
+    t = {}
+    t0 = time.perf_counter()
+    aabb = oracle.compute_aabb_spherocylinders(b["center"], b["quat"], b["radius"], b["length"], fast=True)
+    brad = oracle.bounding_radius_spherocylinders(b["radius"], b["length"])
+    t["aabb"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lo, hi, R = oracle.grow(aabb, brad, args.buffer)
+    pairs = oracle.search(oracle.SEARCH_AABB, lo, hi, b["center"], R, fast=True)
+    t["search"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    seg = oracle.spherocylinder_segments(b["center"], b["quat"], b["radius"], b["length"], fast=True)
+    out = oracle.contact_spherocylinders(pairs, seg, b["center"], fast=True)
+    t["narrow"] = time.perf_counter() - t0
+    mt = stepper.mob_trans.cpu().numpy()
+    mr = stepper.mob_rot.cpu().numpy()
+    k = max(2, args.cpu_iters)
+    t0 = time.perf_counter()
+    oracle.solve_cqpp_contact(pairs, out["normal"], out["ra"], out["rb"], mt, mr, 5e-3, out["sep"],
+                              np.zeros(len(pairs)), max_iters=k, tol=args.tol, threads=True, fast=True)
+    t["solve_sample"] = time.perf_counter() - t0
+    per_iter = t["solve_sample"] / (k + 1)  # k iterations + the initial operator apply
+    step_s = t["aabb"] + t["search"] + t["narrow"] + per_iter * (gpu_iters + 1)
+    return {"value": round(1.0 / step_s, 6), "unit": "timesteps/s", "cores": threads, "kind": "port",
+            "sample": "full-size AABB (%.2fs, OpenMP), cell-list search (%.2fs, 1 thread), narrow phase (%.2fs, "
+                      "OpenMP) once + %d BBPGD iterations on %d OpenMP threads (%.3fs/iter), solve extrapolated to the "
+                      "GPU's %d iterations; contacts %d" % (t["aabb"], t["search"], t["narrow"], k, threads, per_iter,
+                                                           gpu_iters, len(pairs))}
+
+
+if __name__ == "__main__":
+    main()

@@ -194,6 +194,12 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
                            const double* mob_rot, double dt, mhip_stream_t stream);
 int mhip_contact_op_destroy(mhip_contact_op_t handle);
 int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, mhip_stream_t stream);
+/* Per-kernel timing of the fused solver (measurement support, no effect on results): when enabled,
+ * mhip_bbpgd_solve_contact brackets every k_body / k_constraint launch with HIP events on `stream` and accumulates
+ * their device durations.  get_profile returns the totals in milliseconds and the number of timed iterations
+ * (launches of each kernel) since profiling was enabled.  All out pointers [host]. */
+int mhip_contact_op_set_profiling(mhip_contact_op_t handle, int enable);
+int mhip_contact_op_get_profile(mhip_contact_op_t handle, double* body_ms, double* constraint_ms, size_t* iterations);
 /* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate */
 int mhip_contact_op_body_velocity(mhip_contact_op_t handle, const double** velocity /*[host] out: device pointer*/);
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     "mhip_contact_op_destroy": [_vp],
     "mhip_contact_op_apply": [_vp, _vp, _vp, _vp],
     "mhip_contact_op_body_velocity": [_vp, C.POINTER(_vp)],
+    "mhip_contact_op_set_profiling": [_vp, _i],
+    "mhip_contact_op_get_profile": [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_sz)],
     "mhip_bbpgd_solve_dense": [_sz, _vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
                                C.POINTER(SolveResult), _vp],
     "mhip_bbpgd_solve_contact": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
@@ -98,6 +100,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise MhipError("%s is missing: run `python -m mundy_amd.build` (or __graft_entry__.build()); "
                             "mundy_amd has no CPU fallback" % LIB_PATH)
+        # torch ships its own libamdhip64; it must be mapped first so that torch's allocator/streams and this
+        # library share ONE HIP runtime (loading the system runtime first leaves the process with a runtime that
+        # cannot see torch's device context)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)

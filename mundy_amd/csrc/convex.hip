@@ -12,6 +12,7 @@
 //                                 all kept in a device-resident state block                                  [a26/a27]
 // x/x_tmp and g/g_tmp ping-pong by iteration parity instead of being copied (K20); mhip_bbpgd_solve_* restores the
 // reference's post-conditions (which array holds what) once, at the end.
+#include <cstdlib>
 #include <vector>
 
 #include "mhip_internal.hpp"
@@ -196,6 +197,7 @@ struct OpView {
   const int2* pairs;
   const double *normal, *ra, *rb, *mt, *mr;
   const int32_t *inc_ptr, *inc;  // body -> incident constraints, entry = (c << 1) | side, ascending
+  const double* half;            // per incidence entry: (n_c, r_side), 6 doubles (3 when translation only)
   double* vel;                   // [N][6]
   double dt;
 };
@@ -212,7 +214,12 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
   return xt[c];
 }
 
-template <int MODE, bool ROT>
+// Body sweep.  G lanes cooperate on one body: lane `sub` walks the body's half-edge records sub, sub+G, ... (a
+// contiguous, coalesced stream: records are stored in incidence order), then a G-lane butterfly adds the partial sums.
+// The order is fixed (no atomics), so results are bitwise reproducible run to run.
+//   half-edge record e -> (n_c, r_side) gathered once at operator creation: 48 B (24 B translation-only)
+// algorithmic bytes: per half edge 4 (entry) + 48 (record) + 16 (x_tmp, g_tmp gathered); per body 4 + 16 + 48.
+template <int MODE, bool ROT, int G>
 __global__ void __launch_bounds__(kBlock)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
@@ -228,28 +235,45 @@ __global__ void __launch_bounds__(kBlock)
     step = st->step;
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (b >= op.N) return;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t b = t / G;
+  const int sub = static_cast<int>(t % G);
+  if (b >= op.N) return;  // whole groups leave together (G divides the wave size)
+  constexpr int HW = ROT ? 6 : 3;
   V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
-  for (int32_t k = beg; k < end; ++k) {
+  for (int32_t k = beg + sub; k < end; k += G) {
     const int32_t e = op.inc[k];
     const size_t c = static_cast<size_t>(e >> 1);
     const bool target = e & 1;
     const double lam = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
-    const V3 n = load3(op.normal, c);
-    const V3 f{lam * n.x, lam * n.y, lam * n.z};
-    if (target) {
-      F = F + f;  // F_tgt += +lam n  (NgpLcp.cpp:470-472)
-      if (ROT) T = T + cross(load3(op.rb, c), f);
+    V3 n, r{0.0, 0.0, 0.0};
+    if (ROT) {  // 48-byte records, 16-byte aligned: three 16-byte loads
+      const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * HW);
+      const double2 h0 = H2[0], h1 = H2[1], h2 = H2[2];
+      n = V3{h0.x, h0.y, h1.x};
+      r = V3{h1.y, h2.x, h2.y};
     } else {
-      F = F + V3{-f.x, -f.y, -f.z};  // F_src += -lam n  (NgpLcp.cpp:467-469)
-      if (ROT) {
-        const V3 ta = cross(load3(op.ra, c), f);
-        T = T + V3{-ta.x, -ta.y, -ta.z};
-      }
+      const double* H = op.half + (size_t)k * HW;
+      n = V3{H[0], H[1], H[2]};
+    }
+    V3 f{lam * n.x, lam * n.y, lam * n.z};
+    if (!target) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
+    F = F + f;
+    if (ROT) T = T + cross(r, f);  // torque about the body centre, r x (+/- lam n)
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) {
+    F.x += __shfl_xor(F.x, off, 64);
+    F.y += __shfl_xor(F.y, off, 64);
+    F.z += __shfl_xor(F.z, off, 64);
+    if (ROT) {
+      T.x += __shfl_xor(T.x, off, 64);
+      T.y += __shfl_xor(T.y, off, 64);
+      T.z += __shfl_xor(T.z, off, 64);
     }
   }
+  if (sub != 0) return;
   const double mt = op.mt[b];
   double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
   V3 W{0.0, 0.0, 0.0};
@@ -428,6 +452,25 @@ __global__ void __launch_bounds__(kBlock) k_inc_sort(size_t N, const int32_t* __
   }
 }
 
+// half-edge records in incidence order: the body sweep then streams them instead of gathering normals / arms
+template <bool ROT>
+__global__ void __launch_bounds__(kBlock)
+    k_half_build(size_t nent, const int32_t* __restrict__ inc, const double* __restrict__ normal,
+                 const double* __restrict__ ra, const double* __restrict__ rb, double* __restrict__ half) {
+  constexpr int HW = ROT ? 6 : 3;
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < nent; k += (size_t)gridDim.x * blockDim.x) {
+    const int32_t e = inc[k];
+    const size_t c = static_cast<size_t>(e >> 1);
+    double* H = half + k * HW;
+    const V3 n = load3(normal, c);
+    H[0] = n.x; H[1] = n.y; H[2] = n.z;
+    if (ROT) {
+      const V3 r = (e & 1) ? load3(rb, c) : load3(ra, c);
+      H[3] = r.x; H[4] = r.y; H[5] = r.z;
+    }
+  }
+}
+
 }  // namespace mhip
 
 using namespace mhip;
@@ -435,8 +478,14 @@ using namespace mhip;
 struct mhip_contact_op {
   OpView view{};
   bool rot = false;
-  DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws;
+  DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half;
+  int lanes_per_body = 8;
   SolverState* host_state = nullptr;  // pinned
+  // optional per-kernel timing (mhip_contact_op_set_profiling)
+  bool profile = false;
+  std::vector<hipEvent_t> events;  // 3 per enqueued iteration: before body, between, after constraint
+  double body_ms = 0.0, constraint_ms = 0.0;
+  size_t timed_iterations = 0;
 };
 
 namespace {
@@ -444,14 +493,23 @@ namespace {
 int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double* X1, const double* G0,
                    const double* G1, Space sp, hipStream_t s) {
   if (op->view.N == 0) return MHIP_SUCCESS;
-  const unsigned grid = grid_exact(op->view.N);
+  const int G = op->lanes_per_body;
+  const unsigned grid = grid_exact(op->view.N * (size_t)G);
   const SolverState* st = op->state.as<SolverState>();
-#define BODY(M, R) k_body<M, R><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
+#define BODY3(M, R, GG) k_body<M, R, GG><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
+#define BODY(M, R)                 \
+  do {                             \
+    if (G == 4) BODY3(M, R, 4);    \
+    else if (G == 8) BODY3(M, R, 8); \
+    else if (G == 32) BODY3(M, R, 32); \
+    else BODY3(M, R, 16);          \
+  } while (0)
   if (op->rot) {
     if (mode == X_APPLY) BODY(X_APPLY, true); else if (mode == X_INIT) BODY(X_INIT, true); else BODY(X_SOLVE, true);
   } else {
     if (mode == X_APPLY) BODY(X_APPLY, false); else if (mode == X_INIT) BODY(X_INIT, false); else BODY(X_SOLVE, false);
   }
+#undef BODY3
 #undef BODY
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -648,8 +706,27 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
   }
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "incidence build failed: %s", hipGetErrorString(he)));
+  if (int e = op->half.reserve((2 * C + 2) * (op->rot ? 6 : 3) * sizeof(double))) return bail(e);
+  if (C > 0) {
+    if (op->rot)
+      k_half_build<true><<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), normal, ra, rb,
+                                                            op->half.as<double>());
+    else
+      k_half_build<false><<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), normal, ra, rb,
+                                                             op->half.as<double>());
+    he = hipGetLastError();
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "half-edge build failed: %s", hipGetErrorString(he)));
+  }
+  {
+    // lanes per body ~ half the mean degree, so most bodies finish in two passes of their group
+    const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
+    const char* env = getenv("MHIP_LANES_PER_BODY");
+    op->lanes_per_body = env ? atoi(env) : (mean_deg <= 4.0 ? 4 : (mean_deg <= 8.0 ? 8 : 16));
+    if (op->lanes_per_body != 4 && op->lanes_per_body != 8 && op->lanes_per_body != 16 && op->lanes_per_body != 32)
+      op->lanes_per_body = 8;
+  }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
-                    op->vel.as<double>(), dt};
+                    op->half.as<double>(), op->vel.as<double>(), dt};
   *handle = op;
   return MHIP_SUCCESS;
 }
@@ -657,8 +734,9 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
 int mhip_contact_op_destroy(mhip_contact_op_t op) {
   if (!op) return MHIP_SUCCESS;
   op->inc_ptr.release(); op->inc.release(); op->cursor.release(); op->vel.release();
-  op->partials.release(); op->state.release(); op->scanws.release();
+  op->partials.release(); op->state.release(); op->scanws.release(); op->half.release();
   if (op->host_state) (void)hipHostFree(op->host_state);
+  for (auto& ev : op->events) (void)hipEventDestroy(ev);
   delete op;
   return MHIP_SUCCESS;
 }
@@ -672,6 +750,22 @@ int mhip_contact_op_apply(mhip_contact_op_t op, const double* x, double* y, mhip
   // APPLY reads the iterate from X0 and writes y through G1
   return op_launch_constraint(op, X_APPLY, const_cast<double*>(x), nullptr, nullptr, y, nullptr, none, 0,
                               grid_for(op->view.C), s);
+}
+
+int mhip_contact_op_set_profiling(mhip_contact_op_t op, int enable) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  op->profile = enable != 0;
+  op->body_ms = op->constraint_ms = 0.0;
+  op->timed_iterations = 0;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_get_profile(mhip_contact_op_t op, double* body_ms, double* constraint_ms, size_t* iterations) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  if (body_ms) *body_ms = op->body_ms;
+  if (constraint_ms) *constraint_ms = op->constraint_ms;
+  if (iterations) *iterations = op->timed_iterations;
+  return MHIP_SUCCESS;
 }
 
 int mhip_contact_op_body_velocity(mhip_contact_op_t op, const double** velocity) {
@@ -707,19 +801,42 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   if (int e = op_launch_constraint(op, X_INIT, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
   k_finalize<X_INIT><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
   MHIP_LAUNCH_CHECK();
-  unsigned enqueued = 0, chunk = 8;
+  unsigned enqueued = 0, chunk = 8, last_todo = 0, iter_before = 0;
+  const bool prof = op->profile;
+  if (prof && op->events.empty()) {
+    op->events.resize(3 * 64);
+    for (auto& ev : op->events) MHIP_HIP(hipEventCreate(&ev));
+  }
   for (;;) {
     MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
     MHIP_HIP(hipStreamSynchronize(s));
+    if (prof && last_todo) {
+      // iterations of the last chunk that did real work: those that advanced iter, plus the converging one
+      unsigned eff = op->host_state->iter - iter_before + ((op->host_state->converged && op->host_state->iter < config->max_iters) ? 1u : 0u);
+      if (eff > last_todo) eff = last_todo;
+      for (unsigned k = 0; k < eff; ++k) {
+        float a = 0.f, b = 0.f;
+        MHIP_HIP(hipEventElapsedTime(&a, op->events[3 * k], op->events[3 * k + 1]));
+        MHIP_HIP(hipEventElapsedTime(&b, op->events[3 * k + 1], op->events[3 * k + 2]));
+        op->body_ms += a;
+        op->constraint_ms += b;
+      }
+      op->timed_iterations += eff;
+    }
     if (op->host_state->done || enqueued >= config->max_iters) break;
+    iter_before = op->host_state->iter;
     const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
     for (unsigned k = 0; k < todo; ++k) {
+      if (prof) MHIP_HIP(hipEventRecord(op->events[3 * k], s));
       if (int e = op_launch_body(op, X_SOLVE, x_tmp, x, g_tmp, g, sp, s)) return e;
+      if (prof) MHIP_HIP(hipEventRecord(op->events[3 * k + 1], s));
       if (int e = op_launch_constraint(op, X_SOLVE, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
+      if (prof) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       k_finalize<X_SOLVE><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
       MHIP_LAUNCH_CHECK();
     }
     enqueued += todo;
+    last_todo = todo;
     if (chunk < 64) chunk *= 2;
   }
   k_finish<<<grid_for(C), kBlock, 0, s>>>(C, st, x_tmp, x, g_tmp, g);

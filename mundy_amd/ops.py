@@ -333,6 +333,15 @@ class ContactOperator:
         capi.check(capi.load().mhip_deep_copy(6 * n, _ptr(out), p, _stream()))
         return out
 
+    def set_profiling(self, enable=True):
+        capi.check(capi.load().mhip_contact_op_set_profiling(self._h, 1 if enable else 0))
+
+    def get_profile(self):
+        """(k_body ms, k_constraint ms, timed iterations) accumulated by the fused solver since set_profiling"""
+        a, b, n = C.c_double(), C.c_double(), C.c_size_t()
+        capi.check(capi.load().mhip_contact_op_get_profile(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, int(n.value)
+
     def close(self):
         if getattr(self, "_h", None):
             capi.load().mhip_contact_op_destroy(self._h)

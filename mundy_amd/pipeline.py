@@ -51,7 +51,7 @@ class ContactStepper:
         # dry local drag U = F/(6 pi mu r), W = T/(8 pi mu r^3) (NgpLcp.cpp:484-486, Bacteria.cpp:810-848); the
         # per-body coefficients are set-up data computed once on the host (same numbers feed the CPU oracle)
         if kind == "sphere":
-            self.bounding_radius = radius
+            self.bounding_radius = radius.clone()
             eff = radius
         else:
             self.bounding_radius = ops.bounding_radius_spherocylinders(radius, length)
@@ -67,6 +67,31 @@ class ContactStepper:
         self.contacts = None
 
     # -- stages -----------------------------------------------------------------------------------------------------
+    _BODY_ARRAYS = ("center", "radius", "quat", "length", "bounding_radius", "mob_trans", "mob_rot")
+
+    def snapshot(self):
+        """device copies of every per-body array (to restart a step from the same input)"""
+        return {k: getattr(self, k).clone() for k in self._BODY_ARRAYS if getattr(self, k, None) is not None}
+
+    def restore(self, snap):
+        for k, v in snap.items():
+            getattr(self, k).copy_(v)
+
+    def reorder_bodies(self, cell_size=None, lo=None):
+        """Z-order (Morton) permutation of all per-body arrays by centre (what the reference's
+        zmorton helpers are advertised for): neighbours in space become neighbours in memory, so every gather of
+        the contact sweeps hits nearby lines.  Returns the permutation (new position k holds old body perm[k])."""
+        if cell_size is None:
+            cell_size = 2.0 * float(self.bounding_radius.max())
+        if lo is None:
+            lo = self.center.min(dim=0).values.tolist() if self.box is None else [0.0, 0.0, 0.0]
+        perm = ops.morton_order(self.center, lo, cell_size)
+        for name in self._BODY_ARRAYS:
+            t = getattr(self, name, None)
+            if t is not None:
+                t.copy_(ops.gather_rows(perm, t))
+        return perm
+
     def compute_aabb(self):
         if self.kind == "sphere":
             self.aabb = ops.compute_aabb_spheres(self.center, self.radius)
@@ -93,6 +118,8 @@ class ContactStepper:
             self.op.close()
         self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c["ra"], rb=c["rb"],
                                       mob_rot=self.mob_rot)
+        if getattr(self, "profile_next", False):
+            self.op.set_profiling(True)  # per-kernel HIP-event timing of the fused iteration (bench.py roofline)
         nc = self.links.num_pairs
         if rebuilt or self.lam is None or not self.warm_start or self.lam.shape[0] != nc:
             self.lam = torch.zeros(nc, dtype=torch.float64, device=self.center.device)  # NgpLcp.cpp:890-891

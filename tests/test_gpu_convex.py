@@ -112,8 +112,11 @@ def _gpu_op(ops, P, dt=5e-3):
 
 
 @pytest.mark.parametrize("maker,n", [(_sphere_problem, 3000), (_rod_problem, 3000)])
-def test_contact_operator_apply_bit_exact(ops, oracle, maker, n):
-    # fixed-order body sums: the GPU operator reproduces the serial scatter/mobility/gather of NgpLcp.cpp:442-530
+def test_contact_operator_apply(ops, oracle, maker, n):
+    # the GPU operator against the serial scatter/mobility/gather of NgpLcp.cpp:442-530.  Per-contact terms are the
+    # same expressions; the per-body sums run as a fixed G-lane tree instead of serially, so the bar is rounding
+    # level (1e-12 of the result scale) -- and bitwise reproducibility run to run, which the serial reference
+    # (atomics on a parallel backend) does not have.
     from gpu_util import assert_bits_equal, dev, host
     P = maker(oracle, n, seed=3)
     rng = np.random.default_rng(0)
@@ -121,14 +124,15 @@ def test_contact_operator_apply_bit_exact(ops, oracle, maker, n):
     op = _gpu_op(ops, P)
     y = host(op.apply(dev(x)))
     yo = oracle.contact_op_apply(P["pairs"], P["normal"], P["ra"], P["rb"], P["mt"], P["mr"], 5e-3, x, P["N"])
-    assert_bits_equal(y, yo, "A x")
+    np.testing.assert_allclose(y, yo, rtol=1e-12, atol=1e-12 * np.abs(yo).max())
+    assert_bits_equal(host(op.apply(dev(x))), y, "A x twice")
     # pairs in arbitrary (unsorted, shuffled) order give the same operator
     perm = rng.permutation(len(x))
     Q = dict(P, pairs=np.ascontiguousarray(P["pairs"][perm]), normal=np.ascontiguousarray(P["normal"][perm]))
     if P["ra"] is not None:
         Q.update(ra=np.ascontiguousarray(P["ra"][perm]), rb=np.ascontiguousarray(P["rb"][perm]))
     y2 = host(_gpu_op(ops, Q).apply(dev(x[perm])))
-    np.testing.assert_allclose(y2, yo[perm], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(y2, yo[perm], rtol=1e-12, atol=1e-12 * np.abs(yo).max())
     op.close()
 
 
