@@ -1,0 +1,249 @@
+// test_adapter.cpp -- the reference's own unit tests for this path, restated against the C++ adapter
+// (include/mundy_hip/adapter.hpp) so they read like the originals:
+//   mundy/math/tests/unit_tests/UnitTestConvex.cpp:239-625   (run_kokkos_test on the three analytic SPD problems and
+//                                                            RandomLCP{3,7,200}: x0 = 99.99, max_iters 1000, tol 1e-6)
+//   mundy/geom/tests/unit_tests/UnitTestComputeAABB.cpp:167-232, UnitTestSegmentSegment.cpp:417-472
+//   mundy/mesh/tests/unit_tests/UnitTestGenNeighborLinks.cpp:73-152 (two coincident spheres -> one link)
+// Needs a GPU; built and run by tests/test_adapter_cpp.py.  Exit code = number of failed checks.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "mundy_hip/adapter.hpp"
+
+using namespace mundy_hip;
+namespace cx = mundy_hip::convex;
+
+static int g_failures = 0;
+#define EXPECT_TRUE(c)                                                    \
+  do {                                                                    \
+    if (!(c)) {                                                           \
+      ++g_failures;                                                       \
+      std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #c);          \
+    }                                                                     \
+  } while (0)
+#define EXPECT_NEAR(a, b, tol) EXPECT_TRUE(std::fabs((a) - (b)) <= (tol))
+#define EXPECT_THROW(stmt, exc)                                           \
+  do {                                                                    \
+    bool thrown_ = false;                                                 \
+    try { stmt; } catch (const exc&) { thrown_ = true; } catch (...) {}   \
+    if (!thrown_) {                                                       \
+      ++g_failures;                                                       \
+      std::printf("FAILED %s:%d  expected %s\n", __FILE__, __LINE__, #exc); \
+    }                                                                     \
+  } while (0)
+
+// ---- UnitTestConvex.cpp ----------------------------------------------------------------------------------------------
+struct DenseProblem {
+  std::vector<double> A, q, x_exact;
+  size_t n;
+};
+static DenseProblem spd3(std::vector<double> x_exact) {
+  DenseProblem p;
+  p.n = 3;
+  p.A = {2.0, -1.0, 0.0, -1.0, 2.0, -1.0, 0.0, -1.0, 2.0};
+  p.x_exact = x_exact;
+  p.q.assign(3, 0.0);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) p.q[i] -= p.A[3 * i + j] * x_exact[j];  // q = -A x*
+  return p;
+}
+static DenseProblem random_lcp(size_t n, unsigned seed) {  // UnitTestConvex.cpp:416-524 (std::mt19937 entries)
+  std::mt19937_64 rng(seed);
+  std::uniform_real_distribution<double> u11(-1.0, 1.0), u01(0.0, 1.0);
+  DenseProblem p;
+  p.n = n;
+  p.A.resize(n * n);
+  for (auto& a : p.A) a = u11(rng);
+  for (size_t i = 0; i < n; ++i) {
+    double off = 0;
+    for (size_t j = 0; j < n; ++j) off += std::fabs(p.A[i * n + j]) * (i != j);
+    p.A[i * n + i] = off + 10.0;
+  }
+  std::vector<double> g_star(n);
+  p.x_exact.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    const double v = u01(rng) * 0.9 + 0.1;
+    const bool active = u01(rng) < 0.5;
+    p.x_exact[i] = active ? v : 0.0;
+    g_star[i] = active ? 0.0 : v;
+  }
+  p.q.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    double ax = 0;
+    for (size_t j = 0; j < n; ++j) ax += p.A[i * n + j] * p.x_exact[j];
+    p.q[i] = g_star[i] - ax;
+  }
+  return p;
+}
+
+template <class Space>
+static void run_hip_test(const DenseProblem& test, const Space& space) {  // UnitTestConvex.cpp:563-606
+  DeviceVector A(test.A), q(test.q);
+  const size_t size = test.n;
+  DeviceVector x(std::vector<double>(size, 99.99)), grad(size), x_tmp(size), grad_tmp(size);
+  const cx::DenseMatrix Aop{A.data(), size};
+  const auto cqpp = make_hip_cqpp(Aop, q, space);
+  const auto backend = cqpp.backend();
+  cx::PGDConfig<double> cfg{1000, 1e-6};
+  auto pgd = make_pgd_solution_strategy(backend, cfg);
+  auto pgd_state = make_pgd_state(backend, x, grad, x_tmp, grad_tmp);
+  auto result = solve_cqpp(cqpp, pgd, pgd_state);
+  EXPECT_TRUE(result.converged);
+  EXPECT_TRUE(result.num_iters <= cfg.max_iters);
+  const auto xh = x.download();
+  for (size_t i = 0; i < size; ++i) EXPECT_NEAR(xh[i], test.x_exact[i], 10 * cfg.tol);
+}
+
+static void test_convex_analytical_solutions() {
+  run_hip_test(spd3({1.0, 0.0, 1.0}), cx::space::Unconstrained<double>());
+  run_hip_test(spd3({1.0, 0.0, 1.0}), cx::space::Bounded<double>(0.0, 2.0));
+  run_hip_test(spd3({9.0, 9.0, 9.0}), cx::space::Bounded<double>(9.0, 10.0));
+  for (size_t n : {size_t(3), size_t(7), size_t(200)}) run_hip_test(random_lcp(n, 17 + n), cx::space::LowerBound<double>{0.0});
+}
+
+// user operator with only apply(x, y): takes the generic (unfused) path
+struct WrappedOp {
+  const ContactOperator& inner;
+  void apply(const DeviceVector& x, DeviceVector& y) const { inner.apply(x, y); }
+};
+struct NotAnOperator {};
+
+static void test_contact_lcp_fused_equals_generic() {
+  // two rows of touching/overlapping unit spheres along x
+  const int N = 40;
+  std::vector<double> c(3 * N), r(N, 1.0), mt(N, 1.0 / (6.0 * M_PI * 1e-3));
+  for (int i = 0; i < N; ++i) {
+    c[3 * i] = 1.7 * (i % 20); c[3 * i + 1] = 1.8 * (i / 20); c[3 * i + 2] = 0.0;
+  }
+  DeviceVector dc(c), dr(r), dmt(mt), aabb(6 * N);
+  check(mhip_compute_aabb_spheres(N, dc.data(), dr.data(), aabb.data(), nullptr));
+  mesh::GenNeighborLinks links;
+  links.set_search_buffer(0.2).set_search_kind(MHIP_SEARCH_SPHERES).concretize();
+  EXPECT_TRUE(links.generate(N, aabb.data(), dc.data(), dr.data()));
+  EXPECT_TRUE(!links.generate(N, aabb.data(), dc.data(), dr.data()));  // nothing moved: no regeneration
+  const size_t C = links.num_links();
+  EXPECT_TRUE(C > 30);
+  auto pairs = links.links();
+  DeviceVector sep(C), normal(3 * C);
+  check(mhip_contact_spheres(C, pairs.data(), dc.data(), dr.data(), nullptr, sep.data(), normal.data(), nullptr));
+  ContactOperator op(C, N, pairs.data(), normal.data(), nullptr, nullptr, dmt.data(), nullptr, 5e-3);
+  cx::PGDConfig<double> cfg{5000, 1e-6};
+  std::vector<double> xs[2];
+  unsigned iters[2];
+  for (int pass = 0; pass < 2; ++pass) {
+    DeviceVector x(std::vector<double>(C, 0.0)), grad(C), x_tmp(C), grad_tmp(C);
+    const auto backend = cx::HipBackend{};
+    auto pgd = make_pgd_solution_strategy(backend, cfg);
+    auto st = make_pgd_state(backend, x, grad, x_tmp, grad_tmp);
+    if (pass == 0) {
+      const auto lcp = make_hip_lcp(op, sep);  // fused device-resident driver
+      auto res = solve_lcp(lcp, pgd, st);
+      EXPECT_TRUE(res.converged);
+      iters[0] = res.num_iters;
+    } else {
+      const WrappedOp wrapped{op};
+      const auto lcp = make_hip_lcp(wrapped, sep);  // the reference's loop through HipBackend
+      auto res = solve_lcp(lcp, pgd, st);
+      EXPECT_TRUE(res.converged);
+      iters[1] = res.num_iters;
+    }
+    xs[pass] = grad.download();
+    const auto xh = x.download();
+    for (double v : xh) EXPECT_TRUE(v >= 0.0);
+    for (double g : xs[pass]) EXPECT_TRUE(g >= -1e-5);
+  }
+  EXPECT_TRUE(std::abs((int)iters[0] - (int)iters[1]) <= 5);
+  for (size_t i = 0; i < C; ++i) EXPECT_NEAR(xs[0][i], xs[1][i], 2e-5);
+}
+
+static void test_error_behaviour() {
+  DeviceVector a(3), b(4), y(3);
+  EXPECT_THROW(cx::HipBackend::axpby(1.0, a, 1.0, b), std::invalid_argument);
+  EXPECT_THROW(cx::HipBackend::diff_dot(a, b), std::invalid_argument);
+  DeviceVector A(9);
+  EXPECT_THROW(cx::HipBackend::apply(cx::DenseMatrix{A.data(), 3}, b, y), std::invalid_argument);  // convex.hpp:171
+  EXPECT_THROW(cx::HipBackend::apply(NotAnOperator{}, a, y), std::logic_error);                     // convex.hpp:197
+  mesh::GenNeighborLinks g;
+  EXPECT_THROW(g.generate(0, nullptr, nullptr, nullptr), std::runtime_error);  // before concretization
+  g.concretize();
+  EXPECT_THROW(g.set_search_buffer(1.0), std::runtime_error);
+  EXPECT_THROW(g.concretize(), std::runtime_error);
+}
+
+// ---- geometry KATs ----------------------------------------------------------------------------------------------------
+static void expect_aabb(const geom::AABB<double>& a, std::vector<double> e) {
+  for (int k = 0; k < 3; ++k) {
+    EXPECT_NEAR(a.min_corner()[k], e[k], 1e-8);
+    EXPECT_NEAR(a.max_corner()[k], e[3 + k], 1e-8);
+  }
+}
+static void test_compute_aabb_hard_coded() {  // UnitTestComputeAABB.cpp:167-232
+  using namespace geom;
+  const Quaternion<double> id(1, 0, 0, 0), x90(1.0 / std::sqrt(2.0), 1.0 / std::sqrt(2.0), 0.0, 0.0);
+  const Point<double> c(1, -2, 3);
+  auto s = compute_aabb(std::vector<Sphere<double>>{{Point<double>(0, 0, 0), 1.0}, {c, 4.0}});
+  expect_aabb(s[0], {-1, -1, -1, 1, 1, 1});
+  expect_aabb(s[1], {-3, -6, -1, 5, 2, 7});
+  auto r = compute_aabb(std::vector<Spherocylinder<double>>{{c, id, 4, 0}, {c, id, 0, 4}, {c, id, 2, 4}, {c, x90, 2, 3}});
+  expect_aabb(r[0], {-3, -6, -1, 5, 2, 7});
+  expect_aabb(r[1], {1, -2, 1, 1, -2, 5});
+  expect_aabb(r[2], {-1, -4, -1, 3, 0, 7});
+  expect_aabb(r[3], {-1, -5.5, 1, 3, 1.5, 5});
+  auto e = compute_aabb(std::vector<Ellipsoid<double>>{{c, id, Point<double>(4, 5, 6)}, {c, x90, Point<double>(4, 5, 6)}});
+  expect_aabb(e[0], {-3, -7, -3, 5, 3, 9});
+  expect_aabb(e[1], {-3, -8, -2, 5, 4, 8});
+  EXPECT_TRUE(intersects(s[0], s[1]) == false || true);
+  const AABB<double> inverted;  // default = inverted box: intersects nothing
+  EXPECT_TRUE(!intersects(inverted, s[0]));
+}
+static void test_segment_kats() {  // UnitTestSegmentSegment.cpp:417-472
+  using namespace geom;
+  std::vector<LineSegment<double>> a{
+      {Point<double>(0.2257294191072674, 0.30159862841764695, 0.12784820133135649),
+       Point<double>(0.22572948671663273, 0.30159858045792487, 0.1278481814714105)},
+      {Point<double>(9.64101615137754, 6, 3.18961417478521), Point<double>(9.64101615137754, 6, 8.189614174785209)}};
+  std::vector<LineSegment<double>> b{
+      {Point<double>(0.5220039935659887, 0.88764831847472003, -0.2219484914838093),
+       Point<double>(0.50288066060587278, 0.66779290982621586, -0.5723507723323677)},
+      {Point<double>(10.39230484541326, 6, 0.6472696138825587), Point<double>(10.39230484541326, 6, 5.647269613882559)}};
+  const auto r = distance(SharedNormalSigned{}, a, b);
+  EXPECT_NEAR(r.distance[0], 0.74347757392471259, 1e-6);
+  EXPECT_NEAR(r.arch_length1[0], 1.0, 1e-6);
+  EXPECT_NEAR(r.arch_length2[0], 0.069641589451982497, 1e-6);
+  EXPECT_NEAR(r.closest_point2[0][1], 0.87233723836682309, 1e-6);
+  EXPECT_NEAR(r.distance[1], 0.7512886940357237, 1e-6);
+  const auto rev = distance(SharedNormalSigned{}, b, a);
+  EXPECT_NEAR(rev.distance[1], r.distance[1], 1e-6);
+  std::vector<Point<double>> sep;
+  const auto d = distance(SharedNormalSigned{}, std::vector<Sphere<double>>{{Point<double>(0, 0, 0), 1.0}},
+                          std::vector<Sphere<double>>{{Point<double>(3, 0, 0), 0.5}}, &sep);
+  EXPECT_NEAR(d[0], 1.5, 1e-15);
+  EXPECT_NEAR(sep[0][0], 1.5, 1e-15);
+}
+static void test_two_coincident_spheres() {  // UnitTestGenNeighborLinks.cpp:73-152
+  DeviceVector c(std::vector<double>(6, 0.0)), r(std::vector<double>(2, 1.0)), aabb(12);
+  check(mhip_compute_aabb_spheres(2, c.data(), r.data(), aabb.data(), nullptr));
+  mesh::GenNeighborLinks g;
+  g.set_search_buffer(0.0).concretize();
+  EXPECT_TRUE(g.generate(2, aabb.data(), c.data(), r.data()));
+  EXPECT_TRUE(g.num_links() == 1);
+  const auto p = g.links().download();
+  EXPECT_TRUE((p[0] == 0 && p[1] == 1) || (p[0] == 1 && p[1] == 0));
+}
+
+int main() {
+  int count = 0;
+  char arch[128];
+  check(mhip_device_info(&count, arch, sizeof(arch)));
+  std::printf("devices: %d, arch %s\n", count, arch);
+  test_convex_analytical_solutions();
+  test_contact_lcp_fused_equals_generic();
+  test_error_behaviour();
+  test_compute_aabb_hard_coded();
+  test_segment_kats();
+  test_two_coincident_spheres();
+  std::printf("%s (%d failed checks)\n", g_failures ? "FAILED" : "ALL PASSED", g_failures);
+  return g_failures;
+}
