@@ -218,11 +218,50 @@ int mhip_bbpgd_solve_dense(size_t n, const double* A, const double* q, const mhi
 int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
                              const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
                              double* g_tmp, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+/* Staged form of the same fused iteration for domain-decomposed runs: the host interleaves the halo
+ * exchange and the cross-rank reduction between the stages, all asynchronously on `stream`:
+ *     begin;  body(init) -> [ghost velocity halo] -> constraint(init, local3) -> [all-gather local3] -> finalize(init)
+ *     repeat: body -> [halo] -> constraint(local3) -> [all-gather] -> finalize;   poll every k iterations;   end
+ * mhip_contact_op_set_partition: bodies [first, first+count) of the local index space are owned (swept by the body
+ * stage), the rest are ghosts whose rows of `velocity` ([num_bodies][6], caller owned so the halo can write it) are
+ * filled by the exchange; counted_contacts[c] != 0 marks contacts this rank contributes to the reductions (NULL: all).
+ * local3 / gathered are DEVICE arrays of (max residual term, sum dx^2, sum dx dg) triples; finalize reduces the
+ * `nparts` gathered triples in order, so every rank derives bit-identical step sizes.
+ * Replaces: stk::all_reduce_max / stk::all_reduce_sum x3 per iteration (scrap/lcp_spheres/NGPSpheresLCP.cpp:371,
+ * :450-452) with one 3-double all-gather, and the ghost field refresh of :1057 (left "TODO" there). */
+int mhip_contact_op_set_partition(mhip_contact_op_t handle, size_t body_first, size_t body_count,
+                                  const unsigned char* counted_contacts, double* velocity);
+int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
+                           const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
+                           double* g_tmp, mhip_stream_t stream);
+int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream);
+int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream);
+int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gathered, int nparts,
+                              mhip_stream_t stream);
+int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, int* done /*[host]*/,
+                          mhip_stream_t stream); /* synchronises */
+int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
 /* Same algorithm driven kernel-by-kernel through the S1 vector entry points above (what the C++ adapter's
  * HipBackend does): the unfused reference structure, kept as an in-library cross-check of the fused path. */
 int mhip_bbpgd_solve_contact_unfused(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
                                      const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
                                      double* g_tmp, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Stream compaction helpers (filter_view, mundy/mesh/src/mundy_mesh/GenNeighborLinkers.hpp:141-183: exclusive scan +
+ * stable scatter; the total is read back on the host exactly as :155-156 does).
+ *   filter_pairs_owned : keep pairs with at least one endpoint in [first, first+count) (drops ghost-ghost pairs);
+ *                        counted_out[k] = 1 iff the kept pair's source (lower index) is owned.  pairs_out may alias
+ *                        neither input.  *count_out [host].
+ *   select_aabb_overlap: indices (ascending) of the boxes aabb[i] grown by `buffer` that intersect (closed test) the
+ *                        box `box6` [host: min xyz, max xyz] -- the ghost candidates for a neighbouring rank.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_filter_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, size_t count, int32_t* pairs_out,
+                            unsigned char* counted_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
+int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const double* box6 /*[host]*/,
+                             int32_t* idx_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
+/* min / max corner over n boxes grown by `buffer`: out6 [host] (an empty set gives the inverted box) */
+int mhip_aabb_bounds(size_t n, const double* aabb, double buffer, double* out6 /*[host]*/, mhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Time integration either side of the solve: x += dt * U (scrap/lcp_spheres/NgpLcp.cpp:898) and, for

@@ -200,6 +200,12 @@ struct OpView {
   const double* half;            // per incidence entry: (n_c, r_side), 6 doubles (3 when translation only)
   double* vel;                   // [N][6]
   double dt;
+  // domain decomposition: bodies [body_first, body_first + body_count) are owned by this rank and swept
+  // by k_body; the other rows of vel are ghosts filled by the halo exchange.  counted[c] != 0 marks the contacts this
+  // rank contributes to the global reductions (a contact duplicated on two ranks is counted by the owner of its
+  // lower body).  Defaults: all bodies, all contacts.
+  size_t body_first, body_count;
+  const unsigned char* counted;
 };
 
 // the iterate a constraint carries in a given mode; bitwise identical wherever it is evaluated
@@ -236,9 +242,9 @@ __global__ void __launch_bounds__(kBlock)
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  const size_t b = t / G;
   const int sub = static_cast<int>(t % G);
-  if (b >= op.N) return;  // whole groups leave together (G divides the wave size)
+  if (t / G >= op.body_count) return;  // whole groups leave together (G divides the wave size)
+  const size_t b = op.body_first + t / G;
   constexpr int HW = ROT ? 6 : 3;
   V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
@@ -329,12 +335,14 @@ __global__ void __launch_bounds__(kBlock)
       const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
       gn[c] = g;
       if (MODE == X_SOLVE) xn[c] = xc;
-      const double r = residual_term(resid_kind, xc, g, sp);
-      if (r > rmax) rmax = r;
-      if (MODE == X_SOLVE) {
-        const double dx = xc - xt[c];
-        num += dx * dx;            // diff_dot(x, x_old)              (convex.hpp:507)
-        den += dx * (g - gt[c]);   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+      if (op.counted == nullptr || op.counted[c]) {
+        const double r = residual_term(resid_kind, xc, g, sp);
+        if (r > rmax) rmax = r;
+        if (MODE == X_SOLVE) {
+          const double dx = xc - xt[c];
+          num += dx * dx;            // diff_dot(x, x_old)              (convex.hpp:507)
+          den += dx * (g - gt[c]);   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+        }
       }
     }
   }
@@ -389,6 +397,29 @@ __global__ void __launch_bounds__(kBlock) k_finalize(int nparts, const double* _
     st->step = num / den;
     st->iter += 1;
     if (st->iter >= max_iters) st->done = 1;
+  }
+}
+
+// block partials -> one (max, num, den) triple (this rank's contribution to the all-gather of SURVEY 8e step 3)
+__global__ void __launch_bounds__(kBlock) k_reduce_local3(int nparts, const double* __restrict__ partials,
+                                                         const SolverState* __restrict__ st, int check_done,
+                                                         double* __restrict__ out3) {
+  __shared__ double scratch[kBlock / 64];
+  if (check_done && st->done) return;
+  double rmax = kLowest, num = 0.0, den = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    const double m = partials[3 * i];
+    if (m > rmax) rmax = m;
+    num += partials[3 * i + 1];
+    den += partials[3 * i + 2];
+  }
+  rmax = block_max(rmax, scratch);
+  num = block_sum(num, scratch);
+  den = block_sum(den, scratch);
+  if (threadIdx.x == 0) {
+    out3[0] = rmax;
+    out3[1] = num;
+    out3[2] = den;
   }
 }
 
@@ -481,6 +512,14 @@ struct mhip_contact_op {
   DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half;
   int lanes_per_body = 8;
   SolverState* host_state = nullptr;  // pinned
+  // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
+  struct Stage {
+    const double* q = nullptr;
+    double *x = nullptr, *g = nullptr, *x_tmp = nullptr, *g_tmp = nullptr;
+    Space sp{0, 0, 0};
+    mhip_pgd_config cfg{0, 0, 0};
+    bool active = false;
+  } stage;
   // optional per-kernel timing (mhip_contact_op_set_profiling)
   bool profile = false;
   std::vector<hipEvent_t> events;  // 3 per enqueued iteration: before body, between, after constraint
@@ -494,7 +533,8 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
                    const double* G1, Space sp, hipStream_t s) {
   if (op->view.N == 0) return MHIP_SUCCESS;
   const int G = op->lanes_per_body;
-  const unsigned grid = grid_exact(op->view.N * (size_t)G);
+  if (op->view.body_count == 0) return MHIP_SUCCESS;
+  const unsigned grid = grid_exact(op->view.body_count * (size_t)G);
   const SolverState* st = op->state.as<SolverState>();
 #define BODY3(M, R, GG) k_body<M, R, GG><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
 #define BODY(M, R)                 \
@@ -726,7 +766,7 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
       op->lanes_per_body = 8;
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
-                    op->half.as<double>(), op->vel.as<double>(), dt};
+                    op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr};
   *handle = op;
   return MHIP_SUCCESS;
 }
@@ -845,6 +885,104 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   result->num_iters = op->host_state->iter;
   result->residual = op->host_state->residual;
   result->converged = op->host_state->converged;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_set_partition(mhip_contact_op_t op, size_t body_first, size_t body_count,
+                                  const unsigned char* counted_contacts, double* velocity) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(body_first + body_count <= op->view.N, MHIP_ERR_INVALID_ARGUMENT,
+               "owned body range [%zu, %zu) exceeds the %zu local bodies", body_first, body_first + body_count,
+               op->view.N);
+  op->view.body_first = body_first;
+  op->view.body_count = body_count;
+  op->view.counted = counted_contacts;
+  op->view.vel = velocity ? velocity : op->vel.as<double>();
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_space* space,
+                           const mhip_pgd_config* config, double* x, double* g, double* x_tmp, double* g_tmp,
+                           mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  if (int e = check_config(config)) return e;
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  const size_t C = op->view.C;
+  MHIP_REQUIRE(C == 0 || (q && x && g && x_tmp && g_tmp), MHIP_ERR_INVALID_ARGUMENT,
+               "solver vectors must not be null");
+  MHIP_REQUIRE(C == 0 || (x != x_tmp && g != g_tmp && x != g), MHIP_ERR_INVALID_ARGUMENT,
+               "solver vectors must not alias");
+  op->stage.q = q; op->stage.x = x; op->stage.g = g; op->stage.x_tmp = x_tmp; op->stage.g_tmp = g_tmp;
+  op->stage.sp = sp;
+  op->stage.cfg = *config;
+  op->stage.active = true;
+  MHIP_HIP(hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState), as_stream(stream)));
+  return launch_copy(C, x_tmp, x, as_stream(stream));
+}
+
+int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  auto& st = op->stage;
+  return op_launch_body(op, init ? X_INIT : X_SOLVE, st.x_tmp, st.x, st.g_tmp, st.g, st.sp, as_stream(stream));
+}
+
+int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  MHIP_REQUIRE(local3 != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local3 is null");
+  auto& st = op->stage;
+  hipStream_t s = as_stream(stream);
+  const unsigned cgrid = grid_for(op->view.C);
+  if (int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, st.x_tmp, st.x, st.g_tmp, st.g, st.q, st.sp,
+                                   st.cfg.residual_kind, cgrid, s))
+    return e;
+  k_reduce_local3<<<1, kBlock, 0, s>>>(op->view.C == 0 ? 0 : (int)cgrid, op->partials.as<double>(),
+                                       op->state.as<SolverState>(), init ? 0 : 1, local3);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gathered, int nparts,
+                              mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  MHIP_REQUIRE(gathered != nullptr && nparts >= 1, MHIP_ERR_INVALID_ARGUMENT, "gathered triples missing");
+  const auto& cfg = op->stage.cfg;
+  SolverState* st = op->state.as<SolverState>();
+  if (init)
+    k_finalize<X_INIT><<<1, kBlock, 0, as_stream(stream)>>>(nparts, gathered, st, cfg.residual_kind, cfg.tol,
+                                                            cfg.max_iters);
+  else
+    k_finalize<X_SOLVE><<<1, kBlock, 0, as_stream(stream)>>>(nparts, gathered, st, cfg.residual_kind, cfg.tol,
+                                                             cfg.max_iters);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result, int* done, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && result != nullptr && done != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  hipStream_t s = as_stream(stream);
+  MHIP_HIP(hipMemcpyAsync(op->host_state, op->state.ptr, sizeof(SolverState), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  result->num_iters = op->host_state->iter;
+  result->residual = op->host_state->residual;
+  result->converged = op->host_state->converged;
+  *done = op->host_state->done;
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  auto& st = op->stage;
+  hipStream_t s = as_stream(stream);
+  if (op->view.C > 0) {
+    k_finish<<<grid_for(op->view.C), kBlock, 0, s>>>(op->view.C, op->state.as<SolverState>(), st.x_tmp, st.x,
+                                                     st.g_tmp, st.g);
+    MHIP_LAUNCH_CHECK();
+  }
+  int done = 0;
+  mhip_solve_result r{};
+  if (int e = mhip_bbpgd_stage_poll(op, result ? result : &r, &done, stream)) return e;
+  st.active = false;
   return MHIP_SUCCESS;
 }
 

@@ -1,0 +1,314 @@
+"""Domain-decomposed contact step over the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI), Hilbert-curve partition of the bodies, ghost-body halo at every neighbour-list
+rebuild and a ghost-velocity halo + one 3-double all-gather per BBPGD iteration.
+
+What the reference does at the same places (all through STK/MPI): RCB partition `stk::balance::balanceStkMesh`
+(scrap/lcp_spheres/NGPSpheresLCP.cpp:956), `stk::search::coarse_search(..., comm, ...)` + `change_ghosting`
+(mundy_mesh/GenNeighborLinkers.hpp:658, :687-711), per-iteration `stk::all_reduce_max` + 3 x `stk::all_reduce_sum`
+(NGPSpheresLCP.cpp:371, :450-452) and a ghost field refresh it leaves as a TODO (:1057).
+
+Scheme (the reference's symmetric-pair trick, NGPSpheresLCP.cpp:455-499, made exact):
+  * bodies are sorted along a Hilbert curve (same visiting order as mundy_math/Hilbert.hpp:48-83) and cut into equal
+    contiguous ranges; global id = position in that order, so every rank's local index order (ghosts from lower ranks,
+    owned, ghosts from higher ranks) is also global-id order and local pairs (i < j) keep their global orientation;
+  * a contact between bodies of two ranks is kept on BOTH ranks; each rank sums forces only for the bodies it owns
+    (`mhip_contact_op_set_partition`), so no force reduction is needed; the duplicated contact carries bit-identical
+    (x, g) on both ranks because its inputs (geometry, both body velocities, global step size) are identical;
+  * per iteration: body sweep -> send owned boundary velocities to the ranks that hold them as ghosts -> constraint
+    sweep -> all-gather of (max, num, den) -> every rank reduces the triples in rank order (same step everywhere).
+    A duplicated contact is counted once in the reductions, by the owner of its lower body.
+torch.distributed carries the messages; with the gloo backend (tests, several ranks sharing one GPU) buffers are
+staged through the host.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi, ops
+
+
+# ---- Hilbert ordering -------------------------------------------------------------------------------------------------
+def hilbert_positions(level):
+    """Lattice points of a (2^level)^3 cube in the visiting order of mundy::math::hilbert_3d
+    (mundy_math/Hilbert.hpp:48-83) started from the origin with axes (x, y, z) -- a level-by-level, vectorised form of
+    that recursion (each state expands into its 8 children in curve order)."""
+    cur = np.zeros((1, 3), dtype=np.int64)
+    d = np.eye(3, dtype=np.int64)[None, :, :]  # [M, 3 axes (dr1, dr2, dr3), xyz]
+    s = 1 << level
+    while s > 1:
+        h = s // 2
+        neg = (d < 0).astype(np.int64)                       # stencil: 1 where an axis component is negative
+        cn = cur - h * (neg * d).sum(axis=1)                 # current_position_new
+        d1, d2, d3 = d[:, 0], d[:, 1], d[:, 2]
+        kids = [
+            (cn, d2, d3, d1),
+            (cn + h * d1, d3, d1, d2),
+            (cn + h * (d1 + d2), d3, d1, d2),
+            (cn + h * d2, -d1, -d2, d3),
+            (cn + h * (d2 + d3), -d1, -d2, d3),
+            (cn + h * (d1 + d2 + d3), -d3, d1, -d2),
+            (cn + h * (d1 + d3), -d3, d1, -d2),
+            (cn + h * d3, d2, -d3, -d1),
+        ]
+        cur = np.stack([k[0] for k in kids], axis=1).reshape(-1, 3)
+        d = np.stack([np.stack(k[1:], axis=1) for k in kids], axis=1).reshape(-1, 3, 3)
+        s = h
+    return cur
+
+
+_KEY_TABLES = {}
+
+
+def hilbert_key_table(level):
+    """key[ix, iy, iz] = index of the lattice point along the curve"""
+    if level not in _KEY_TABLES:
+        pos = hilbert_positions(level)
+        n = 1 << level
+        table = np.empty((n, n, n), dtype=np.int64)
+        table[pos[:, 0], pos[:, 1], pos[:, 2]] = np.arange(len(pos))
+        _KEY_TABLES[level] = table
+    return _KEY_TABLES[level]
+
+
+def hilbert_order(center, lo, hi, level=6):
+    """permutation that sorts points along the Hilbert curve of a (2^level)^3 lattice over [lo, hi]; ties (same
+    cell) keep index order.  Host-side set-up step (the reference repartitions on the host too)."""
+    center = np.asarray(center)
+    n = 1 << level
+    span = np.maximum(np.asarray(hi, dtype=np.float64) - np.asarray(lo, dtype=np.float64), 1e-300)
+    cell = np.clip(np.floor((center - lo) / span * n).astype(np.int64), 0, n - 1)
+    key = hilbert_key_table(level)[cell[:, 0], cell[:, 1], cell[:, 2]]
+    return np.argsort(key, kind="stable")
+
+
+def partition_ranges(n_total, world):
+    """equal contiguous ranges of the curve order: rank r owns global ids [start[r], start[r+1])"""
+    base, rem = divmod(n_total, world)
+    counts = np.array([base + (1 if r < rem else 0) for r in range(world)], dtype=np.int64)
+    return np.concatenate([[0], np.cumsum(counts)])
+
+
+def halo_layout(count_matrix, rank):
+    """Pure bookkeeping of the ghost halo.  count_matrix[s][d] = number of bodies rank s sends to rank d.
+    Returns (recv_counts per peer, ghosts_lo, ghosts_hi, recv_offsets): ghosts from lower ranks come first in the
+    local index space, then the owned bodies, then ghosts from higher ranks (peer order within each group)."""
+    world = len(count_matrix)
+    recv = [int(count_matrix[p][rank]) if p != rank else 0 for p in range(world)]
+    n_lo = sum(recv[:rank])
+    n_hi = sum(recv[rank + 1:])
+    offsets, acc = [], 0
+    for p in range(world):
+        offsets.append(acc)
+        acc += recv[p]
+    return recv, n_lo, n_hi, offsets
+
+
+# ---- communication ------------------------------------------------------------------------------------------------------
+class Comm:
+    """Thin wrapper over torch.distributed: P2P halo + small all-gathers.  nccl: device buffers go straight to RCCL;
+    any other backend (gloo in the tests): staged through host memory."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.direct = self.enabled and dist.get_backend(group) == "nccl"
+
+    def all_gather(self, t):
+        """t: 1-D tensor (device or host) -> [world, len] tensor on the same device"""
+        if self.world == 1:
+            return t.reshape(1, -1).clone()
+        if self.direct and t.is_cuda:
+            out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out.reshape(-1), t.contiguous(), group=self.group)
+            return out
+        src = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src, group=self.group)
+        return torch.stack(parts).to(t.device)
+
+    def exchange(self, send, recv):
+        """send / recv: {peer: contiguous tensor}; recv tensors are filled in place."""
+        if self.world == 1 or (not send and not recv):
+            return
+        if self.direct:
+            p2p = [dist.P2POp(dist.irecv, t, p, group=self.group) for p, t in sorted(recv.items()) if t.numel()]
+            p2p += [dist.P2POp(dist.isend, t, p, group=self.group) for p, t in sorted(send.items()) if t.numel()]
+            if p2p:
+                for w in dist.batch_isend_irecv(p2p):
+                    w.wait()  # orders the current stream after the transfer; no host block with nccl
+            return
+        stage_r = {p: torch.empty(t.shape, dtype=t.dtype) for p, t in recv.items() if t.numel()}
+        works = [dist.irecv(b, src=p, group=self.group) for p, b in sorted(stage_r.items())]
+        works += [dist.isend(t.detach().cpu().contiguous(), dst=p, group=self.group)
+                  for p, t in sorted(send.items()) if t.numel()]
+        for w in works:
+            w.wait()
+        for p, b in stage_r.items():
+            recv[p].copy_(b)
+
+
+# ---- the distributed stepper ----------------------------------------------------------------------------------------------
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DistributedContactStepper:
+    """This rank's slice of a spherocylinder system: owned bodies in global-id order (a contiguous range of the
+    Hilbert order), plus per-step ghosts.  step() = AABB -> ghost halo -> local neighbour list (ghost-ghost pairs
+    dropped) -> contacts -> staged BBPGD with a velocity halo per iteration -> Euler update of the owned bodies."""
+
+    RECORD = 10  # gid, centre 3, quat 4, radius, length
+
+    def __init__(self, center, quat, radius, length, gid_first, *, comm=None, dt=5e-3, viscosity=1e-3,
+                 search_buffer=0.1, cfg=None, poll_every=16):
+        from . import synth
+        self.comm = comm or Comm()
+        self.center, self.quat, self.radius, self.length = center, quat, radius, length
+        self.n = center.shape[0]
+        self.gid_first = int(gid_first)
+        self.dt, self.viscosity, self.buffer = float(dt), float(viscosity), float(search_buffer)
+        self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)
+        self.poll_every = int(poll_every)
+        self.links = ops.GenNeighborLinks().set_search_buffer(search_buffer).set_search_kind(ops.SEARCH_AABB).concretize()
+        self._synth = synth
+        self.op = None
+        self.stats = {}
+
+    # -- ghost halo -----------------------------------------------------------------------------------------------------
+    def _exchange_ghosts(self):
+        lib, comm = capi.load(), self.comm
+        n, dev = self.n, self.center.device
+        aabb = ops.compute_aabb_spherocylinders(self.center, self.quat, self.radius, self.length)
+        box = (C.c_double * 6)()
+        capi.check(lib.mhip_aabb_bounds(n, _p(aabb), self.buffer, box, _stream()))
+        boxes = comm.all_gather(torch.tensor(list(box), dtype=torch.float64)).tolist()
+        send_idx, send_cnt = {}, [0] * comm.world
+        for p in range(comm.world):
+            if p == comm.rank:
+                continue
+            idx = torch.empty(n, dtype=torch.int32, device=dev)
+            cnt = C.c_size_t(0)
+            pb = (C.c_double * 6)(*boxes[p])
+            capi.check(lib.mhip_select_aabb_overlap(n, _p(aabb), self.buffer, pb, _p(idx), C.byref(cnt), _stream()))
+            send_idx[p], send_cnt[p] = idx[: cnt.value], int(cnt.value)
+        counts = comm.all_gather(torch.tensor(send_cnt, dtype=torch.int64)).tolist()  # counts[s][d]
+        recv_cnt, n_lo, n_hi, _ = halo_layout(counts, comm.rank)
+        # records of the owned bodies, gathered per peer
+        gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
+        rec = torch.cat([gid[:, None], self.center, self.quat, self.radius[:, None], self.length[:, None]], dim=1)
+        send = {p: ops.gather_rows(send_idx[p], rec) if send_cnt[p] else rec[:0] for p in send_idx}
+        recv = {p: torch.empty((recv_cnt[p], self.RECORD), dtype=torch.float64, device=dev)
+                for p in range(comm.world) if p != comm.rank}
+        comm.exchange(send, recv)
+        lo = [recv[p] for p in range(comm.rank) if recv_cnt[p]]
+        hi = [recv[p] for p in range(comm.rank + 1, comm.world) if recv_cnt[p]]
+        local = torch.cat(lo + [rec] + hi, dim=0).contiguous()
+        self.n_lo, self.n_hi, self.n_local = n_lo, n_hi, local.shape[0]
+        self.local = dict(gid=local[:, 0].contiguous(), center=local[:, 1:4].contiguous(),
+                          quat=local[:, 4:8].contiguous(), radius=local[:, 8].contiguous(),
+                          length=local[:, 9].contiguous())
+        # velocity halo plan: what I send each iteration (owned rows, as local indices) and where receives land
+        order = [p for p in range(comm.world) if p != comm.rank and send_cnt[p]]
+        self.vel_send_peers = order
+        self.vel_send_idx = (torch.cat([send_idx[p] for p in order]) + n_lo).to(torch.int32) if order else None
+        self.vel_send_split = [send_cnt[p] for p in order]
+        self.vel_recv = {}
+        off = 0
+        for p in range(comm.world):
+            if p == comm.rank:
+                off = n_lo + n  # ghosts of higher ranks sit after the owned block
+                continue
+            if recv_cnt[p]:
+                self.vel_recv[p] = (off, off + recv_cnt[p])
+            off += recv_cnt[p]
+        self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=sum(send_cnt))
+
+    def _halo_velocity(self):
+        if self.comm.world == 1:
+            return
+        send = {}
+        if self.vel_send_idx is not None:
+            buf = ops.gather_rows(self.vel_send_idx, self.vel)
+            off = 0
+            for p, k in zip(self.vel_send_peers, self.vel_send_split):
+                send[p] = buf[off:off + k]
+                off += k
+        recv = {p: self.vel[a:b] for p, (a, b) in self.vel_recv.items()}
+        self.comm.exchange(send, recv)
+
+    # -- one step -------------------------------------------------------------------------------------------------------------
+    def step(self, integrate=True):
+        lib, comm = capi.load(), self.comm
+        self._exchange_ghosts()
+        L, dev = self.local, self.center.device
+        nl = self.n_local
+        aabb = ops.compute_aabb_spherocylinders(L["center"], L["quat"], L["radius"], L["length"])
+        brad = ops.bounding_radius_spherocylinders(L["radius"], L["length"])
+        self.links.generate(aabb, L["center"], brad, force=True)
+        c_all = self.links.num_pairs
+        pairs = torch.empty((c_all, 2), dtype=torch.int32, device=dev)
+        counted = torch.empty(c_all, dtype=torch.uint8, device=dev)
+        cnt = C.c_size_t(0)
+        capi.check(lib.mhip_filter_pairs_owned(c_all, _p(self.links.pairs), self.n_lo, self.n, _p(pairs), _p(counted),
+                                               C.byref(cnt), _stream()))
+        nc = int(cnt.value)
+        pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
+        seg = ops.spherocylinder_segments(L["center"], L["quat"], L["radius"], L["length"])
+        con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False)
+        mt, mr = self._synth.dry_mobility(brad.cpu().numpy(), viscosity=self.viscosity)
+        mob_t, mob_r = torch.from_numpy(mt).to(dev), torch.from_numpy(mr).to(dev)
+        if self.op is not None:
+            self.op.close()
+        op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, ra=con["ra"], rb=con["rb"],
+                                           mob_rot=mob_r)
+        self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
+        self._keep = (pairs, counted, con, mob_t, mob_r, seg)
+        capi.check(lib.mhip_contact_op_set_partition(op._h, self.n_lo, self.n, _p(counted), _p(self.vel)))
+        # staged BBPGD
+        x = torch.zeros(nc, dtype=torch.float64, device=dev)
+        g, x_tmp, g_tmp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        sp = capi.Space(ops.SPACE_LOWER_BOUND, 0.0, 0.0)
+        pc = capi.PgdConfig(int(self.cfg.max_iters), float(self.cfg.tol), int(self.cfg.residual_kind))
+        local3 = torch.empty(3, dtype=torch.float64, device=dev)
+        capi.check(lib.mhip_bbpgd_stage_begin(op._h, _p(con["sep"]), C.byref(sp), C.byref(pc), _p(x), _p(g),
+                                              _p(x_tmp), _p(g_tmp), _stream()))
+
+        def iteration(init):
+            capi.check(lib.mhip_bbpgd_stage_body(op._h, init, _stream()))
+            self._halo_velocity()
+            capi.check(lib.mhip_bbpgd_stage_constraint(op._h, init, _p(local3), _stream()))
+            gathered = comm.all_gather(local3)
+            capi.check(lib.mhip_bbpgd_stage_finalize(op._h, init, _p(gathered), comm.world, _stream()))
+            return gathered
+
+        iteration(1)
+        res, done = capi.SolveResult(), C.c_int(0)
+        enq = 0
+        while True:
+            capi.check(lib.mhip_bbpgd_stage_poll(op._h, C.byref(res), C.byref(done), _stream()))
+            if done.value or enq >= self.cfg.max_iters:
+                break
+            todo = min(self.poll_every, self.cfg.max_iters - enq)
+            for _ in range(todo):
+                self._last = iteration(0)
+            enq += todo
+        capi.check(lib.mhip_bbpgd_stage_end(op._h, C.byref(res), _stream()))
+        self.lam, self.grad, self.contacts, self.pairs, self.counted = x, g, con, pairs, counted
+        if integrate:
+            a, b = self.n_lo, self.n_lo + self.n
+            own_c, own_q = L["center"][a:b], L["quat"][a:b]
+            ops.integrate_euler(self.dt, self.vel[a:b], own_c, own_q)
+            self.center.copy_(own_c)
+            self.quat.copy_(own_q)
+        owned_contacts = int(counted.sum().item()) if nc else 0
+        self.stats.update(local_bodies=nl, local_contacts=nc, owned_contacts=owned_contacts,
+                          num_iters=int(res.num_iters), residual=float(res.residual), converged=bool(res.converged))
+        return dict(self.stats)

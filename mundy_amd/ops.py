@@ -398,8 +398,8 @@ def morton_order(center, lo, cell_size):
 
 def gather_rows(perm, src):
     src2 = src if src.dim() == 2 else src.unsqueeze(1)
-    dst = torch.empty_like(src2)
-    capi.check(capi.load().mhip_gather_rows(src2.shape[0], src2.shape[1], _ptr(perm, torch.int32), _ptr(src2),
+    dst = torch.empty((perm.shape[0], src2.shape[1]), dtype=src2.dtype, device=src2.device)
+    capi.check(capi.load().mhip_gather_rows(perm.shape[0], src2.shape[1], _ptr(perm, torch.int32), _ptr(src2),
                                             _ptr(dst), _stream()))
     return dst if src.dim() == 2 else dst.squeeze(1)
 

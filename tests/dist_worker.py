@@ -1,0 +1,95 @@
+"""Worker of tests/test_gpu_distributed.py: `python -m torch.distributed.run --nproc-per-node W tests/dist_worker.py`.
+All ranks share cuda:0 (gloo carries the halo through the host), each owns a Hilbert range of one global rod system;
+rank 0 also solves the whole system on one rank and checks the distributed result against it."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    n_total = int(os.environ.get("DIST_BODIES", "12000"))
+    tol = 1e-5
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    from mundy_amd import distributed as D, ops, pipeline, synth
+
+    b = synth.spherocylinders(n_total, seed=7)
+    order = D.hilbert_order(b["center"], 0.0, b["box"], level=5)
+    starts = D.partition_ranges(n_total, world)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    g_center, g_quat = b["center"][order], b["quat"][order]
+    g_radius, g_length = b["radius"][order], b["length"][order]
+    a, e = int(starts[rank]), int(starts[rank + 1])
+    cfg = ops.PGDConfig(max_iters=20000, tol=tol)
+    st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]), a,
+                                     comm=D.Comm(), search_buffer=0.1, cfg=cfg, poll_every=8)
+    stats = st.step(integrate=False)
+    gid = st.local["gid"].cpu().numpy().astype(np.int64)
+    pairs = st.pairs.cpu().numpy()
+    out = dict(stats=stats, gpairs=gid[pairs], counted=st.counted.cpu().numpy().astype(bool),
+               g=st.grad.cpu().numpy(), x=st.lam.cpu().numpy(),
+               vel=st.vel[st.n_lo:st.n_lo + st.n].cpu().numpy(), first=a)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(out, gathered, dst=0)
+    ok = True
+    if rank == 0:
+        ref = pipeline.ContactStepper("spherocylinder", dev(g_center), dev(g_radius), dev(g_quat), dev(g_length),
+                                      search_buffer=0.1, cfg=cfg)
+        rs = ref.step(integrate=False)
+        rp = ref.links.pairs.cpu().numpy().astype(np.int64)
+        rg = (ref.op.apply(ref.lam) + ref.contacts["sep"]).cpu().numpy()
+        rvel = ref.op.body_velocity().cpu().numpy()
+        key = lambda p: p[:, 0] * n_total + p[:, 1]  # noqa: E731
+        allp = np.concatenate([o["gpairs"][o["counted"]] for o in gathered])
+        allg = np.concatenate([o["g"][o["counted"]] for o in gathered])
+        allx = np.concatenate([o["x"][o["counted"]] for o in gathered])
+        srt = np.argsort(key(allp))
+        checks = {}
+        checks["pair set == single-rank neighbour list"] = np.array_equal(allp[srt], rp)
+        checks["all ranks converged"] = all(o["stats"]["converged"] for o in gathered) and rs.converged
+        iters = [o["stats"]["num_iters"] for o in gathered]
+        checks["same iteration count on every rank"] = len(set(iters)) == 1
+        checks["iterations close to single rank (%d vs %d)" % (iters[0], rs.num_iters)] = \
+            abs(iters[0] - rs.num_iters) <= max(10, 0.2 * rs.num_iters)
+        if checks["pair set == single-rank neighbour list"]:
+            dg = np.abs(allg[srt] - rg).max()
+            checks["gradient vs single rank (max diff %.3g)" % dg] = dg <= 20 * tol
+            checks["LCP conditions"] = allx.min() >= 0 and allg.min() >= -10 * tol and \
+                np.abs(np.minimum(allx, allg)).max() <= 10 * tol
+        vel = np.concatenate([o["vel"] for o in gathered])
+        dv = np.abs(vel - rvel).max() / max(1e-30, np.abs(rvel).max())
+        checks["owned velocities vs single rank (rel %.3g)" % dv] = dv <= 1e-3
+        # duplicated (cross-rank) contacts carry bit-identical (x, g) on both ranks
+        dup = {}
+        n_dup = 0
+        for o in gathered:
+            for p, c, x, g in zip(o["gpairs"], o["counted"], o["x"], o["g"]):
+                k = (int(p[0]), int(p[1]))
+                if k in dup:
+                    n_dup += 1
+                    if dup[k] != (x.tobytes(), g.tobytes()):
+                        checks["duplicate contact %s bitwise equal" % (k,)] = False
+                elif world > 1:
+                    dup[k] = (x.tobytes(), g.tobytes())
+        checks["%d duplicated cross-rank contacts found" % n_dup] = (n_dup > 0) or world == 1
+        checks["ghosts exchanged"] = world == 1 or all(o["stats"]["ghosts"] > 0 for o in gathered)
+        for k, v in checks.items():
+            print(("ok   " if v else "FAIL ") + k)
+            ok = ok and bool(v)
+        print("DIST_RESULT", "PASS" if ok else "FAIL", "world", world, "contacts", len(rp), "iters", iters,
+              "single", rs.num_iters)
+    flag = torch.tensor([1 if ok else 0])
+    dist.broadcast(flag, src=0)
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""Host logic of the domain-decomposed path, on CPU: the Hilbert ordering against the reference's KAT lists, the
+partition / halo bookkeeping, and the Comm wrapper in a 2-rank gloo run (no GPU, no compute calls)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_hilbert_positions_match_reference_kats(oracle):
+    # mundy/math/tests/unit_tests/UnitTestHilbert.cpp:48-295 (s = 2, 4, 8) and the oracle's recursive generator
+    from mundy_amd import distributed as D
+    kat = json.load(open(os.path.join(GOLD, "hilbert_kat.json")))
+    for level, name in ((1, "Cube2"), (2, "Cube4"), (3, "Cube8")):
+        np.testing.assert_array_equal(D.hilbert_positions(level), np.array(kat[name]["positions"], dtype=np.int64))
+    for level in (4, 5):
+        np.testing.assert_array_equal(D.hilbert_positions(level), oracle.hilbert_3d(1 << level).astype(np.int64))
+    t = D.hilbert_key_table(3)
+    pos = D.hilbert_positions(3)
+    assert sorted(t.ravel().tolist()) == list(range(512))
+    np.testing.assert_array_equal(t[pos[:, 0], pos[:, 1], pos[:, 2]], np.arange(512))
+    # consecutive curve points are lattice neighbours (what makes contiguous ranges compact domains)
+    assert np.all(np.abs(np.diff(D.hilbert_positions(5), axis=0)).sum(axis=1) == 1)
+
+
+def test_hilbert_order_and_partition():
+    from mundy_amd import distributed as D
+    rng = np.random.default_rng(0)
+    c = rng.uniform(0, 10, (5000, 3))
+    order = D.hilbert_order(c, 0.0, 10.0, level=4)
+    assert sorted(order.tolist()) == list(range(5000))
+    cell = np.clip(np.floor(c / 10.0 * 16).astype(int), 0, 15)
+    key = D.hilbert_key_table(4)[cell[:, 0], cell[:, 1], cell[:, 2]]
+    assert np.all(np.diff(key[order]) >= 0)
+    same = np.diff(key[order]) == 0
+    assert np.all(np.diff(order)[same] > 0)          # ties keep index order (stable)
+    starts = D.partition_ranges(5003, 4)
+    assert starts.tolist() == [0, 1251, 2502, 3753, 5003]
+    # compactness: a quarter of the curve spans far less than the whole box in at least one direction
+    q = c[order[:1250]]
+    assert (q.max(axis=0) - q.min(axis=0)).min() < 7.0
+
+
+def test_halo_layout():
+    from mundy_amd import distributed as D
+    counts = [[0, 5, 0, 2], [3, 0, 7, 0], [0, 4, 0, 1], [6, 0, 8, 0]]
+    recv, n_lo, n_hi, off = D.halo_layout(counts, 2)
+    assert recv == [0, 7, 0, 8] and n_lo == 7 and n_hi == 8 and off == [0, 0, 7, 7]
+    recv, n_lo, n_hi, off = D.halo_layout(counts, 0)
+    assert recv == [0, 3, 0, 6] and n_lo == 0 and n_hi == 9
+
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group(backend="gloo")
+from mundy_amd import distributed as D
+comm = D.Comm()
+r, w = comm.rank, comm.world
+assert w == 2 and not comm.direct
+g = comm.all_gather(torch.tensor([float(r), 10.0 + r, 20.0 + r], dtype=torch.float64))
+assert g.tolist() == [[0.0, 10.0, 20.0], [1.0, 11.0, 21.0]], g
+send = {1 - r: torch.full((3 + r, 6), float(r), dtype=torch.float64)}
+recv = {1 - r: torch.empty((4 - r, 6), dtype=torch.float64)}
+comm.exchange(send, recv)
+assert torch.all(recv[1 - r] == float(1 - r))
+comm.exchange({}, {})
+counts = comm.all_gather(torch.tensor([0, 5] if r == 0 else [3, 0], dtype=torch.int64)).tolist()
+assert counts == [[0, 5], [3, 0]]
+dist.destroy_process_group()
+print("COMM_OK", r)
+'''
+
+
+def test_comm_two_ranks_gloo(tmp_path):
+    script = tmp_path / "comm_worker.py"
+    script.write_text(WORKER % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29571", str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert p.stdout.count("COMM_OK") == 2
