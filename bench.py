@@ -13,9 +13,10 @@ L = 2) at 40 % volume fraction, random positions/orientations (overlaps allowed,
 Every step starts from the same pristine input (restored by a device copy inside the timed region), so all steps do
 identical work.  Inputs are resident in HBM before the timed region starts.
 
-N > 1: each rank advances its own 10^6-body shard of the synthetic system (weak scaling, no data-path collective in
-this round: shards are independent boxes -- "replicas" of the path; the RCCL ghost halo is the next row of SURVEY 8e).
-`value` = timesteps of 10^6-spherocylinder shards completed per second over all ranks.
+N > 1 (weak scaling): ONE system of N x 10^6 spherocylinders in a box grown to keep the 40 % volume fraction, cut along
+a Hilbert curve into N contiguous ranges, one per GPU (mundy_amd/distributed.py): ghost-body halo at the neighbour-list
+build, and per BBPGD iteration a ghost-velocity halo (RCCL send/recv) + one 3-double all-gather.
+`value` = timesteps of 10^6-spherocylinder shards completed per second over all ranks (= N x global timesteps/s).
 """
 import argparse
 import json
@@ -56,11 +57,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mundy_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # MUNDY_BENCH_BACKEND=gloo lets several ranks share one GPU (development boxes have one): same code path, the halo
+    # is staged through the host.  The driver's multi-GPU runs use the default, nccl (= RCCL).
+    backend = os.environ.get("MUNDY_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     from mundy_amd import build as hip_build
     if rank == 0:
@@ -71,8 +79,9 @@ def main():
 
     n = args.bodies
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    # each rank's shard: its own index range of the counter-based generator (first = rank * n)
-    b = synth.spherocylinders(n, seed=1234, first=rank * n)
+    if world > 1:
+        return main_distributed(args, rank, world, dist, ops, synth, dev)
+    b = synth.spherocylinders(n, seed=1234)
     center, quat = dev(b["center"]), dev(b["quat"])
     radius, length = dev(b["radius"]), dev(b["length"])
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
@@ -158,7 +167,7 @@ def main():
                                    "AABB+%.2g neighbour list, frictionless LCP tol %.0e" % (args.buffer, args.tol),
                        "bodies_per_gpu": n, "contacts_per_gpu": contacts, "bbpgd_iters_per_step": iters,
                        "converged": [bool(s.converged) for s in stats],
-                       "parallelism": "1 shard per GPU, independent shards (no halo collective yet)"},
+                       "parallelism": "single GPU (N > 1: hilbert domain decomposition with RCCL halo)"},
             "contact_pairs_per_sec": round(world * contacts * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(world * sum(iters) / elapsed, 1),
             "roofline": roof, "cpu_baseline": cpu,
@@ -168,6 +177,85 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main_distributed(args, rank, world, dist, ops, synth, dev):
+    """N > 1: one Hilbert-partitioned system of world x bodies rods, RCCL halo (see module docstring)."""
+    from mundy_amd import distributed as D
+    n = args.bodies
+    n_total = n * world
+    # every rank derives the same global order from the counter-based generator (no set-up communication)
+    centers, box = synth.spherocylinder_centers(np.arange(n_total), n_total, seed=1234)
+    order = D.hilbert_order(centers, 0.0, box, level=7)
+    starts = D.partition_ranges(n_total, world)
+    a, e = int(starts[rank]), int(starts[rank + 1])
+    mine = order[a:e]
+    del centers
+    b = synth.spherocylinders(len(mine), seed=1234, n_total=n_total, indices=mine)
+    cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
+    st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
+                                     comm=D.Comm(), search_buffer=args.buffer, cfg=cfg, poll_every=32)
+    pristine_c, pristine_q = st.center.clone(), st.quat.clone()
+
+    def one_step(profile):
+        st.center.copy_(pristine_c)
+        st.quat.copy_(pristine_q)
+        st.profile = profile
+        return st.step(integrate=True)
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(False)
+    sync()
+    t0 = time.perf_counter()
+    stats = [one_step(True) for _ in range(args.steps)]
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    tot = torch.tensor([stats[-1]["owned_contacts"], stats[-1]["ghosts"], stats[-1]["local_contacts"]],
+                       dtype=torch.float64, device="cuda")
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    contacts_global, ghosts_global = int(tot[0].item()), int(tot[1].item())
+    iters = [s["num_iters"] for s in stats]
+    roof, extra = None, {}
+    if st.prof["iters"] > 0:
+        c_local = stats[-1]["local_contacts"]
+        con_ms = st.prof["con_ms"] / st.prof["iters"]
+        body_ms = st.prof["body_ms"] / st.prof["iters"]
+        con_bytes = 216.0 * c_local
+        achieved = con_bytes / (con_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_constraint<X_SOLVE,rot> (+k_reduce_local3), rank 0", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(con_ms, 4), "launches": st.prof["iters"], "bytes_per_launch": con_bytes}
+        extra = {"k_body": {"avg_launch_ms": round(body_ms, 4),
+                            "achieved_GBs": round((136.0 * c_local + 68.0 * n) / (body_ms * 1e-3) / 1e9, 1)}}
+    if rank == 0:
+        out = {
+            "metric": "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",
+            "value": round(world * args.steps / elapsed, 4), "unit": "timesteps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[3]: %dM spherocylinders r=0.5 L=2 at 40%% volume fraction, one system "
+                                   "Hilbert-partitioned over %d GPUs, AABB+%.2g neighbour list, frictionless LCP tol %.0e"
+                                   % (world, world, args.buffer, args.tol),
+                       "bodies_per_gpu": n, "bodies_total": n_total, "contacts_total": contacts_global,
+                       "ghost_bodies_total": ghosts_global, "bbpgd_iters_per_step": iters,
+                       "converged": [bool(s["converged"]) for s in stats],
+                       "parallelism": "hilbert domain decomposition dd%d: ghost-body halo per rebuild; per BBPGD "
+                                      "iteration ghost-velocity send/recv + 3-double all-gather (RCCL)" % world},
+            "contact_pairs_per_sec": round(contacts_global * args.steps / elapsed, 1),
+            "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
+            "roofline": roof, "cpu_baseline": None,
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    dist.destroy_process_group()
 
 
 def cpu_baseline(b, stepper, args, gpu_iters):

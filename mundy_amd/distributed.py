@@ -119,12 +119,13 @@ class Comm:
 
     def all_gather(self, t):
         """t: 1-D tensor (device or host) -> [world, len] tensor on the same device"""
-        if self.world == 1:
+        if self.world == 1 and not self.direct:
             return t.reshape(1, -1).clone()
-        if self.direct and t.is_cuda:
-            out = torch.empty((self.world, t.numel()), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out.reshape(-1), t.contiguous(), group=self.group)
-            return out
+        if self.direct:  # RCCL moves device memory only: host scalars (boxes, counts) ride through the GPU
+            src = t.contiguous() if t.is_cuda else t.cuda()
+            out = torch.empty((self.world, src.numel()), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(out.reshape(-1), src, group=self.group)
+            return out if t.is_cuda else out.cpu()
         src = t.detach().cpu().contiguous()
         parts = [torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(parts, src, group=self.group)
@@ -181,6 +182,8 @@ class DistributedContactStepper:
         self._synth = synth
         self.op = None
         self.stats = {}
+        self.profile = False          # per-stage torch.cuda.Event timing (same stream as the kernels)
+        self.prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 
     # -- ghost halo -----------------------------------------------------------------------------------------------------
     def _exchange_ghosts(self):
@@ -281,24 +284,45 @@ class DistributedContactStepper:
         capi.check(lib.mhip_bbpgd_stage_begin(op._h, _p(con["sep"]), C.byref(sp), C.byref(pc), _p(x), _p(g),
                                               _p(x_tmp), _p(g_tmp), _stream()))
 
+        events = []
+
+        def mark():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+
         def iteration(init):
+            prof = self.profile and not init
+            e0 = mark() if prof else None
             capi.check(lib.mhip_bbpgd_stage_body(op._h, init, _stream()))
+            e1 = mark() if prof else None
             self._halo_velocity()
+            e2 = mark() if prof else None
             capi.check(lib.mhip_bbpgd_stage_constraint(op._h, init, _p(local3), _stream()))
+            e3 = mark() if prof else None
             gathered = comm.all_gather(local3)
             capi.check(lib.mhip_bbpgd_stage_finalize(op._h, init, _p(gathered), comm.world, _stream()))
-            return gathered
+            if prof:
+                events.append((e0, e1, e2, e3))
 
         iteration(1)
         res, done = capi.SolveResult(), C.c_int(0)
-        enq = 0
+        enq, iter_before = 0, 0
         while True:
             capi.check(lib.mhip_bbpgd_stage_poll(op._h, C.byref(res), C.byref(done), _stream()))
+            if events:  # only the iterations that did work: those that advanced iter, plus the converging one
+                eff = min(len(events), int(res.num_iters) - iter_before + (1 if res.converged else 0))
+                for e0, e1, e2, e3 in events[:eff]:
+                    self.prof["body_ms"] += e0.elapsed_time(e1)
+                    self.prof["con_ms"] += e2.elapsed_time(e3)
+                self.prof["iters"] += eff
+                events.clear()
             if done.value or enq >= self.cfg.max_iters:
                 break
+            iter_before = int(res.num_iters)
             todo = min(self.poll_every, self.cfg.max_iters - enq)
             for _ in range(todo):
-                self._last = iteration(0)
+                iteration(0)
             enq += todo
         capi.check(lib.mhip_bbpgd_stage_end(op._h, C.byref(res), _stream()))
         self.lam, self.grad, self.contacts, self.pairs, self.counted = x, g, con, pairs, counted

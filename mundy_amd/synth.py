@@ -42,11 +42,20 @@ def spheres(n, radius=1.0, volume_fraction=0.40, seed=1234, first=0):
     return dict(center=np.ascontiguousarray(c), radius=np.full(n, float(radius)), box=L)
 
 
-def spherocylinders(n, radius=0.5, length=2.0, volume_fraction=0.40, seed=1234, first=0, n_total=None):
+def spherocylinder_centers(indices, n_total, radius=0.5, length=2.0, volume_fraction=0.40, seed=1234):
+    """centres only, for explicit global indices (used to order a large system before a rank materialises its slice)"""
+    idx = np.asarray(indices)
+    vol = np.pi * radius ** 2 * length + 4.0 / 3.0 * np.pi * radius ** 3
+    L = box_edge(n_total, vol, volume_fraction)
+    return np.ascontiguousarray(np.stack([uniform01(seed, idx, s) * L for s in (0, 1, 2)], axis=1)), L
+
+
+def spherocylinders(n, radius=0.5, length=2.0, volume_fraction=0.40, seed=1234, first=0, n_total=None, indices=None):
     """n spherocylinders (centre, unit quaternion, radius, length).  Orientation: axis u uniform on the sphere,
     q = quat_from_parallel_transport(zhat, u) (randomize.hpp:79-84, Quaternion.hpp:1489-1505).  Body volume
     pi r^2 L + 4/3 pi r^3; the box edge comes from n_total (default n) so shards of one system share a box."""
-    idx = np.arange(first, first + n)
+    idx = np.arange(first, first + n) if indices is None else np.asarray(indices)
+    n = len(idx)
     vol = np.pi * radius ** 2 * length + 4.0 / 3.0 * np.pi * radius ** 3
     L = box_edge(n if n_total is None else n_total, vol, volume_fraction)
     c = np.stack([uniform01(seed, idx, s) * L for s in (0, 1, 2)], axis=1)

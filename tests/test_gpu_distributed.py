@@ -45,6 +45,8 @@ def test_nccl_transport_single_rank():
         assert comm.direct and comm.world == 1
         t = torch.arange(3, dtype=torch.float64, device="cuda")
         assert torch.equal(comm.all_gather(t), t.reshape(1, 3))
+        h = torch.tensor([4, 5], dtype=torch.int64)          # host scalars ride through the GPU with nccl
+        assert comm.all_gather(h).tolist() == [[4, 5]] and not comm.all_gather(h).is_cuda
         b = synth.spherocylinders(8000, seed=3)
         cfg = ops.PGDConfig(max_iters=20000, tol=1e-6)
         st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), 0,
