@@ -89,6 +89,21 @@ int mhip_distance_point_segment(size_t n, const double* p, const double* a0, con
 int mhip_distance_segment_segment(size_t n, const double* a0, const double* a1, const double* b0, const double* b1,
                                   double* dist, double* cp1, double* cp2, double* s, double* t, double* sep,
                                   mhip_stream_t stream);
+/* Ellipsoids: shared-normal signed distance by 3x3 multistart L-BFGS(10) over the normal's (theta, phi).
+ * Replaces: distance(SharedNormalSigned, Ellipsoid, Ellipsoid, cp1, cp2, n1, n2)
+ *           mundy/geom/src/mundy_geom/distance/EllipsoidEllipsoid.hpp:106-151, distance(Point, Ellipsoid, cp, n)
+ *           .../PointEllipsoid.hpp:94-135, minimiser mundy/math/src/mundy_math/impl/minimize_impl.hpp:151-605.
+ * radii [n][3] = body-frame semi-axes.  Tolerance against the host: 1e-4 (the reference's own,
+ * UnitTestEllipsoidEllipsoid.cpp:52-53): device sin/cos differ from libm in the last bits. */
+int mhip_distance_ellipsoid_ellipsoid(size_t n, const double* c1, const double* q1, const double* r1,
+                                      const double* c2, const double* q2, const double* r2, double* dist, double* cp1,
+                                      double* cp2, double* n1, double* n2, mhip_stream_t stream);
+int mhip_distance_point_ellipsoid(size_t n, const double* p, const double* c, const double* q, const double* r,
+                                  double* dist, double* cp, double* normal, mhip_stream_t stream);
+/* neighbour-list form: sep, normal = n1, foot points cp1/cp2, lever arms ra/rb about the body centres */
+int mhip_contact_ellipsoids(size_t c, const int32_t* pairs, const double* center, const double* quat,
+                            const double* radii, double* sep, double* normal, double* cp1, double* cp2, double* ra,
+                            double* rb, mhip_stream_t stream);
 /* contact generation over a neighbour list: sep = |c_j - c_i| - r_i - r_j, normal = (c_j - c_i)/|c_j - c_i|.
  * box [host] = NULL (free space) or 3 doubles: PeriodicScaledMetric::sep (periodicity.hpp:812-816) minimum image. */
 int mhip_contact_spheres(size_t c, const int32_t* pairs, const double* center, const double* radius,

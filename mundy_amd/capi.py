@@ -56,6 +56,9 @@ SIGNATURES = {
     "mhip_distance_sphere_sphere": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_distance_point_segment": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_distance_segment_segment": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_distance_ellipsoid_ellipsoid": [_sz] + [_vp] * 12,
+    "mhip_distance_point_ellipsoid": [_sz] + [_vp] * 8,
+    "mhip_contact_ellipsoids": [_sz] + [_vp] * 11,
     "mhip_contact_spheres": [_sz, _vp, _vp, _vp, C.POINTER(_d), _vp, _vp, _vp],
     "mhip_contact_spherocylinders": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_broadphase_create": [C.POINTER(_vp)],

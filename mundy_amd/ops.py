@@ -124,6 +124,34 @@ def distance_segment_segment(a0, a1, b0, b1):
     return dist, cp1, cp2, s, t, sep
 
 
+def distance_ellipsoid_ellipsoid(c1, q1, r1, c2, q2, r2):
+    n = c1.shape[0]
+    out = dict(dist=_new(c1, n), cp1=_new(c1, n, 3), cp2=_new(c1, n, 3), n1=_new(c1, n, 3), n2=_new(c1, n, 3))
+    capi.check(capi.load().mhip_distance_ellipsoid_ellipsoid(
+        n, _ptr(c1, cols=3), _ptr(q1, cols=4), _ptr(r1, cols=3), _ptr(c2, cols=3), _ptr(q2, cols=4), _ptr(r2, cols=3),
+        _ptr(out["dist"]), _ptr(out["cp1"]), _ptr(out["cp2"]), _ptr(out["n1"]), _ptr(out["n2"]), _stream()))
+    return out
+
+
+def distance_point_ellipsoid(p, c, q, r):
+    n = p.shape[0]
+    dist, cp, nrm = _new(p, n), _new(p, n, 3), _new(p, n, 3)
+    capi.check(capi.load().mhip_distance_point_ellipsoid(n, _ptr(p, cols=3), _ptr(c, cols=3), _ptr(q, cols=4),
+                                                         _ptr(r, cols=3), _ptr(dist), _ptr(cp), _ptr(nrm), _stream()))
+    return dist, cp, nrm
+
+
+def contact_ellipsoids(pairs, center, quat, radii):
+    c = pairs.shape[0]
+    out = dict(sep=_new(center, c), normal=_new(center, c, 3), cp1=_new(center, c, 3), cp2=_new(center, c, 3),
+               ra=_new(center, c, 3), rb=_new(center, c, 3))
+    capi.check(capi.load().mhip_contact_ellipsoids(
+        c, _ptr(pairs, torch.int32, 2), _ptr(center, cols=3), _ptr(quat, cols=4), _ptr(radii, cols=3),
+        _ptr(out["sep"]), _ptr(out["normal"]), _ptr(out["cp1"]), _ptr(out["cp2"]), _ptr(out["ra"]), _ptr(out["rb"]),
+        _stream()))
+    return out
+
+
 def contact_spheres(pairs, center, radius, box=None, out=None):
     c = pairs.shape[0]
     sep, normal = (_new(center, c), _new(center, c, 3)) if out is None else out

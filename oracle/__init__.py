@@ -371,3 +371,29 @@ def hilbert_3d(s, cur=(0.0, 0.0, 0.0), dr1=(1.0, 0.0, 0.0), dr2=(0.0, 1.0, 0.0),
     pos = np.empty((s * s * s, 3))
     lib().o_hilbert_3d(C.c_size_t(s), _p(_f(cur)), _p(_f(dr1)), _p(_f(dr2)), _p(_f(dr3)), _p(pos))
     return pos
+
+
+# ---- ellipsoids / minimize ------------------------------------------------------------------------------------------
+def distance_ellipsoid_ellipsoid(c1, q1, r1, c2, q2, r2, fast=False):
+    c1, q1, r1, c2, q2, r2 = _f(c1), _f(q1), _f(r1), _f(c2), _f(q2), _f(r2)
+    n = len(c1)
+    out = dict(dist=np.empty(n), cp1=np.empty((n, 3)), cp2=np.empty((n, 3)), n1=np.empty((n, 3)), n2=np.empty((n, 3)))
+    lib(fast).o_distance_ellipsoid_ellipsoid(C.c_size_t(n), _p(c1), _p(q1), _p(r1), _p(c2), _p(q2), _p(r2),
+                                             _p(out["dist"]), _p(out["cp1"]), _p(out["cp2"]), _p(out["n1"]),
+                                             _p(out["n2"]))
+    return out
+
+
+def distance_point_ellipsoid(p, c, q, r):
+    p, c, q, r = _f(p), _f(c), _f(q), _f(r)
+    n = len(p)
+    dist, cp, nrm = np.empty(n), np.empty((n, 3)), np.empty((n, 3))
+    lib().o_distance_point_ellipsoid(C.c_size_t(n), _p(p), _p(c), _p(q), _p(r), _p(dist), _p(cp), _p(nrm))
+    return dist, cp, nrm
+
+
+def minimize_test(kind, x0):
+    x = _f(x0).copy()
+    L = lib()
+    L.o_minimize_test.restype = C.c_double
+    return L.o_minimize_test(C.c_int(kind), _p(x)), x

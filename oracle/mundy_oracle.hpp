@@ -352,6 +352,327 @@ inline double contact_spheres_periodic(const PeriodicScaledMetric& m, const V3& 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// mundy::math minimize: allocation-free L-BFGS + Fletcher line search + central differences
+// (mundy/math/src/mundy_math/impl/minimize_impl.hpp:46-605, mundy_math/minimize.hpp:42-51)
+// ---------------------------------------------------------------------------------------------------------------
+namespace minimize {
+constexpr double kEps = 2.220446049250313e-16;  // Kokkos::Experimental::epsilon_v<double>
+
+inline double put_in_range(double mn, double mx, double v) { return (v < mn) ? mn : (v > mx) ? mx : v; }
+
+// minimize_impl.hpp:57-87
+inline double poly_min_extrap(double f0, double d0, double f1, double d1, double limit = 1) {
+  const double n = 3 * (f1 - f0) - 2 * d0 - d1;
+  const double e = d0 + d1 - 2 * (f1 - f0);
+  const double temp_sqr = std::max(n * n - 3 * e * d0, 0.0);
+  if (temp_sqr < 0) return 0.5;
+  if (std::fabs(e) <= kEps) return 0.5;
+  const double temp = std::sqrt(temp_sqr);
+  const double x1 = (temp - n) / (3 * e);
+  const double x2 = -(temp + n) / (3 * e);
+  const double y1 = f0 + d0 * x1 + n * x1 * x1 + e * x1 * x1 * x1;
+  const double y2 = f0 + d0 * x2 + n * x2 * x2 + e * x2 * x2 * x2;
+  const double x = (y1 < y2) ? x1 : x2;
+  return put_in_range(0, limit, x);
+}
+
+template <size_t N>
+struct Vec {
+  double v[N];
+  double& operator[](size_t i) { return v[i]; }
+  const double& operator[](size_t i) const { return v[i]; }
+};
+template <size_t N>
+inline double vdot(const Vec<N>& a, const Vec<N>& b) {  // right fold, as mundy::math::dot
+  double acc = a[N - 1] * b[N - 1];
+  for (size_t i = N - 1; i-- > 0;) acc = a[i] * b[i] + acc;
+  return acc;
+}
+
+// central_differences (minimize_impl.hpp:194-230)
+template <size_t N, class F>
+inline Vec<N> central_diff(const F& f, const Vec<N>& x, double eps) {
+  Vec<N> der, e = x;
+  for (size_t i = 0; i < N; ++i) {
+    const double old_val = e[i];
+    e[i] += eps;
+    const double delta_plus = f(e);
+    e[i] = old_val - eps;
+    const double delta_minus = f(e);
+    der[i] = (delta_plus - delta_minus) / ((old_val + eps) - (old_val - eps));
+    e[i] = old_val;
+  }
+  return der;
+}
+
+// line_search (minimize_impl.hpp:233-405); f and der are functions of the scalar step
+template <class F, class D>
+inline double line_search(const F& f, double f0, const D& der, double d0, double rho, double sigma, double min_f,
+                          size_t max_iter) {
+  const double tau1a = 1.4, tau1b = 9, tau2 = 1.0 / 10.0, tau3 = 1.0 / 2.0;
+  if (std::fabs(d0) <= std::fabs(f0) * kEps) return 0;
+  if (f0 <= min_f) return 0;
+  const double mu = (min_f - f0) / (rho * d0);
+  double alpha = 1;
+  if (mu < 0) alpha = -alpha;
+  alpha = put_in_range(0, 0.65 * mu, alpha);
+  double last_alpha = 0, last_val = f0, last_val_der = d0;
+  double a, b, a_val, b_val, a_val_der, b_val_der;
+  const double thresh = std::fabs(sigma * d0);
+  size_t itr = 0;
+  while (true) {
+    ++itr;
+    const double val = f(alpha);
+    const double val_der = der(alpha);
+    if (val <= min_f) return alpha;
+    if (val > f0 + rho * alpha * d0 || val >= last_val) {
+      a_val = last_val; a_val_der = last_val_der; b_val = val; b_val_der = val_der;
+      a = last_alpha; b = alpha;
+      break;
+    }
+    if (std::fabs(val_der) <= thresh) return alpha;
+    if (last_alpha == alpha || itr >= max_iter) return alpha;
+    if (val_der >= 0) {
+      a_val = val; a_val_der = val_der; b_val = last_val; b_val_der = last_val_der;
+      a = alpha; b = last_alpha;
+      break;
+    }
+    const double temp = alpha;
+    double first, last;
+    if (mu > 0) {
+      first = std::min(mu, alpha + tau1a * (alpha - last_alpha));
+      last = std::min(mu, alpha + tau1b * (alpha - last_alpha));
+    } else {
+      first = std::max(mu, alpha + tau1a * (alpha - last_alpha));
+      last = std::max(mu, alpha + tau1b * (alpha - last_alpha));
+    }
+    if (last_alpha < alpha) {
+      alpha = last_alpha + (alpha - last_alpha) * poly_min_extrap(last_val, last_val_der, val, val_der, 1e10);
+    } else {
+      alpha = alpha + (last_alpha - alpha) * poly_min_extrap(val, val_der, last_val, last_val_der, 1e10);
+    }
+    alpha = put_in_range(first, last, alpha);
+    last_alpha = temp;
+    last_val = val;
+    last_val_der = val_der;
+  }
+  while (true) {
+    ++itr;
+    const double first = a + tau2 * (b - a);
+    const double last = b - tau3 * (b - a);
+    alpha = a + (b - a) * poly_min_extrap(a_val, a_val_der, b_val, b_val_der);
+    alpha = put_in_range(first, last, alpha);
+    const double val = f(alpha);
+    const double val_der = der(alpha);
+    if (val <= min_f || itr >= max_iter) return alpha;
+    if (a == first || b == last) return b;
+    const double max_possible_alpha = std::max(std::fabs(a), std::fabs(b));
+    if (std::fabs(max_possible_alpha * d0) <= std::fabs(f0) * kEps) return alpha;
+    if (val > f0 + rho * alpha * d0 || val >= a_val) {
+      b = alpha; b_val = val; b_val_der = val_der;
+    } else {
+      if (std::fabs(val_der) <= thresh) return alpha;
+      if ((b - a) * val_der >= 0) {
+        b = a; b_val = a_val; b_val_der = a_val_der;
+      }
+      a = alpha; a_val = val; a_val_der = val_der;
+    }
+  }
+}
+
+// lbfgs_search_strategy (minimize_impl.hpp:407-566), M = history size
+template <size_t M, size_t N>
+struct Lbfgs {
+  struct Item {
+    Vec<N> s, y;
+    double rho;
+  };
+  Item data[M];
+  double alpha[M];
+  bool been_used = false;
+  size_t current_size = 0;
+  Vec<N> prev_x, prev_derivative, prev_direction;
+
+  const Vec<N>& next_direction(const Vec<N>& x, const Vec<N>& g) {
+    for (size_t k = 0; k < N; ++k) prev_direction[k] = -g[k];
+    if (!been_used) {
+      been_used = true;
+    } else {
+      Item t;
+      for (size_t k = 0; k < N; ++k) {
+        t.s[k] = x[k] - prev_x[k];
+        t.y[k] = g[k] - prev_derivative[k];
+      }
+      const double temp = vdot(t.s, t.y);
+      if (std::fabs(temp) > kEps) {
+        t.rho = 1.0 / temp;
+        if (current_size < M) {
+          data[current_size++] = t;
+        } else {
+          for (size_t i = 1; i < M; ++i) data[i - 1] = data[i];  // rotate_data: drop the oldest (:556-565)
+          data[M - 1] = t;
+        }
+      } else {
+        current_size = 0;
+      }
+      if (current_size > 0) {
+        for (size_t i = 0; i < M; ++i) alpha[i] = 0.0;
+        for (size_t i = current_size; i-- > 0;) {
+          alpha[i] = data[i].rho * vdot(data[i].s, prev_direction);
+          for (size_t k = 0; k < N; ++k) prev_direction[k] = prev_direction[k] - alpha[i] * data[i].y[k];
+        }
+        double H_0 = 1.0 / data[current_size - 1].rho / vdot(data[current_size - 1].y, data[current_size - 1].y);
+        H_0 = put_in_range(0.001, 1000.0, H_0);
+        for (size_t k = 0; k < N; ++k) prev_direction[k] = H_0 * prev_direction[k];
+        for (size_t i = 0; i < current_size; ++i) {
+          const double beta = data[i].rho * vdot(data[i].y, prev_direction);
+          for (size_t k = 0; k < N; ++k) prev_direction[k] = prev_direction[k] + (alpha[i] - beta) * data[i].s[k];
+        }
+      }
+    }
+    prev_x = x;
+    prev_derivative = g;
+    return prev_direction;
+  }
+};
+
+// find_min_using_approximate_derivatives (minimize.hpp:42-51 + minimize_impl.hpp:568-599).  NB the reference's callers
+// pass their "min_objective_delta" as the THIRD argument, which is min_allowable_cost.
+template <size_t M, size_t N, class F>
+inline double find_min(const F& cost_func, Vec<N>& x, double min_allowable_cost = -std::numeric_limits<double>::infinity(),
+                       double min_objective_delta = 1e-7, double derivative_eps = 1e-7) {
+  Lbfgs<M, N> strat;
+  // objective_delta_stop_strategy (minimize_impl.hpp:151-191)
+  bool stop_used = false;
+  double prev_funct_value = 0;
+  auto should_continue = [&](double funct_value) {
+    if (stop_used && std::fabs(funct_value - prev_funct_value) < min_objective_delta) return false;
+    stop_used = true;
+    prev_funct_value = funct_value;
+    return true;
+  };
+  double cost = cost_func(x);
+  Vec<N> g = central_diff(cost_func, x, derivative_eps);
+  while (should_continue(cost) && cost > min_allowable_cost) {
+    const Vec<N> s = strat.next_direction(x, g);
+    auto phi = [&](double a) {
+      Vec<N> p;
+      for (size_t k = 0; k < N; ++k) p[k] = x[k] + a * s[k];
+      return cost_func(p);
+    };
+    auto dphi = [&](double a) { return (phi(a + derivative_eps) - phi(a - derivative_eps)) /
+                                       ((a + derivative_eps) - (a - derivative_eps)); };
+    const double alpha = line_search(phi, cost, dphi, vdot(g, s), 0.01, 0.9, min_allowable_cost, 100);
+    for (size_t k = 0; k < N; ++k) x[k] = alpha * s[k] + x[k];
+    g = central_diff(cost_func, x, derivative_eps);
+    cost = cost_func(x);
+  }
+  return cost;
+}
+}  // namespace minimize
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ellipsoids (mundy_geom/primitives/Ellipsoid.hpp:420-468, distance/EllipsoidEllipsoid.hpp:62-151,
+// distance/PointEllipsoid.hpp:61-135)
+// ---------------------------------------------------------------------------------------------------------------
+struct Ellipsoid {
+  V3 center;
+  Quat q;
+  V3 radii;
+};
+// Ellipsoid.hpp:420-460
+inline V3 map_body_frame_normal_to_ellipsoid(const V3& nhat, const Ellipsoid& el) {
+  const double r1 = el.radii.x, r2 = el.radii.y, r3 = el.radii.z;
+  const double sign0 = std::copysign(1.0, nhat.x), sign1 = std::copysign(1.0, nhat.y), sign2 = std::copysign(1.0, nhat.z);
+  double alpha1, alpha2;
+  if (sign0 * nhat.x > kZeroTol) {
+    const double tmp0 = 1.0 / (r1 * nhat.x);
+    const double tmp1 = tmp0 * r2 * nhat.y;
+    const double tmp2 = tmp0 * r3 * nhat.z;
+    alpha1 = 1.0 / (1.0 + tmp1 * tmp1);
+    alpha2 = 1.0 / (1.0 + tmp2 * tmp2 * alpha1);
+  } else if (sign1 * nhat.y > kZeroTol) {
+    const double tmp = r3 * nhat.z / (r2 * nhat.y);
+    alpha1 = 0.0;
+    alpha2 = 1.0 / (1.0 + tmp * tmp);
+  } else {
+    alpha1 = 0.0;
+    alpha2 = 0.0;
+  }
+  const double sa1 = std::sqrt(alpha1), sa2 = std::sqrt(alpha2);
+  const double x = 0.5 * sign0 * ((1.0 + sign0) * r1 + (1.0 - sign0) * r1) * sa1 * sa2;
+  const double y = 0.5 * sign1 * ((1.0 + sign1) * r2 + (1.0 - sign1) * r2) * std::sqrt(1.0 - alpha1) * sa2;
+  const double z = 0.5 * sign2 * ((1.0 + sign2) * r3 + (1.0 - sign2) * r3) * std::sqrt(1.0 - alpha2);
+  return {x, y, z};
+}
+// Ellipsoid.hpp:462-468
+inline V3 map_surface_normal_to_foot_point(const V3& lab_nhat, const Ellipsoid& el) {
+  const V3 body_nhat = qrot(conjugate(el.q), lab_nhat);
+  const V3 foot = map_body_frame_normal_to_ellipsoid(body_nhat, el);
+  return qrot(el.q, foot) + el.center;
+}
+struct EllipsoidPairResult {
+  double dist;
+  V3 cp1, cp2, n1, n2;
+};
+// EllipsoidEllipsoid.hpp:62-151
+inline EllipsoidPairResult distance_ellipsoid_ellipsoid(const Ellipsoid& e1, const Ellipsoid& e2) {
+  EllipsoidPairResult r;
+  auto objective = [&](const minimize::Vec<2>& tp) {
+    const double st = std::sin(tp[0]), ct = std::cos(tp[0]), sp = std::sin(tp[1]), cp = std::cos(tp[1]);
+    r.n1 = {st * cp, st * sp, ct};
+    r.n2 = {-r.n1.x, -r.n1.y, -r.n1.z};
+    r.cp1 = map_surface_normal_to_foot_point(r.n1, e1);
+    r.cp2 = map_surface_normal_to_foot_point(r.n2, e2);
+    return distance_point_point(r.cp1, r.cp2);
+  };
+  constexpr double pi = 3.141592653589793;
+  const double half_pi = 0.5 * pi, one_third_pi = pi / 3.0, five_third_pi = 5.0 * one_third_pi;
+  const double theta_guesses[3] = {0.0, half_pi, pi};
+  const double phi_guesses[3] = {one_third_pi, pi, five_third_pi};
+  double global_dist = std::numeric_limits<double>::infinity();
+  minimize::Vec<2> best{{0.0, 0.0}};
+  for (int t = 0; t < 3; ++t)
+    for (int p = 0; p < 3; ++p) {
+      minimize::Vec<2> tp{{theta_guesses[t], phi_guesses[p]}};
+      const double d = minimize::find_min<10, 2>(objective, tp, kRelaxedZeroTol);
+      if (d < global_dist) {
+        global_dist = d;
+        best = tp;
+      }
+    }
+  objective(best);
+  r.dist = dot(r.cp2 - r.cp1, r.n1);
+  return r;
+}
+// PointEllipsoid.hpp:94-135
+inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3& closest, V3& normal) {
+  auto objective = [&](const minimize::Vec<2>& tp) {
+    const double st = std::sin(tp[0]), ct = std::cos(tp[0]), sp = std::sin(tp[1]), cp = std::cos(tp[1]);
+    normal = {st * cp, st * sp, ct};
+    closest = map_surface_normal_to_foot_point(normal, el);
+    return distance_point_point(closest, point);
+  };
+  constexpr double pi = 3.141592653589793;
+  const double half_pi = 0.5 * pi, one_third_pi = pi / 3.0, five_third_pi = 5.0 * one_third_pi;
+  const double theta_guesses[3] = {0.0, half_pi, pi};
+  const double phi_guesses[3] = {one_third_pi, pi, five_third_pi};
+  double global_dist = std::numeric_limits<double>::infinity();
+  minimize::Vec<2> best{{0.0, 0.0}};
+  for (int t = 0; t < 3; ++t)
+    for (int p = 0; p < 3; ++p) {
+      minimize::Vec<2> tp{{theta_guesses[t], phi_guesses[p]}};
+      const double d = minimize::find_min<10, 2>(objective, tp, kRelaxedZeroTol);
+      if (d < global_dist) {
+        global_dist = d;
+        best = tp;
+      }
+    }
+  objective(best);
+  return dot(point - closest, normal);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // mundy::math::convex -- spaces, residual policies, BB step, BBPGD (convex.hpp)
 // ---------------------------------------------------------------------------------------------------------------
 enum SpaceKind : int { kUnconstrained = 0, kLowerBound = 1, kUpperBound = 2, kBounded = 3 };

@@ -148,6 +148,58 @@ void o_contact_spherocylinders(size_t C, const int32_t* pairs, const double* seg
   }
 }
 
+// ---- ellipsoids / minimize ------------------------------------------------------------------------------------------
+void o_distance_ellipsoid_ellipsoid(size_t n, const double* c1, const double* q1, const double* r1, const double* c2,
+                                    const double* q2, const double* r2, double* dist, double* cp1, double* cp2,
+                                    double* n1, double* n2) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (size_t i = 0; i < n; ++i) {
+    const EllipsoidPairResult r = distance_ellipsoid_ellipsoid({ld3(c1, i), ldq(q1, i), ld3(r1, i)},
+                                                               {ld3(c2, i), ldq(q2, i), ld3(r2, i)});
+    dist[i] = r.dist;
+    if (cp1) st3(cp1, i, r.cp1);
+    if (cp2) st3(cp2, i, r.cp2);
+    if (n1) st3(n1, i, r.n1);
+    if (n2) st3(n2, i, r.n2);
+  }
+}
+void o_distance_point_ellipsoid(size_t n, const double* p, const double* c, const double* q, const double* r,
+                                double* dist, double* cp, double* nrm) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (size_t i = 0; i < n; ++i) {
+    V3 closest, normal;
+    dist[i] = distance_point_ellipsoid(ld3(p, i), {ld3(c, i), ldq(q, i), ld3(r, i)}, closest, normal);
+    if (cp) st3(cp, i, closest);
+    if (nrm) st3(nrm, i, normal);
+  }
+}
+// UnitTestMinimize.cpp:45-105 problems: kind 0 quadratic1, 1 quadratic2 (N = 2), 2 rosenbrock (N = 42)
+double o_minimize_test(int kind, double* x) {
+  using namespace minimize;
+  if (kind == 2) {
+    Vec<42> v;
+    for (int i = 0; i < 42; ++i) v[i] = x[i];
+    auto rosen = [](const Vec<42>& y) {
+      double sum = 0.0;
+      for (size_t i = 0; i < 41; ++i) sum += 2.0 * std::pow(y[i + 1] - y[i] * y[i], 2.0) + std::pow(1.0 - y[i], 2.0);
+      return sum;
+    };
+    const double c = find_min<10, 42>(rosen, v, 1e-7);
+    for (int i = 0; i < 42; ++i) x[i] = v[i];
+    return c;
+  }
+  Vec<2> v{{x[0], x[1]}};
+  double c;
+  if (kind == 0)
+    c = find_min<10, 2>([](const Vec<2>& y) { return y[0] * y[0] + y[1] * y[1]; }, v, 1e-7);
+  else
+    c = find_min<10, 2>([](const Vec<2>& y) { return (y[0] - 2.0) * (y[0] - 2.0) + (y[1] + 1.0) * (y[1] + 1.0); }, v,
+                        1e-7);
+  x[0] = v[0];
+  x[1] = v[1];
+  return c;
+}
+
 // ---- periodicity --------------------------------------------------------------------------------------------------
 void o_periodic_sep(size_t n, const double* box, const double* p1, const double* p2, double* out) {
   const PeriodicScaledMetric pm(V3{box[0], box[1], box[2]});

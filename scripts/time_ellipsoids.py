@@ -1,0 +1,13 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0, ".")
+from mundy_amd import ops
+rng = np.random.default_rng(0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+def ell():
+    c = rng.uniform(0, 4, (n, 3)); q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return dev(c), dev(q), dev(rng.uniform(0.4, 1.0, (n, 3)))
+a, b = ell(), ell()
+ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize()
+t = time.perf_counter(); ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize(); dt = time.perf_counter() - t
+print("ellipsoid pairs %d: %.3f s  -> %.3f us/pair, %.3g pairs/s" % (n, dt, 1e6 * dt / n, n / dt))
