@@ -256,6 +256,26 @@ int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gath
 int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, int* done /*[host]*/,
                           mhip_stream_t stream); /* synchronises */
 int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+/* In-kernel small problems: convex::MundyMathBackend<Scalar, N> (convex.hpp:288-350) runs the same solver
+ * on fixed-size Vector/Matrix inside a kernel; here one thread solves one dense n x n problem (1 <= n <= 16) of a
+ * batch: A [batch][n][n] row major, q [batch][n], x [batch][n] (initial guess in, solution out), grad [batch][n],
+ * per-problem num_iters / residual / converged (all device arrays).  Right-fold dot products and no |alpha|,|beta|
+ * fast paths, exactly as that backend evaluates them. */
+int mhip_solve_small_cqpp_batch(size_t batch, int n, const double* A, const double* q,
+                                const mhip_space* space /*[host]*/, const mhip_pgd_config* config /*[host]*/,
+                                double* x, double* grad, unsigned* num_iters, double* residual, int* converged,
+                                mhip_stream_t stream);
+/* The scrap app's own solver variant: resolve_collisions, scrap/lcp_spheres/NgpLcp.cpp:558-759 --
+ * Dai-Fletcher residual |min(g,0)| / |g| with the 1e-12 active-set test (:376-405), strict `< max_allowable_overlap`
+ * convergence, first step 1/residual, BB1/BB2 alternating by the parity of ite_count with the `|b| < 1e-12` guard
+ * (:716-731), ite_count counting started iterations.  lam is the initial guess (in) and the multipliers (out);
+ * lam_tmp, g, g_tmp are work vectors [C] (g = sep + dt*sep_dot on return).  *max_speed [host] receives max|U| over
+ * bodies (ComputeMaxVelocity :743-755; CollisionResult.max_displacement = max_speed * dt).  result->num_iters = ite_count,
+ * result->residual = max_abs_projected_sep. */
+int mhip_scrap_bbpgd_solve_contact(mhip_contact_op_t op, const double* sep, double max_allowable_overlap,
+                                   unsigned max_iterations, double* lam, double* lam_tmp, double* g, double* g_tmp,
+                                   mhip_solve_result* result /*[host]*/, double* max_speed /*[host]*/,
+                                   mhip_stream_t stream);
 /* Same algorithm driven kernel-by-kernel through the S1 vector entry points above (what the C++ adapter's
  * HipBackend does): the unfused reference structure, kept as an in-library cross-check of the fused path. */
 int mhip_bbpgd_solve_contact_unfused(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,

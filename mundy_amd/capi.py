@@ -85,6 +85,10 @@ SIGNATURES = {
                                C.POINTER(SolveResult), _vp],
     "mhip_bbpgd_solve_contact": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
                                  C.POINTER(SolveResult), _vp],
+    "mhip_solve_small_cqpp_batch": [_sz, _i, _vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
+                                    _vp, _vp],
+    "mhip_scrap_bbpgd_solve_contact": [_vp, _vp, _d, C.c_uint, _vp, _vp, _vp, _vp, C.POINTER(SolveResult),
+                                       C.POINTER(_d), _vp],
     "mhip_contact_op_set_partition": [_vp, _sz, _sz, _vp, _vp],
     "mhip_bbpgd_stage_begin": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp, _vp],
     "mhip_bbpgd_stage_body": [_vp, _i, _vp],

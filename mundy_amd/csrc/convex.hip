@@ -118,6 +118,84 @@ __global__ void __launch_bounds__(kBlock) k_gemv(size_t n, const double* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MundyMathBackend<Scalar, N> (convex.hpp:288-350): the whole BBPGD solve inside one thread on a small dense problem.
+// Right-fold dots (as mundy::math::dot / Matrix * Vector), no |alpha|,|beta| < 1e-15 branches, reduce_max from -inf:
+// bit-identical to a scalar evaluation of that backend.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSmallMax = 16;
+
+__device__ inline double rfold_dot(const double* a, const double* b, int n) {
+  double acc = a[n - 1] * b[n - 1];
+  for (int i = n - 2; i >= 0; --i) acc = a[i] * b[i] + acc;
+  return acc;
+}
+
+__global__ void __launch_bounds__(64)
+    k_small_cqpp(size_t batch, int n, const double* __restrict__ A, const double* __restrict__ q, Space sp,
+                 int resid_kind, unsigned max_iters, double tol, double* __restrict__ xout, double* __restrict__ gout,
+                 unsigned* __restrict__ iters, double* __restrict__ resout, int* __restrict__ conv) {
+  const size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= batch) return;
+  const double* Ap = A + p * (size_t)n * n;
+  const double* qp = q + p * (size_t)n;
+  double x[kSmallMax], g[kSmallMax], xt[kSmallMax], gt[kSmallMax], d1[kSmallMax], d2[kSmallMax];
+  auto apply = [&](const double* in, double* out) {
+    for (int i = 0; i < n; ++i) out[i] = rfold_dot(Ap + (size_t)i * n, in, n);
+  };
+  auto resid = [&](const double* xx, const double* gg) {
+    double mx = -__builtin_huge_val();
+    for (int i = 0; i < n; ++i) {
+      const double v = residual_term(resid_kind, xx[i], gg[i], sp);
+      if (v > mx) mx = v;
+    }
+    return resid_kind == MHIP_RESIDUAL_PROJECTED_GRADIENT ? mx : mx / kSmallStep;
+  };
+  for (int i = 0; i < n; ++i) {
+    x[i] = xout[p * (size_t)n + i];
+    xt[i] = x[i];
+    g[i] = 0.0;
+  }
+  apply(xt, gt);
+  for (int i = 0; i < n; ++i) gt[i] = 1.0 * qp[i] + 1.0 * gt[i];
+  double res = resid(xt, gt);
+  double step = 1.0 / res;
+  unsigned iter = 0;
+  bool converged = res <= tol;
+  if (converged)
+    for (int i = 0; i < n; ++i) g[i] = gt[i];
+  while (!(converged || iter >= max_iters)) {
+    for (int i = 0; i < n; ++i) x[i] = sp.project(1.0 * xt[i] + (-step) * gt[i]);
+    apply(x, g);
+    for (int i = 0; i < n; ++i) g[i] = 1.0 * qp[i] + 1.0 * g[i];
+    res = resid(x, g);
+    if (res <= tol) {
+      converged = true;
+      break;
+    }
+    for (int i = 0; i < n; ++i) {
+      d1[i] = x[i] - xt[i];
+      d2[i] = g[i] - gt[i];
+    }
+    const double num = rfold_dot(d1, d1, n);
+    double den = rfold_dot(d1, d2, n);
+    den += kBBEps * (fabs(den) < kBBEps ? 1.0 : 0.0);
+    step = num / den;
+    for (int i = 0; i < n; ++i) {
+      xt[i] = x[i];
+      gt[i] = g[i];
+    }
+    ++iter;
+  }
+  for (int i = 0; i < n; ++i) {
+    xout[p * (size_t)n + i] = x[i];
+    gout[p * (size_t)n + i] = g[i];
+  }
+  iters[p] = iter;
+  resout[p] = res;
+  conv[p] = converged ? 1 : 0;
+}
+
 // thread-local scratch for the blocking S1 reductions (the stream is synchronised before they return)
 struct ReduceScratch {
   DeviceBuffer dev;  // kMaxGrid partials + 1 result
@@ -186,7 +264,8 @@ int launch_copy(size_t n, double* dst, const double* src, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------------
 struct SolverState {  // device resident
   double step, residual, num, den;
-  unsigned iter;
+  unsigned iter;   // reported iteration count
+  unsigned flips;  // completed non-terminal iterations = parity of the x/x_tmp ping-pong
   int converged, done, converged_at_init;
 };
 
@@ -234,7 +313,7 @@ __global__ void __launch_bounds__(kBlock)
   double step = 0.0;
   if (MODE == X_SOLVE) {
     if (st->done) return;
-    if (st->iter & 1u) {
+    if (st->flips & 1u) {
       xt = X1;
       gt = G1;
     }
@@ -305,7 +384,7 @@ __global__ void __launch_bounds__(kBlock)
   double step = 0.0;
   if (MODE == X_SOLVE) {
     if (st->done) return;
-    if (st->iter & 1u) {
+    if (st->flips & 1u) {
       xt = X1; gt = G1; xn = X0; gn = G0;
     }
     step = st->step;
@@ -380,6 +459,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize(int nparts, const double* _
   if (MODE == X_INIT) {
     st->step = 1.0 / res;  // Dai-Fletcher initial step (convex.hpp:626-627)
     st->iter = 0;
+    st->flips = 0;
     st->converged = (res <= tol) ? 1 : 0;
     st->converged_at_init = st->converged;
     st->done = (st->converged || max_iters == 0) ? 1 : 0;
@@ -396,6 +476,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize(int nparts, const double* _
     st->den = den;
     st->step = num / den;
     st->iter += 1;
+    st->flips += 1;
     if (st->iter >= max_iters) st->done = 1;
   }
 }
@@ -423,11 +504,143 @@ __global__ void __launch_bounds__(kBlock) k_reduce_local3(int nparts, const doub
   }
 }
 
+// ---- the scrap app's BBPGD variant: resolve_collisions, scrap/lcp_spheres/NgpLcp.cpp:558-759 ----------
+//   residual  = max_i ( lam_i < 1e-12 ? |min(g_i, 0)| : |g_i| )      (ComputeMaxAbsProjectedSep, :376-405)
+//   converged iff residual < max_allowable_overlap (strict, :627, :671); first step 1/residual (:633)
+//   step      = BB1 (xx/xg) when ite_count is even, BB2 (xg/gg) when odd; |b| < 1e-12 -> b += 1e-12 (:716-731)
+//   ite_count counts started iterations, the converging one included (:636)
+//   quirk kept: the first projected step uses the gradient WITHOUT the A x_0 term (signed_sep_dot is still zero at
+//   :639; signed_sep_dot_tmp holds it) -- identical to the consistent form when the initial guess is zero.
+template <bool ROT, bool INIT>
+__global__ void __launch_bounds__(kBlock)
+    k_scrap_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
+                       double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q,
+                       double* __restrict__ partials) {
+  __shared__ double scratch[kBlock / 64];
+  const double* xt = X0;
+  const double* gt = G0;
+  double* xn = X1;
+  double* gn = INIT ? G0 : G1;
+  double step = 0.0;
+  bool first = false;
+  if (!INIT) {
+    if (st->done) return;
+    if (st->flips & 1u) {
+      xt = X1; gt = G1; xn = X0; gn = G0;
+    }
+    step = st->step;
+    first = (st->iter == 0);
+  }
+  const Space sp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
+  double rmax = kLowest, xx = 0.0, xg = 0.0, gg = 0.0;
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = op.pairs[c];
+    // UpdateConGammas (:532-548): max(lam_tmp - alpha * (sep + dt * sep_dot), 0)
+    const double gu = first ? q[c] : gt[c];
+    const double xc = INIT ? xt[c] : sp.project(xt[c] - step * gu);
+    const V3 n = load3(op.normal, c);
+    const double2* vi2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.x);
+    const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
+    const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
+    V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
+    if (ROT) {
+      const double2 a2 = vi2[2], b2 = vj2[2];
+      vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
+      vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    }
+    const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
+    const double g = q[c] + op.dt * sdot;  // sep_new = sep_old + dt * sep_dot
+    gn[c] = g;
+    if (!INIT) xn[c] = xc;
+    const double r = (xc < 1e-12) ? fabs((g < 0.0) ? g : 0.0) : fabs(g);
+    if (r > rmax) rmax = r;
+    if (!INIT) {
+      const double dx = xc - xt[c];
+      const double dg = g - gt[c];  // = dt * (sep_dot - sep_dot_tmp)
+      xx += dx * dx;
+      xg += dx * dg;
+      gg += dg * dg;
+    }
+  }
+  const double m = block_max(rmax, scratch);
+  const double s0 = block_sum(xx, scratch), s1 = block_sum(xg, scratch), s2 = block_sum(gg, scratch);
+  if (threadIdx.x == 0) {
+    partials[4 * blockIdx.x] = m;
+    partials[4 * blockIdx.x + 1] = s0;
+    partials[4 * blockIdx.x + 2] = s1;
+    partials[4 * blockIdx.x + 3] = s2;
+  }
+}
+
+// the first scrap iteration's body sweep must use the same (quirky) gradient as k_scrap_constraint: the host passes q
+// in place of g_tmp for that one launch (see mhip_scrap_bbpgd_solve_contact).
+template <bool INIT>
+__global__ void __launch_bounds__(kBlock) k_scrap_finalize(int nparts, const double* __restrict__ partials,
+                                                          SolverState* __restrict__ st, double tol,
+                                                          unsigned max_iters) {
+  __shared__ double scratch[kBlock / 64];
+  if (!INIT && st->done) return;
+  double rmax = kLowest, xx = 0.0, xg = 0.0, gg = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    if (partials[4 * i] > rmax) rmax = partials[4 * i];
+    xx += partials[4 * i + 1];
+    xg += partials[4 * i + 2];
+    gg += partials[4 * i + 3];
+  }
+  rmax = block_max(rmax, scratch);
+  xx = block_sum(xx, scratch);
+  xg = block_sum(xg, scratch);
+  gg = block_sum(gg, scratch);
+  if (threadIdx.x != 0) return;
+  st->residual = rmax;
+  if (INIT) {
+    st->iter = 0;
+    st->flips = 0;
+    st->converged = (rmax < tol) ? 1 : 0;
+    st->converged_at_init = st->converged;
+    st->done = (st->converged || max_iters == 0) ? 1 : 0;
+    st->step = 1.0 / rmax;
+    return;
+  }
+  st->iter += 1;  // ++ite_count at the top of the loop body (:636)
+  if (rmax < tol) {
+    st->converged = 1;
+    st->done = 1;
+    return;
+  }
+  double a, b;
+  if (st->iter % 2 == 0) {
+    a = xx; b = xg;   // Barzilai-Borwein choice 1
+  } else {
+    a = xg; b = gg;   // choice 2
+  }
+  if (fabs(b) < 1e-12) b += 1e-12;
+  st->num = a;
+  st->den = b;
+  st->step = a / b;
+  st->flips += 1;
+  if (st->iter >= max_iters) st->done = 1;
+}
+
+// ComputeMaxVelocity (NgpLcp.cpp:743-755): max |U| over bodies
+__global__ void __launch_bounds__(kBlock) k_max_speed(size_t n, const double* __restrict__ vel,
+                                                     double* __restrict__ partials) {
+  __shared__ double scratch[kBlock / 64];
+  double m = 0.0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double vx = vel[6 * i], vy = vel[6 * i + 1], vz = vel[6 * i + 2];
+    const double v = sqrt(vx * vx + vy * vy + vz * vz);
+    if (v > m) m = v;
+  }
+  const double r = block_max(m, scratch);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
 // restores the reference's post-conditions (see file header)
 __global__ void __launch_bounds__(kBlock) k_finish(size_t n, const SolverState* __restrict__ st,
                                                   double* __restrict__ X0, double* __restrict__ X1,
                                                   double* __restrict__ G0, double* __restrict__ G1) {
-  const bool p = st->iter & 1u;
+  const bool p = st->flips & 1u;
   const int mode = st->converged_at_init ? 0 : (st->converged ? (p ? 1 : 3) : 2);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     if (mode == 0) {
@@ -714,7 +927,7 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
   if (int e = op->cursor.reserve((N + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->inc.reserve((2 * C + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->vel.reserve((6 * N + 2) * sizeof(double))) return bail(e);
-  if (int e = op->partials.reserve((3 * kMaxGrid + 8) * sizeof(double))) return bail(e);
+  if (int e = op->partials.reserve((4 * kMaxGrid + 8) * sizeof(double))) return bail(e);
   if (int e = op->state.reserve(sizeof(SolverState) + 64)) return bail(e);
   if (int e = op->scanws.reserve(scan_workspace_bytes(N + 1) + 64)) return bail(e);
   {
@@ -881,6 +1094,95 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   }
   k_finish<<<grid_for(C), kBlock, 0, s>>>(C, st, x_tmp, x, g_tmp, g);
   MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipStreamSynchronize(s));
+  result->num_iters = op->host_state->iter;
+  result->residual = op->host_state->residual;
+  result->converged = op->host_state->converged;
+  return MHIP_SUCCESS;
+}
+
+int mhip_solve_small_cqpp_batch(size_t batch, int n, const double* A, const double* q, const mhip_space* space,
+                                const mhip_pgd_config* config, double* x, double* grad, unsigned* num_iters,
+                                double* residual, int* converged, mhip_stream_t stream) {
+  if (int e = check_config(config)) return e;
+  Space sp;
+  if (int e = to_space(space, &sp)) return e;
+  MHIP_REQUIRE(n >= 1 && n <= kSmallMax, MHIP_ERR_INVALID_ARGUMENT, "small-problem size must be in [1, %d], got %d",
+               kSmallMax, n);
+  if (batch == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(A && q && x && grad && num_iters && residual && converged, MHIP_ERR_INVALID_ARGUMENT,
+               "null argument");
+  k_small_cqpp<<<grid_exact(batch, 64), 64, 0, as_stream(stream)>>>(batch, n, A, q, sp, config->residual_kind,
+                                                                   config->max_iters, config->tol, x, grad, num_iters,
+                                                                   residual, converged);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_scrap_bbpgd_solve_contact(mhip_contact_op_t op, const double* sep, double max_allowable_overlap,
+                                   unsigned max_iterations, double* lam, double* lam_tmp, double* g, double* g_tmp,
+                                   mhip_solve_result* result, double* max_speed, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
+  const size_t C = op->view.C;
+  hipStream_t s = as_stream(stream);
+  result->num_iters = 0;
+  result->residual = -1.0;  // maximum_abs_projected_sep's initial value (:617)
+  result->converged = 1;
+  if (max_speed) *max_speed = 0.0;
+  if (C == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(sep && lam && lam_tmp && g && g_tmp, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not be null");
+  MHIP_REQUIRE(lam != lam_tmp && g != g_tmp && lam != g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not alias");
+  SolverState* st = op->state.as<SolverState>();
+  double* parts = op->partials.as<double>();
+  const unsigned cgrid = grid_for(C);
+  const Space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
+  auto constraint = [&](bool init) {
+#define SCON(R, I) k_scrap_constraint<R, I><<<cgrid, kBlock, 0, s>>>(op->view, st, lam_tmp, lam, g_tmp, g, sep, parts)
+    if (op->rot) { if (init) SCON(true, true); else SCON(true, false); }
+    else { if (init) SCON(false, true); else SCON(false, false); }
+#undef SCON
+  };
+  // gkm1 = D^T M D xkm1 with xkm1 = the given multipliers (:576-611)
+  if (int e = launch_copy(C, lam_tmp, lam, s)) return e;
+  MHIP_HIP(hipMemsetAsync(st, 0, sizeof(SolverState), s));
+  if (int e = op_launch_body(op, X_INIT, lam_tmp, lam, g_tmp, g, lcp, s)) return e;
+  constraint(true);
+  MHIP_LAUNCH_CHECK();
+  k_scrap_finalize<true><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, max_allowable_overlap, max_iterations);
+  MHIP_LAUNCH_CHECK();
+  unsigned enqueued = 0, chunk = 8;
+  for (;;) {
+    MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    if (op->host_state->done || enqueued >= max_iterations) break;
+    const unsigned todo = (max_iterations - enqueued < chunk) ? max_iterations - enqueued : chunk;
+    for (unsigned k = 0; k < todo; ++k) {
+      // first iteration: the projected step sees sep only (signed_sep_dot == 0 at :639) -> q stands in for g_tmp
+      const double* gbody = (enqueued + k == 0) ? sep : g_tmp;
+      if (int e = op_launch_body(op, X_SOLVE, lam_tmp, lam, gbody, g, lcp, s)) return e;
+      constraint(false);
+      MHIP_LAUNCH_CHECK();
+      k_scrap_finalize<false><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, max_allowable_overlap, max_iterations);
+      MHIP_LAUNCH_CHECK();
+    }
+    enqueued += todo;
+    if (chunk < 64) chunk *= 2;
+  }
+  k_finish<<<grid_for(C), kBlock, 0, s>>>(C, st, lam_tmp, lam, g_tmp, g);
+  MHIP_LAUNCH_CHECK();
+  if (max_speed && op->view.N > 0) {
+    ReduceScratch& rs = reduce_scratch();
+    if (int e = rs.ensure()) return e;
+    double* mp = rs.dev.as<double>();
+    const unsigned g2 = grid_for(op->view.N);
+    k_max_speed<<<g2, kBlock, 0, s>>>(op->view.N, op->view.vel, mp);
+    MHIP_LAUNCH_CHECK();
+    k_reduce_final<2><<<1, kBlock, 0, s>>>((int)g2, mp, mp + kMaxGrid);
+    MHIP_LAUNCH_CHECK();
+    MHIP_HIP(hipMemcpyAsync(rs.host, mp + kMaxGrid, sizeof(double), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    *max_speed = rs.host[0] < 0.0 ? 0.0 : rs.host[0];
+  }
   MHIP_HIP(hipStreamSynchronize(s));
   result->num_iters = op->host_state->iter;
   result->residual = op->host_state->residual;

@@ -409,6 +409,43 @@ def solve_cqpp(A, q, space, x0, cfg=None, state=None, fused=True):
     return x, g, SolveResult(int(res.num_iters), float(res.residual), bool(res.converged))
 
 
+def solve_small_cqpp_batch(A, q, space, x0, cfg=None):
+    """make_mundy_math_cqpp + solve_cqpp on a batch of small dense problems, one thread each (convex.hpp:288-350,
+    :722-733).  A [b, n, n], q [b, n], x0 [b, n]; returns (x, grad, num_iters, residual, converged) device tensors."""
+    cfg = cfg or PGDConfig()
+    b, n = q.shape
+    if A.shape != (b, n, n):
+        raise ValueError("A must be [batch, n, n]")
+    x = x0.clone()
+    g = torch.empty_like(x)
+    it = torch.empty(b, dtype=torch.int32, device=q.device)
+    res = torch.empty(b, dtype=torch.float64, device=q.device)
+    conv = torch.empty(b, dtype=torch.int32, device=q.device)
+    sp, pc = _space(space), _cfg(cfg)
+    capi.check(capi.load().mhip_solve_small_cqpp_batch(b, n, _ptr(A), _ptr(q), C.byref(sp), C.byref(pc), _ptr(x),
+                                                       _ptr(g), _ptr(it, torch.int32), _ptr(res),
+                                                       _ptr(conv, torch.int32), _stream()))
+    return x, g, it, res, conv.bool()
+
+
+@dataclass
+class CollisionResult:  # scrap/lcp_spheres/NgpLcp.cpp:550-554
+    max_abs_projected_sep: float = 0.0
+    ite_count: int = 0
+    max_displacement: float = 0.0
+
+
+def resolve_collisions(op, sep, lam, dt, max_allowable_overlap=1e-5, max_col_iterations=10000):
+    """The scrap app's own BBPGD (resolve_collisions, NgpLcp.cpp:558-759) on a ContactOperator.  `lam` is the initial
+    guess and receives the multipliers.  Returns (lam, g = sep + dt*sep_dot, CollisionResult)."""
+    lam_tmp, g, g_tmp = torch.empty_like(lam), torch.empty_like(lam), torch.empty_like(lam)
+    res, spd = capi.SolveResult(), C.c_double(0.0)
+    capi.check(capi.load().mhip_scrap_bbpgd_solve_contact(
+        op._h, _ptr(sep), float(max_allowable_overlap), int(max_col_iterations), _ptr(lam), _ptr(lam_tmp), _ptr(g),
+        _ptr(g_tmp), C.byref(res), C.byref(spd), _stream()))
+    return lam, g, CollisionResult(float(res.residual), int(res.num_iters), float(spd.value) * float(dt))
+
+
 def solve_lcp(A, q, x0, cfg=None, state=None, fused=True):
     """solve_lcp (convex.hpp:839-845): 0 <= A x + q  _|_  x >= 0."""
     return solve_cqpp(A, q, LCP_SPACE, x0, cfg, state, fused)

@@ -397,3 +397,30 @@ def minimize_test(kind, x0):
     L = lib()
     L.o_minimize_test.restype = C.c_double
     return L.o_minimize_test(C.c_int(kind), _p(x)), x
+
+
+def scrap_resolve_collisions(pairs, normal, ra, rb, mt, mr, dt, sep, lam0, max_allowable_overlap=1e-5, max_iters=10000):
+    """resolve_collisions of scrap/lcp_spheres/NgpLcp.cpp:558-759 (dry).  Returns (lam, g = sep + dt*sep_dot, result)."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    c = len(pairs)
+    lam, g = _f(lam0).copy(), np.zeros(c)
+    res, it, spd = C.c_double(), C.c_int(), C.c_double()
+    mt = _f(mt)
+    lib().o_scrap_resolve_collisions(
+        C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(_f(normal)), _p(None if ra is None else _f(ra)),
+        _p(None if rb is None else _f(rb)), _p(mt), _p(None if mr is None else _f(mr)), C.c_double(dt), _p(_f(sep)),
+        C.c_double(max_allowable_overlap), C.c_int(max_iters), _p(lam), _p(g), C.byref(res), C.byref(it), C.byref(spd))
+    return lam, g, dict(max_abs_projected_sep=res.value, ite_count=it.value, max_speed=spd.value)
+
+
+def solve_small_cqpp_batch(A, q, space, x0, resid_kind=RESID_PROJECTED_DIFF, max_iters=1000, tol=1e-8):
+    """MundyMathBackend (convex.hpp:288-350): a batch of independent n x n problems, one after the other."""
+    A, q = _f(A), _f(q)
+    b, n = q.shape
+    x = _f(x0).copy()
+    g = np.zeros((b, n))
+    it, res, conv = np.zeros(b, np.uint32), np.zeros(b), np.zeros(b, np.int32)
+    lib().o_solve_small_cqpp_batch(C.c_size_t(b), C.c_size_t(n), _p(A), _p(q), C.c_int(space[0]), C.c_double(space[1]),
+                                   C.c_double(space[2]), C.c_int(resid_kind), C.c_uint(max_iters), C.c_double(tol),
+                                   _p(x), _p(g), _p(it), _p(res), _p(conv))
+    return x, g, it, res, conv.astype(bool)

@@ -798,6 +798,69 @@ SolveResult solve_cqpp(const Op& A, const double* q, const Space& sp, int resid_
   return {iter, res, converged ? 1 : 0};
 }
 
+// MundyMathBackend<Scalar, N> (convex.hpp:288-350): the same solver on fixed-size Vector/Matrix inside a kernel.
+// Differences from KokkosBackend that change bits: dot products and matrix rows are RIGHT folds
+// (impl/VectorImpl.hpp:339-344, impl/MatrixImpl.hpp:348-355), axpby / wrapped_axpbyz have no |alpha|,|beta| < 1e-15
+// branches (:314-322), reduce_max starts from -infinity (:346).
+inline double rfold_dot(const double* a, const double* b, size_t n) {
+  double acc = a[n - 1] * b[n - 1];
+  for (size_t i = n - 1; i-- > 0;) acc = a[i] * b[i] + acc;
+  return acc;
+}
+inline SolveResult solve_cqpp_small(size_t n, const double* A, const double* q, const Space& sp, int resid_kind,
+                                    unsigned max_iters, double tol, double* x, double* g) {
+  std::vector<double> xt(n), gt(n), d1(n), d2(n);
+  auto apply = [&](const double* in, double* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = rfold_dot(A + i * n, in, n);
+  };
+  auto resid = [&](const double* xx, const double* gg) {
+    double mx = -std::numeric_limits<double>::infinity();
+    for (size_t i = 0; i < n; ++i) {
+      double v;
+      if (resid_kind == kProjectedGradient)
+        v = (xx[i] < kZeroTol) ? std::max(0.0, gg[i]) : std::fabs(gg[i]);
+      else
+        v = std::fabs(xx[i] - sp.project(xx[i] - 1e-6 * gg[i]));
+      if (v > mx) mx = v;
+    }
+    return resid_kind == kProjectedGradient ? mx : mx / 1e-6;
+  };
+  for (size_t i = 0; i < n; ++i) xt[i] = x[i];
+  apply(xt.data(), gt.data());
+  for (size_t i = 0; i < n; ++i) gt[i] = 1.0 * q[i] + 1.0 * gt[i];
+  double res = resid(xt.data(), gt.data());
+  double step = 1.0 / res;
+  unsigned iter = 0;
+  bool converged = res <= tol;
+  if (converged)
+    for (size_t i = 0; i < n; ++i) g[i] = gt[i];
+  while (!(converged || iter >= max_iters)) {
+    for (size_t i = 0; i < n; ++i) x[i] = sp.project(1.0 * xt[i] + (-step) * gt[i]);
+    apply(x, g);
+    for (size_t i = 0; i < n; ++i) g[i] = 1.0 * q[i] + 1.0 * g[i];
+    res = resid(x, g);
+    if (res <= tol) {
+      converged = true;
+      break;
+    }
+    for (size_t i = 0; i < n; ++i) {
+      d1[i] = x[i] - xt[i];
+      d2[i] = g[i] - gt[i];
+    }
+    const double num = rfold_dot(d1.data(), d1.data(), n);
+    double den = rfold_dot(d1.data(), d2.data(), n);
+    constexpr double eps = kZeroTol * 10;
+    den += eps * (std::fabs(den) < eps);
+    step = num / den;
+    for (size_t i = 0; i < n; ++i) {
+      xt[i] = x[i];
+      gt[i] = g[i];
+    }
+    ++iter;
+  }
+  return {iter, res, converged ? 1 : 0};
+}
+
 // Dense operator, row-major n x n (KokkosBlas::gemv "N", convex.hpp:168-174).
 struct DenseOp {
   const double* A;
@@ -872,6 +935,73 @@ struct ContactOp {
     }
   }
 };
+
+// The scrap app's own matrix-free BBPGD (scrap/lcp_spheres/NgpLcp.cpp:558-759, DRY mobility), serial order.
+// Differs from convex.hpp's PGDStrategy: Dai-Fletcher residual with a 1e-12 active-set test (:376-405), strict `<`
+// convergence test, BB1/BB2 alternating by the parity of ite_count with `|b| < 1e-12 -> b += 1e-12` (:716-731),
+// ite_count counts started iterations, and the first projected step uses signed_sep_dot (still zero) rather than
+// signed_sep_dot_tmp (:639) -- all reproduced as written.
+struct ScrapResult {
+  double max_abs_projected_sep;
+  int ite_count;
+  double max_speed;
+};
+inline ScrapResult scrap_resolve_collisions(const ContactOp& A, const double* sep, double max_allowable_overlap,
+                                            int max_col_iterations, double* lam, double* lam_tmp, double* sep_dot_dt,
+                                            double* sep_dot_dt_tmp) {
+  // sep_dot_dt holds dt * signed_sep_dot (the operator returns dt * sdot); the scrap code keeps sdot and multiplies by
+  // dt at each use: sep_new = sep + dt*sdot, gkdiff = dt*(sdot - sdot_tmp).  Same products, formed once here.
+  const size_t C = A.C;
+  int ite_count = 0;
+  std::copy(lam, lam + C, lam_tmp);
+  std::fill(sep_dot_dt, sep_dot_dt + C, 0.0);
+  std::fill(sep_dot_dt_tmp, sep_dot_dt_tmp + C, 0.0);
+  A(lam_tmp, sep_dot_dt_tmp);
+  auto residual = [&](const double* x, const double* gdt) {
+    double mx = std::numeric_limits<double>::lowest();
+    for (size_t i = 0; i < C; ++i) {
+      const double sep_new = sep[i] + gdt[i];
+      const double v = (x[i] < 1e-12) ? std::fabs(std::min(sep_new, 0.0)) : std::fabs(sep_new);
+      if (v > mx) mx = v;
+    }
+    return mx;
+  };
+  double res = residual(lam_tmp, sep_dot_dt_tmp);
+  if (!(res < max_allowable_overlap)) {
+    double alpha = 1.0 / res;
+    while (ite_count < max_col_iterations) {
+      ++ite_count;
+      for (size_t i = 0; i < C; ++i) lam[i] = std::max(lam_tmp[i] - alpha * (sep[i] + sep_dot_dt[i]), 0.0);
+      A(lam, sep_dot_dt);
+      res = residual(lam, sep_dot_dt);
+      if (res < max_allowable_overlap) break;
+      double xx = 0, xg = 0, gg = 0;
+      for (size_t i = 0; i < C; ++i) {
+        const double xd = lam[i] - lam_tmp[i];
+        const double gd = sep_dot_dt[i] - sep_dot_dt_tmp[i];
+        xx += xd * xd;
+        xg += xd * gd;
+        gg += gd * gd;
+      }
+      double a, b;
+      if (ite_count % 2 == 0) {
+        a = xx; b = xg;
+      } else {
+        a = xg; b = gg;
+      }
+      if (std::fabs(b) < 1e-12) b += 1e-12;
+      alpha = a / b;
+      std::copy(lam, lam + C, lam_tmp);
+      std::copy(sep_dot_dt, sep_dot_dt + C, sep_dot_dt_tmp);
+    }
+  }
+  double max_speed = 0.0;
+  for (size_t b = 0; b < A.N; ++b) {
+    const double v = std::sqrt(A.U[3 * b] * A.U[3 * b] + A.U[3 * b + 1] * A.U[3 * b + 1] + A.U[3 * b + 2] * A.U[3 * b + 2]);
+    if (v > max_speed) max_speed = v;
+  }
+  return {res, ite_count, max_speed};
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Neighbour search oracle.  The reference's search is stk::search::coarse_search (Trilinos 16.0.0, absent) at

@@ -261,6 +261,18 @@ void o_solve_cqpp_dense(size_t n, const double* A, const double* q, int kind, do
   *converged = r.converged;
 }
 
+void o_solve_small_cqpp_batch(size_t batch, size_t n, const double* A, const double* q, int kind, double lo, double hi,
+                              int resid_kind, unsigned max_iters, double tol, double* x, double* g, unsigned* iters,
+                              double* res, int* conv) {
+  for (size_t b = 0; b < batch; ++b) {
+    const SolveResult r = solve_cqpp_small(n, A + b * n * n, q + b * n, Space{kind, lo, hi}, resid_kind, max_iters, tol,
+                                           x + b * n, g + b * n);
+    iters[b] = r.num_iters;
+    res[b] = r.residual;
+    conv[b] = r.converged;
+  }
+}
+
 void o_contact_op_apply(size_t C, size_t N, const int32_t* pairs, const double* normal, const double* ra,
                         const double* rb, const double* mt, const double* mr, double dt, const double* x, double* y) {
   ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}};
@@ -276,6 +288,20 @@ void o_solve_cqpp_contact(size_t C, size_t N, const int32_t* pairs, const double
   *num_iters = r.num_iters;
   *res = r.residual;
   *converged = r.converged;
+}
+
+void o_scrap_resolve_collisions(size_t C, size_t N, const int32_t* pairs, const double* normal, const double* ra,
+                                const double* rb, const double* mt, const double* mr, double dt, const double* sep,
+                                double max_allowable_overlap, int max_iters, double* lam, double* g,
+                                double* res, int* ite_count, double* max_speed) {
+  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}};
+  std::vector<double> lam_tmp(C), gdt(C), gdt_tmp(C);
+  const ScrapResult r = scrap_resolve_collisions(op, sep, max_allowable_overlap, max_iters, lam, lam_tmp.data(),
+                                                 gdt.data(), gdt_tmp.data());
+  for (size_t i = 0; i < C; ++i) g[i] = sep[i] + gdt[i];
+  *res = r.max_abs_projected_sep;
+  *ite_count = r.ite_count;
+  *max_speed = r.max_speed;
 }
 
 // OpenMP version of the same unfused BBPGD (CPU baseline): identical kernel structure -- projection pass, operator

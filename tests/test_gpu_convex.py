@@ -166,6 +166,66 @@ def test_fused_bbpgd_matches_oracle_and_unfused(ops, oracle, maker, n):
     op.close()
 
 
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 4000), (_rod_problem, 3000)])
+def test_scrap_variant_matches_oracle(ops, oracle, maker, n):
+    # resolve_collisions of scrap/lcp_spheres/NgpLcp.cpp:558-759 (BB1/BB2 alternation, Dai-Fletcher residual)
+    from gpu_util import dev, host
+    P = maker(oracle, n, seed=21)
+    C = len(P["pairs"])
+    tol = 1e-5
+    op = _gpu_op(ops, P)
+    lam, g, res = ops.resolve_collisions(op, dev(P["sep"]), dev(np.zeros(C)), 5e-3, max_allowable_overlap=tol)
+    lo, go, ro = oracle.scrap_resolve_collisions(P["pairs"], P["normal"], P["ra"], P["rb"], P["mt"], P["mr"], 5e-3,
+                                                 P["sep"], np.zeros(C), max_allowable_overlap=tol)
+    assert res.max_abs_projected_sep < tol and ro["max_abs_projected_sep"] < tol
+    assert abs(res.ite_count - ro["ite_count"]) <= max(5, 0.15 * ro["ite_count"])
+    lam, g = host(lam), host(g)
+    assert lam.min() >= 0 and g.min() > -tol
+    np.testing.assert_allclose(g, go, atol=20 * tol)
+    assert res.max_displacement == pytest.approx(ro["max_speed"] * 5e-3, rel=1e-3)
+    # and it solves the same LCP as the convex.hpp solver
+    x2, g2, r2 = ops.solve_lcp(op, dev(P["sep"]), dev(np.zeros(C)), ops.PGDConfig(max_iters=10000, tol=tol))
+    np.testing.assert_allclose(g, host(g2), atol=40 * tol)
+    # nonzero initial guess exercises the first-step quirk (:639) identically on both sides
+    lam0 = np.abs(np.sin(np.arange(C))) * 0.01
+    lam_b, g_b, res_b = ops.resolve_collisions(op, dev(P["sep"]), dev(lam0), 5e-3, max_allowable_overlap=tol)
+    lo_b, go_b, ro_b = oracle.scrap_resolve_collisions(P["pairs"], P["normal"], P["ra"], P["rb"], P["mt"], P["mr"],
+                                                       5e-3, P["sep"], lam0, max_allowable_overlap=tol)
+    assert abs(res_b.ite_count - ro_b["ite_count"]) <= max(5, 0.15 * ro_b["ite_count"])
+    np.testing.assert_allclose(host(g_b), go_b, atol=20 * tol)
+    op.close()
+
+
+def test_in_kernel_small_problems_bit_exact(ops, oracle):
+    # MundyMathBackend.  Same scalar arithmetic in the same order -> bit-exact against the oracle, including
+    # iteration counts; the reference's own problems (UnitTestConvex.cpp:608-615) are in the batch.
+    from gpu_util import assert_bits_equal, dev, host
+    from test_oracle_convex_kat import random_lcp
+    rng = np.random.default_rng(3)
+    for n in (1, 3, 7, 16):
+        batch = 3000
+        As, qs, xs = [], [], []
+        for b in range(batch):
+            A, q, x_star = random_lcp(n, seed=1000 * n + b) if n > 1 else (np.array([[2.0]]), np.array([-1.0]), np.array([0.5]))
+            As.append(A); qs.append(q); xs.append(x_star)
+        A, q, x_star = np.array(As), np.array(qs), np.array(xs)
+        x0 = np.full((batch, n), 99.99)
+        cfg = ops.PGDConfig(max_iters=1000, tol=1e-6)
+        for space in ((1, 0.0, 0.0), (3, 0.05, 0.6)):
+            x, g, it, res, conv = ops.solve_small_cqpp_batch(dev(A), dev(q), space, dev(x0), cfg)
+            xo, go, ito, reso, convo = oracle.solve_small_cqpp_batch(A, q, space, x0, max_iters=1000, tol=1e-6)
+            assert_bits_equal(host(x), xo, "small x n=%d" % n)
+            assert_bits_equal(host(g), go, "small g n=%d" % n)
+            np.testing.assert_array_equal(host(it), ito.astype(np.int32))
+            assert_bits_equal(host(res), reso, "small residual")
+            np.testing.assert_array_equal(host(conv), convo)
+            if space[0] == 1:
+                assert convo.all()
+                np.testing.assert_allclose(host(x), x_star, atol=1e-5, rtol=0)
+    with pytest.raises(ValueError, match="size"):
+        ops.solve_small_cqpp_batch(dev(np.zeros((1, 17, 17))), dev(np.zeros((1, 17))), (1, 0.0, 0.0), dev(np.zeros((1, 17))))
+
+
 def test_state_vector_postconditions(ops, oracle):
     # what the caller-owned state holds on return (convex.hpp:614-666): converged -> x final / x_tmp previous iterate;
     # converged at init -> grad == grad_tmp; max_iters hit -> x == x_tmp

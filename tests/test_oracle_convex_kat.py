@@ -129,3 +129,19 @@ def test_contact_lcp_matches_dense_and_threaded(oracle):
     # the LCP solution (g, and the net body forces D x) is unique even when x is not
     # (tol 1e-6: at |x| ~ 60 the projected-diff residual is quantised in steps of ulp(x)/1e-6 ~ 7e-9)
     np.testing.assert_allclose(gt, g, atol=1e-5)
+
+
+def test_mundy_math_backend_problems(oracle):
+    # Convex.MundyMathAnalyticalSolutions (UnitTestConvex.cpp:529-561, :608-615): the in-kernel backend on the three
+    # 3x3 analytic problems and RandomLCP<3>, <7>: x0 = 99.99, max_iters 1000, tol 1e-6, |x - x*| <= 10 tol
+    for name, A, x_star, space in CASES:
+        x, g, it, res, conv = oracle.solve_small_cqpp_batch(A[None], (-A @ x_star)[None], space,
+                                                            np.full((1, 3), 99.99), max_iters=1000, tol=TOL)
+        assert conv[0] and it[0] <= 1000
+        np.testing.assert_allclose(x[0], x_star, atol=10 * TOL, rtol=0)
+    for n in (3, 7):
+        A, q, x_star = random_lcp(n, seed=100 + n)
+        x, g, it, res, conv = oracle.solve_small_cqpp_batch(A[None], q[None], (oracle.LOWER_BOUND, 0.0, 0.0),
+                                                            np.full((1, n), 99.99), max_iters=1000, tol=TOL)
+        assert conv[0]
+        np.testing.assert_allclose(x[0], x_star, atol=10 * TOL, rtol=0)
