@@ -114,6 +114,19 @@ int mhip_contact_spherocylinders(size_t c, const int32_t* pairs, const double* s
                                  double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
                                  double* t, mhip_stream_t stream);
 
+/* Mixed shapes (BASELINE configs[4]): kind[n] = 0 sphere, 1 spherocylinder, 2 ellipsoid; shape[n][3] = (r,-,-) /
+ * (r,L,-) / (r1,r2,r3); quat is ignored for spheres.  compute_aabb dispatches on kind (compute_aabb.hpp:72-127) and
+ * also returns the bounding radii (compute_bounding_radius.hpp:61-93).  contact_mixed bins the pairs by shape class and
+ * runs one distance routine per class: S-S, S-R (scrap/.../SphereSpherocylinderLinker.cpp:210-239), R-R, E-E as above;
+ * S-E = distance(Point, Ellipsoid) - r and R-E = shared-normal minimisation with the rod's support map are build
+ * extensions (the reference's SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp are empty stubs): parity unpinned.
+ * class_counts [host, 6] (optional) = pairs per class in the order SS, SR, SE, RR, RE, EE (synchronises if given). */
+int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center, const double* quat,
+                            const double* shape, double* aabb, double* bounding_radius, mhip_stream_t stream);
+int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
+                       const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
+                       double* rb, size_t* class_counts /*[host]*/, mhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Broad phase (seam S3).
  * Replaces: stk::search::coarse_search(domain, range, MORTON_LBVH, comm, results, exec, symmetry) +

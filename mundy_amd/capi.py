@@ -59,6 +59,8 @@ SIGNATURES = {
     "mhip_distance_ellipsoid_ellipsoid": [_sz] + [_vp] * 12,
     "mhip_distance_point_ellipsoid": [_sz] + [_vp] * 8,
     "mhip_contact_ellipsoids": [_sz] + [_vp] * 11,
+    "mhip_compute_aabb_mixed": [_sz] + [_vp] * 7,
+    "mhip_contact_mixed": [_sz] + [_vp] * 11 + [C.POINTER(_sz), _vp],
     "mhip_contact_spheres": [_sz, _vp, _vp, _vp, C.POINTER(_d), _vp, _vp, _vp],
     "mhip_contact_spherocylinders": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_broadphase_create": [C.POINTER(_vp)],

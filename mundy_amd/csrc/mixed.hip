@@ -1,0 +1,250 @@
+// mixed.hip -- bodies of mixed shape (BASELINE configs[4]: sphere / spherocylinder / ellipsoid): kind-dispatched AABBs
+// and contact generation with the pairs binned by shape class, so that each launch runs ONE distance routine and
+// wavefronts do not diverge between a 30-flop sphere test and a 10^5-flop ellipsoid minimisation.
+//   classes (lower kind first): S-S, S-R, S-E, R-R, R-E, E-E
+//   1. k_pair_class        class id per pair
+//   2. 6 x (flag, scan, scatter)   stable counting sort of pair indices by class (device-resident class offsets)
+//   3. one kernel per class over its index range, results scattered back to the pairs' own slots
+// S-E and R-E have no reference implementation (empty stubs SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp): build
+// extensions, parity unpinned (see the oracle).  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
+// (r,-,-) / (r,L,-) / (r1,r2,r3).
+#include "ellipsoid_device.hpp"
+
+namespace mhip {
+
+struct BodyD {
+  int kind;
+  V3 c;
+  Quat q;
+  V3 s;
+};
+__device__ inline BodyD load_body(const int32_t* kind, const double* c, const double* q, const double* shape,
+                                  size_t i) {
+  return {kind[i], load3(c, i), load4q(q, i), load3(shape, i)};
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_aabb_mixed(size_t n, const int32_t* __restrict__ kind, const double* __restrict__ center,
+                 const double* __restrict__ quat, const double* __restrict__ shape, double* __restrict__ aabb,
+                 double* __restrict__ brad) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const BodyD b = load_body(kind, center, quat, shape, i);
+    Box bx;
+    double R;
+    if (b.kind == 0) {
+      bx = aabb_sphere(b.c, b.s.x);
+      R = b.s.x;
+    } else if (b.kind == 1) {
+      const V3 d = rod_half_axis(b.q, b.s.y);
+      bx = aabb_segment(b.c - d, b.c + d, b.s.x);
+      R = 0.5 * b.s.y + b.s.x;
+    } else {
+      bx = aabb_ellipsoid(b.c, b.q, b.s);
+      R = dmax(b.s.x, dmax(b.s.y, b.s.z));
+    }
+    double* o = aabb + 6 * i;
+    o[0] = bx.lo.x; o[1] = bx.lo.y; o[2] = bx.lo.z; o[3] = bx.hi.x; o[4] = bx.hi.y; o[5] = bx.hi.z;
+    if (brad) brad[i] = R;
+  }
+}
+
+__device__ inline int class_of(int ka, int kb) {  // ka <= kb -> 0..5
+  const int t = ka * 3 + kb;                      // 0 SS, 1 SR, 2 SE, 4 RR, 5 RE, 8 EE
+  return t < 3 ? t : (t < 6 ? t - 1 : 5);
+}
+
+__global__ void __launch_bounds__(kBlock) k_pair_class(size_t nc, const int2* __restrict__ pairs,
+                                                      const int32_t* __restrict__ kind, int32_t* __restrict__ cls) {
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < nc; k += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[k];
+    const int a = kind[ij.x], b = kind[ij.y];
+    cls[k] = class_of(a < b ? a : b, a < b ? b : a);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_class_flags(size_t nc, const int32_t* __restrict__ cls, int which,
+                                                       int32_t* __restrict__ flags) {
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < nc; k += (size_t)gridDim.x * blockDim.x)
+    flags[k] = (cls[k] == which) ? 1 : 0;
+}
+__global__ void __launch_bounds__(kBlock)
+    k_class_scatter(size_t nc, const int32_t* __restrict__ flags, const int32_t* __restrict__ pos, int which,
+                    int32_t* __restrict__ class_start, int32_t* __restrict__ order) {
+  const int32_t base = class_start[which];
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < nc; k += (size_t)gridDim.x * blockDim.x)
+    if (flags[k]) order[base + pos[k]] = static_cast<int32_t>(k);
+  if (blockIdx.x == 0 && threadIdx.x == 0) class_start[which + 1] = base + pos[nc];
+}
+
+struct MixedOut {
+  double *sep, *normal, *cp1, *cp2, *ra, *rb;
+};
+__device__ inline void store_contact(const MixedOut& o, size_t k, bool swapped, double sep, V3 n, V3 cpA, V3 cpB, V3 ci,
+                                     V3 cj) {
+  // canonical (A, B) = (lower kind, higher kind); the list's (i, j) may be (B, A)
+  const V3 c1 = swapped ? cpB : cpA, c2 = swapped ? cpA : cpB;
+  if (swapped) n = V3{-n.x, -n.y, -n.z};
+  if (o.sep) o.sep[k] = sep;
+  if (o.normal) store3(o.normal, k, n);
+  if (o.cp1) store3(o.cp1, k, c1);
+  if (o.cp2) store3(o.cp2, k, c2);
+  if (o.ra) store3(o.ra, k, c1 - ci);
+  if (o.rb) store3(o.rb, k, c2 - cj);
+}
+
+// rod support point for outward normal n: c + sign(n.a) (L/2) a + r n
+__device__ inline V3 rod_support(const BodyD& b, V3 n) {
+  const V3 a = qrot(b.q, V3{0.0, 0.0, 1.0});
+  const double h = 0.5 * b.s.y;
+  const double sg = copysign(1.0, dot(n, a));
+  return (b.c + (sg * h) * a) + b.s.x * n;
+}
+
+template <int CLS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    k_contact_class(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
+                    const int2* __restrict__ pairs, const int32_t* __restrict__ kind, const double* __restrict__ center,
+                    const double* __restrict__ quat, const double* __restrict__ shape, MixedOut out) {
+  const int32_t beg = class_start[CLS], end = class_start[CLS + 1];
+  for (int32_t t = beg + blockIdx.x * blockDim.x + threadIdx.x; t < end; t += gridDim.x * blockDim.x) {
+    const size_t k = static_cast<size_t>(order[t]);
+    const int2 ij = pairs[k];
+    const BodyD bi = load_body(kind, center, quat, shape, ij.x), bj = load_body(kind, center, quat, shape, ij.y);
+    const bool swapped = bi.kind > bj.kind;
+    const BodyD& A = swapped ? bj : bi;
+    const BodyD& B = swapped ? bi : bj;
+    if (CLS == 0) {  // sphere - sphere
+      V3 d;
+      const double cc = dist_point_point(A.c, B.c, d);
+      const double inv = 1.0 / cc;
+      store_contact(out, k, swapped, cc - A.s.x - B.s.x, d * inv, A.c, B.c, bi.c, bj.c);
+    } else if (CLS == 1) {  // sphere - rod (SphereSpherocylinderLinker.cpp:210-239)
+      const V3 hd = rod_half_axis(B.q, B.s.y);
+      V3 closest, sepv;
+      double tt;
+      const double dist = dist_point_segment(A.c, B.c - hd, B.c + hd, closest, tt, sepv);
+      const double radius_sum = A.s.x + B.s.x;
+      const double inv = 1.0 / dist;
+      store_contact(out, k, swapped, dist - radius_sum, (closest - A.c) * inv, A.c, closest, bi.c, bj.c);
+    } else if (CLS == 2) {  // sphere - ellipsoid: distance(Point, Ellipsoid) - r
+      V3 closest, ne;
+      const double d = dist_point_ellipsoid(A.c, EllipsoidD{B.c, B.q, B.s}, closest, ne);
+      store_contact(out, k, swapped, d - A.s.x, V3{-ne.x, -ne.y, -ne.z}, A.c, closest, bi.c, bj.c);
+    } else if (CLS == 3) {  // rod - rod
+      const V3 da = rod_half_axis(A.q, A.s.y), db = rod_half_axis(B.q, B.s.y);
+      const SegSeg r = dist_segment_segment(A.c - da, A.c + da, B.c - db, B.c + db);
+      const double radius_sum = A.s.x + B.s.x;
+      const double inv = 1.0 / r.dist;
+      store_contact(out, k, swapped, r.dist - radius_sum, (r.cp2 - r.cp1) * inv, r.cp1, r.cp2, bi.c, bj.c);
+    } else if (CLS == 4) {  // rod - ellipsoid (extension: shared-normal minimisation with the rod's support map)
+      const EllipsoidD el{B.c, B.q, B.s};
+      auto eval = [&](lbfgs::V2 tp, V3& n1, V3& f1, V3& f2) {
+        const double st = sin(tp.a), ct = cos(tp.a), sp = sin(tp.b), cp = cos(tp.b);
+        n1 = V3{st * cp, st * sp, ct};
+        f1 = rod_support(A, n1);
+        f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, el);
+        V3 sv;
+        return dist_point_point(f1, f2, sv);
+      };
+      auto objective = [&](lbfgs::V2 tp) {
+        V3 n1, f1, f2;
+        return eval(tp, n1, f1, f2);
+      };
+      const double pi = 3.141592653589793;
+      const double tg[3] = {0.0, 0.5 * pi, pi}, pg[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
+      double best = __builtin_huge_val();
+      lbfgs::V2 btp{0.0, 0.0};
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          lbfgs::V2 tp{tg[a], pg[b]};
+          const double d = lbfgs::find_min(objective, tp, 1e-8);
+          if (d < best) {
+            best = d;
+            btp = tp;
+          }
+        }
+      V3 n1, f1, f2;
+      eval(btp, n1, f1, f2);
+      store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, bi.c, bj.c);
+    } else {  // ellipsoid - ellipsoid
+      const EllipsoidPair r = dist_ellipsoid_ellipsoid(EllipsoidD{A.c, A.q, A.s}, EllipsoidD{B.c, B.q, B.s});
+      store_contact(out, k, swapped, r.dist, r.n1, r.cp1, r.cp2, bi.c, bj.c);
+    }
+  }
+}
+
+struct MixedScratch {
+  DeviceBuffer cls, flags, pos, order, start, scanws;
+  int32_t* host = nullptr;
+};
+MixedScratch& mixed_scratch() {
+  thread_local MixedScratch s;
+  return s;
+}
+
+}  // namespace mhip
+
+using namespace mhip;
+
+extern "C" {
+
+int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center, const double* quat,
+                            const double* shape, double* aabb, double* bounding_radius, mhip_stream_t stream) {
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(kind && center && quat && shape && aabb, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  k_aabb_mixed<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, kind, center, quat, shape, aabb, bounding_radius);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
+                       const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
+                       double* rb, size_t* class_counts, mhip_stream_t stream) {
+  if (class_counts)
+    for (int k = 0; k < 6; ++k) class_counts[k] = 0;
+  if (c == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(pairs && kind && center && quat && shape, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(c < (1u << 31), MHIP_ERR_RUNTIME, "too many pairs");
+  hipStream_t s = as_stream(stream);
+  MixedScratch& ms = mixed_scratch();
+  for (DeviceBuffer* b : {&ms.cls, &ms.flags, &ms.pos, &ms.order})
+    if (int e = b->reserve((c + 2) * sizeof(int32_t))) return e;
+  if (int e = ms.start.reserve(16 * sizeof(int32_t))) return e;
+  if (int e = ms.scanws.reserve(scan_workspace_bytes(c + 2) + 64)) return e;
+  if (!ms.host) MHIP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ms.host), 64));
+  const int2* p2 = reinterpret_cast<const int2*>(pairs);
+  int32_t* start = ms.start.as<int32_t>();
+  MHIP_HIP(hipMemsetAsync(start, 0, 16 * sizeof(int32_t), s));
+  const unsigned g = grid_for(c);
+  k_pair_class<<<g, kBlock, 0, s>>>(c, p2, kind, ms.cls.as<int32_t>());
+  MHIP_LAUNCH_CHECK();
+  for (int k = 0; k < 6; ++k) {
+    k_class_flags<<<g, kBlock, 0, s>>>(c, ms.cls.as<int32_t>(), k, ms.flags.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+    if (int e = exclusive_scan_i32(ms.flags.as<int32_t>(), ms.pos.as<int32_t>(), c, ms.scanws.ptr, s)) return e;
+    k_class_scatter<<<g, kBlock, 0, s>>>(c, ms.flags.as<int32_t>(), ms.pos.as<int32_t>(), k, start,
+                                         ms.order.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+  }
+  const MixedOut out{sep, normal, cp1, cp2, ra, rb};
+  const int32_t* order = ms.order.as<int32_t>();
+#define CLASS(K, BLK, GRID) \
+  k_contact_class<K, BLK><<<GRID, BLK, 0, s>>>(start, order, p2, kind, center, quat, shape, out)
+  const unsigned gs = g;                                                     // cheap classes: grid-stride over <= c
+  const unsigned ge = static_cast<unsigned>(c / 64 + 1 > 65535 * 8 ? 65535 * 8 : c / 64 + 1);  // L-BFGS classes
+  CLASS(0, kBlock, gs);
+  CLASS(1, kBlock, gs);
+  CLASS(3, kBlock, gs);
+  CLASS(2, 64, ge);
+  CLASS(4, 64, ge);
+  CLASS(5, 64, ge);
+#undef CLASS
+  MHIP_LAUNCH_CHECK();
+  if (class_counts) {
+    MHIP_HIP(hipMemcpyAsync(ms.host, start, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < 6; ++k) class_counts[k] = static_cast<size_t>(ms.host[k + 1] - ms.host[k]);
+  }
+  return MHIP_SUCCESS;
+}
+
+}  // extern "C"

@@ -152,6 +152,32 @@ def contact_ellipsoids(pairs, center, quat, radii):
     return out
 
 
+KIND_SPHERE, KIND_ROD, KIND_ELLIPSOID = 0, 1, 2
+
+
+def compute_aabb_mixed(kind, center, quat, shape):
+    n = kind.shape[0]
+    aabb, brad = _new(center, n, 6), _new(center, n)
+    capi.check(capi.load().mhip_compute_aabb_mixed(n, _ptr(kind, torch.int32), _ptr(center, cols=3),
+                                                   _ptr(quat, cols=4), _ptr(shape, cols=3), _ptr(aabb), _ptr(brad),
+                                                   _stream()))
+    return aabb, brad
+
+
+def contact_mixed(pairs, kind, center, quat, shape, want_counts=False):
+    c = pairs.shape[0]
+    out = dict(sep=_new(center, c), normal=_new(center, c, 3), cp1=_new(center, c, 3), cp2=_new(center, c, 3),
+               ra=_new(center, c, 3), rb=_new(center, c, 3))
+    counts = (C.c_size_t * 6)() if want_counts else None
+    capi.check(capi.load().mhip_contact_mixed(
+        c, _ptr(pairs, torch.int32, 2), _ptr(kind, torch.int32), _ptr(center, cols=3), _ptr(quat, cols=4),
+        _ptr(shape, cols=3), _ptr(out["sep"]), _ptr(out["normal"]), _ptr(out["cp1"]), _ptr(out["cp2"]),
+        _ptr(out["ra"]), _ptr(out["rb"]), counts, _stream()))
+    if want_counts:
+        out["class_counts"] = dict(zip(("SS", "SR", "SE", "RR", "RE", "EE"), [int(v) for v in counts]))
+    return out
+
+
 def contact_spheres(pairs, center, radius, box=None, out=None):
     c = pairs.shape[0]
     sep, normal = (_new(center, c), _new(center, c, 3)) if out is None else out

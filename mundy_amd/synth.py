@@ -71,6 +71,29 @@ def spherocylinders(n, radius=0.5, length=2.0, volume_fraction=0.40, seed=1234, 
                 length=np.full(n, float(length)), box=L)
 
 
+def mixed_bodies(n, volume_fraction=0.40, seed=1234, sphere_radius=0.5, rod=(0.5, 2.0), ellipsoid=(0.8, 0.5, 0.4)):
+    """BASELINE configs[4]: n bodies, kind = index mod 3 (0 sphere, 1 spherocylinder, 2 ellipsoid), centres uniform
+    in the box that gives the requested volume fraction, orientations uniform (unit quaternions from 4 normal
+    deviates via Box-Muller on the counter-based stream).  shape rows: (r,0,0) / (r,L,0) / (r1,r2,r3)."""
+    idx = np.arange(n)
+    kind = (idx % 3).astype(np.int32)
+    vols = np.array([4.0 / 3.0 * np.pi * sphere_radius ** 3,
+                     np.pi * rod[0] ** 2 * rod[1] + 4.0 / 3.0 * np.pi * rod[0] ** 3,
+                     4.0 / 3.0 * np.pi * ellipsoid[0] * ellipsoid[1] * ellipsoid[2]])
+    L = float((vols[kind].sum() / volume_fraction) ** (1.0 / 3.0))
+    c = np.stack([uniform01(seed, idx, s) * L for s in (0, 1, 2)], axis=1)
+    u = [np.maximum(uniform01(seed, idx, 10 + s), 1e-300) for s in range(4)]
+    g = np.stack([np.sqrt(-2 * np.log(u[0])) * np.cos(2 * np.pi * u[1]), np.sqrt(-2 * np.log(u[0])) * np.sin(2 * np.pi * u[1]),
+                  np.sqrt(-2 * np.log(u[2])) * np.cos(2 * np.pi * u[3]), np.sqrt(-2 * np.log(u[2])) * np.sin(2 * np.pi * u[3])],
+                 axis=1)
+    q = g / np.linalg.norm(g, axis=1, keepdims=True)
+    shape = np.zeros((n, 3))
+    shape[kind == 0] = [sphere_radius, 0.0, 0.0]
+    shape[kind == 1] = [rod[0], rod[1], 0.0]
+    shape[kind == 2] = list(ellipsoid)
+    return dict(kind=kind, center=np.ascontiguousarray(c), quat=np.ascontiguousarray(q), shape=shape, box=L)
+
+
 def dry_mobility(radius, viscosity=1e-3, bounding_radius=None):
     """dry local drag (NgpLcp.cpp:484-486; Bacteria.cpp:810-848): U = F / (6 pi mu r), W = T / (8 pi mu r^3).
     For rods the effective radius is the bounding radius when given."""

@@ -424,3 +424,28 @@ def solve_small_cqpp_batch(A, q, space, x0, resid_kind=RESID_PROJECTED_DIFF, max
                                    C.c_double(space[2]), C.c_int(resid_kind), C.c_uint(max_iters), C.c_double(tol),
                                    _p(x), _p(g), _p(it), _p(res), _p(conv))
     return x, g, it, res, conv.astype(bool)
+
+
+# ---- mixed shapes -----------------------------------------------------------------------------------------------------
+KIND_SPHERE, KIND_ROD, KIND_ELLIPSOID = 0, 1, 2
+
+
+def aabb_mixed(kind, center, quat, shape, fast=False):
+    kind = np.ascontiguousarray(kind, dtype=np.int32)
+    center, quat, shape = _f(center), _f(quat), _f(shape)
+    n = len(kind)
+    aabb, brad = np.empty((n, 6)), np.empty(n)
+    lib(fast).o_aabb_mixed(C.c_size_t(n), _p(kind), _p(center), _p(quat), _p(shape), _p(aabb), _p(brad))
+    return aabb, brad
+
+
+def contact_mixed(pairs, kind, center, quat, shape, fast=False):
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    kind = np.ascontiguousarray(kind, dtype=np.int32)
+    center, quat, shape = _f(center), _f(quat), _f(shape)
+    c = len(pairs)
+    out = dict(sep=np.empty(c), normal=np.empty((c, 3)), cp1=np.empty((c, 3)), cp2=np.empty((c, 3)),
+               ra=np.empty((c, 3)), rb=np.empty((c, 3)))
+    lib(fast).o_contact_mixed(C.c_size_t(c), _p(pairs), _p(kind), _p(center), _p(quat), _p(shape), _p(out["sep"]),
+                              _p(out["normal"]), _p(out["cp1"]), _p(out["cp2"]), _p(out["ra"]), _p(out["rb"]))
+    return out

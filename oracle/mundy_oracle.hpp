@@ -673,6 +673,116 @@ inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3&
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Mixed-shape contact generation (BASELINE configs[4]).  Body kinds: 0 sphere, 1 spherocylinder, 2 ellipsoid;
+// shape = (r, -, -) / (r, L, -) / (r1, r2, r3).  Per pair class:
+//   S-S  contact_spheres                               (SphereSphere.hpp:54-59, NgpLcp.cpp:360-372)
+//   R-R  contact_segments                              (LineSegmentLineSegment.hpp:189-318 + linker assembly)
+//   E-E  distance_ellipsoid_ellipsoid                  (EllipsoidEllipsoid.hpp:106-151)
+//   S-R  point-segment distance minus (r_s + r_rod), normal = (closest - centre)/dist, contact points = sphere centre
+//        and centreline point (scrap/.../SphereSpherocylinderLinker.cpp:210-239; LineSegmentSphere.hpp:56-61)
+//   S-E  distance(Point, Ellipsoid) - r_s (the reference's SphereEllipsoid.hpp:21-33 is an empty stub, so
+//        this routing is a build-side definition: PARITY UNPINNED), normal = -ellipsoid normal
+//   R-E  NO reference function exists (LineSegmentEllipsoid.hpp:21-33 is an empty stub).  Build extension, PARITY
+//        UNPINNED: the same shared-normal minimisation as E-E with the spherocylinder's support map
+//        foot(n) = c + sign(n.a) (L/2) a + r n  in place of the ellipsoid foot point.
+// The pair is evaluated in canonical class order (lower kind first) and flipped back if the list order is the reverse.
+// ---------------------------------------------------------------------------------------------------------------
+enum BodyKind : int { kSphere = 0, kRod = 1, kEllipsoid = 2 };
+struct MixedBody {
+  int kind;
+  V3 c;
+  Quat q;
+  V3 shape;
+};
+struct MixedContact {
+  double sep;
+  V3 normal, cp1, cp2;
+};
+inline V3 rod_support_point(const MixedBody& b, const V3& n) {
+  const V3 a = qrot(b.q, V3{0.0, 0.0, 1.0});
+  const double h = 0.5 * b.shape.y;
+  const double sgn = std::copysign(1.0, dot(n, a));
+  return (b.c + (sgn * h) * a) + b.shape.x * n;
+}
+inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody& B) {
+  MixedContact o;
+  if (A.kind == kSphere && B.kind == kSphere) {
+    o.sep = contact_spheres(A.c, A.shape.x, B.c, B.shape.x, o.normal);
+    o.cp1 = A.c;
+    o.cp2 = B.c;
+  } else if (A.kind == kRod && B.kind == kRod) {
+    const V3 da = spherocylinder_half_axis(A.q, A.shape.y), db = spherocylinder_half_axis(B.q, B.shape.y);
+    const RodContact rc = contact_segments(A.c - da, A.c + da, A.shape.x, B.c - db, B.c + db, B.shape.x);
+    o.sep = rc.sep; o.normal = rc.normal; o.cp1 = rc.cp1; o.cp2 = rc.cp2;
+  } else if (A.kind == kEllipsoid && B.kind == kEllipsoid) {
+    const EllipsoidPairResult r = distance_ellipsoid_ellipsoid({A.c, A.q, A.shape}, {B.c, B.q, B.shape});
+    o.sep = r.dist; o.normal = r.n1; o.cp1 = r.cp1; o.cp2 = r.cp2;
+  } else if (A.kind == kSphere && B.kind == kRod) {
+    const V3 d = spherocylinder_half_axis(B.q, B.shape.y);
+    V3 closest, sepv;
+    double t;
+    const double dist = distance_point_segment(A.c, B.c - d, B.c + d, closest, t, sepv);
+    const double radius_sum = A.shape.x + B.shape.x;
+    o.sep = dist - radius_sum;
+    const double inv = 1.0 / dist;
+    o.normal = (closest - A.c) * inv;
+    o.cp1 = A.c;
+    o.cp2 = closest;
+  } else if (A.kind == kSphere && B.kind == kEllipsoid) {
+    V3 closest, ne;
+    const double d = distance_point_ellipsoid(A.c, {B.c, B.q, B.shape}, closest, ne);
+    o.sep = d - A.shape.x;
+    o.normal = {-ne.x, -ne.y, -ne.z};
+    o.cp1 = A.c;
+    o.cp2 = closest;
+  } else {  // rod - ellipsoid (extension)
+    const Ellipsoid el{B.c, B.q, B.shape};
+    V3 n1, f1, f2;
+    auto objective = [&](const minimize::Vec<2>& tp) {
+      const double st = std::sin(tp[0]), ct = std::cos(tp[0]), sp = std::sin(tp[1]), cp = std::cos(tp[1]);
+      n1 = {st * cp, st * sp, ct};
+      f1 = rod_support_point(A, n1);
+      f2 = map_surface_normal_to_foot_point({-n1.x, -n1.y, -n1.z}, el);
+      return distance_point_point(f1, f2);
+    };
+    constexpr double pi = 3.141592653589793;
+    const double tg[3] = {0.0, 0.5 * pi, pi}, pg[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
+    double best = std::numeric_limits<double>::infinity();
+    minimize::Vec<2> btp{{0.0, 0.0}};
+    for (int t = 0; t < 3; ++t)
+      for (int p = 0; p < 3; ++p) {
+        minimize::Vec<2> tp{{tg[t], pg[p]}};
+        const double d = minimize::find_min<10, 2>(objective, tp, kRelaxedZeroTol);
+        if (d < best) {
+          best = d;
+          btp = tp;
+        }
+      }
+    objective(btp);
+    o.sep = dot(f2 - f1, n1);
+    o.normal = n1; o.cp1 = f1; o.cp2 = f2;
+  }
+  return o;
+}
+inline MixedContact contact_mixed(const MixedBody& bi, const MixedBody& bj) {
+  if (bi.kind <= bj.kind) return contact_mixed_canonical(bi, bj);
+  MixedContact o = contact_mixed_canonical(bj, bi);
+  std::swap(o.cp1, o.cp2);
+  o.normal = {-o.normal.x, -o.normal.y, -o.normal.z};
+  return o;
+}
+inline AABB compute_aabb_mixed(const MixedBody& b) {
+  if (b.kind == kSphere) return compute_aabb_sphere(b.c, b.shape.x);
+  if (b.kind == kRod) return compute_aabb_spherocylinder(b.c, b.q, b.shape.x, b.shape.y);
+  return compute_aabb_ellipsoid(b.c, b.q, b.shape);
+}
+inline double bounding_radius_mixed(const MixedBody& b) {
+  if (b.kind == kSphere) return bounding_radius_sphere(b.shape.x);
+  if (b.kind == kRod) return bounding_radius_spherocylinder(b.shape.x, b.shape.y);
+  return bounding_radius_ellipsoid(b.shape);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // mundy::math::convex -- spaces, residual policies, BB step, BBPGD (convex.hpp)
 // ---------------------------------------------------------------------------------------------------------------
 enum SpaceKind : int { kUnconstrained = 0, kLowerBound = 1, kUpperBound = 2, kBounded = 3 };

@@ -200,6 +200,35 @@ double o_minimize_test(int kind, double* x) {
   return c;
 }
 
+// ---- mixed shapes ---------------------------------------------------------------------------------------------------
+static MixedBody ld_body(const int32_t* kind, const double* c, const double* q, const double* shape, size_t i) {
+  return {kind[i], ld3(c, i), ldq(q, i), ld3(shape, i)};
+}
+void o_aabb_mixed(size_t n, const int32_t* kind, const double* c, const double* q, const double* shape, double* aabb,
+                  double* brad) {
+#pragma omp parallel for
+  for (size_t i = 0; i < n; ++i) {
+    const MixedBody b = ld_body(kind, c, q, shape, i);
+    st_aabb(aabb, i, compute_aabb_mixed(b));
+    brad[i] = bounding_radius_mixed(b);
+  }
+}
+void o_contact_mixed(size_t C, const int32_t* pairs, const int32_t* kind, const double* c, const double* q,
+                     const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
+                     double* rb) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (size_t k = 0; k < C; ++k) {
+    const int32_t i = pairs[2 * k], j = pairs[2 * k + 1];
+    const MixedContact m = contact_mixed(ld_body(kind, c, q, shape, i), ld_body(kind, c, q, shape, j));
+    sep[k] = m.sep;
+    st3(normal, k, m.normal);
+    st3(cp1, k, m.cp1);
+    st3(cp2, k, m.cp2);
+    st3(ra, k, m.cp1 - ld3(c, i));
+    st3(rb, k, m.cp2 - ld3(c, j));
+  }
+}
+
 // ---- periodicity --------------------------------------------------------------------------------------------------
 void o_periodic_sep(size_t n, const double* box, const double* p1, const double* p2, double* out) {
   const PeriodicScaledMetric pm(V3{box[0], box[1], box[2]});
