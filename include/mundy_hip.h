@@ -223,9 +223,9 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
 int mhip_contact_op_destroy(mhip_contact_op_t handle);
 int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, mhip_stream_t stream);
 /* Per-kernel timing of the fused solver (measurement support, no effect on results): when enabled,
- * mhip_bbpgd_solve_contact brackets every k_body / k_constraint launch with HIP events on `stream` and accumulates
- * their device durations.  get_profile returns the totals in milliseconds and the number of timed iterations
- * (launches of each kernel) since profiling was enabled.  All out pointers [host]. */
+ * mhip_bbpgd_solve_contact brackets the k_body / k_constraint launches of every 8th iteration with HIP events on
+ * `stream` and accumulates their device durations.  get_profile returns the totals in milliseconds and the number of timed iterations
+ * (sampled launches of each kernel) since profiling was enabled.  All out pointers [host]. */
 int mhip_contact_op_set_profiling(mhip_contact_op_t handle, int enable);
 int mhip_contact_op_get_profile(mhip_contact_op_t handle, double* body_ms, double* constraint_ms, size_t* iterations);
 /* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate */
@@ -318,6 +318,13 @@ int mhip_aabb_bounds(size_t n, const double* aabb, double buffer, double* out6 /
  * ---------------------------------------------------------------------------------------------------------------- */
 int mhip_integrate_euler(size_t n, double dt, const double* velocity, double* center, double* quat,
                          mhip_stream_t stream);
+
+/* Periodic box: PeriodicScaledMetric::sep (minimum-image separation p1 -> p2) and wrap_rigid of a
+ * Sphere / Spherocylinder / Ellipsoid (the centre is wrapped into [0, box), orientation and size untouched).
+ * Replaces: mundy/geom/src/mundy_geom/periodicity.hpp:812-823, :1088-1113, :1156-1160.  box [host] 3 doubles. */
+int mhip_periodic_sep(size_t n, const double* box, const double* p1, const double* p2, double* out,
+                      mhip_stream_t stream);
+int mhip_wrap_rigid(size_t n, const double* box, double* center, mhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Body reordering: Z-order (Morton) permutation of bodies by centre, z most significant as

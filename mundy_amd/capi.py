@@ -103,6 +103,8 @@ SIGNATURES = {
     "mhip_aabb_bounds": [_sz, _vp, _d, C.POINTER(_d), _vp],
     "mhip_bbpgd_solve_contact_unfused": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
                                          C.POINTER(SolveResult), _vp],
+    "mhip_periodic_sep": [_sz, C.POINTER(_d), _vp, _vp, _vp, _vp],
+    "mhip_wrap_rigid": [_sz, C.POINTER(_d), _vp, _vp],
     "mhip_integrate_euler": [_sz, _d, _vp, _vp, _vp, _vp],
     "mhip_morton_order": [_sz, _vp, C.POINTER(_d), _d, _vp, _vp],
     "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],

@@ -91,19 +91,25 @@ __global__ void __launch_bounds__(kBlock)
   if (threadIdx.x == 0) partials[7 * blockIdx.x + 6] = rr;
 }
 
-__global__ void k_grid_params(int nparts, const double* __restrict__ partials, BpArgs A, int cell_capacity,
+__global__ void __launch_bounds__(kBlock) k_grid_params(int nparts, const double* __restrict__ partials, BpArgs A, int cell_capacity,
                               GridParams* __restrict__ gp) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ double scratch[kBlock / 64];
   double mn[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308};
   double mx[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
   double reach = 0.0;
-  for (int i = 0; i < nparts; ++i) {
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
     for (int k = 0; k < 3; ++k) {
       mn[k] = dmin(mn[k], partials[7 * i + k]);
       mx[k] = dmax(mx[k], partials[7 * i + 3 + k]);
     }
     reach = dmax(reach, partials[7 * i + 6]);
   }
+  for (int k = 0; k < 3; ++k) {
+    mn[k] = -block_max(-mn[k], scratch);
+    mx[k] = block_max(mx[k], scratch);
+  }
+  reach = block_max(reach, scratch);
+  if (threadIdx.x != 0) return;
   double h = 2.0 * reach * (1.0 + 1e-12);
   if (!(h > 0.0)) h = 1.0;
   for (int k = 0; k < 3; ++k) {
@@ -379,7 +385,7 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   const unsigned g = grid_for(n);
   k_bounds<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, h->partials.as<double>());
   MHIP_LAUNCH_CHECK();
-  k_grid_params<<<1, 64, 0, s>>>((int)g, h->partials.as<double>(), A, cell_capacity, gp);
+  k_grid_params<<<1, kBlock, 0, s>>>((int)g, h->partials.as<double>(), A, cell_capacity, gp);
   MHIP_LAUNCH_CHECK();
   MHIP_HIP(hipMemsetAsync(h->cell_cnt.ptr, 0, (cell_capacity + 1) * sizeof(int32_t), s));
   k_cell_count<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, gp, h->cell_of.as<int32_t>(),

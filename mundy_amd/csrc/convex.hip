@@ -19,6 +19,7 @@
 
 namespace mhip {
 
+constexpr unsigned kProfileStride = 8;         // profiling brackets every 8th iteration (event records cost ~10 us)
 constexpr double kSmallStep = 1e-6;            // convex.hpp:479
 constexpr double kBBEps = 1e-15 * 10;          // convex.hpp:511
 constexpr double kLowest = -1.7976931348623157e308;  // Kokkos::Max<double> identity
@@ -285,7 +286,26 @@ struct OpView {
   // lower body).  Defaults: all bodies, all contacts.
   size_t body_first, body_count;
   const unsigned char* counted;
+  int xcd_aware;  // XCD-contiguous tile mapping (performance only; MHIP_XCD_AWARE=0 disables it for A/B runs)
 };
+
+// XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
+// so blockIdx % 8 labels the XCD).  Tiles of 256 work items are assigned so that each XCD sweeps ONE contiguous eighth
+// of the range: with Z-ordered bodies the rows its workgroups gather (body velocities, x/g of neighbouring contacts)
+// then come from a compact slab that mostly stays in that XCD's L2, instead of every L2 seeing every slab.
+// Placement is a performance assumption only: any mapping gives the same results.
+struct XcdTiles {
+  size_t first, step, end;  // this workgroup's tiles: first, first + step, ... < end
+};
+__device__ inline XcdTiles xcd_tiles(size_t ntiles, int enabled) {
+  const unsigned nb = gridDim.x;
+  if (!enabled || nb < 8 || (nb & 7u)) return {blockIdx.x, nb, ntiles};  // small grids: plain grid-stride
+  const unsigned xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, per_xcd = nb >> 3;
+  const size_t per = (ntiles + 7) / 8;  // tiles per XCD slab
+  const size_t lo = xcd * per;
+  const size_t hi = (lo + per < ntiles) ? lo + per : ntiles;
+  return {lo + local, per_xcd, hi};
+}
 
 // the iterate a constraint carries in a given mode; bitwise identical wherever it is evaluated
 template <int MODE>
@@ -320,7 +340,11 @@ __global__ void __launch_bounds__(kBlock)
     step = st->step;
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  // one tile = one workgroup's worth of bodies; tiles are XCD-contiguous (see xcd_tiles), the grid covers them once
+  const XcdTiles tl = xcd_tiles(gridDim.x, op.xcd_aware);
+  const size_t tile = tl.first + (size_t)0 * tl.step;
+  if (tile >= tl.end) return;
+  const size_t t = tile * (size_t)blockDim.x + threadIdx.x;
   const int sub = static_cast<int>(t % G);
   if (t / G >= op.body_count) return;  // whole groups leave together (G divides the wave size)
   const size_t b = op.body_first + t / G;
@@ -392,7 +416,10 @@ __global__ void __launch_bounds__(kBlock)
   if (MODE == X_INIT) gn = G0;  // g_tmp = A x_tmp + q
   const bool step_is_zero = fabs(-step) < kZeroTol;
   double rmax = kLowest, num = 0.0, den = 0.0;
-  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
+  const XcdTiles tl = xcd_tiles((op.C + kBlock - 1) / kBlock, op.xcd_aware);
+  for (size_t tile = tl.first; tile < tl.end; tile += tl.step) {
+    const size_t c = tile * kBlock + threadIdx.x;
+    if (c >= op.C) continue;
     const int2 ij = op.pairs[c];
     const double xc = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
     const V3 n = load3(op.normal, c);
@@ -747,7 +774,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   if (op->view.N == 0) return MHIP_SUCCESS;
   const int G = op->lanes_per_body;
   if (op->view.body_count == 0) return MHIP_SUCCESS;
-  const unsigned grid = grid_exact(op->view.body_count * (size_t)G);
+  const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
   const SolverState* st = op->state.as<SolverState>();
 #define BODY3(M, R, GG) k_body<M, R, GG><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
 #define BODY(M, R)                 \
@@ -979,7 +1006,8 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
       op->lanes_per_body = 8;
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
-                    op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr};
+                    op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, 0};
+  if (const char* xe = getenv("MHIP_XCD_AWARE")) op->view.xcd_aware = atoi(xe) ? 1 : 0;
   *handle = op;
   return MHIP_SUCCESS;
 }
@@ -1067,24 +1095,25 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       // iterations of the last chunk that did real work: those that advanced iter, plus the converging one
       unsigned eff = op->host_state->iter - iter_before + ((op->host_state->converged && op->host_state->iter < config->max_iters) ? 1u : 0u);
       if (eff > last_todo) eff = last_todo;
-      for (unsigned k = 0; k < eff; ++k) {
+      for (unsigned k = 0; k < eff; k += kProfileStride) {  // every kProfileStride-th iteration is bracketed
         float a = 0.f, b = 0.f;
         MHIP_HIP(hipEventElapsedTime(&a, op->events[3 * k], op->events[3 * k + 1]));
         MHIP_HIP(hipEventElapsedTime(&b, op->events[3 * k + 1], op->events[3 * k + 2]));
         op->body_ms += a;
         op->constraint_ms += b;
+        op->timed_iterations += 1;
       }
-      op->timed_iterations += eff;
     }
     if (op->host_state->done || enqueued >= config->max_iters) break;
     iter_before = op->host_state->iter;
     const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
     for (unsigned k = 0; k < todo; ++k) {
-      if (prof) MHIP_HIP(hipEventRecord(op->events[3 * k], s));
+      const bool pk = prof && (k % kProfileStride == 0);
+      if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k], s));
       if (int e = op_launch_body(op, X_SOLVE, x_tmp, x, g_tmp, g, sp, s)) return e;
-      if (prof) MHIP_HIP(hipEventRecord(op->events[3 * k + 1], s));
+      if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 1], s));
       if (int e = op_launch_constraint(op, X_SOLVE, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
-      if (prof) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
+      if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       k_finalize<X_SOLVE><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
       MHIP_LAUNCH_CHECK();
     }

@@ -102,6 +102,18 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// PeriodicScaledMetric::sep / wrap (mundy_geom/periodicity.hpp:812-823); wrap_rigid of a Sphere / Spherocylinder /
+// Ellipsoid wraps its centre, orientation and size untouched (:1088-1113, :1156-1160)
+__global__ void __launch_bounds__(kBlock) k_periodic_sep(size_t n, Periodic pm, const double* __restrict__ p1,
+                                                        const double* __restrict__ p2, double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store3(out, i, periodic_sep(pm, load3(p1, i), load3(p2, i)));
+}
+__global__ void __launch_bounds__(kBlock) k_wrap_rigid(size_t n, Periodic pm, double* __restrict__ center) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store3(center, i, periodic_wrap(pm, load3(center, i)));
+}
+
 struct ReorderScratch {
   DeviceBuffer code, hist, ptr, scanws;
 };
@@ -154,6 +166,27 @@ int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* 
   MHIP_REQUIRE(src != dst, MHIP_ERR_INVALID_ARGUMENT, "gather cannot run in place");
   if (n == 0) return MHIP_SUCCESS;
   k_gather_rows<<<grid_for(n * width), kBlock, 0, as_stream(stream)>>>(n, width, perm, src, dst);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_periodic_sep(size_t n, const double* box, const double* p1, const double* p2, double* out,
+                      mhip_stream_t stream) {
+  MHIP_REQUIRE(box != nullptr && box[0] > 0 && box[1] > 0 && box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
+               "periodic box must be positive");
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(p1 && p2 && out, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  k_periodic_sep<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, make_periodic(box), p1, p2, out);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_wrap_rigid(size_t n, const double* box, double* center, mhip_stream_t stream) {
+  MHIP_REQUIRE(box != nullptr && box[0] > 0 && box[1] > 0 && box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
+               "periodic box must be positive");
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(center != nullptr, MHIP_ERR_INVALID_ARGUMENT, "center is null");
+  k_wrap_rigid<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, make_periodic(box), center);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

@@ -495,6 +495,20 @@ def gather_rows(perm, src):
     return dst if src.dim() == 2 else dst.squeeze(1)
 
 
+def periodic_sep(box, p1, p2):
+    out = torch.empty_like(p1)
+    b = (C.c_double * 3)(*[float(v) for v in box])
+    capi.check(capi.load().mhip_periodic_sep(p1.shape[0], b, _ptr(p1, cols=3), _ptr(p2, cols=3), _ptr(out), _stream()))
+    return out
+
+
+def wrap_rigid(box, center):
+    """wrap_rigid_inplace of spheres / spherocylinders / ellipsoids: their centres are wrapped into [0, box)"""
+    b = (C.c_double * 3)(*[float(v) for v in box])
+    capi.check(capi.load().mhip_wrap_rigid(center.shape[0], b, _ptr(center, cols=3), _stream()))
+    return center
+
+
 def integrate_euler(dt, velocity, center, quat=None):
     capi.check(capi.load().mhip_integrate_euler(center.shape[0], float(dt), _ptr(velocity, cols=6),
                                                 _ptr(center, cols=3), _ptr(quat, cols=4, allow_none=True), _stream()))

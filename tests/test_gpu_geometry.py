@@ -165,3 +165,18 @@ def test_contact_spherocylinders_bit_exact(ops, oracle):
     # empty list is fine
     e = ops.contact_spherocylinders(dev(pairs[:0]), dev(seg), dev(c))
     assert e["sep"].shape[0] == 0
+
+
+def test_periodic_metric_bit_exact(ops, oracle):
+    # PeriodicScaledMetric::sep / wrap (periodicity.hpp:812-823) and wrap_rigid of centres
+    from gpu_util import assert_bits_equal, dev, host
+    rng = np.random.default_rng(12)
+    box = np.array([3.0, 5.0, 7.5])
+    n = 100_000
+    p1, p2 = rng.uniform(-40, 40, (n, 3)), rng.uniform(-40, 40, (n, 3))
+    p1[:100] = np.round(p1[:100])          # points on cell faces / half-way images
+    p2[:100] = p1[:100] + box * rng.integers(-3, 4, (100, 3)) * 0.5
+    assert_bits_equal(host(ops.periodic_sep(box, dev(p1), dev(p2))), oracle.periodic_sep(box, p1, p2), "periodic sep")
+    w = host(ops.wrap_rigid(box, dev(p1)))
+    assert_bits_equal(w, oracle.periodic_wrap(box, p1), "wrap_rigid")
+    assert np.all(w >= 0) and np.all(w < box)
