@@ -356,6 +356,9 @@ __global__ void __launch_bounds__(kBlock)
     const size_t c = static_cast<size_t>(e >> 1);
     const bool target = e & 1;
     const double lam = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
+    // an inactive contact (lam == 0: most of a neighbour list) adds +/-0 to the sums, which leaves them bit for bit
+    // unchanged -- so its 48-byte record is never fetched
+    if (lam == 0.0) continue;
     V3 n, r{0.0, 0.0, 0.0};
     if (ROT) {  // 48-byte records, 16-byte aligned: three 16-byte loads
       const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * HW);

@@ -131,7 +131,7 @@ static void test_contact_lcp_fused_equals_generic() {
   ContactOperator op(C, N, pairs.data(), normal.data(), nullptr, nullptr, dmt.data(), nullptr, 5e-3);
   cx::PGDConfig<double> cfg{5000, 1e-6};
   std::vector<double> xs[2];
-  unsigned iters[2];
+  unsigned iters[2] = {0, 0};
   for (int pass = 0; pass < 2; ++pass) {
     DeviceVector x(std::vector<double>(C, 0.0)), grad(C), x_tmp(C), grad_tmp(C);
     const auto backend = cx::HipBackend{};
