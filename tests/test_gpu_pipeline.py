@@ -1,0 +1,101 @@
+"""The whole step through the host-side pipeline (mundy_amd/pipeline.py) against the same step on the CPU oracle:
+BASELINE.json configs[1] (100k spheres, frictionless LCP, one GPU, fp64) and a short multi-step rod trajectory."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    assert torch.cuda.is_available()
+    from mundy_amd import ops, pipeline, synth
+    return ops, pipeline, synth
+
+
+def test_config2_100k_spheres_lcp(mods, oracle):
+    ops, pipeline, synth = mods
+    from gpu_util import assert_bits_equal, dev, host
+    s = synth.spheres(100_000)                       # r = 1, phi = 0.40
+    c, r = s["center"], s["radius"]
+    tol = 1e-5
+    st = pipeline.ContactStepper("sphere", dev(c), dev(r), search_buffer=0.25, search_kind=ops.SEARCH_SPHERES,
+                                 cfg=ops.PGDConfig(max_iters=10000, tol=tol))
+    res = st.step(integrate=False)
+    lo, hi, R = oracle.grow(oracle.compute_aabb_spheres(c, r), r, 0.25)
+    pairs = oracle.search(oracle.SEARCH_SPHERES, lo, hi, c, R)
+    np.testing.assert_array_equal(host(st.links.pairs), pairs)          # bit-exact neighbour indices / counts
+    osep, onrm = oracle.contact_spheres(pairs, c, r)
+    assert_bits_equal(host(st.contacts["sep"]), osep, "sep")
+    assert_bits_equal(host(st.contacts["normal"]), onrm, "normal")
+    mt, _ = synth.dry_mobility(r)
+    xo, go, ro = oracle.solve_cqpp_contact(pairs, onrm, None, None, mt, None, 5e-3, osep, np.zeros(len(pairs)),
+                                           max_iters=10000, tol=tol, threads=True, fast=True)
+    assert res.converged and ro["converged"]
+    # BB step lengths amplify summation-order rounding (the OpenMP oracle's own count varies run to run): same ballpark
+    assert 0.5 * ro["num_iters"] <= res.num_iters <= 2.0 * ro["num_iters"]
+    g = host(st.op.apply(st.lam) + st.contacts["sep"])
+    np.testing.assert_allclose(g, go, atol=20 * tol)                      # fp64 tolerance on the constraint gradient
+    lam = host(st.lam)
+    assert lam.min() >= 0 and np.abs(np.minimum(lam, g)).max() <= 10 * tol
+    # impulses per body (D lam) are unique even where individual multipliers are not
+    F = np.zeros((len(r), 3)); Fo = np.zeros((len(r), 3))
+    for arr, x in ((F, lam), (Fo, xo)):
+        np.add.at(arr, pairs[:, 0], -x[:, None] * onrm)
+        np.add.at(arr, pairs[:, 1], x[:, None] * onrm)
+    assert np.abs(F - Fo).max() <= 1e-3 * max(1.0, np.abs(Fo).max())
+
+
+def test_three_step_rod_trajectory(mods, oracle):
+    # positions after three full steps (neighbour list -> contacts -> LCP -> Euler with quaternion update) track the
+    # oracle's trajectory; the LCP is solved tightly so the comparison is about the path, not solver slack
+    ops, pipeline, synth = mods
+    from gpu_util import dev, host
+    b = synth.spherocylinders(4000, volume_fraction=0.25)
+    tol, dt, buf = 1e-6, 5e-3, 0.3   # 1e-6: the projected-diff residual is quantised at ~ulp(x)/1e-6 ~ 1e-8
+    st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]),
+                                 dev(b["length"]), dt=dt, search_buffer=buf, cfg=ops.PGDConfig(max_iters=20000, tol=tol))
+    c, q = b["center"].copy(), b["quat"].copy()
+    r, L = b["radius"], b["length"]
+    brad = oracle.bounding_radius_spherocylinders(r, L)
+    mt, mr = synth.dry_mobility(r, bounding_radius=brad)
+    for step in range(3):
+        s = st.step(integrate=True, force_rebuild=True)
+        aabb = oracle.compute_aabb_spherocylinders(c, q, r, L)
+        lo, hi, R = oracle.grow(aabb, brad, buf)
+        pairs = oracle.search(oracle.SEARCH_AABB, lo, hi, c, R)
+        seg = oracle.spherocylinder_segments(c, q, r, L)
+        con = oracle.contact_spherocylinders(pairs, seg, c)
+        x, g, ro = oracle.solve_cqpp_contact(pairs, con["normal"], con["ra"], con["rb"], mt, mr, dt, con["sep"],
+                                             np.zeros(len(pairs)), max_iters=20000, tol=tol, threads=True, fast=False)
+        assert s.converged and ro["converged"]
+        # body velocities from the multipliers, then the reference's Euler + rotate_quaternion update
+        F = np.zeros((len(r), 3)); T = np.zeros((len(r), 3))
+        f = x[:, None] * con["normal"]
+        np.add.at(F, pairs[:, 0], -f); np.add.at(F, pairs[:, 1], f)
+        np.add.at(T, pairs[:, 0], -np.cross(con["ra"], f)); np.add.at(T, pairs[:, 1], np.cross(con["rb"], f))
+        U, W = mt[:, None] * F, mr[:, None] * T
+        c = c + dt * U
+        w = np.linalg.norm(W, axis=1)
+        mv = w >= 1e-15
+        sw, cw = np.sin(0.5 * w * dt), np.cos(0.5 * w * dt)
+        winv = np.where(mv, 1.0 / np.where(mv, w, 1.0), 0.0)
+        sq, p = q[:, 0], q[:, 1:]
+        xyz = (sq * sw * winv)[:, None] * W + cw[:, None] * p + (sw * winv)[:, None] * np.cross(W, p)
+        qw = sq * cw - np.sum(W * p, axis=1) * sw * winv
+        qn = np.concatenate([qw[:, None], xyz], axis=1)
+        qn /= np.linalg.norm(qn, axis=1, keepdims=True)
+        q = np.where(mv[:, None], qn, q)
+        if step == 0:
+            np.testing.assert_array_equal(host(st.links.pairs), pairs)
+        # the two solves agree to ~tol in the constraint gradient; bodies move O(0.1-1) per step in this overlapping
+        # start, so 2e-4 absolute is a 1e-3..1e-4 relative check of the whole path (a sign or index slip is O(1))
+        assert np.abs(host(st.center) - c).max() <= 2e-4, (step, np.abs(host(st.center) - c).max())
+        assert np.abs(np.abs(np.sum(host(st.quat) * q, axis=1)) - 1.0).max() <= 1e-6, step
+        c, q = host(st.center).copy(), host(st.quat).copy()   # re-anchor: compare per-step maps, not drift
+    # overlaps are gone (to the linearisation) after the steps
+    seg = oracle.spherocylinder_segments(c, q, r, L)
+    pairs = oracle.search(oracle.SEARCH_AABB, *oracle.grow(oracle.compute_aabb_spherocylinders(c, q, r, L), brad, 0.0)[:2], c,
+                          brad)
+    assert oracle.contact_spherocylinders(pairs, seg, c)["sep"].min() > -0.05
