@@ -131,6 +131,29 @@ class Comm:
         dist.all_gather(parts, src, group=self.group)
         return torch.stack(parts).to(t.device)
 
+    def all_gather_into(self, out, t):
+        """device fast path: out [world, len] and t [len] are preallocated device tensors (no allocation per call)"""
+        if self.direct:
+            dist.all_gather_into_tensor(out.view(-1), t, group=self.group)
+        elif self.world == 1:
+            out.copy_(t.view(1, -1))
+        else:
+            out.copy_(self.all_gather(t))
+        return out
+
+    def make_plan(self, send, recv):
+        """Pre-builds the grouped send/recv of a halo whose buffers do not change between calls (nccl only)."""
+        if not self.direct or self.world == 1:
+            return None
+        p2p = [dist.P2POp(dist.irecv, t, p, group=self.group) for p, t in sorted(recv.items()) if t.numel()]
+        p2p += [dist.P2POp(dist.isend, t, p, group=self.group) for p, t in sorted(send.items()) if t.numel()]
+        return p2p
+
+    def run_plan(self, plan):
+        if plan:
+            for w in dist.batch_isend_irecv(plan):
+                w.wait()
+
     def exchange(self, send, recv):
         """send / recv: {peer: contiguous tensor}; recv tensors are filled in place."""
         if self.world == 1 or (not send and not recv):
@@ -234,18 +257,28 @@ class DistributedContactStepper:
             off += recv_cnt[p]
         self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=sum(send_cnt))
 
+    def _prepare_velocity_halo(self):
+        """fixed send buffer + receive views into self.vel, and (nccl) a reusable grouped send/recv plan"""
+        self._vsend, self._vsend_buf = {}, None
+        if self.vel_send_idx is not None:
+            self._vsend_buf = torch.empty((self.vel_send_idx.shape[0], 6), dtype=torch.float64, device=self.vel.device)
+            off = 0
+            for p, k in zip(self.vel_send_peers, self.vel_send_split):
+                self._vsend[p] = self._vsend_buf[off:off + k]
+                off += k
+        self._vrecv = {p: self.vel[a:b] for p, (a, b) in self.vel_recv.items()}
+        self._vplan = self.comm.make_plan(self._vsend, self._vrecv)
+
     def _halo_velocity(self):
         if self.comm.world == 1:
             return
-        send = {}
-        if self.vel_send_idx is not None:
-            buf = ops.gather_rows(self.vel_send_idx, self.vel)
-            off = 0
-            for p, k in zip(self.vel_send_peers, self.vel_send_split):
-                send[p] = buf[off:off + k]
-                off += k
-        recv = {p: self.vel[a:b] for p, (a, b) in self.vel_recv.items()}
-        self.comm.exchange(send, recv)
+        if self._vsend_buf is not None:
+            capi.check(capi.load().mhip_gather_rows(self._vsend_buf.shape[0], 6, _p(self.vel_send_idx), _p(self.vel),
+                                                    _p(self._vsend_buf), _stream()))
+        if self._vplan is not None:
+            self.comm.run_plan(self._vplan)
+        else:
+            self.comm.exchange(self._vsend, self._vrecv)
 
     # -- one step -------------------------------------------------------------------------------------------------------------
     def step(self, integrate=True):
@@ -281,6 +314,10 @@ class DistributedContactStepper:
         sp = capi.Space(ops.SPACE_LOWER_BOUND, 0.0, 0.0)
         pc = capi.PgdConfig(int(self.cfg.max_iters), float(self.cfg.tol), int(self.cfg.residual_kind))
         local3 = torch.empty(3, dtype=torch.float64, device=dev)
+        gathered = torch.empty((comm.world, 3), dtype=torch.float64, device=dev)
+        self._prepare_velocity_halo()
+        h, stream = op._h, _stream()
+        p_local3, p_gathered = _p(local3), _p(gathered)
         capi.check(lib.mhip_bbpgd_stage_begin(op._h, _p(con["sep"]), C.byref(sp), C.byref(pc), _p(x), _p(g),
                                               _p(x_tmp), _p(g_tmp), _stream()))
 
@@ -292,34 +329,36 @@ class DistributedContactStepper:
             return e
 
         def iteration(init):
-            prof = self.profile and not init
+            prof = self.profile and not init and (self._it_count % 8 == 0)  # sampled: event records are not free
+            self._it_count += 1
             e0 = mark() if prof else None
-            capi.check(lib.mhip_bbpgd_stage_body(op._h, init, _stream()))
+            capi.check(lib.mhip_bbpgd_stage_body(h, init, stream))
             e1 = mark() if prof else None
             self._halo_velocity()
             e2 = mark() if prof else None
-            capi.check(lib.mhip_bbpgd_stage_constraint(op._h, init, _p(local3), _stream()))
+            capi.check(lib.mhip_bbpgd_stage_constraint(h, init, p_local3, stream))
             e3 = mark() if prof else None
-            gathered = comm.all_gather(local3)
-            capi.check(lib.mhip_bbpgd_stage_finalize(op._h, init, _p(gathered), comm.world, _stream()))
+            comm.all_gather_into(gathered, local3)
+            capi.check(lib.mhip_bbpgd_stage_finalize(h, init, p_gathered, comm.world, stream))
             if prof:
-                events.append((e0, e1, e2, e3))
+                events.append((self._it_count - 1, e0, e1, e2, e3))
 
+        self._it_count = 0
         iteration(1)
         res, done = capi.SolveResult(), C.c_int(0)
-        enq, iter_before = 0, 0
+        enq = 0
         while True:
             capi.check(lib.mhip_bbpgd_stage_poll(op._h, C.byref(res), C.byref(done), _stream()))
-            if events:  # only the iterations that did work: those that advanced iter, plus the converging one
-                eff = min(len(events), int(res.num_iters) - iter_before + (1 if res.converged else 0))
-                for e0, e1, e2, e3 in events[:eff]:
-                    self.prof["body_ms"] += e0.elapsed_time(e1)
-                    self.prof["con_ms"] += e2.elapsed_time(e3)
-                self.prof["iters"] += eff
+            if events:  # only iterations that did work: index (1-based after init) <= iterations actually run
+                ran = int(res.num_iters) + (1 if res.converged else 0)
+                for k, e0, e1, e2, e3 in events:
+                    if k <= ran:
+                        self.prof["body_ms"] += e0.elapsed_time(e1)
+                        self.prof["con_ms"] += e2.elapsed_time(e3)
+                        self.prof["iters"] += 1
                 events.clear()
             if done.value or enq >= self.cfg.max_iters:
                 break
-            iter_before = int(res.num_iters)
             todo = min(self.poll_every, self.cfg.max_iters - enq)
             for _ in range(todo):
                 iteration(0)

@@ -1,0 +1,21 @@
+"""Host overhead of the staged (multi-rank) solver path, measured at world size 1 over nccl on one GPU: the same 10^6-rod
+step through DistributedContactStepper (Python-driven stages + all-gather per iteration) vs the fused C++ driver."""
+import sys, time
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, ".")
+from mundy_amd import distributed as D, ops, pipeline, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29733", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+b = synth.spherocylinders(n)
+order = D.hilbert_order(b["center"], 0.0, b["box"], level=7)
+c, q, r, L = (b[k][order] for k in ("center", "quat", "radius", "length"))
+cfg = ops.PGDConfig(max_iters=10000, tol=1e-5)
+st = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=D.Comm(), cfg=cfg, poll_every=32)
+ref = pipeline.ContactStepper("spherocylinder", dev(c), dev(r), dev(q), dev(L), search_buffer=0.1, cfg=cfg)
+for name, fn in (("staged", lambda: st.step(integrate=False)), ("fused", lambda: ref.step(integrate=False))):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    it = out["num_iters"] if isinstance(out, dict) else out.num_iters
+    print("%s: %.1f ms/step, %d iterations, %.3f ms/iteration" % (name, 1e3 * dt, it, 1e3 * dt / max(it, 1)))
+dist.destroy_process_group()

@@ -180,3 +180,25 @@ def test_periodic_metric_bit_exact(ops, oracle):
     w = host(ops.wrap_rigid(box, dev(p1)))
     assert_bits_equal(w, oracle.periodic_wrap(box, p1), "wrap_rigid")
     assert np.all(w >= 0) and np.all(w < box)
+
+
+def test_degenerate_inputs_follow_the_reference(ops, oracle):
+    # degenerate bodies as the reference treats them: zero-length rod == sphere-like segment, zero radius, identical
+    # segments (distance 0 -> the contact normal is 0/0: NaN on both sides, no guard in the reference, SphereSphere.hpp:66-76)
+    from gpu_util import assert_bits_equal, dev, host
+    c = np.array([[0.0, 0, 0], [0.0, 0, 0], [3.0, 0, 0], [3.0, 0.0, 0]])
+    q = np.array([[1.0, 0, 0, 0]] * 4)
+    r = np.array([0.5, 0.5, 0.0, 0.25])
+    L = np.array([0.0, 2.0, 2.0, 0.0])
+    seg = oracle.spherocylinder_segments(c, q, r, L)
+    pairs = np.array([[0, 1], [0, 2], [1, 2], [2, 3], [0, 3]], dtype=np.int32)
+    got = ops.contact_spherocylinders(dev(pairs), dev(seg), dev(c))
+    exp = oracle.contact_spherocylinders(pairs, seg, c)
+    for k in ("sep", "s", "t", "cp1", "cp2"):
+        assert_bits_equal(host(got[k]), exp[k], "degenerate " + k)
+    gn, en = host(got["normal"]), exp["normal"]
+    assert np.array_equal(np.isnan(gn), np.isnan(en)) and np.isnan(en[0]).all()   # coincident centrelines
+    np.testing.assert_array_equal(gn[~np.isnan(en)], en[~np.isnan(en)])
+    d, sep = ops.distance_sphere_sphere(dev(c[:1]), dev(r[:1]), dev(c[1:2]), dev(r[1:2]))
+    od, osep = oracle.distance_sphere_sphere(c[:1], r[:1], c[1:2], r[1:2])
+    assert host(d)[0] == od[0] == -1.0 and np.isnan(host(sep)).all() and np.isnan(osep).all()
