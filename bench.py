@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+CON_BYTES, BODY_BYTES_PER_CONTACT, BODY_BYTES_PER_BODY = 184.0, 104.0, 116.0  # algorithmic bytes, see roofline()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -129,11 +130,12 @@ def main():
     value = world * args.steps / elapsed
 
     # ---- roofline of the dominant kernel (k_constraint of the fused BBPGD iteration) -------------------------------
-    # algorithmic bytes per constraint: pair 8 + normal 24 + lever arms 48 + 2 x 48 gathered body
-    # velocities + x_tmp, g_tmp, q 24 read; x, g 16 written = 216 B;  k_body: 2 x (x_tmp, g_tmp 16 + normal 24 +
-    # arm 24 + incidence entry 4) = 136 B per constraint + 68 B per body (row pointer 4, mobilities 16, velocity 48)
-    con_bytes = 216.0 * contacts
-    body_bytes = 136.0 * contacts + 68.0 * n
+    # algorithmic bytes per constraint, rod-compressed kinematics: pair 8 + normal 24 + arclengths 16 +
+    # 2 x 48 gathered body rows + x_tmp, g_tmp, q 24 read; x, g 16 written = 184 B;  k_body: 2 x (x_tmp, g_tmp 16 +
+    # 32-byte half-edge record + incidence entry 4) = 104 B per constraint + 116 B per body (row pointer 4,
+    # mobilities 16, axis 24, velocity row 48, angular velocity 24)
+    con_bytes = CON_BYTES * contacts
+    body_bytes = BODY_BYTES_PER_CONTACT * contacts + BODY_BYTES_PER_BODY * n
     roof, extra = None, {}
     if prof["iters"] > 0:
         con_ms = prof["con_ms"] / prof["iters"]
@@ -228,13 +230,13 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
         c_local = stats[-1]["local_contacts"]
         con_ms = st.prof["con_ms"] / st.prof["iters"]
         body_ms = st.prof["body_ms"] / st.prof["iters"]
-        con_bytes = 216.0 * c_local
+        con_bytes = CON_BYTES * c_local
         achieved = con_bytes / (con_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "k_constraint<X_SOLVE,rot> (+k_reduce_local3), rank 0", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_ms": round(con_ms, 4), "launches": st.prof["iters"], "bytes_per_launch": con_bytes}
         extra = {"k_body": {"avg_launch_ms": round(body_ms, 4),
-                            "achieved_GBs": round((136.0 * c_local + 68.0 * n) / (body_ms * 1e-3) / 1e9, 1)}}
+                            "achieved_GBs": round((BODY_BYTES_PER_CONTACT * c_local + BODY_BYTES_PER_BODY * n) / (body_ms * 1e-3) / 1e9, 1)}}
     if rank == 0:
         out = {
             "metric": "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",

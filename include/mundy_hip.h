@@ -220,6 +220,15 @@ typedef struct mhip_contact_op* mhip_contact_op_t;
 int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
                            const double* normal, const double* ra, const double* rb, const double* mob_trans,
                            const double* mob_rot, double dt, mhip_stream_t stream);
+/* Spherocylinders: the same operator with rod-compressed kinematics.  A rod's contact point lies on its centreline,
+ * cp = c + (s - 1/2)(p1 - p0), so each lever arm is one scalar; the sweeps stream (s, t) [16 B per contact] instead of
+ * (ra, rb) [48 B] and 32-byte instead of 48-byte half-edge records (-18 % bytes per BBPGD iteration).  arc_s / arc_t
+ * [C] and seg [N][8] are the outputs of mhip_contact_spherocylinders / mhip_spherocylinder_segments.  Same operator up
+ * to rounding (the arm (s - 1/2) u replaces (p0 + s u) - c). */
+int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies,
+                                const int32_t* pairs, const double* normal, const double* arc_s, const double* arc_t,
+                                const double* seg, const double* mob_trans, const double* mob_rot, double dt,
+                                mhip_stream_t stream);
 int mhip_contact_op_destroy(mhip_contact_op_t handle);
 int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, mhip_stream_t stream);
 /* Per-kernel timing of the fused solver (measurement support, no effect on results): when enabled,
@@ -228,7 +237,8 @@ int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, 
  * (sampled launches of each kernel) since profiling was enabled.  All out pointers [host]. */
 int mhip_contact_op_set_profiling(mhip_contact_op_t handle, int enable);
 int mhip_contact_op_get_profile(mhip_contact_op_t handle, double* body_ms, double* constraint_ms, size_t* iterations);
-/* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate */
+/* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate (valid in stream order after
+ * that call; for a partitioned operator only the owned rows are meaningful) */
 int mhip_contact_op_body_velocity(mhip_contact_op_t handle, const double** velocity /*[host] out: device pointer*/);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -271,6 +271,7 @@ struct SolverState {  // device resident
 };
 
 enum XMode { X_APPLY = 0, X_INIT = 1, X_SOLVE = 2 };
+enum Kinematics { KIN_TRANS = 0, KIN_RIGID = 1, KIN_ROD = 2 };  // spheres | explicit lever arms | rod-compressed
 
 struct OpView {
   size_t C, N;
@@ -286,6 +287,14 @@ struct OpView {
   // lower body).  Defaults: all bodies, all contacts.
   size_t body_first, body_count;
   const unsigned char* counted;
+  // rod-compressed kinematics (KIN_ROD): a rod's contact point lies on its centreline, cp = c + (s - 1/2) u with
+  // u = p1 - p0, so the lever arm is ONE scalar per contact side plus a per-body axis (an L2-resident table):
+  //   torque  T_b = u_b x sum_e coef_e f_e          velocity at the contact  v = U_b + coef (W_b x u_b) = U_b + coef Z_b
+  // The sweeps then stream (s, t) [16 B] instead of (ra, rb) [48 B], 32-byte half-edge records instead of 48-byte
+  // ones, and gather the same 48-byte body rows, which now hold (U, Z).  W is kept in `omega` for the integrator.
+  const double *arc_s, *arc_t;  // [C] arclength parameters of the two closest points
+  const double* axis;           // [N][3] u = p1 - p0
+  double* omega;                // [N][3] angular velocity W
   int xcd_aware;  // XCD-contiguous tile mapping (performance only; MHIP_XCD_AWARE=0 disables it for A/B runs)
 };
 
@@ -324,7 +333,7 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 // The order is fixed (no atomics), so results are bitwise reproducible run to run.
 //   half-edge record e -> (n_c, r_side) gathered once at operator creation: 48 B (24 B translation-only)
 // algorithmic bytes: per half edge 4 (entry) + 48 (record) + 16 (x_tmp, g_tmp gathered); per body 4 + 16 + 48.
-template <int MODE, bool ROT, int G>
+template <int MODE, int KIN, int G>
 __global__ void __launch_bounds__(kBlock)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
@@ -348,7 +357,7 @@ __global__ void __launch_bounds__(kBlock)
   const int sub = static_cast<int>(t % G);
   if (t / G >= op.body_count) return;  // whole groups leave together (G divides the wave size)
   const size_t b = op.body_first + t / G;
-  constexpr int HW = ROT ? 6 : 3;
+  constexpr int HW = (KIN == KIN_RIGID) ? 6 : (KIN == KIN_ROD ? 4 : 3);
   V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
   for (int32_t k = beg + sub; k < end; k += G) {
@@ -360,11 +369,17 @@ __global__ void __launch_bounds__(kBlock)
     // unchanged -- so its 48-byte record is never fetched
     if (lam == 0.0) continue;
     V3 n, r{0.0, 0.0, 0.0};
-    if (ROT) {  // 48-byte records, 16-byte aligned: three 16-byte loads
+    double coef = 0.0;
+    if (KIN == KIN_RIGID) {  // 48-byte records, 16-byte aligned: three 16-byte loads
       const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * HW);
       const double2 h0 = H2[0], h1 = H2[1], h2 = H2[2];
       n = V3{h0.x, h0.y, h1.x};
       r = V3{h1.y, h2.x, h2.y};
+    } else if (KIN == KIN_ROD) {  // 32-byte records: (n, s - 1/2)
+      const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * HW);
+      const double2 h0 = H2[0], h1 = H2[1];
+      n = V3{h0.x, h0.y, h1.x};
+      coef = h1.y;
     } else {
       const double* H = op.half + (size_t)k * HW;
       n = V3{H[0], H[1], H[2]};
@@ -372,14 +387,15 @@ __global__ void __launch_bounds__(kBlock)
     V3 f{lam * n.x, lam * n.y, lam * n.z};
     if (!target) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
     F = F + f;
-    if (ROT) T = T + cross(r, f);  // torque about the body centre, r x (+/- lam n)
+    if (KIN == KIN_RIGID) T = T + cross(r, f);  // torque about the body centre, r x (+/- lam n)
+    if (KIN == KIN_ROD) T = T + coef * f;       // S = sum coef f; the torque is u x S, formed once per body below
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
     F.x += __shfl_xor(F.x, off, 64);
     F.y += __shfl_xor(F.y, off, 64);
     F.z += __shfl_xor(F.z, off, 64);
-    if (ROT) {
+    if (KIN != KIN_TRANS) {
       T.x += __shfl_xor(T.x, off, 64);
       T.y += __shfl_xor(T.y, off, 64);
       T.z += __shfl_xor(T.z, off, 64);
@@ -389,16 +405,24 @@ __global__ void __launch_bounds__(kBlock)
   const double mt = op.mt[b];
   double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
   V3 W{0.0, 0.0, 0.0};
-  if (ROT) {
+  if (KIN == KIN_RIGID) {
     const double mr = op.mr[b];
     W = V3{mr * T.x, mr * T.y, mr * T.z};
+  }
+  if (KIN == KIN_ROD) {
+    const double mr = op.mr[b];
+    const V3 u = load3(op.axis, b);
+    const V3 tq = cross(u, T);  // T holds S = sum coef f
+    const V3 w{mr * tq.x, mr * tq.y, mr * tq.z};
+    store3(op.omega, b, w);
+    W = cross(w, u);  // the row carries Z = W x u: the contact-point velocity is U + coef Z
   }
   v[0] = make_double2(mt * F.x, mt * F.y);  // U = F / (6 pi r mu)  (NgpLcp.cpp:484-486)
   v[1] = make_double2(mt * F.z, W.x);
   v[2] = make_double2(W.y, W.z);
 }
 
-template <int MODE, bool ROT>
+template <int MODE, int KIN>
 __global__ void __launch_bounds__(kBlock)
     k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
@@ -430,10 +454,16 @@ __global__ void __launch_bounds__(kBlock)
     const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
     const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
     V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
-    if (ROT) {
+    if (KIN == KIN_RIGID) {
       const double2 a2 = vi2[2], b2 = vj2[2];
       vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
       vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    }
+    if (KIN == KIN_ROD) {
+      const double2 a2 = vi2[2], b2 = vj2[2];
+      const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+      vi = vi + ci * V3{a1.y, a2.x, a2.y};
+      vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
     // sdot = -n . (v_src - v_tgt)  (NgpLcp.cpp:526-528)
     const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
@@ -541,7 +571,7 @@ __global__ void __launch_bounds__(kBlock) k_reduce_local3(int nparts, const doub
 //   ite_count counts started iterations, the converging one included (:636)
 //   quirk kept: the first projected step uses the gradient WITHOUT the A x_0 term (signed_sep_dot is still zero at
 //   :639; signed_sep_dot_tmp holds it) -- identical to the consistent form when the initial guess is zero.
-template <bool ROT, bool INIT>
+template <int KIN, bool INIT>
 __global__ void __launch_bounds__(kBlock)
     k_scrap_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                        double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q,
@@ -573,10 +603,16 @@ __global__ void __launch_bounds__(kBlock)
     const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
     const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
     V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
-    if (ROT) {
+    if (KIN == KIN_RIGID) {
       const double2 a2 = vi2[2], b2 = vj2[2];
       vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
       vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    }
+    if (KIN == KIN_ROD) {
+      const double2 a2 = vi2[2], b2 = vj2[2];
+      const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+      vi = vi + ci * V3{a1.y, a2.x, a2.y};
+      vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
     const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
     const double g = q[c] + op.dt * sdot;  // sep_new = sep_old + dt * sep_dot
@@ -727,21 +763,40 @@ __global__ void __launch_bounds__(kBlock) k_inc_sort(size_t N, const int32_t* __
 }
 
 // half-edge records in incidence order: the body sweep then streams them instead of gathering normals / arms
-template <bool ROT>
+template <int KIN>
 __global__ void __launch_bounds__(kBlock)
     k_half_build(size_t nent, const int32_t* __restrict__ inc, const double* __restrict__ normal,
-                 const double* __restrict__ ra, const double* __restrict__ rb, double* __restrict__ half) {
-  constexpr int HW = ROT ? 6 : 3;
+                 const double* __restrict__ ra, const double* __restrict__ rb, const double* __restrict__ arc_s,
+                 const double* __restrict__ arc_t, double* __restrict__ half) {
+  constexpr int HW = (KIN == KIN_RIGID) ? 6 : (KIN == KIN_ROD ? 4 : 3);
   for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < nent; k += (size_t)gridDim.x * blockDim.x) {
     const int32_t e = inc[k];
     const size_t c = static_cast<size_t>(e >> 1);
     double* H = half + k * HW;
     const V3 n = load3(normal, c);
     H[0] = n.x; H[1] = n.y; H[2] = n.z;
-    if (ROT) {
+    if (KIN == KIN_RIGID) {
       const V3 r = (e & 1) ? load3(rb, c) : load3(ra, c);
       H[3] = r.x; H[4] = r.y; H[5] = r.z;
     }
+    if (KIN == KIN_ROD) H[3] = ((e & 1) ? arc_t[c] : arc_s[c]) - 0.5;
+  }
+}
+
+// rod axes u = p1 - p0 from the 64-byte segment records
+__global__ void __launch_bounds__(kBlock) k_rod_axes(size_t n, const double* __restrict__ seg, double* __restrict__ axis) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double* r = seg + 8 * i;
+    store3(axis, i, V3{r[3], r[4], r[5]} - V3{r[0], r[1], r[2]});
+  }
+}
+// (U, Z) rows + omega -> (U, W) rows for the integrator
+__global__ void __launch_bounds__(kBlock) k_assemble_velocity(size_t n, const double* __restrict__ vel,
+                                                             const double* __restrict__ omega,
+                                                             double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    out[6 * i] = vel[6 * i]; out[6 * i + 1] = vel[6 * i + 1]; out[6 * i + 2] = vel[6 * i + 2];
+    out[6 * i + 3] = omega[3 * i]; out[6 * i + 4] = omega[3 * i + 1]; out[6 * i + 5] = omega[3 * i + 2];
   }
 }
 
@@ -751,8 +806,10 @@ using namespace mhip;
 
 struct mhip_contact_op {
   OpView view{};
-  bool rot = false;
-  DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half;
+  bool rot = false;  // any rotational kinematics (KIN_RIGID or KIN_ROD)
+  int kin = KIN_TRANS;
+  hipStream_t last_stream = nullptr;
+  DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half, axis, omega, vel_out;
   int lanes_per_body = 8;
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
@@ -778,6 +835,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   const int G = op->lanes_per_body;
   if (op->view.body_count == 0) return MHIP_SUCCESS;
   const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
+  op->last_stream = s;
   const SolverState* st = op->state.as<SolverState>();
 #define BODY3(M, R, GG) k_body<M, R, GG><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
 #define BODY(M, R)                 \
@@ -787,11 +845,12 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
     else if (G == 32) BODY3(M, R, 32); \
     else BODY3(M, R, 16);          \
   } while (0)
-  if (op->rot) {
-    if (mode == X_APPLY) BODY(X_APPLY, true); else if (mode == X_INIT) BODY(X_INIT, true); else BODY(X_SOLVE, true);
-  } else {
-    if (mode == X_APPLY) BODY(X_APPLY, false); else if (mode == X_INIT) BODY(X_INIT, false); else BODY(X_SOLVE, false);
-  }
+#define BODYK(K) \
+  do { if (mode == X_APPLY) BODY(X_APPLY, K); else if (mode == X_INIT) BODY(X_INIT, K); else BODY(X_SOLVE, K); } while (0)
+  if (op->kin == KIN_ROD) BODYK(KIN_ROD);
+  else if (op->kin == KIN_RIGID) BODYK(KIN_RIGID);
+  else BODYK(KIN_TRANS);
+#undef BODYK
 #undef BODY3
 #undef BODY
   MHIP_LAUNCH_CHECK();
@@ -804,11 +863,12 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
   const SolverState* st = op->state.as<SolverState>();
   double* parts = op->partials.as<double>();
 #define CON(M, R) k_constraint<M, R><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts)
-  if (op->rot) {
-    if (mode == X_APPLY) CON(X_APPLY, true); else if (mode == X_INIT) CON(X_INIT, true); else CON(X_SOLVE, true);
-  } else {
-    if (mode == X_APPLY) CON(X_APPLY, false); else if (mode == X_INIT) CON(X_INIT, false); else CON(X_SOLVE, false);
-  }
+#define CONK(K) \
+  do { if (mode == X_APPLY) CON(X_APPLY, K); else if (mode == X_INIT) CON(X_INIT, K); else CON(X_SOLVE, K); } while (0)
+  if (op->kin == KIN_ROD) CONK(KIN_ROD);
+  else if (op->kin == KIN_RIGID) CONK(KIN_RIGID);
+  else CONK(KIN_TRANS);
+#undef CONK
 #undef CON
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -934,17 +994,15 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
   return MHIP_SUCCESS;
 }
 
-int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
-                           const double* normal, const double* ra, const double* rb, const double* mob_trans,
-                           const double* mob_rot, double dt, mhip_stream_t stream) {
+static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_constraints, size_t num_bodies,
+                             const int32_t* pairs, const double* normal, const double* ra, const double* rb,
+                             const double* arc_s, const double* arc_t, const double* seg, const double* mob_trans,
+                             const double* mob_rot, double dt, mhip_stream_t stream) {
   MHIP_REQUIRE(handle != nullptr, MHIP_ERR_INVALID_ARGUMENT, "handle is null");
   *handle = nullptr;
   const size_t C = num_constraints, N = num_bodies;
   MHIP_REQUIRE(C == 0 || (pairs && normal), MHIP_ERR_INVALID_ARGUMENT, "pairs / normal must not be null");
   MHIP_REQUIRE(N == 0 || mob_trans, MHIP_ERR_INVALID_ARGUMENT, "mob_trans must not be null");
-  const int nrot = (ra != nullptr) + (rb != nullptr) + (mob_rot != nullptr);
-  MHIP_REQUIRE(nrot == 0 || nrot == 3, MHIP_ERR_INVALID_ARGUMENT,
-               "ra, rb and mob_rot must be given together (rigid bodies) or all be null (translation only)");
   MHIP_REQUIRE(C < (1u << 30) && N < (1u << 31), MHIP_ERR_RUNTIME, "problem too large for 32-bit incidence entries");
   hipStream_t s = as_stream(stream);
   mhip_contact_op* op = new mhip_contact_op();
@@ -952,7 +1010,8 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
     mhip_contact_op_destroy(op);
     return e;
   };
-  op->rot = (nrot == 3);
+  op->kin = kin;
+  op->rot = (kin != KIN_TRANS);
   if (int e = op->inc_ptr.reserve((N + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->cursor.reserve((N + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->inc.reserve((2 * C + 2) * sizeof(int32_t))) return bail(e);
@@ -989,17 +1048,25 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
   }
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "incidence build failed: %s", hipGetErrorString(he)));
-  if (int e = op->half.reserve((2 * C + 2) * (op->rot ? 6 : 3) * sizeof(double))) return bail(e);
-  if (C > 0) {
-    if (op->rot)
-      k_half_build<true><<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), normal, ra, rb,
-                                                            op->half.as<double>());
-    else
-      k_half_build<false><<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), normal, ra, rb,
-                                                             op->half.as<double>());
-    he = hipGetLastError();
-    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "half-edge build failed: %s", hipGetErrorString(he)));
+  const int hw = (kin == KIN_RIGID) ? 6 : (kin == KIN_ROD ? 4 : 3);
+  if (int e = op->half.reserve((2 * C + 2) * hw * sizeof(double))) return bail(e);
+  if (kin == KIN_ROD) {
+    if (int e = op->axis.reserve((3 * N + 2) * sizeof(double))) return bail(e);
+    if (int e = op->omega.reserve((3 * N + 2) * sizeof(double))) return bail(e);
+    he = hipMemsetAsync(op->omega.ptr, 0, (3 * N + 2) * sizeof(double), s);
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
+    if (N > 0) k_rod_axes<<<grid_for(N), kBlock, 0, s>>>(N, seg, op->axis.as<double>());
   }
+  if (C > 0) {
+    const size_t ne = 2 * C;
+    int32_t* inc = op->inc.as<int32_t>();
+    double* half = op->half.as<double>();
+    if (kin == KIN_ROD) k_half_build<KIN_ROD><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
+    else if (kin == KIN_RIGID) k_half_build<KIN_RIGID><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
+    else k_half_build<KIN_TRANS><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
+  }
+  he = hipGetLastError();
+  if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "half-edge build failed: %s", hipGetErrorString(he)));
   {
     // lanes per body ~ half the mean degree, so most bodies finish in two passes of their group
     const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
@@ -1009,16 +1076,38 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
       op->lanes_per_body = 8;
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
-                    op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, 0};
+                    op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
+                    op->axis.as<double>(), op->omega.as<double>(), 0};
   if (const char* xe = getenv("MHIP_XCD_AWARE")) op->view.xcd_aware = atoi(xe) ? 1 : 0;
   *handle = op;
   return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
+                           const double* normal, const double* ra, const double* rb, const double* mob_trans,
+                           const double* mob_rot, double dt, mhip_stream_t stream) {
+  const int nrot = (ra != nullptr) + (rb != nullptr) + (mob_rot != nullptr);
+  MHIP_REQUIRE(nrot == 0 || nrot == 3, MHIP_ERR_INVALID_ARGUMENT,
+               "ra, rb and mob_rot must be given together (rigid bodies) or all be null (translation only)");
+  return create_contact_op(handle, nrot == 3 ? KIN_RIGID : KIN_TRANS, num_constraints, num_bodies, pairs, normal, ra,
+                           rb, nullptr, nullptr, nullptr, mob_trans, mob_rot, dt, stream);
+}
+
+int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies,
+                                const int32_t* pairs, const double* normal, const double* arc_s, const double* arc_t,
+                                const double* seg, const double* mob_trans, const double* mob_rot, double dt,
+                                mhip_stream_t stream) {
+  MHIP_REQUIRE(num_constraints == 0 || (arc_s && arc_t), MHIP_ERR_INVALID_ARGUMENT, "arclength arrays must not be null");
+  MHIP_REQUIRE(num_bodies == 0 || (seg && mob_rot), MHIP_ERR_INVALID_ARGUMENT, "seg / mob_rot must not be null");
+  return create_contact_op(handle, KIN_ROD, num_constraints, num_bodies, pairs, normal, nullptr, nullptr, arc_s, arc_t,
+                           seg, mob_trans, mob_rot, dt, stream);
 }
 
 int mhip_contact_op_destroy(mhip_contact_op_t op) {
   if (!op) return MHIP_SUCCESS;
   op->inc_ptr.release(); op->inc.release(); op->cursor.release(); op->vel.release();
   op->partials.release(); op->state.release(); op->scanws.release(); op->half.release();
+  op->axis.release(); op->omega.release(); op->vel_out.release();
   if (op->host_state) (void)hipHostFree(op->host_state);
   for (auto& ev : op->events) (void)hipEventDestroy(ev);
   delete op;
@@ -1054,7 +1143,19 @@ int mhip_contact_op_get_profile(mhip_contact_op_t op, double* body_ms, double* c
 
 int mhip_contact_op_body_velocity(mhip_contact_op_t op, const double** velocity) {
   MHIP_REQUIRE(op != nullptr && velocity != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
-  *velocity = op->vel.as<double>();
+  if (op->kin == KIN_ROD) {
+    // rod-compressed rows hold (U, W x u); assemble (U, W) in stream order after the last sweep
+    const size_t N = op->view.N;
+    if (int e = op->vel_out.reserve((6 * N + 2) * sizeof(double))) return e;
+    if (N > 0) {
+      k_assemble_velocity<<<grid_for(N), kBlock, 0, op->last_stream>>>(N, op->view.vel, op->omega.as<double>(),
+                                                                      op->vel_out.as<double>());
+      MHIP_LAUNCH_CHECK();
+    }
+    *velocity = op->vel_out.as<double>();
+    return MHIP_SUCCESS;
+  }
+  *velocity = op->view.vel;
   return MHIP_SUCCESS;
 }
 
@@ -1170,8 +1271,9 @@ int mhip_scrap_bbpgd_solve_contact(mhip_contact_op_t op, const double* sep, doub
   const Space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
   auto constraint = [&](bool init) {
 #define SCON(R, I) k_scrap_constraint<R, I><<<cgrid, kBlock, 0, s>>>(op->view, st, lam_tmp, lam, g_tmp, g, sep, parts)
-    if (op->rot) { if (init) SCON(true, true); else SCON(true, false); }
-    else { if (init) SCON(false, true); else SCON(false, false); }
+    if (op->kin == KIN_ROD) { if (init) SCON(KIN_ROD, true); else SCON(KIN_ROD, false); }
+    else if (op->kin == KIN_RIGID) { if (init) SCON(KIN_RIGID, true); else SCON(KIN_RIGID, false); }
+    else { if (init) SCON(KIN_TRANS, true); else SCON(KIN_TRANS, false); }
 #undef SCON
   };
   // gkm1 = D^T M D xkm1 with xkm1 = the given multipliers (:576-611)

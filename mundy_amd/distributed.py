@@ -298,13 +298,14 @@ class DistributedContactStepper:
         nc = int(cnt.value)
         pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
         seg = ops.spherocylinder_segments(L["center"], L["quat"], L["radius"], L["length"])
-        con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False)
+        con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False, arms="arclength")
         mt, mr = self._synth.dry_mobility(brad.cpu().numpy(), viscosity=self.viscosity)
         mob_t, mob_r = torch.from_numpy(mt).to(dev), torch.from_numpy(mr).to(dev)
         if self.op is not None:
             self.op.close()
-        op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, ra=con["ra"], rb=con["rb"],
-                                           mob_rot=mob_r)
+        # rod-compressed kinematics: velocity rows (and the halo) carry (U, W x u); (U, W) comes from body_velocity()
+        op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
+                                           rod=(con["s"], con["t"], seg))
         self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
         self._keep = (pairs, counted, con, mob_t, mob_r, seg)
         capi.check(lib.mhip_contact_op_set_partition(op._h, self.n_lo, self.n, _p(counted), _p(self.vel)))
@@ -368,7 +369,7 @@ class DistributedContactStepper:
         if integrate:
             a, b = self.n_lo, self.n_lo + self.n
             own_c, own_q = L["center"][a:b], L["quat"][a:b]
-            ops.integrate_euler(self.dt, self.vel[a:b], own_c, own_q)
+            ops.integrate_euler(self.dt, op.body_velocity()[a:b], own_c, own_q)
             self.center.copy_(own_c)
             self.quat.copy_(own_q)
         owned_contacts = int(counted.sum().item()) if nc else 0

@@ -187,12 +187,17 @@ def contact_spheres(pairs, center, radius, box=None, out=None):
     return sep, normal
 
 
-def contact_spherocylinders(pairs, seg, center, want_points=True, out=None):
+def contact_spherocylinders(pairs, seg, center, want_points=True, out=None, arms="vector"):
+    """arms="vector": lever arms ra / rb [C,3]; arms="arclength": only (s, t), for ContactOperator(rod=...)."""
     c = pairs.shape[0]
     if out is None:
-        out = dict(sep=_new(seg, c), normal=_new(seg, c, 3), ra=_new(seg, c, 3), rb=_new(seg, c, 3))
+        out = dict(sep=_new(seg, c), normal=_new(seg, c, 3))
+        if arms == "vector":
+            out.update(ra=_new(seg, c, 3), rb=_new(seg, c, 3))
+        if want_points or arms == "arclength":
+            out.update(s=_new(seg, c), t=_new(seg, c))
         if want_points:
-            out.update(cp1=_new(seg, c, 3), cp2=_new(seg, c, 3), s=_new(seg, c), t=_new(seg, c))
+            out.update(cp1=_new(seg, c, 3), cp2=_new(seg, c, 3))
     g = lambda k: _ptr(out.get(k), allow_none=True, name=k)  # noqa: E731
     capi.check(capi.load().mhip_contact_spherocylinders(c, _ptr(pairs, torch.int32, 2), _ptr(seg, cols=8),
                                                         _ptr(center, cols=3), g("sep"), g("normal"), g("cp1"),
@@ -359,15 +364,22 @@ def gemv(A, x):
 class ContactOperator:
     """Matrix-free A = dt D^T M D over a neighbour list (the LinearOp of seam S2; apply(x, y) as convex.hpp:133-136)."""
 
-    def __init__(self, pairs, normal, mob_trans, dt, ra=None, rb=None, mob_rot=None):
+    def __init__(self, pairs, normal, mob_trans, dt, ra=None, rb=None, mob_rot=None, rod=None):
+        """rod = (arc_s, arc_t, seg): spherocylinders with rod-compressed lever arms (mhip_contact_op_create_rods)."""
         self.num_constraints = pairs.shape[0]
         self.num_bodies = mob_trans.shape[0]
-        self._keep = (pairs, normal, ra, rb, mob_trans, mob_rot)  # the handle holds views of these
+        self._keep = (pairs, normal, ra, rb, mob_trans, mob_rot, rod)  # the handle holds views of these
         h = C.c_void_p()
-        capi.check(capi.load().mhip_contact_op_create(
-            C.byref(h), self.num_constraints, self.num_bodies, _ptr(pairs, torch.int32, 2), _ptr(normal, cols=3),
-            _ptr(ra, allow_none=True, name="ra"), _ptr(rb, allow_none=True, name="rb"), _ptr(mob_trans),
-            _ptr(mob_rot, allow_none=True, name="mob_rot"), float(dt), _stream()))
+        if rod is not None:
+            arc_s, arc_t, seg = rod
+            capi.check(capi.load().mhip_contact_op_create_rods(
+                C.byref(h), self.num_constraints, self.num_bodies, _ptr(pairs, torch.int32, 2), _ptr(normal, cols=3),
+                _ptr(arc_s), _ptr(arc_t), _ptr(seg, cols=8), _ptr(mob_trans), _ptr(mob_rot), float(dt), _stream()))
+        else:
+            capi.check(capi.load().mhip_contact_op_create(
+                C.byref(h), self.num_constraints, self.num_bodies, _ptr(pairs, torch.int32, 2), _ptr(normal, cols=3),
+                _ptr(ra, allow_none=True, name="ra"), _ptr(rb, allow_none=True, name="rb"), _ptr(mob_trans),
+                _ptr(mob_rot, allow_none=True, name="mob_rot"), float(dt), _stream()))
         self._h = h
         self._device = normal.device
 

@@ -32,7 +32,7 @@ class ContactStepper:
 
     def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
                  search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
-                 mob_rot=None):
+                 mob_rot=None, rod_kinematics=True):
         if kind not in ("sphere", "spherocylinder"):
             raise ValueError("kind must be 'sphere' or 'spherocylinder'")
         if kind == "spherocylinder" and (quat is None or length is None):
@@ -45,6 +45,9 @@ class ContactStepper:
         self.box = periodic_box
         self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)  # NgpLcp.cpp:851-852
         self.warm_start = warm_start
+        # spherocylinders: lever arms as one arclength per contact (mhip_contact_op_create_rods) -- same operator up to
+        # rounding, 18 % fewer bytes per solver iteration; False selects the (ra, rb) vector form
+        self.rod_kinematics = bool(rod_kinematics)
         self.links = (ops.GenNeighborLinks().set_search_buffer(search_buffer).set_search_kind(search_kind)
                       .set_periodic_box(periodic_box).concretize())
         n = center.shape[0]
@@ -109,15 +112,20 @@ class ContactStepper:
             self.contacts = dict(sep=sep, normal=normal, ra=None, rb=None)
         else:
             ops.spherocylinder_segments(self.center, self.quat, self.radius, self.length, out=self.seg)
-            self.contacts = ops.contact_spherocylinders(pairs, self.seg, self.center, want_points=False)
+            self.contacts = ops.contact_spherocylinders(pairs, self.seg, self.center, want_points=False,
+                                                        arms="arclength" if self.rod_kinematics else "vector")
         return self.contacts
 
     def resolve_collisions(self, rebuilt):
         c = self.contacts
         if self.op is not None:
             self.op.close()
-        self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c["ra"], rb=c["rb"],
-                                      mob_rot=self.mob_rot)
+        if self.kind != "sphere" and self.rod_kinematics:
+            self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, mob_rot=self.mob_rot,
+                                          rod=(c["s"], c["t"], self.seg))
+        else:
+            self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c.get("ra"),
+                                          rb=c.get("rb"), mob_rot=self.mob_rot)
         if getattr(self, "profile_next", False):
             self.op.set_profiling(True)  # per-kernel HIP-event timing of the fused iteration (bench.py roofline)
         nc = self.links.num_pairs

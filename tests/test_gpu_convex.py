@@ -101,17 +101,27 @@ def _rod_problem(oracle, n, seed, buffer=0.1):
     seg = oracle.spherocylinder_segments(c, b["quat"], b["radius"], b["length"])
     out = oracle.contact_spherocylinders(pairs, seg, c)
     mt, mr = synth.dry_mobility(b["radius"], bounding_radius=brad)
-    return dict(N=n, pairs=pairs, sep=out["sep"], normal=out["normal"], ra=out["ra"], rb=out["rb"], mt=mt, mr=mr)
+    return dict(N=n, pairs=pairs, sep=out["sep"], normal=out["normal"], ra=out["ra"], rb=out["rb"], mt=mt, mr=mr,
+                s=out["s"], t=out["t"], seg=seg)
+
+
+def _rod_problem_arclength(oracle, n, seed, buffer=0.1):
+    # same system; the GPU operator is built from (s, t, seg) (mhip_contact_op_create_rods) while the oracle keeps
+    # the reference's (ra, rb) vectors
+    return dict(_rod_problem(oracle, n, seed, buffer), rod=True)
 
 
 def _gpu_op(ops, P, dt=5e-3):
     from gpu_util import dev
     opt = lambda a: None if a is None else dev(a)  # noqa: E731
+    if P.get("rod"):
+        return ops.ContactOperator(dev(P["pairs"]), dev(P["normal"]), dev(P["mt"]), dt, mob_rot=dev(P["mr"]),
+                                   rod=(dev(P["s"]), dev(P["t"]), dev(P["seg"])))
     return ops.ContactOperator(dev(P["pairs"]), dev(P["normal"]), dev(P["mt"]), dt, ra=opt(P["ra"]), rb=opt(P["rb"]),
                                mob_rot=opt(P["mr"]))
 
 
-@pytest.mark.parametrize("maker,n", [(_sphere_problem, 3000), (_rod_problem, 3000)])
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 3000), (_rod_problem, 3000), (_rod_problem_arclength, 3000)])
 def test_contact_operator_apply(ops, oracle, maker, n):
     # the GPU operator against the serial scatter/mobility/gather of NgpLcp.cpp:442-530.  Per-contact terms are the
     # same expressions; the per-body sums run as a fixed G-lane tree instead of serially, so the bar is rounding
@@ -130,13 +140,31 @@ def test_contact_operator_apply(ops, oracle, maker, n):
     perm = rng.permutation(len(x))
     Q = dict(P, pairs=np.ascontiguousarray(P["pairs"][perm]), normal=np.ascontiguousarray(P["normal"][perm]))
     if P["ra"] is not None:
-        Q.update(ra=np.ascontiguousarray(P["ra"][perm]), rb=np.ascontiguousarray(P["rb"][perm]))
+        Q.update({k: np.ascontiguousarray(P[k][perm]) for k in ("ra", "rb", "s", "t")})
     y2 = host(_gpu_op(ops, Q).apply(dev(x[perm])))
     np.testing.assert_allclose(y2, yo[perm], rtol=1e-12, atol=1e-12 * np.abs(yo).max())
     op.close()
 
 
-@pytest.mark.parametrize("maker,n", [(_sphere_problem, 4000), (_rod_problem, 4000)])
+def test_rod_operator_body_velocity_matches_vector_form(ops, oracle):
+    # the rod-compressed operator keeps (U, W x u) in its velocity rows; body_velocity() hands back (U, W), equal to
+    # the vector-arm operator's to rounding (arm (s - 1/2) u vs (p0 + s u) - c: one ulp of the centre coordinate)
+    from gpu_util import assert_bits_equal, dev, host
+    P = _rod_problem(oracle, 3000, seed=5)
+    x = dev(np.random.default_rng(1).uniform(0, 1, len(P["pairs"])))
+    opv, opr = _gpu_op(ops, P), _gpu_op(ops, dict(P, rod=True))
+    yv, yr = host(opv.apply(x)), host(opr.apply(x))
+    vv, vr = host(opv.body_velocity()), host(opr.body_velocity())
+    scale = np.abs(vv).max(axis=0)
+    assert np.all(scale > 0)
+    np.testing.assert_allclose(vr, vv, rtol=0, atol=1e-12 * scale.max())
+    np.testing.assert_allclose(yr, yv, rtol=1e-12, atol=1e-12 * np.abs(yv).max())
+    assert_bits_equal(host(opr.body_velocity()), vr, "body velocity twice")
+    opv.close()
+    opr.close()
+
+
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 4000), (_rod_problem, 4000), (_rod_problem_arclength, 4000)])
 def test_fused_bbpgd_matches_oracle_and_unfused(ops, oracle, maker, n):
     from gpu_util import dev, host
     P = maker(oracle, n, seed=11)
@@ -166,7 +194,7 @@ def test_fused_bbpgd_matches_oracle_and_unfused(ops, oracle, maker, n):
     op.close()
 
 
-@pytest.mark.parametrize("maker,n", [(_sphere_problem, 4000), (_rod_problem, 3000)])
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 4000), (_rod_problem, 3000), (_rod_problem_arclength, 3000)])
 def test_scrap_variant_matches_oracle(ops, oracle, maker, n):
     # resolve_collisions of scrap/lcp_spheres/NgpLcp.cpp:558-759 (BB1/BB2 alternation, Dai-Fletcher residual)
     from gpu_util import dev, host
