@@ -31,8 +31,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CON_BYTES, BODY_BYTES_PER_CONTACT, BODY_BYTES_PER_BODY = 184.0, 104.0, 116.0  # algorithmic bytes, see roofline()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def kernel_bytes(contacts, bodies):
+    """Algorithmic bytes per launch of the two sweeps of one fused BBPGD iteration (rod-compressed kinematics).
+
+    "compulsory": every array touched once -- what HBM must move even with perfect caches; this is roofline.achieved.
+    "gather_counted": SURVEY 8(d)'s convention, where a gathered row is charged to every contact that reads it.  The
+    body rows (48 MB at 10^6 rods) and the iterate largely come from L2 / Infinity Cache, so the gather-counted rate
+    can exceed the HBM peak; it is reported next to the compulsory one, never instead of it.
+      k_constraint  streams per constraint: pair 8 + normal 24 + arclengths 16 + packed (x, g) 16 + q 8 read,
+                    packed (x, g) 16 written = 88 B; gathers two 48-byte body rows (U, W x u)
+      k_body        per half edge: incidence entry 4 + 32-byte record + 16-byte iterate gather; per body: row pointer
+                    4 + mobilities 16 + axis 24 + velocity row 48 + angular velocity 24 = 116 B
+    """
+    return {
+        "k_constraint": {"compulsory": 88.0 * contacts + 48.0 * bodies, "gather_counted": (88.0 + 96.0) * contacts},
+        "k_body": {"compulsory": (2 * 36.0 + 16.0) * contacts + 116.0 * bodies,
+                   "gather_counted": 2 * 52.0 * contacts + 116.0 * bodies},
+    }
+
+
+def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label=""):
+    kb = kernel_bytes(contacts, bodies)
+    ms = {"k_constraint": con_ms, "k_body": body_ms}
+    ent = {}
+    for k in ms:
+        a = kb[k]["compulsory"] / (ms[k] * 1e-3) / 1e9
+        ent[k] = {"bound": "hbm", "kernel": k + "<X_SOLVE,KIN_ROD>" + label, "achieved": round(a, 1),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
+                  "avg_launch_ms": round(ms[k], 4), "launches": launches, "bytes_per_launch": kb[k]["compulsory"],
+                  "achieved_gather_counted": round(kb[k]["gather_counted"] / (ms[k] * 1e-3) / 1e9, 1)}
+    dominant = max(ms, key=ms.get)  # the sweep with the longer launch is the one the step waits on
+    other = "k_body" if dominant == "k_constraint" else "k_constraint"
+    return ent[dominant], {other: ent[other]}, dominant, other
 
 
 def parse():
@@ -129,30 +162,18 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (k_constraint of the fused BBPGD iteration) -------------------------------
-    # algorithmic bytes per constraint, rod-compressed kinematics: pair 8 + normal 24 + arclengths 16 +
-    # 2 x 48 gathered body rows + x_tmp, g_tmp, q 24 read; x, g 16 written = 184 B;  k_body: 2 x (x_tmp, g_tmp 16 +
-    # 32-byte half-edge record + incidence entry 4) = 104 B per constraint + 116 B per body (row pointer 4,
-    # mobilities 16, axis 24, velocity row 48, angular velocity 24)
-    con_bytes = CON_BYTES * contacts
-    body_bytes = BODY_BYTES_PER_CONTACT * contacts + BODY_BYTES_PER_BODY * n
+    # ---- roofline of the dominant sweep of the fused BBPGD iteration (see kernel_bytes) -----------------------------
     roof, extra = None, {}
     if prof["iters"] > 0:
-        con_ms = prof["con_ms"] / prof["iters"]
-        body_ms = prof["body_ms"] / prof["iters"]
-        achieved = con_bytes / (con_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_constraint<X_SOLVE,rot>", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_ms": round(con_ms, 4), "launches": prof["iters"], "bytes_per_launch": con_bytes}
-        extra = {"k_body": {"avg_launch_ms": round(body_ms, 4),
-                            "achieved_GBs": round(body_bytes / (body_ms * 1e-3) / 1e9, 1)}}
+        roof, extra, dom, oth = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"],
+                                                 prof["body_ms"] / prof["iters"], prof["iters"])
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (scripts/profile_bench.sh:
         # separate FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE + WRITE_SIZE as the gfx950 guide prescribes)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and n == 1_000_000 and args.buffer == 0.1:
             tj = json.load(open(tpath))
-            roof["traffic"] = tj.get("k_constraint", {}).get("hbm_bytes_per_launch")
-            extra["k_body"]["traffic"] = tj.get("k_body", {}).get("hbm_bytes_per_launch")
+            roof["traffic"] = tj.get(dom, {}).get("hbm_bytes_per_launch")
+            extra[oth]["traffic"] = tj.get(oth, {}).get("hbm_bytes_per_launch")
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this box's host cores, rank 0 ---------
     cpu = None
@@ -227,16 +248,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     iters = [s["num_iters"] for s in stats]
     roof, extra = None, {}
     if st.prof["iters"] > 0:
-        c_local = stats[-1]["local_contacts"]
-        con_ms = st.prof["con_ms"] / st.prof["iters"]
-        body_ms = st.prof["body_ms"] / st.prof["iters"]
-        con_bytes = CON_BYTES * c_local
-        achieved = con_bytes / (con_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_constraint<X_SOLVE,rot> (+k_reduce_local3), rank 0", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_ms": round(con_ms, 4), "launches": st.prof["iters"], "bytes_per_launch": con_bytes}
-        extra = {"k_body": {"avg_launch_ms": round(body_ms, 4),
-                            "achieved_GBs": round((BODY_BYTES_PER_CONTACT * c_local + BODY_BYTES_PER_BODY * n) / (body_ms * 1e-3) / 1e9, 1)}}
+        roof, extra, _, _ = roofline_entries(stats[-1]["local_contacts"], n, st.prof["con_ms"] / st.prof["iters"],
+                                             st.prof["body_ms"] / st.prof["iters"], st.prof["iters"], ", rank 0")
     if rank == 0:
         out = {
             "metric": "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",

@@ -316,13 +316,29 @@ __device__ inline XcdTiles xcd_tiles(size_t ntiles, int enabled) {
   return {lo + local, per_xcd, hi};
 }
 
-// the iterate a constraint carries in a given mode; bitwise identical wherever it is evaluated
-template <int MODE>
+// the iterate a constraint carries in a given mode; bitwise identical wherever it is evaluated.
+// PACKED: the fused and staged solvers keep (x, g) of one iterate interleaved, 16 bytes per constraint in an
+// operator-owned ping-pong pair, so the body sweep's gather of a half edge's iterate is ONE 16-byte access instead of
+// two 8-byte accesses into separate arrays (the gathers, not the streams, are what k_body waits on).  xt then points
+// at the packed array of the current iterate; in X_INIT it is the caller's plain x in both layouts.
+template <int MODE, bool PACKED>
 __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, const double* __restrict__ gt,
-                                   double step, bool step_is_zero, const Space& sp) {
+                                   double step, bool step_is_zero, const Space& sp, double* x_old = nullptr,
+                                   double* g_old = nullptr) {
   if (MODE == X_SOLVE) {
+    double xv, gv;
+    if (PACKED) {
+      const double2 p = reinterpret_cast<const double2*>(xt)[c];
+      xv = p.x;
+      gv = p.y;
+    } else {
+      xv = xt[c];
+      gv = gt[c];
+    }
+    if (x_old) *x_old = xv;
+    if (g_old) *g_old = gv;
     // wrapped_axpbyz(1, x_tmp, -step, g_tmp, x, space) with its beta ~ 0 branch (convex.hpp:228-247, :647)
-    const double v = step_is_zero ? 1.0 * xt[c] : 1.0 * xt[c] + (-step) * gt[c];
+    const double v = step_is_zero ? 1.0 * xv : 1.0 * xv + (-step) * gv;
     return sp.project(v);
   }
   return xt[c];
@@ -333,7 +349,7 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 // The order is fixed (no atomics), so results are bitwise reproducible run to run.
 //   half-edge record e -> (n_c, r_side) gathered once at operator creation: 48 B (24 B translation-only)
 // algorithmic bytes: per half edge 4 (entry) + 48 (record) + 16 (x_tmp, g_tmp gathered); per body 4 + 16 + 48.
-template <int MODE, int KIN, int G>
+template <int MODE, int KIN, int G, bool PACKED>
 __global__ void __launch_bounds__(kBlock)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
@@ -364,7 +380,7 @@ __global__ void __launch_bounds__(kBlock)
     const int32_t e = op.inc[k];
     const size_t c = static_cast<size_t>(e >> 1);
     const bool target = e & 1;
-    const double lam = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
+    const double lam = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp);
     // an inactive contact (lam == 0: most of a neighbour list) adds +/-0 to the sums, which leaves them bit for bit
     // unchanged -- so its 48-byte record is never fetched
     if (lam == 0.0) continue;
@@ -422,7 +438,7 @@ __global__ void __launch_bounds__(kBlock)
   v[2] = make_double2(W.y, W.z);
 }
 
-template <int MODE, int KIN>
+template <int MODE, int KIN, bool PACKED>
 __global__ void __launch_bounds__(kBlock)
     k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
@@ -441,6 +457,10 @@ __global__ void __launch_bounds__(kBlock)
     step = st->step;
   }
   if (MODE == X_INIT) gn = G0;  // g_tmp = A x_tmp + q
+  if (MODE == X_INIT && PACKED) {  // X0 = packed buffer of the first iterate, G0 = the caller's plain x
+    xt = G0;
+    xn = X0;
+  }
   const bool step_is_zero = fabs(-step) < kZeroTol;
   double rmax = kLowest, num = 0.0, den = 0.0;
   const XcdTiles tl = xcd_tiles((op.C + kBlock - 1) / kBlock, op.xcd_aware);
@@ -448,7 +468,8 @@ __global__ void __launch_bounds__(kBlock)
     const size_t c = tile * kBlock + threadIdx.x;
     if (c >= op.C) continue;
     const int2 ij = op.pairs[c];
-    const double xc = iterate_x<MODE>(c, xt, gt, step, step_is_zero, sp);
+    double x_old = 0.0, g_old = 0.0;
+    const double xc = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
     const V3 n = load3(op.normal, c);
     const double2* vi2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.x);
     const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
@@ -472,15 +493,19 @@ __global__ void __launch_bounds__(kBlock)
       gn[c] = y;
     } else {
       const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
-      gn[c] = g;
-      if (MODE == X_SOLVE) xn[c] = xc;
+      if (PACKED) {
+        reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
+      } else {
+        gn[c] = g;
+        if (MODE == X_SOLVE) xn[c] = xc;
+      }
       if (op.counted == nullptr || op.counted[c]) {
         const double r = residual_term(resid_kind, xc, g, sp);
         if (r > rmax) rmax = r;
         if (MODE == X_SOLVE) {
-          const double dx = xc - xt[c];
+          const double dx = xc - x_old;
           num += dx * dx;            // diff_dot(x, x_old)              (convex.hpp:507)
-          den += dx * (g - gt[c]);   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+          den += dx * (g - g_old);   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
         }
       }
     }
@@ -724,6 +749,23 @@ __global__ void __launch_bounds__(kBlock) k_finish(size_t n, const SolverState* 
   }
 }
 
+// the same post-conditions from the packed ping-pong pair P0 (the "tmp" role at even parity) / P1
+__global__ void __launch_bounds__(kBlock) k_finish_packed(size_t n, const SolverState* __restrict__ st,
+                                                         const double2* __restrict__ P0,
+                                                         const double2* __restrict__ P1, double* __restrict__ x,
+                                                         double* __restrict__ g, double* __restrict__ x_tmp,
+                                                         double* __restrict__ g_tmp) {
+  const bool p = st->flips & 1u;
+  const double2 *cur, *old;  // latest iterate, previous iterate
+  if (st->converged_at_init) { cur = P0; old = P0; }
+  else if (st->converged) { cur = p ? P0 : P1; old = p ? P1 : P0; }  // the converging sweep wrote the "new" side
+  else { cur = p ? P1 : P0; old = cur; }                            // rolled forward: x == x_tmp (convex.hpp:662-663)
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double2 a = cur[i], b = old[i];
+    x[i] = a.x; g[i] = a.y; x_tmp[i] = b.x; g_tmp[i] = b.y;
+  }
+}
+
 // ---- incidence index build --------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_inc_count(size_t C, size_t N, const int2* __restrict__ pairs,
                                                      int32_t* __restrict__ deg, int* __restrict__ bad) {
@@ -810,6 +852,7 @@ struct mhip_contact_op {
   int kin = KIN_TRANS;
   hipStream_t last_stream = nullptr;
   DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half, axis, omega, vel_out;
+  DeviceBuffer iterate;  // packed (x, g) ping-pong pair of the fused / staged solvers: 2 x C x 16 bytes
   int lanes_per_body = 8;
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
@@ -830,14 +873,18 @@ struct mhip_contact_op {
 namespace {
 
 int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double* X1, const double* G0,
-                   const double* G1, Space sp, hipStream_t s) {
+                   const double* G1, Space sp, hipStream_t s, bool packed = false) {
   if (op->view.N == 0) return MHIP_SUCCESS;
   const int G = op->lanes_per_body;
   if (op->view.body_count == 0) return MHIP_SUCCESS;
   const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
   op->last_stream = s;
   const SolverState* st = op->state.as<SolverState>();
-#define BODY3(M, R, GG) k_body<M, R, GG><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp)
+#define BODY3(M, R, GG)                                                                          \
+  do {                                                                                           \
+    if (packed && M == X_SOLVE) k_body<M, R, GG, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+    else k_body<M, R, GG, false><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);      \
+  } while (0)
 #define BODY(M, R)                 \
   do {                             \
     if (G == 4) BODY3(M, R, 4);    \
@@ -858,11 +905,18 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
 }
 
 int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, double* G0, double* G1,
-                         const double* q, Space sp, int resid_kind, unsigned grid, hipStream_t s) {
+                         const double* q, Space sp, int resid_kind, unsigned grid, hipStream_t s,
+                         bool packed = false) {
   if (op->view.C == 0) return MHIP_SUCCESS;
   const SolverState* st = op->state.as<SolverState>();
   double* parts = op->partials.as<double>();
-#define CON(M, R) k_constraint<M, R><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts)
+#define CON(M, R)                                                                                              \
+  do {                                                                                                         \
+    if (packed && M != X_APPLY)                                                                                \
+      k_constraint<M, R, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts); \
+    else                                                                                                       \
+      k_constraint<M, R, false><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts); \
+  } while (0)
 #define CONK(K) \
   do { if (mode == X_APPLY) CON(X_APPLY, K); else if (mode == X_INIT) CON(X_INIT, K); else CON(X_SOLVE, K); } while (0)
   if (op->kin == KIN_ROD) CONK(KIN_ROD);
@@ -1107,7 +1161,7 @@ int mhip_contact_op_destroy(mhip_contact_op_t op) {
   if (!op) return MHIP_SUCCESS;
   op->inc_ptr.release(); op->inc.release(); op->cursor.release(); op->vel.release();
   op->partials.release(); op->state.release(); op->scanws.release(); op->half.release();
-  op->axis.release(); op->omega.release(); op->vel_out.release();
+  op->axis.release(); op->omega.release(); op->vel_out.release(); op->iterate.release();
   if (op->host_state) (void)hipHostFree(op->host_state);
   for (auto& ev : op->events) (void)hipEventDestroy(ev);
   delete op;
@@ -1180,10 +1234,12 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   double* parts = op->partials.as<double>();
   const unsigned cgrid = grid_for(C);
   const int rk = config->residual_kind;
-  // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res
-  if (int e = launch_copy(C, x_tmp, x, s)) return e;
-  if (int e = op_launch_body(op, X_INIT, x_tmp, x, g_tmp, g, sp, s)) return e;
-  if (int e = op_launch_constraint(op, X_INIT, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
+  if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
+  double* P0 = op->iterate.as<double>();
+  double* P1 = P0 + 2 * C;
+  // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res   (the pair lands packed in P0)
+  if (int e = op_launch_body(op, X_INIT, x, x, nullptr, nullptr, sp, s)) return e;
+  if (int e = op_launch_constraint(op, X_INIT, P0, P1, x, nullptr, q, sp, rk, cgrid, s, true)) return e;
   k_finalize<X_INIT><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
   MHIP_LAUNCH_CHECK();
   unsigned enqueued = 0, chunk = 8, last_todo = 0, iter_before = 0;
@@ -1214,9 +1270,9 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
     for (unsigned k = 0; k < todo; ++k) {
       const bool pk = prof && (k % kProfileStride == 0);
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k], s));
-      if (int e = op_launch_body(op, X_SOLVE, x_tmp, x, g_tmp, g, sp, s)) return e;
+      if (int e = op_launch_body(op, X_SOLVE, P0, P1, nullptr, nullptr, sp, s, true)) return e;
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 1], s));
-      if (int e = op_launch_constraint(op, X_SOLVE, x_tmp, x, g_tmp, g, q, sp, rk, cgrid, s)) return e;
+      if (int e = op_launch_constraint(op, X_SOLVE, P0, P1, nullptr, nullptr, q, sp, rk, cgrid, s, true)) return e;
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       k_finalize<X_SOLVE><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
       MHIP_LAUNCH_CHECK();
@@ -1225,7 +1281,8 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
     last_todo = todo;
     if (chunk < 64) chunk *= 2;
   }
-  k_finish<<<grid_for(C), kBlock, 0, s>>>(C, st, x_tmp, x, g_tmp, g);
+  k_finish_packed<<<grid_for(C), kBlock, 0, s>>>(C, st, reinterpret_cast<const double2*>(P0),
+                                                 reinterpret_cast<const double2*>(P1), x, g, x_tmp, g_tmp);
   MHIP_LAUNCH_CHECK();
   MHIP_HIP(hipStreamSynchronize(s));
   result->num_iters = op->host_state->iter;
@@ -1353,14 +1410,18 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.sp = sp;
   op->stage.cfg = *config;
   op->stage.active = true;
+  if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   MHIP_HIP(hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState), as_stream(stream)));
-  return launch_copy(C, x_tmp, x, as_stream(stream));
+  return MHIP_SUCCESS;
 }
 
 int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   auto& st = op->stage;
-  return op_launch_body(op, init ? X_INIT : X_SOLVE, st.x_tmp, st.x, st.g_tmp, st.g, st.sp, as_stream(stream));
+  double* P0 = op->iterate.as<double>();
+  double* P1 = P0 + 2 * op->view.C;
+  if (init) return op_launch_body(op, X_INIT, st.x, st.x, nullptr, nullptr, st.sp, as_stream(stream));
+  return op_launch_body(op, X_SOLVE, P0, P1, nullptr, nullptr, st.sp, as_stream(stream), true);
 }
 
 int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
@@ -1369,8 +1430,10 @@ int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, 
   auto& st = op->stage;
   hipStream_t s = as_stream(stream);
   const unsigned cgrid = grid_for(op->view.C);
-  if (int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, st.x_tmp, st.x, st.g_tmp, st.g, st.q, st.sp,
-                                   st.cfg.residual_kind, cgrid, s))
+  double* P0 = op->iterate.as<double>();
+  double* P1 = P0 + 2 * op->view.C;
+  if (int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, P0, P1, init ? st.x : nullptr, nullptr, st.q, st.sp,
+                                   st.cfg.residual_kind, cgrid, s, true))
     return e;
   k_reduce_local3<<<1, kBlock, 0, s>>>(op->view.C == 0 ? 0 : (int)cgrid, op->partials.as<double>(),
                                        op->state.as<SolverState>(), init ? 0 : 1, local3);
@@ -1411,8 +1474,9 @@ int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result, mhip_s
   auto& st = op->stage;
   hipStream_t s = as_stream(stream);
   if (op->view.C > 0) {
-    k_finish<<<grid_for(op->view.C), kBlock, 0, s>>>(op->view.C, op->state.as<SolverState>(), st.x_tmp, st.x,
-                                                     st.g_tmp, st.g);
+    const double2* P0 = op->iterate.as<double2>();
+    k_finish_packed<<<grid_for(op->view.C), kBlock, 0, s>>>(op->view.C, op->state.as<SolverState>(), P0,
+                                                            P0 + op->view.C, st.x, st.g, st.x_tmp, st.g_tmp);
     MHIP_LAUNCH_CHECK();
   }
   int done = 0;

@@ -35,7 +35,7 @@ def main():
     pairs = st.pairs.cpu().numpy()
     out = dict(stats=stats, gpairs=gid[pairs], counted=st.counted.cpu().numpy().astype(bool),
                g=st.grad.cpu().numpy(), x=st.lam.cpu().numpy(),
-               vel=st.vel[st.n_lo:st.n_lo + st.n].cpu().numpy(), first=a)
+               vel=st.op.body_velocity()[st.n_lo:st.n_lo + st.n].cpu().numpy(), first=a)
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(out, gathered, dst=0)
     ok = True
