@@ -295,25 +295,22 @@ struct OpView {
   const double *arc_s, *arc_t;  // [C] arclength parameters of the two closest points
   const double* axis;           // [N][3] u = p1 - p0
   double* omega;                // [N][3] angular velocity W
-  int xcd_aware;  // XCD-contiguous tile mapping (performance only; MHIP_XCD_AWARE=0 disables it for A/B runs)
+  int xcd_aware;  // T of xcd_tile(): consecutive tiles per XCD within a window (performance only; 0 = off)
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
-// so blockIdx % 8 labels the XCD).  Tiles of 256 work items are assigned so that each XCD sweeps ONE contiguous eighth
-// of the range: with Z-ordered bodies the rows its workgroups gather (body velocities, x/g of neighbouring contacts)
-// then come from a compact slab that mostly stays in that XCD's L2, instead of every L2 seeing every slab.
+// so blockIdx % 8 labels the XCD).  Work is cut into tiles of 256 items.  Within every window of 8 T consecutive tiles
+// the tiles are permuted so that one XCD gets T CONSECUTIVE tiles: with Z-ordered bodies the rows its workgroups
+// gather (body rows, the iterate of neighbouring contacts) then come from a compact range that is fetched into ONE L2
+// instead of all eight, while the eight XCDs together still sweep the arrays front to back (the window is what is
+// resident on the chip at one time, so the HBM streams stay sequential).  T = 0 disables the permutation.
 // Placement is a performance assumption only: any mapping gives the same results.
-struct XcdTiles {
-  size_t first, step, end;  // this workgroup's tiles: first, first + step, ... < end
-};
-__device__ inline XcdTiles xcd_tiles(size_t ntiles, int enabled) {
-  const unsigned nb = gridDim.x;
-  if (!enabled || nb < 8 || (nb & 7u)) return {blockIdx.x, nb, ntiles};  // small grids: plain grid-stride
-  const unsigned xcd = blockIdx.x & 7u, local = blockIdx.x >> 3, per_xcd = nb >> 3;
-  const size_t per = (ntiles + 7) / 8;  // tiles per XCD slab
-  const size_t lo = xcd * per;
-  const size_t hi = (lo + per < ntiles) ? lo + per : ntiles;
-  return {lo + local, per_xcd, hi};
+__device__ inline size_t xcd_tile(size_t lin, size_t ntiles, unsigned T) {
+  if (T == 0) return lin;
+  const size_t W = 8 * (size_t)T;
+  const size_t g = lin / W, r = lin % W;
+  if ((g + 1) * W > ntiles) return lin;  // the last, partial window keeps the identity
+  return g * W + (r % 8) * T + r / 8;
 }
 
 // the iterate a constraint carries in a given mode; bitwise identical wherever it is evaluated.
@@ -349,7 +346,7 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 // The order is fixed (no atomics), so results are bitwise reproducible run to run.
 //   half-edge record e -> (n_c, r_side) gathered once at operator creation: 48 B (24 B translation-only)
 // algorithmic bytes: per half edge 4 (entry) + 48 (record) + 16 (x_tmp, g_tmp gathered); per body 4 + 16 + 48.
-template <int MODE, int KIN, int G, bool PACKED>
+template <int MODE, int KIN, int G, int U, bool PACKED>
 __global__ void __launch_bounds__(kBlock)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
@@ -365,10 +362,8 @@ __global__ void __launch_bounds__(kBlock)
     step = st->step;
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  // one tile = one workgroup's worth of bodies; tiles are XCD-contiguous (see xcd_tiles), the grid covers them once
-  const XcdTiles tl = xcd_tiles(gridDim.x, op.xcd_aware);
-  const size_t tile = tl.first + (size_t)0 * tl.step;
-  if (tile >= tl.end) return;
+  // one tile = one workgroup's worth of bodies (see xcd_tile), the grid covers them once
+  const size_t tile = xcd_tile(blockIdx.x, gridDim.x, op.xcd_aware);
   const size_t t = tile * (size_t)blockDim.x + threadIdx.x;
   const int sub = static_cast<int>(t % G);
   if (t / G >= op.body_count) return;  // whole groups leave together (G divides the wave size)
@@ -376,35 +371,51 @@ __global__ void __launch_bounds__(kBlock)
   constexpr int HW = (KIN == KIN_RIGID) ? 6 : (KIN == KIN_ROD ? 4 : 3);
   V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
-  for (int32_t k = beg + sub; k < end; k += G) {
-    const int32_t e = op.inc[k];
-    const size_t c = static_cast<size_t>(e >> 1);
-    const bool target = e & 1;
-    const double lam = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp);
-    // an inactive contact (lam == 0: most of a neighbour list) adds +/-0 to the sums, which leaves them bit for bit
-    // unchanged -- so its 48-byte record is never fetched
-    if (lam == 0.0) continue;
-    V3 n, r{0.0, 0.0, 0.0};
-    double coef = 0.0;
-    if (KIN == KIN_RIGID) {  // 48-byte records, 16-byte aligned: three 16-byte loads
-      const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * HW);
-      const double2 h0 = H2[0], h1 = H2[1], h2 = H2[2];
-      n = V3{h0.x, h0.y, h1.x};
-      r = V3{h1.y, h2.x, h2.y};
-    } else if (KIN == KIN_ROD) {  // 32-byte records: (n, s - 1/2)
-      const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * HW);
-      const double2 h0 = H2[0], h1 = H2[1];
-      n = V3{h0.x, h0.y, h1.x};
-      coef = h1.y;
-    } else {
-      const double* H = op.half + (size_t)k * HW;
-      n = V3{H[0], H[1], H[2]};
+  // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
+  // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight (entries k, k+G, ...),
+  // every level's U loads issued back to back before the first use.
+  for (int32_t k0 = beg + sub; k0 < end; k0 += G * U) {
+    int32_t e[U];
+    double lam[U];
+    double2 h0[U], h1[U], h2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t k = k0 + u * G;
+      e[u] = (k < end) ? op.inc[k] : -1;
     }
-    V3 f{lam * n.x, lam * n.y, lam * n.z};
-    if (!target) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
-    F = F + f;
-    if (KIN == KIN_RIGID) T = T + cross(r, f);  // torque about the body centre, r x (+/- lam n)
-    if (KIN == KIN_ROD) T = T + coef * f;       // S = sum coef f; the torque is u x S, formed once per body below
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      lam[u] = (e[u] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(e[u] >> 1), xt, gt, step, step_is_zero, sp)
+                           : 0.0;
+    // an inactive contact (lam == 0: most of a neighbour list) adds +/-0 to the sums, which leaves them bit for bit
+    // unchanged -- so its record is never fetched
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      h0[u] = h1[u] = h2[u] = make_double2(0.0, 0.0);
+      if (lam[u] != 0.0) {
+        const size_t k = static_cast<size_t>(k0 + u * G);
+        if (KIN == KIN_TRANS) {
+          const double* H = op.half + k * HW;
+          h0[u] = make_double2(H[0], H[1]);
+          h1[u] = make_double2(H[2], 0.0);
+        } else {  // 48-byte (n, r) / 32-byte (n, s - 1/2) records, 16-byte aligned
+          const double2* H2 = reinterpret_cast<const double2*>(op.half + k * HW);
+          h0[u] = H2[0];
+          h1[u] = H2[1];
+          if (KIN == KIN_RIGID) h2[u] = H2[2];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (lam[u] == 0.0) continue;
+      const V3 n{h0[u].x, h0[u].y, h1[u].x};
+      V3 f{lam[u] * n.x, lam[u] * n.y, lam[u] * n.z};
+      if (!(e[u] & 1)) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
+      F = F + f;
+      if (KIN == KIN_RIGID) T = T + cross(V3{h1[u].y, h2[u].x, h2[u].y}, f);  // torque r x (+/- lam n)
+      if (KIN == KIN_ROD) T = T + h1[u].y * f;  // S = sum coef f; the torque is u x S, formed once per body below
+    }
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
@@ -463,9 +474,9 @@ __global__ void __launch_bounds__(kBlock)
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
   double rmax = kLowest, num = 0.0, den = 0.0;
-  const XcdTiles tl = xcd_tiles((op.C + kBlock - 1) / kBlock, op.xcd_aware);
-  for (size_t tile = tl.first; tile < tl.end; tile += tl.step) {
-    const size_t c = tile * kBlock + threadIdx.x;
+  const size_t ntiles = (op.C + kBlock - 1) / kBlock;
+  for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
+    const size_t c = xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
     if (c >= op.C) continue;
     const int2 ij = op.pairs[c];
     double x_old = 0.0, g_old = 0.0;
@@ -854,6 +865,7 @@ struct mhip_contact_op {
   DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half, axis, omega, vel_out;
   DeviceBuffer iterate;  // packed (x, g) ping-pong pair of the fused / staged solvers: 2 x C x 16 bytes
   int lanes_per_body = 8;
+  int body_unroll = 1;  // independent half-edge chains per lane (k_body's U)
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
   struct Stage {
@@ -880,17 +892,24 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
   op->last_stream = s;
   const SolverState* st = op->state.as<SolverState>();
-#define BODY3(M, R, GG)                                                                          \
-  do {                                                                                           \
-    if (packed && M == X_SOLVE) k_body<M, R, GG, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
-    else k_body<M, R, GG, false><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);      \
+#define BODY4(M, R, GG, UU)                                                                        \
+  do {                                                                                             \
+    if (packed && M == X_SOLVE)                                                                    \
+      k_body<M, R, GG, UU, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);        \
+    else                                                                                           \
+      k_body<M, R, GG, UU, false><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);       \
   } while (0)
-#define BODY(M, R)                 \
-  do {                             \
-    if (G == 4) BODY3(M, R, 4);    \
-    else if (G == 8) BODY3(M, R, 8); \
-    else if (G == 32) BODY3(M, R, 32); \
-    else BODY3(M, R, 16);          \
+#define BODY(M, R)                                    \
+  do {                                                \
+    const int lay = G * 10 + op->body_unroll;         \
+    if (lay == 41) BODY4(M, R, 4, 1);                 \
+    else if (lay == 44) BODY4(M, R, 4, 4);            \
+    else if (lay == 81) BODY4(M, R, 8, 1);            \
+    else if (lay == 82) BODY4(M, R, 8, 2);            \
+    else if (lay == 84) BODY4(M, R, 8, 4);            \
+    else if (lay == 162) BODY4(M, R, 16, 2);          \
+    else if (lay == 321) BODY4(M, R, 32, 1);          \
+    else BODY4(M, R, 16, 1);                          \
   } while (0)
 #define BODYK(K) \
   do { if (mode == X_APPLY) BODY(X_APPLY, K); else if (mode == X_INIT) BODY(X_INIT, K); else BODY(X_SOLVE, K); } while (0)
@@ -898,7 +917,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   else if (op->kin == KIN_RIGID) BODYK(KIN_RIGID);
   else BODYK(KIN_TRANS);
 #undef BODYK
-#undef BODY3
+#undef BODY4
 #undef BODY
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -1122,17 +1141,24 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "half-edge build failed: %s", hipGetErrorString(he)));
   {
-    // lanes per body ~ half the mean degree, so most bodies finish in two passes of their group
+    // G lanes per body, each keeping U half-edge chains in flight: G * U ~ twice the mean degree, so most bodies are
+    // done in one pass.  Measured at 10^6 rods (mean degree 15.2, MI355X): (16,1) 0.198 ms, (8,1) 0.164, (8,2) 0.154,
+    // (4,4) 0.157, (8,4) 0.150 per sweep.
     const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
     const char* env = getenv("MHIP_LANES_PER_BODY");
-    op->lanes_per_body = env ? atoi(env) : (mean_deg <= 4.0 ? 4 : (mean_deg <= 8.0 ? 8 : 16));
+    op->lanes_per_body = env ? atoi(env) : (mean_deg <= 8.0 ? 4 : 8);
+    op->body_unroll = 4;
     if (op->lanes_per_body != 4 && op->lanes_per_body != 8 && op->lanes_per_body != 16 && op->lanes_per_body != 32)
       op->lanes_per_body = 8;
+    if (const char* ue = getenv("MHIP_BODY_UNROLL")) op->body_unroll = atoi(ue);
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
                     op->axis.as<double>(), op->omega.as<double>(), 0};
-  if (const char* xe = getenv("MHIP_XCD_AWARE")) op->view.xcd_aware = atoi(xe) ? 1 : 0;
+  if (const char* xe = getenv("MHIP_XCD_TILE")) {  // A/B runs; clamped so a window stays a few thousand tiles
+    const int t = atoi(xe);
+    op->view.xcd_aware = t < 0 ? 0 : (t > 4096 ? 4096 : t);
+  }
   *handle = op;
   return MHIP_SUCCESS;
 }

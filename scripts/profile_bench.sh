@@ -15,6 +15,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -T --kernel-include-regex "k_cons
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_write" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --max-iters 40 > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" || { tail -20 "$OUT/pmc_write.err"; exit 1; }
 echo "write pass done"
+# L2 hit rate and wave stall split of the two sweeps (diagnostics; TCC 2 slots + SQ 4 slots)
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_l2" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --max-iters 40 > "$OUT/bench_pmc_l2.json" 2> "$OUT/pmc_l2.err" || { tail -20 "$OUT/pmc_l2.err"; echo "l2 pass failed (diagnostic only)"; }
+echo "l2 pass done"
 cd - > /dev/null
 python3 scripts/summarize_profile.py "$OUT" > "$OUT/summary.txt"
 cat "$OUT/summary.txt"

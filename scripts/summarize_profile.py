@@ -85,3 +85,22 @@ if traffic:
     print("\n## HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
     for k, v in traffic.items():
         print("%-14s %.4g bytes" % (k, v["hbm_bytes_per_launch"]))
+
+# diagnostic pass: L2 hit rate and the wave-cycle split of the two sweeps
+f = find("pmc_l2", "*counter_collection.csv")
+if f:
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if k in KERNELS:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print("\n## L2 hit rate / wave cycle split, mean per launch over all launches of the pass (%s)" % os.path.relpath(f, out))
+    for k in KERNELS:
+        if not acc[k]:
+            continue
+        m = {c: sum(v) / len(v) for c, v in acc[k].items()}
+        hit, miss = m.get("TCC_HIT_sum", 0.0), m.get("TCC_MISS_sum", 0.0)
+        wc = m.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        print("%-14s L2 hit %.3f (hit %.4g miss %.4g)  wave cycles %.4g: wait_any %.2f wait_inst %.2f active %.2f"
+              % (k, hit / max(1.0, hit + miss), hit, miss, wc, m.get("SQ_WAIT_ANY", 0.0) / wc,
+                 m.get("SQ_WAIT_INST_ANY", 0.0) / wc, m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc))

