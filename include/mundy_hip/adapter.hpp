@@ -353,6 +353,17 @@ class ContactOperator {
     check(mhip_contact_op_create(&h_, num_constraints, num_bodies, pairs, normal, ra, rb, mob_trans, mob_rot, dt,
                                  stream));
   }
+  /// Spherocylinders: lever arms as arclengths (s, t) along the rods' segments (mhip_contact_op_create_rods).
+  struct Rods {
+    const double* arc_s;
+    const double* arc_t;
+    const double* segments;  // [num_bodies][8] from mhip_spherocylinder_segments
+  };
+  ContactOperator(size_t num_constraints, size_t num_bodies, const int32_t* pairs, const double* normal, Rods rods,
+                  const double* mob_trans, const double* mob_rot, double dt, mhip_stream_t stream = nullptr) {
+    check(mhip_contact_op_create_rods(&h_, num_constraints, num_bodies, pairs, normal, rods.arc_s, rods.arc_t,
+                                      rods.segments, mob_trans, mob_rot, dt, stream));
+  }
   ~ContactOperator() { mhip_contact_op_destroy(h_); }
   ContactOperator(const ContactOperator&) = delete;
   ContactOperator& operator=(const ContactOperator&) = delete;
