@@ -336,6 +336,22 @@ int mhip_periodic_sep(size_t n, const double* box, const double* p1, const doubl
                       mhip_stream_t stream);
 int mhip_wrap_rigid(size_t n, const double* box, double* center, mhip_stream_t stream);
 
+/* Triclinic cell: PeriodicMetric (periodicity.hpp:233-332).  cell [host] = 3x3 unit-cell matrix, row
+ * major, lattice vectors as COLUMNS; its inverse is math::inverse (Matrix.hpp:1596-1601: adjugate / determinant).
+ *   mhip_unit_cell_inverse        host-only: that inverse, for callers that want fractional coordinates
+ *   mhip_periodic_sep_triclinic   sep(p1, p2) = h * min_image(h_inv * (p2 - p1))          (:304-307)
+ *   mhip_wrap_rigid_triclinic     centre <- h * safe_unit_mod1(h_inv * centre)             (:312-314, :1088-1113)
+ *   mhip_shift_image_triclinic    p + h * images, images [n][3] int32                      (:323-327)
+ *   mhip_contact_spheres_triclinic  mhip_contact_spheres with this metric's minimum image */
+int mhip_unit_cell_inverse(const double* cell, double* cell_inv);
+int mhip_periodic_sep_triclinic(size_t n, const double* cell, const double* p1, const double* p2, double* out,
+                                mhip_stream_t stream);
+int mhip_wrap_rigid_triclinic(size_t n, const double* cell, double* center, mhip_stream_t stream);
+int mhip_shift_image_triclinic(size_t n, const double* cell, const double* p, const int32_t* images, double* out,
+                               mhip_stream_t stream);
+int mhip_contact_spheres_triclinic(size_t c, const int32_t* pairs, const double* center, const double* radius,
+                                   const double* cell, double* sep, double* normal, mhip_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Body reordering: Z-order (Morton) permutation of bodies by centre, z most significant as
  * zorder_knn::Less (mundy/math/src/mundy_math/zmort.hpp:195-220) orders non-negative lattice coordinates.

@@ -106,6 +106,11 @@ SIGNATURES = {
                                          C.POINTER(SolveResult), _vp],
     "mhip_periodic_sep": [_sz, C.POINTER(_d), _vp, _vp, _vp, _vp],
     "mhip_wrap_rigid": [_sz, C.POINTER(_d), _vp, _vp],
+    "mhip_unit_cell_inverse": [C.POINTER(_d), C.POINTER(_d)],
+    "mhip_periodic_sep_triclinic": [_sz, C.POINTER(_d), _vp, _vp, _vp, _vp],
+    "mhip_wrap_rigid_triclinic": [_sz, C.POINTER(_d), _vp, _vp],
+    "mhip_shift_image_triclinic": [_sz, C.POINTER(_d), _vp, _vp, _vp, _vp],
+    "mhip_contact_spheres_triclinic": [_sz, _vp, _vp, _vp, C.POINTER(_d), _vp, _vp, _vp],
     "mhip_integrate_euler": [_sz, _d, _vp, _vp, _vp, _vp],
     "mhip_morton_order": [_sz, _vp, C.POINTER(_d), _d, _vp, _vp],
     "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],

@@ -159,4 +159,43 @@ __device__ inline V3 periodic_wrap(const Periodic& pm, V3 p) {
           pm.scale.z * unit_mod1(pm.scale_inv.z * p.z)};
 }
 
+// Triclinic cell: PeriodicMetric (mundy_geom/periodicity.hpp:233-332).  h holds the lattice vectors as columns
+// (row-major storage); h_inv = math::inverse(h) = adjugate / determinant with the Laplace expansion and right folds of
+// mundy_math/impl/MatrixImpl.hpp:481-506, mundy_math/Matrix.hpp:1596-1601 (the +/-1 cofactor factors are exact).
+struct Triclinic {
+  double h[9], hi[9];
+};
+__host__ __device__ inline double det2(double a, double b, double c, double d) { return a * d + (-(b * c)); }
+__host__ __device__ inline double minor_det3(const double* m, int r, int c) {
+  const int r0 = (r == 0) ? 1 : 0, r1 = (r == 2) ? 1 : 2, c0 = (c == 0) ? 1 : 0, c1 = (c == 2) ? 1 : 2;
+  return det2(m[3 * r0 + c0], m[3 * r0 + c1], m[3 * r1 + c0], m[3 * r1 + c1]);
+}
+__host__ __device__ inline double determinant3(const double* m) {
+  const double t0 = m[0] * minor_det3(m, 0, 0), t1 = -(m[1] * minor_det3(m, 0, 1)), t2 = m[2] * minor_det3(m, 0, 2);
+  return t0 + (t1 + t2);
+}
+__host__ __device__ inline void inverse3(const double* m, double* out) {
+  const double det = determinant3(m);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)  // adjugate(i, j) = cofactor(j, i), sign by flat-index parity
+      out[3 * i + j] = (minor_det3(m, j, i) * (((3 * j + i) % 2 == 0) ? 1.0 : -1.0)) / det;
+}
+__host__ inline Triclinic make_triclinic(const double* h) {
+  Triclinic t;
+  for (int i = 0; i < 9; ++i) t.h[i] = h[i];
+  inverse3(t.h, t.hi);
+  return t;
+}
+__host__ __device__ inline V3 matvec3(const double* m, V3 v) {  // per-row dot (MatrixImpl.hpp:348-355)
+  return {dot(V3{m[0], m[1], m[2]}, v), dot(V3{m[3], m[4], m[5]}, v), dot(V3{m[6], m[7], m[8]}, v)};
+}
+__device__ inline V3 periodic_sep(const Triclinic& pm, V3 p1, V3 p2) {  // periodicity.hpp:304-307
+  const V3 f = matvec3(pm.hi, p2 - p1);
+  return matvec3(pm.h, V3{min_image1(f.x), min_image1(f.y), min_image1(f.z)});
+}
+__device__ inline V3 periodic_wrap(const Triclinic& pm, V3 p) {  // periodicity.hpp:312-314
+  const V3 f = matvec3(pm.hi, p);
+  return matvec3(pm.h, V3{unit_mod1(f.x), unit_mod1(f.y), unit_mod1(f.z)});
+}
+
 }  // namespace mhip

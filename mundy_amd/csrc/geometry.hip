@@ -132,10 +132,10 @@ __global__ void __launch_bounds__(kBlock)
 
 // ---- contact generation over a neighbour list -------------------------------------------------------------------------
 // spheres: algorithmic bytes per contact = pair 8 + 2 x (centre 24 + radius 8) gathered + sep 8 + normal 24 = 104 B
-template <bool PERIODIC>
+template <bool PERIODIC, class Metric>
 __global__ void __launch_bounds__(kBlock)
     k_contact_spheres(size_t nc, const int2* __restrict__ pairs, const double* __restrict__ center,
-                      const double* __restrict__ radius, Periodic pm, double* __restrict__ sep,
+                      const double* __restrict__ radius, Metric pm, double* __restrict__ sep,
                       double* __restrict__ normal) {
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nc; c += (size_t)gridDim.x * blockDim.x) {
     const int2 ij = pairs[c];
@@ -287,6 +287,18 @@ int mhip_contact_spheres(size_t c, const int32_t* pairs, const double* center, c
     k_contact_spheres<false><<<grid_for(c), kBlock, 0, as_stream(stream)>>>(c, p2, center, radius,
                                                                            make_periodic(one), sep, normal);
   }
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_spheres_triclinic(size_t c, const int32_t* pairs, const double* center, const double* radius,
+                                   const double* cell, double* sep, double* normal, mhip_stream_t stream) {
+  const size_t n = c;
+  REQ_PTR(pairs); REQ_PTR(center); REQ_PTR(radius);
+  MHIP_REQUIRE(cell != nullptr && determinant3(cell) != 0.0, MHIP_ERR_INVALID_ARGUMENT, "unit cell matrix is singular");
+  if (c == 0) return MHIP_SUCCESS;
+  k_contact_spheres<true><<<grid_for(c), kBlock, 0, as_stream(stream)>>>(c, reinterpret_cast<const int2*>(pairs), center,
+                                                                        radius, make_triclinic(cell), sep, normal);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

@@ -104,14 +104,25 @@ __global__ void __launch_bounds__(kBlock)
 
 // PeriodicScaledMetric::sep / wrap (mundy_geom/periodicity.hpp:812-823); wrap_rigid of a Sphere / Spherocylinder /
 // Ellipsoid wraps its centre, orientation and size untouched (:1088-1113, :1156-1160)
-__global__ void __launch_bounds__(kBlock) k_periodic_sep(size_t n, Periodic pm, const double* __restrict__ p1,
+template <class Metric>
+__global__ void __launch_bounds__(kBlock) k_periodic_sep(size_t n, Metric pm, const double* __restrict__ p1,
                                                         const double* __restrict__ p2, double* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store3(out, i, periodic_sep(pm, load3(p1, i), load3(p2, i)));
 }
-__global__ void __launch_bounds__(kBlock) k_wrap_rigid(size_t n, Periodic pm, double* __restrict__ center) {
+template <class Metric>
+__global__ void __launch_bounds__(kBlock) k_wrap_rigid(size_t n, Metric pm, double* __restrict__ center) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     store3(center, i, periodic_wrap(pm, load3(center, i)));
+}
+// PeriodicMetric::shift_image: translate(point, h * num_images)  (periodicity.hpp:323-327)
+__global__ void __launch_bounds__(kBlock) k_shift_image(size_t n, Triclinic pm, const double* __restrict__ p,
+                                                       const int32_t* __restrict__ images, double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const V3 k{static_cast<double>(images[3 * i]), static_cast<double>(images[3 * i + 1]),
+               static_cast<double>(images[3 * i + 2])};
+    store3(out, i, load3(p, i) + matvec3(pm.h, k));
+  }
 }
 
 struct ReorderScratch {
@@ -187,6 +198,42 @@ int mhip_wrap_rigid(size_t n, const double* box, double* center, mhip_stream_t s
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(center != nullptr, MHIP_ERR_INVALID_ARGUMENT, "center is null");
   k_wrap_rigid<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, make_periodic(box), center);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_unit_cell_inverse(const double* cell, double* cell_inv) {
+  MHIP_REQUIRE(cell && cell_inv, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(determinant3(cell) != 0.0, MHIP_ERR_INVALID_ARGUMENT, "unit cell matrix is singular");
+  inverse3(cell, cell_inv);
+  return MHIP_SUCCESS;
+}
+
+int mhip_periodic_sep_triclinic(size_t n, const double* cell, const double* p1, const double* p2, double* out,
+                                mhip_stream_t stream) {
+  MHIP_REQUIRE(cell != nullptr && determinant3(cell) != 0.0, MHIP_ERR_INVALID_ARGUMENT, "unit cell matrix is singular");
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(p1 && p2 && out, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  k_periodic_sep<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, make_triclinic(cell), p1, p2, out);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_wrap_rigid_triclinic(size_t n, const double* cell, double* center, mhip_stream_t stream) {
+  MHIP_REQUIRE(cell != nullptr && determinant3(cell) != 0.0, MHIP_ERR_INVALID_ARGUMENT, "unit cell matrix is singular");
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(center != nullptr, MHIP_ERR_INVALID_ARGUMENT, "center is null");
+  k_wrap_rigid<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, make_triclinic(cell), center);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_shift_image_triclinic(size_t n, const double* cell, const double* p, const int32_t* images, double* out,
+                               mhip_stream_t stream) {
+  MHIP_REQUIRE(cell != nullptr, MHIP_ERR_INVALID_ARGUMENT, "unit cell matrix is null");
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(p && images && out, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  k_shift_image<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, make_triclinic(cell), p, images, out);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

@@ -185,17 +185,29 @@ def _p(t):
 
 
 class DistributedContactStepper:
-    """This rank's slice of a spherocylinder system: owned bodies in global-id order (a contiguous range of the
-    Hilbert order), plus per-step ghosts.  step() = AABB -> ghost halo -> local neighbour list (ghost-ghost pairs
-    dropped) -> contacts -> staged BBPGD with a velocity halo per iteration -> Euler update of the owned bodies."""
+    """This rank's slice of a system of spherocylinders -- or of mixed spheres / spherocylinders / ellipsoids
+    (BASELINE configs[4]) -- owned bodies in global-id order (a contiguous range of the Hilbert order), plus per-step
+    ghosts.  step() = AABB -> ghost halo -> local neighbour list (ghost-ghost pairs dropped) -> contacts -> staged
+    BBPGD with a velocity halo per iteration -> Euler update of the owned bodies.
 
-    RECORD = 10  # gid, centre 3, quat 4, radius, length
+    Rod systems use the rod-compressed operator; a mixed system (kind / shape given) bins its contacts by shape class
+    (mhip_contact_mixed) and uses the vector-arm operator."""
+
+    RECORD = 12  # gid, centre 3, quat 4, shape 3 (r,L,- for rods), kind
 
     def __init__(self, center, quat, radius, length, gid_first, *, comm=None, dt=5e-3, viscosity=1e-3,
-                 search_buffer=0.1, cfg=None, poll_every=16):
+                 search_buffer=0.1, cfg=None, poll_every=16, kind=None, shape=None):
         from . import synth
         self.comm = comm or Comm()
-        self.center, self.quat, self.radius, self.length = center, quat, radius, length
+        self.mixed = kind is not None
+        if self.mixed:
+            if shape is None:
+                raise ValueError("a mixed system needs shape [n, 3] next to kind [n]")
+            self.kind, self.shape = kind.to(torch.int32).contiguous(), shape.contiguous()
+        else:
+            self.kind = None
+            self.shape = torch.stack([radius, length, torch.zeros_like(radius)], dim=1).contiguous()
+        self.center, self.quat = center, quat
         self.n = center.shape[0]
         self.gid_first = int(gid_first)
         self.dt, self.viscosity, self.buffer = float(dt), float(viscosity), float(search_buffer)
@@ -208,11 +220,18 @@ class DistributedContactStepper:
         self.profile = False          # per-stage torch.cuda.Event timing (same stream as the kernels)
         self.prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 
+    def _aabb(self, center, quat, shape, kind):
+        """(aabb, bounding radius) of rods or of a mixed set"""
+        if self.mixed:
+            return ops.compute_aabb_mixed(kind, center, quat, shape)
+        r, ln = shape[:, 0].contiguous(), shape[:, 1].contiguous()
+        return ops.compute_aabb_spherocylinders(center, quat, r, ln), ops.bounding_radius_spherocylinders(r, ln)
+
     # -- ghost halo -----------------------------------------------------------------------------------------------------
     def _exchange_ghosts(self):
         lib, comm = capi.load(), self.comm
         n, dev = self.n, self.center.device
-        aabb = ops.compute_aabb_spherocylinders(self.center, self.quat, self.radius, self.length)
+        aabb, _ = self._aabb(self.center, self.quat, self.shape, self.kind)
         box = (C.c_double * 6)()
         capi.check(lib.mhip_aabb_bounds(n, _p(aabb), self.buffer, box, _stream()))
         boxes = comm.all_gather(torch.tensor(list(box), dtype=torch.float64)).tolist()
@@ -229,7 +248,8 @@ class DistributedContactStepper:
         recv_cnt, n_lo, n_hi, _ = halo_layout(counts, comm.rank)
         # records of the owned bodies, gathered per peer
         gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
-        rec = torch.cat([gid[:, None], self.center, self.quat, self.radius[:, None], self.length[:, None]], dim=1)
+        kcol = self.kind.to(torch.float64)[:, None] if self.mixed else torch.ones((n, 1), dtype=torch.float64, device=dev)
+        rec = torch.cat([gid[:, None], self.center, self.quat, self.shape, kcol], dim=1)
         send = {p: ops.gather_rows(send_idx[p], rec) if send_cnt[p] else rec[:0] for p in send_idx}
         recv = {p: torch.empty((recv_cnt[p], self.RECORD), dtype=torch.float64, device=dev)
                 for p in range(comm.world) if p != comm.rank}
@@ -239,8 +259,8 @@ class DistributedContactStepper:
         local = torch.cat(lo + [rec] + hi, dim=0).contiguous()
         self.n_lo, self.n_hi, self.n_local = n_lo, n_hi, local.shape[0]
         self.local = dict(gid=local[:, 0].contiguous(), center=local[:, 1:4].contiguous(),
-                          quat=local[:, 4:8].contiguous(), radius=local[:, 8].contiguous(),
-                          length=local[:, 9].contiguous())
+                          quat=local[:, 4:8].contiguous(), shape=local[:, 8:11].contiguous(),
+                          kind=local[:, 11].to(torch.int32).contiguous())
         # velocity halo plan: what I send each iteration (owned rows, as local indices) and where receives land
         order = [p for p in range(comm.world) if p != comm.rank and send_cnt[p]]
         self.vel_send_peers = order
@@ -286,8 +306,7 @@ class DistributedContactStepper:
         self._exchange_ghosts()
         L, dev = self.local, self.center.device
         nl = self.n_local
-        aabb = ops.compute_aabb_spherocylinders(L["center"], L["quat"], L["radius"], L["length"])
-        brad = ops.bounding_radius_spherocylinders(L["radius"], L["length"])
+        aabb, brad = self._aabb(L["center"], L["quat"], L["shape"], L["kind"])
         self.links.generate(aabb, L["center"], brad, force=True)
         c_all = self.links.num_pairs
         pairs = torch.empty((c_all, 2), dtype=torch.int32, device=dev)
@@ -297,15 +316,22 @@ class DistributedContactStepper:
                                                C.byref(cnt), _stream()))
         nc = int(cnt.value)
         pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
-        seg = ops.spherocylinder_segments(L["center"], L["quat"], L["radius"], L["length"])
-        con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False, arms="arclength")
         mt, mr = self._synth.dry_mobility(brad.cpu().numpy(), viscosity=self.viscosity)
         mob_t, mob_r = torch.from_numpy(mt).to(dev), torch.from_numpy(mr).to(dev)
         if self.op is not None:
             self.op.close()
-        # rod-compressed kinematics: velocity rows (and the halo) carry (U, W x u); (U, W) comes from body_velocity()
-        op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
-                                           rod=(con["s"], con["t"], seg))
+        if self.mixed:
+            seg = None
+            con = ops.contact_mixed(pairs, L["kind"], L["center"], L["quat"], L["shape"])
+            op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, ra=con["ra"], rb=con["rb"],
+                                               mob_rot=mob_r)
+        else:
+            seg = ops.spherocylinder_segments(L["center"], L["quat"], L["shape"][:, 0].contiguous(),
+                                              L["shape"][:, 1].contiguous())
+            con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False, arms="arclength")
+            # rod-compressed kinematics: velocity rows (and the halo) carry (U, W x u); (U, W) = body_velocity()
+            op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
+                                               rod=(con["s"], con["t"], seg))
         self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
         self._keep = (pairs, counted, con, mob_t, mob_r, seg)
         capi.check(lib.mhip_contact_op_set_partition(op._h, self.n_lo, self.n, _p(counted), _p(self.vel)))

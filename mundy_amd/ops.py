@@ -178,12 +178,25 @@ def contact_mixed(pairs, kind, center, quat, shape, want_counts=False):
     return out
 
 
+def _cell(box):
+    """periodic cell argument: 3 edge lengths (PeriodicScaledMetric) or a 3x3 unit-cell matrix with the lattice vectors
+    as columns (PeriodicMetric).  Returns (is_triclinic, ctypes array)."""
+    import numpy as _np
+    a = _np.asarray(box.detach().cpu() if isinstance(box, torch.Tensor) else box, dtype=_np.float64)
+    if a.size == 3:
+        return False, (C.c_double * 3)(*a.reshape(3).tolist())
+    if a.size == 9:
+        return True, (C.c_double * 9)(*a.reshape(9).tolist())
+    raise ValueError("periodic cell must be 3 edge lengths or a 3x3 unit-cell matrix, got shape %s" % (a.shape,))
+
+
 def contact_spheres(pairs, center, radius, box=None, out=None):
     c = pairs.shape[0]
     sep, normal = (_new(center, c), _new(center, c, 3)) if out is None else out
-    boxp = None if box is None else (C.c_double * 3)(*[float(b) for b in box])
-    capi.check(capi.load().mhip_contact_spheres(c, _ptr(pairs, torch.int32, 2), _ptr(center, cols=3), _ptr(radius),
-                                                boxp, _ptr(sep), _ptr(normal), _stream()))
+    tri, boxp = (False, None) if box is None else _cell(box)
+    fn = capi.load().mhip_contact_spheres_triclinic if tri else capi.load().mhip_contact_spheres
+    capi.check(fn(c, _ptr(pairs, torch.int32, 2), _ptr(center, cols=3), _ptr(radius), boxp, _ptr(sep), _ptr(normal),
+                  _stream()))
     return sep, normal
 
 
@@ -508,17 +521,40 @@ def gather_rows(perm, src):
 
 
 def periodic_sep(box, p1, p2):
+    """metric.sep(p1, p2): PeriodicScaledMetric for 3 edge lengths, PeriodicMetric for a 3x3 unit cell"""
     out = torch.empty_like(p1)
-    b = (C.c_double * 3)(*[float(v) for v in box])
-    capi.check(capi.load().mhip_periodic_sep(p1.shape[0], b, _ptr(p1, cols=3), _ptr(p2, cols=3), _ptr(out), _stream()))
+    tri, b = _cell(box)
+    fn = capi.load().mhip_periodic_sep_triclinic if tri else capi.load().mhip_periodic_sep
+    capi.check(fn(p1.shape[0], b, _ptr(p1, cols=3), _ptr(p2, cols=3), _ptr(out), _stream()))
     return out
 
 
 def wrap_rigid(box, center):
-    """wrap_rigid_inplace of spheres / spherocylinders / ellipsoids: their centres are wrapped into [0, box)"""
-    b = (C.c_double * 3)(*[float(v) for v in box])
-    capi.check(capi.load().mhip_wrap_rigid(center.shape[0], b, _ptr(center, cols=3), _stream()))
+    """wrap_rigid_inplace of spheres / spherocylinders / ellipsoids: their centres are wrapped into the unit cell"""
+    tri, b = _cell(box)
+    fn = capi.load().mhip_wrap_rigid_triclinic if tri else capi.load().mhip_wrap_rigid
+    capi.check(fn(center.shape[0], b, _ptr(center, cols=3), _stream()))
     return center
+
+
+def shift_image(cell, p, images):
+    """PeriodicMetric::shift_image: p + h * images (images [n, 3] int32)"""
+    out = torch.empty_like(p)
+    a = _cell(cell)[1] if _cell(cell)[0] else None
+    if a is None:  # edge lengths -> diagonal unit cell (periodic_metric_from_unit_cell, periodicity.hpp:848-855)
+        e = _cell(cell)[1]
+        a = (C.c_double * 9)(e[0], 0, 0, 0, e[1], 0, 0, 0, e[2])
+    capi.check(capi.load().mhip_shift_image_triclinic(p.shape[0], a, _ptr(p, cols=3), _ptr(images, torch.int32, 3),
+                                                      _ptr(out), _stream()))
+    return out
+
+
+def unit_cell_inverse(cell):
+    import numpy as _np
+    a = (C.c_double * 9)(*_np.asarray(cell, dtype=_np.float64).reshape(9).tolist())
+    out = (C.c_double * 9)()
+    capi.check(capi.load().mhip_unit_cell_inverse(a, out))
+    return _np.array(list(out)).reshape(3, 3)
 
 
 def integrate_euler(dt, velocity, center, quat=None):

@@ -28,19 +28,25 @@ class StepStats:
 
 
 class ContactStepper:
-    """One rank's bodies (spheres or spherocylinders) and the per-timestep contact resolution."""
+    """One rank's bodies (spheres, spherocylinders, or a mix with ellipsoids) and the per-timestep contact resolution."""
 
     def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
                  search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
-                 mob_rot=None, rod_kinematics=True):
-        if kind not in ("sphere", "spherocylinder"):
-            raise ValueError("kind must be 'sphere' or 'spherocylinder'")
+                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None):
+        """kind = "sphere" | "spherocylinder" | "mixed".  Mixed systems (BASELINE configs[4]) pass kinds [n] int32
+        (0 sphere, 1 spherocylinder, 2 ellipsoid) and shape [n, 3] = (r,-,-) / (r,L,-) / (r1,r2,r3) instead of
+        radius / length."""
+        if kind not in ("sphere", "spherocylinder", "mixed"):
+            raise ValueError("kind must be 'sphere', 'spherocylinder' or 'mixed'")
         if kind == "spherocylinder" and (quat is None or length is None):
             raise ValueError("spherocylinders need quat and length")
-        if kind == "spherocylinder" and periodic_box is not None:
+        if kind == "mixed" and (quat is None or kinds is None or shape is None):
+            raise ValueError("mixed systems need quat, kinds and shape")
+        if kind != "sphere" and periodic_box is not None:
             raise ValueError("periodic boxes are supported for spheres only")
         self.kind = kind
         self.center, self.radius, self.quat, self.length = center, radius, quat, length
+        self.kinds, self.shape = kinds, shape
         self.dt, self.viscosity = float(dt), float(viscosity)
         self.box = periodic_box
         self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)  # NgpLcp.cpp:851-852
@@ -56,6 +62,9 @@ class ContactStepper:
         if kind == "sphere":
             self.bounding_radius = radius.clone()
             eff = radius
+        elif kind == "mixed":
+            self.bounding_radius = ops.compute_aabb_mixed(kinds, center, quat, shape)[1]
+            eff = self.bounding_radius
         else:
             self.bounding_radius = ops.bounding_radius_spherocylinders(radius, length)
             eff = self.bounding_radius
@@ -63,14 +72,14 @@ class ContactStepper:
         if mob_trans is None:
             mt, mr = synth.dry_mobility(eff.cpu().numpy(), viscosity=self.viscosity)
             mob_trans = torch.from_numpy(mt).to(center.device)
-            mob_rot = torch.from_numpy(mr).to(center.device) if kind == "spherocylinder" else None
-        self.mob_trans, self.mob_rot = mob_trans, (mob_rot if kind == "spherocylinder" else None)
+            mob_rot = torch.from_numpy(mr).to(center.device) if kind != "sphere" else None
+        self.mob_trans, self.mob_rot = mob_trans, (mob_rot if kind != "sphere" else None)
         self.op = None
         self.lam = None
         self.contacts = None
 
     # -- stages -----------------------------------------------------------------------------------------------------
-    _BODY_ARRAYS = ("center", "radius", "quat", "length", "bounding_radius", "mob_trans", "mob_rot")
+    _BODY_ARRAYS = ("center", "radius", "quat", "length", "bounding_radius", "mob_trans", "mob_rot", "shape", "kinds")
 
     def snapshot(self):
         """device copies of every per-body array (to restart a step from the same input)"""
@@ -92,12 +101,14 @@ class ContactStepper:
         for name in self._BODY_ARRAYS:
             t = getattr(self, name, None)
             if t is not None:
-                t.copy_(ops.gather_rows(perm, t))
+                t.copy_(ops.gather_rows(perm, t) if t.dtype == torch.float64 else t[perm.long()])
         return perm
 
     def compute_aabb(self):
         if self.kind == "sphere":
             self.aabb = ops.compute_aabb_spheres(self.center, self.radius)
+        elif self.kind == "mixed":
+            self.aabb = ops.compute_aabb_mixed(self.kinds, self.center, self.quat, self.shape)[0]
         else:
             self.aabb = ops.compute_aabb_spherocylinders(self.center, self.quat, self.radius, self.length)
         return self.aabb
@@ -110,6 +121,8 @@ class ContactStepper:
         if self.kind == "sphere":
             sep, normal = ops.contact_spheres(pairs, self.center, self.radius, box=self.box)
             self.contacts = dict(sep=sep, normal=normal, ra=None, rb=None)
+        elif self.kind == "mixed":  # pairs binned by shape class, one distance routine per class
+            self.contacts = ops.contact_mixed(pairs, self.kinds, self.center, self.quat, self.shape)
         else:
             ops.spherocylinder_segments(self.center, self.quat, self.radius, self.length, out=self.seg)
             self.contacts = ops.contact_spherocylinders(pairs, self.seg, self.center, want_points=False,
@@ -120,7 +133,7 @@ class ContactStepper:
         c = self.contacts
         if self.op is not None:
             self.op.close()
-        if self.kind != "sphere" and self.rod_kinematics:
+        if self.kind == "spherocylinder" and self.rod_kinematics:
             self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, mob_rot=self.mob_rot,
                                           rod=(c["s"], c["t"], self.seg))
         else:

@@ -189,6 +189,37 @@ def periodic_wrap(box, p):
     return out
 
 
+def unit_cell_inverse(h):
+    """math::inverse of the 3x3 unit-cell matrix, the reference's cofactor formula (Matrix.hpp:1596-1601)"""
+    h = _f(np.asarray(h, dtype=np.float64).reshape(3, 3))
+    out = np.empty((3, 3))
+    lib().o_unit_cell_inverse(_p(h), _p(out))
+    return out
+
+
+def periodic_sep_triclinic(h, p1, p2):
+    """PeriodicMetric::sep (periodicity.hpp:304-307); h = 3x3 unit cell, lattice vectors as columns"""
+    h, p1, p2 = _f(np.asarray(h, dtype=np.float64).reshape(3, 3)), _f(p1), _f(p2)
+    out = np.empty_like(p1)
+    lib().o_periodic_sep_triclinic(C.c_size_t(len(p1)), _p(h), _p(p1), _p(p2), _p(out))
+    return out
+
+
+def periodic_wrap_triclinic(h, p):
+    h, p = _f(np.asarray(h, dtype=np.float64).reshape(3, 3)), _f(p)
+    out = np.empty_like(p)
+    lib().o_periodic_wrap_triclinic(C.c_size_t(len(p)), _p(h), _p(p), _p(out))
+    return out
+
+
+def shift_image_triclinic(h, p, images):
+    h, p = _f(np.asarray(h, dtype=np.float64).reshape(3, 3)), _f(p)
+    images = np.ascontiguousarray(images, dtype=np.int32)
+    out = np.empty_like(p)
+    lib().o_shift_image_triclinic(C.c_size_t(len(p)), _p(h), _p(p), _p(images), _p(out))
+    return out
+
+
 # ---- neighbour search ---------------------------------------------------------------------------------------------
 SEARCH_SPHERES, SEARCH_AABB = 0, 1
 

@@ -189,6 +189,64 @@ struct PeriodicScaledMetric {
   }
 };
 
+// Triclinic cell: mundy/geom/src/mundy_geom/periodicity.hpp:233-332 (PeriodicMetric).  h holds the lattice vectors as
+// columns, row-major storage h[3*i+j] = h(i,j).  h_inv = math::inverse(h) = adjugate / determinant
+// (mundy/math/src/mundy_math/Matrix.hpp:1596-1601) with the Laplace-expansion determinant and cofactors of
+// mundy/math/src/mundy_math/impl/MatrixImpl.hpp:481-506 (unary right folds; the +/-1 factors are exact).
+struct PeriodicMetric {
+  double h[9], h_inv[9];
+  static double det2(double a, double b, double c, double d) { return a * d + (-(b * c)); }  // MatrixImpl.hpp:485
+  // minor<r, c> of a 3x3 stored row-major, then its 2x2 determinant
+  static double minor_det(const double* m, int r, int c) {
+    int rows[2], cols[2], k = 0;
+    for (int i = 0; i < 3; ++i)
+      if (i != r) rows[k++] = i;
+    k = 0;
+    for (int j = 0; j < 3; ++j)
+      if (j != c) cols[k++] = j;
+    return det2(m[3 * rows[0] + cols[0]], m[3 * rows[0] + cols[1]], m[3 * rows[1] + cols[0]], m[3 * rows[1] + cols[1]]);
+  }
+  static double determinant(const double* m) {
+    const double t0 = m[0] * minor_det(m, 0, 0), t1 = -(m[1] * minor_det(m, 0, 1)), t2 = m[2] * minor_det(m, 0, 2);
+    return t0 + (t1 + t2);
+  }
+  static void inverse(const double* m, double* out) {
+    const double det = determinant(m);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        // adjugate(i, j) = cofactor(j, i); cofactor sign by flat index parity (MatrixImpl.hpp:505)
+        const double cof = minor_det(m, j, i) * (((3 * j + i) % 2 == 0) ? 1.0 : -1.0);
+        out[3 * i + j] = cof / det;
+      }
+  }
+  explicit PeriodicMetric(const double* cell) {
+    for (int i = 0; i < 9; ++i) h[i] = cell[i];
+    inverse(h, h_inv);
+  }
+  // Matrix * vector = per-row dot (MatrixImpl.hpp:348-355)
+  static V3 matvec(const double* m, const V3& v) {
+    return {dot(V3{m[0], m[1], m[2]}, v), dot(V3{m[3], m[4], m[5]}, v), dot(V3{m[6], m[7], m[8]}, v)};
+  }
+  V3 to_fractional(const V3& p) const { return matvec(h_inv, p); }    // :279-281
+  V3 from_fractional(const V3& f) const { return matvec(h, f); }      // :286-288
+  // :304-307
+  V3 sep(const V3& p1, const V3& p2) const {
+    const V3 f = to_fractional(p2 - p1);
+    return from_fractional({PeriodicScaledMetric::min_image1(f.x), PeriodicScaledMetric::min_image1(f.y),
+                            PeriodicScaledMetric::min_image1(f.z)});
+  }
+  // :312-314
+  V3 wrap(const V3& p) const {
+    const V3 f = to_fractional(p);
+    return from_fractional({PeriodicScaledMetric::unit_mod1(f.x), PeriodicScaledMetric::unit_mod1(f.y),
+                            PeriodicScaledMetric::unit_mod1(f.z)});
+  }
+  // :323-327 translate(point, h * num_images)
+  V3 shift_image(const V3& p, const int* n) const {
+    return p + matvec(h, V3{static_cast<double>(n[0]), static_cast<double>(n[1]), static_cast<double>(n[2])});
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // mundy::geom -- distances
 // ---------------------------------------------------------------------------------------------------------------

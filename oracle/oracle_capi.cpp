@@ -238,6 +238,20 @@ void o_periodic_wrap(size_t n, const double* box, const double* p, double* out) 
   const PeriodicScaledMetric pm(V3{box[0], box[1], box[2]});
   for (size_t i = 0; i < n; ++i) st3(out, i, pm.wrap(ld3(p, i)));
 }
+// triclinic PeriodicMetric (periodicity.hpp:233-332); h row-major 3x3, lattice vectors as columns
+void o_unit_cell_inverse(const double* h, double* h_inv) { PeriodicMetric::inverse(h, h_inv); }
+void o_periodic_sep_triclinic(size_t n, const double* h, const double* p1, const double* p2, double* out) {
+  const PeriodicMetric pm(h);
+  for (size_t i = 0; i < n; ++i) st3(out, i, pm.sep(ld3(p1, i), ld3(p2, i)));
+}
+void o_periodic_wrap_triclinic(size_t n, const double* h, const double* p, double* out) {
+  const PeriodicMetric pm(h);
+  for (size_t i = 0; i < n; ++i) st3(out, i, pm.wrap(ld3(p, i)));
+}
+void o_shift_image_triclinic(size_t n, const double* h, const double* p, const int* images, double* out) {
+  const PeriodicMetric pm(h);
+  for (size_t i = 0; i < n; ++i) st3(out, i, pm.shift_image(ld3(p, i), images + 3 * i));
+}
 
 // ---- neighbour search ---------------------------------------------------------------------------------------------
 // method 0 = O(N^2), 1 = cell list.  Returns the pair count; fetch with o_search_fetch.

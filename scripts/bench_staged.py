@@ -18,4 +18,10 @@ for name, fn in (("staged", lambda: st.step(integrate=False)), ("fused", lambda:
     t = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t
     it = out["num_iters"] if isinstance(out, dict) else out.num_iters
     print("%s: %.1f ms/step, %d iterations, %.3f ms/iteration" % (name, 1e3 * dt, it, 1e3 * dt / max(it, 1)))
+print("fused stage ms:", {k: round(v, 2) for k, v in ref.step(integrate=False, timed=True).timings_ms.items()})
+st.profile = True
+st.prof.update(body_ms=0.0, con_ms=0.0, iters=0)
+out = st.step(integrate=False)
+print("staged sampled sweeps: k_body %.4f ms, k_constraint+local3 %.4f ms over %d iterations; stats %s"
+      % (st.prof["body_ms"] / max(1, st.prof["iters"]), st.prof["con_ms"] / max(1, st.prof["iters"]), st.prof["iters"], out))
 dist.destroy_process_group()

@@ -20,16 +20,23 @@ def main():
     torch.cuda.set_device(0)
     from mundy_amd import distributed as D, ops, pipeline, synth
 
-    b = synth.spherocylinders(n_total, seed=7)
+    mixed = os.environ.get("DIST_MIXED", "0") == "1"   # BASELINE configs[4]: spheres + rods + ellipsoids
+    b = synth.mixed_bodies(n_total, volume_fraction=0.25, seed=7) if mixed else synth.spherocylinders(n_total, seed=7)
     order = D.hilbert_order(b["center"], 0.0, b["box"], level=5)
     starts = D.partition_ranges(n_total, world)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     g_center, g_quat = b["center"][order], b["quat"][order]
-    g_radius, g_length = b["radius"][order], b["length"][order]
     a, e = int(starts[rank]), int(starts[rank + 1])
     cfg = ops.PGDConfig(max_iters=20000, tol=tol)
-    st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]), a,
-                                     comm=D.Comm(), search_buffer=0.1, cfg=cfg, poll_every=8)
+    if mixed:
+        g_kind, g_shape = b["kind"][order], b["shape"][order]
+        st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), None, None, a, comm=D.Comm(),
+                                         search_buffer=0.1, cfg=cfg, poll_every=8, kind=dev(g_kind[a:e]),
+                                         shape=dev(g_shape[a:e]))
+    else:
+        g_radius, g_length = b["radius"][order], b["length"][order]
+        st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]),
+                                         a, comm=D.Comm(), search_buffer=0.1, cfg=cfg, poll_every=8)
     stats = st.step(integrate=False)
     gid = st.local["gid"].cpu().numpy().astype(np.int64)
     pairs = st.pairs.cpu().numpy()
@@ -40,8 +47,12 @@ def main():
     dist.gather_object(out, gathered, dst=0)
     ok = True
     if rank == 0:
-        ref = pipeline.ContactStepper("spherocylinder", dev(g_center), dev(g_radius), dev(g_quat), dev(g_length),
-                                      search_buffer=0.1, cfg=cfg)
+        if mixed:
+            ref = pipeline.ContactStepper("mixed", dev(g_center), None, dev(g_quat), search_buffer=0.1, cfg=cfg,
+                                          kinds=dev(g_kind), shape=dev(g_shape))
+        else:
+            ref = pipeline.ContactStepper("spherocylinder", dev(g_center), dev(g_radius), dev(g_quat), dev(g_length),
+                                          search_buffer=0.1, cfg=cfg)
         rs = ref.step(integrate=False)
         rp = ref.links.pairs.cpu().numpy().astype(np.int64)
         rg = (ref.op.apply(ref.lam) + ref.contacts["sep"]).cpu().numpy()
@@ -85,7 +96,7 @@ def main():
         for k, v in checks.items():
             print(("ok   " if v else "FAIL ") + k)
             ok = ok and bool(v)
-        print("DIST_RESULT", "PASS" if ok else "FAIL", "world", world, "contacts", len(rp), "iters", iters,
+        print("DIST_RESULT", "PASS" if ok else "FAIL", "mixed" if mixed else "rods", "world", world, "contacts", len(rp), "iters", iters,
               "single", rs.num_iters)
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag, src=0)

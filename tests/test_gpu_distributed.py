@@ -19,7 +19,8 @@ def _run(world, port, extra_env=None):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     print(p.stdout[-5000:], p.stderr[-3000:])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "dist_world%d.log" % world), "w") as f:
+    tag = "_mixed" if (extra_env or {}).get("DIST_MIXED") == "1" else ""
+    with open(os.path.join(ROOT, "gpurun_out", "dist_world%d%s.log" % (world, tag)), "w") as f:
         f.write(p.stdout[-20000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_RESULT PASS" in p.stdout
@@ -28,6 +29,11 @@ def _run(world, port, extra_env=None):
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_equals_single_rank(world):
     _run(world, 29610 + world)
+
+
+def test_distributed_mixed_shapes_equals_single_rank():
+    # BASELINE configs[4] as a parity case: spheres + spherocylinders + ellipsoids, Hilbert-partitioned over 2 ranks
+    _run(2, 29620, {"DIST_MIXED": "1", "DIST_BODIES": "9000"})
 
 
 def test_nccl_transport_single_rank():

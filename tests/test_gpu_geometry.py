@@ -182,6 +182,35 @@ def test_periodic_metric_bit_exact(ops, oracle):
     assert np.all(w >= 0) and np.all(w < box)
 
 
+def test_triclinic_metric_bit_exact(ops, oracle):
+    # PeriodicMetric (periodicity.hpp:233-332): sep / wrap_rigid / shift_image / sphere contacts under a tilted cell,
+    # and the diagonal cell of the reference's own test (UnitTestPeriodicity.cpp:627-630)
+    from gpu_util import assert_bits_equal, dev, host
+    rng = np.random.default_rng(21)
+    n = 100_000
+    for h in (np.array([[10.0, 2.0, 1.0], [0.0, 9.0, 3.0], [0.0, 0.0, 8.0]]), np.diag([100.0, 100.0, 100.0]),
+              np.array([[7.0, -1.5, 0.3], [0.4, 6.0, 2.0], [-0.8, 0.9, 5.0]])):
+        assert_bits_equal(ops.unit_cell_inverse(h), oracle.unit_cell_inverse(h), "unit cell inverse")
+        p1, p2 = rng.uniform(-40, 40, (n, 3)), rng.uniform(-40, 40, (n, 3))
+        p1[:64] = np.round(p1[:64])
+        p2[:64] = p1[:64] + (h @ (rng.integers(-3, 4, (64, 3)) * 0.5).T).T   # half-way images: round() ties
+        assert_bits_equal(host(ops.periodic_sep(h, dev(p1), dev(p2))), oracle.periodic_sep_triclinic(h, p1, p2), "sep")
+        assert_bits_equal(host(ops.wrap_rigid(h, dev(p1))), oracle.periodic_wrap_triclinic(h, p1), "wrap_rigid")
+        img = rng.integers(-4, 5, (n, 3)).astype(np.int32)
+        assert_bits_equal(host(ops.shift_image(h, dev(p1), dev(img))), oracle.shift_image_triclinic(h, p1, img),
+                          "shift_image")
+        # sphere contacts with this metric: same kernel as the orthorhombic case, other minimum image
+        pairs = np.stack([np.arange(0, n - 1, 2), np.arange(1, n, 2)], 1).astype(np.int32)
+        r = rng.uniform(0.3, 1.0, n)
+        sep, nrm = ops.contact_spheres(dev(pairs), dev(p1), dev(r), box=h)
+        d = oracle.periodic_sep_triclinic(h, p1[pairs[:, 0]], p1[pairs[:, 1]])
+        cc = np.sqrt(d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]))
+        assert_bits_equal(host(sep), cc - r[pairs[:, 0]] - r[pairs[:, 1]], "triclinic sphere sep")
+        assert_bits_equal(host(nrm), d * (1.0 / cc)[:, None], "triclinic sphere normal")
+    with pytest.raises(Exception):
+        ops.periodic_sep(np.zeros((3, 3)), dev(p1), dev(p2))
+
+
 def test_degenerate_inputs_follow_the_reference(ops, oracle):
     # degenerate bodies as the reference treats them: zero-length rod == sphere-like segment, zero radius, identical
     # segments (distance 0 -> the contact normal is 0/0: NaN on both sides, no guard in the reference, SphereSphere.hpp:66-76)

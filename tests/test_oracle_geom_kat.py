@@ -239,3 +239,44 @@ def test_periodic_scaled_metric(oracle):
     # shifting either point by whole cells leaves sep unchanged (to rounding)
     s2 = oracle.periodic_sep(box, p1 + box * [2, -1, 3], p2)
     np.testing.assert_allclose(np.abs(s2), np.abs(s), atol=1e-9)
+
+
+def test_triclinic_periodic_metric(oracle):
+    # PeriodicMetric (periodicity.hpp:233-332).  First the reference's own test, restated
+    # (UnitTestPeriodicity.cpp:623-660, MinImageDirectVsPeriodic): a diagonal unit cell of edge 100, random points in
+    # the box, minimum-image distance == min over the 27 images, and == the scaled metric's, to the relaxed tolerance.
+    rng = np.random.default_rng(1234)
+    n = 100_000
+    cell = np.diag([100.0, 100.0, 100.0])
+    p1, p2 = rng.uniform(0, 100, (n, 3)), rng.uniform(0, 100, (n, 3))
+    s = oracle.periodic_sep_triclinic(cell, p1, p2)
+    best = np.full(n, np.inf)
+    for i in (-1, 0, 1):
+        for j in (-1, 0, 1):
+            for k in (-1, 0, 1):
+                best = np.minimum(best, np.linalg.norm(p2 + 100.0 * np.array([i, j, k]) - p1, axis=1))
+    np.testing.assert_allclose(np.linalg.norm(s, axis=1), best, atol=1e-10)
+    np.testing.assert_allclose(np.linalg.norm(oracle.periodic_sep([100.0] * 3, p1, p2), axis=1), best, atol=1e-10)
+    # the inverse is the cofactor formula: exact for a diagonal cell, h_inv h = 1 to rounding for a tilted one
+    np.testing.assert_array_equal(oracle.unit_cell_inverse(cell), np.diag([0.01, 0.01, 0.01]))
+    h = np.array([[10.0, 2.0, 1.0], [0.0, 9.0, 3.0], [0.0, 0.0, 8.0]])  # lattice vectors = columns
+    hi = oracle.unit_cell_inverse(h)
+    np.testing.assert_allclose(hi @ h, np.eye(3), atol=1e-15)
+    # tilted cell: sep differs from the direct separation by a lattice vector, fractional sep in [-1/2, 1/2]
+    q1, q2 = rng.uniform(-30, 30, (n, 3)), rng.uniform(-30, 30, (n, 3))
+    st = oracle.periodic_sep_triclinic(h, q1, q2)
+    f = (hi @ st.T).T
+    assert np.all(np.abs(f) <= 0.5 + 1e-12)
+    kk = (hi @ (q2 - q1 - st).T).T
+    np.testing.assert_allclose(kk, np.round(kk), atol=1e-9)
+    # wrap lands in the unit cell and moves by a lattice vector
+    w = oracle.periodic_wrap_triclinic(h, q1)
+    fw = (hi @ w.T).T
+    assert np.all(fw >= -1e-12) and np.all(fw < 1 + 1e-12)
+    kw = (hi @ (q1 - w).T).T
+    np.testing.assert_allclose(kw, np.round(kw), atol=1e-9)
+    # shift_image (UnitTestPeriodicity.cpp:909-948): p + h n, and sep is invariant under it
+    img = rng.integers(-3, 4, (n, 3)).astype(np.int32)
+    sh = oracle.shift_image_triclinic(h, q2, img)
+    np.testing.assert_allclose(sh, q2 + (h @ img.T).T, atol=1e-12)
+    np.testing.assert_allclose(oracle.periodic_sep_triclinic(h, q1, sh), st, atol=1e-9)
