@@ -28,36 +28,78 @@ constexpr double kLowest = -1.7976931348623157e308;  // Kokkos::Max<double> iden
 // S1 vector kernels (KokkosBackend, convex.hpp:201-284).  The |alpha|,|beta| < 1e-15 branches are resolved on the
 // host exactly as the reference does and select the kernel variant.
 // ------------------------------------------------------------------------------------------------------------------
+// Streaming kernels move 16 bytes per lane per access when the vectors are 16-byte aligned (VEC: elements in pairs,
+// the odd tail element by one thread); element-wise arithmetic is unchanged, so results do not depend on VEC.
 template <int MODE>  // 0: a*x+b*y   1: b*y   2: a*x   3: 0
+__device__ inline double axpby_value(double alpha, double x, double beta, double y) {
+  if (MODE == 0) return alpha * x + beta * y;
+  if (MODE == 1) return y * beta;
+  if (MODE == 2) return alpha * x;
+  return 0.0;
+}
+template <int MODE, bool VEC>
 __global__ void __launch_bounds__(kBlock) k_axpby(size_t n, double alpha, const double* __restrict__ x, double beta,
                                                  double* __restrict__ y) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    if (MODE == 0) y[i] = alpha * x[i] + beta * y[i];
-    if (MODE == 1) y[i] *= beta;
-    if (MODE == 2) y[i] = alpha * x[i];
-    if (MODE == 3) y[i] = 0.0;
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    double2* y2 = reinterpret_cast<double2*>(y);
+    for (size_t i = tid; i < n / 2; i += nth) {
+      const double2 a = (MODE == 0 || MODE == 2) ? x2[i] : make_double2(0.0, 0.0);
+      const double2 b = (MODE == 0 || MODE == 1) ? y2[i] : make_double2(0.0, 0.0);
+      y2[i] = make_double2(axpby_value<MODE>(alpha, a.x, beta, b.x), axpby_value<MODE>(alpha, a.y, beta, b.y));
+    }
+    if ((n & 1) && tid == 0) y[n - 1] = axpby_value<MODE>(alpha, MODE == 1 || MODE == 3 ? 0.0 : x[n - 1], beta, y[n - 1]);
+  } else {
+    for (size_t i = tid; i < n; i += nth)
+      y[i] = axpby_value<MODE>(alpha, (MODE == 0 || MODE == 2) ? x[i] : 0.0, beta, (MODE == 0 || MODE == 1) ? y[i] : 0.0);
   }
 }
-template <int MODE>
+template <int MODE, bool VEC>
 __global__ void __launch_bounds__(kBlock) k_wrapped_axpbyz(size_t n, double alpha, const double* __restrict__ x,
                                                           double beta, const double* __restrict__ y,
                                                           double* __restrict__ z, Space sp) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    double v;
-    if (MODE == 0) v = alpha * x[i] + beta * y[i];
-    if (MODE == 1) v = beta * y[i];
-    if (MODE == 2) v = alpha * x[i];
-    if (MODE == 3) v = 0.0;
-    z[i] = sp.project(v);
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    double2* z2 = reinterpret_cast<double2*>(z);
+    for (size_t i = tid; i < n / 2; i += nth) {
+      const double2 a = (MODE == 0 || MODE == 2) ? x2[i] : make_double2(0.0, 0.0);
+      const double2 b = (MODE == 0 || MODE == 1) ? y2[i] : make_double2(0.0, 0.0);
+      z2[i] = make_double2(sp.project(axpby_value<MODE>(alpha, a.x, beta, b.x)),
+                           sp.project(axpby_value<MODE>(alpha, a.y, beta, b.y)));
+    }
+    if ((n & 1) && tid == 0)
+      z[n - 1] = sp.project(axpby_value<MODE>(alpha, (MODE == 0 || MODE == 2) ? x[n - 1] : 0.0, beta,
+                                              (MODE == 0 || MODE == 1) ? y[n - 1] : 0.0));
+  } else {
+    for (size_t i = tid; i < n; i += nth)
+      z[i] = sp.project(axpby_value<MODE>(alpha, (MODE == 0 || MODE == 2) ? x[i] : 0.0, beta,
+                                          (MODE == 0 || MODE == 1) ? y[i] : 0.0));
   }
 }
+template <bool VEC>
 __global__ void __launch_bounds__(kBlock) k_copy(size_t n, double* __restrict__ dst, const double* __restrict__ src) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = src[i];
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    for (size_t i = tid; i < n / 2; i += nth) reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+    if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
+  } else {
+    for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
+  }
 }
 __global__ void __launch_bounds__(kBlock) k_fill(size_t n, double* __restrict__ dst, double v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = v;
+}
+inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15u) == 0;
+}
+// streaming grids: enough workgroups to keep every CU's queue full, capped so the tail wave is short
+inline unsigned stream_grid(size_t work_items) {
+  const size_t g = (work_items + kBlock - 1) / kBlock;
+  return static_cast<unsigned>(g == 0 ? 1 : (g > 8192 ? 8192 : g));
 }
 
 // residual term of one unknown (policies convex.hpp:434-496)
@@ -233,11 +275,16 @@ int reduce_to_host(size_t n, const double* a, const double* b, const double* c, 
 int launch_axpby(size_t n, double alpha, const double* x, double beta, double* y, hipStream_t s) {
   if (n == 0) return MHIP_SUCCESS;
   const bool az = fabs(alpha) < kZeroTol, bz = fabs(beta) < kZeroTol;
-  const unsigned g = grid_for(n);
-  if (!az && !bz) k_axpby<0><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
-  else if (az && !bz) k_axpby<1><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
-  else if (!az && bz) k_axpby<2><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
-  else k_axpby<3><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);
+  const int mode = (!az && !bz) ? 0 : ((az && !bz) ? 1 : ((!az && bz) ? 2 : 3));
+  const bool vec = aligned16(x, y);
+  const unsigned g = stream_grid(vec ? (n + 1) / 2 : n);
+#define AXPBY(M)                                                        \
+  do {                                                                  \
+    if (vec) k_axpby<M, true><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y); \
+    else k_axpby<M, false><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y);  \
+  } while (0)
+  if (mode == 0) AXPBY(0); else if (mode == 1) AXPBY(1); else if (mode == 2) AXPBY(2); else AXPBY(3);
+#undef AXPBY
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -245,17 +292,25 @@ int launch_wrapped_axpbyz(size_t n, double alpha, const double* x, double beta, 
                           hipStream_t s) {
   if (n == 0) return MHIP_SUCCESS;
   const bool az = fabs(alpha) < kZeroTol, bz = fabs(beta) < kZeroTol;
-  const unsigned g = grid_for(n);
-  if (!az && !bz) k_wrapped_axpbyz<0><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
-  else if (az && !bz) k_wrapped_axpbyz<1><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
-  else if (!az && bz) k_wrapped_axpbyz<2><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
-  else k_wrapped_axpbyz<3><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);
+  const int mode = (!az && !bz) ? 0 : ((az && !bz) ? 1 : ((!az && bz) ? 2 : 3));
+  const bool vec = aligned16(x, y, z);
+  const unsigned g = stream_grid(vec ? (n + 1) / 2 : n);
+#define WAXPBYZ(M)                                                                 \
+  do {                                                                             \
+    if (vec) k_wrapped_axpbyz<M, true><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp); \
+    else k_wrapped_axpbyz<M, false><<<g, kBlock, 0, s>>>(n, alpha, x, beta, y, z, sp);    \
+  } while (0)
+  if (mode == 0) WAXPBYZ(0); else if (mode == 1) WAXPBYZ(1); else if (mode == 2) WAXPBYZ(2); else WAXPBYZ(3);
+#undef WAXPBYZ
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
 int launch_copy(size_t n, double* dst, const double* src, hipStream_t s) {
   if (n == 0 || dst == src) return MHIP_SUCCESS;
-  k_copy<<<grid_for(n), kBlock, 0, s>>>(n, dst, src);
+  const bool vec = aligned16(dst, src);
+  const unsigned g = stream_grid(vec ? (n + 1) / 2 : n);
+  if (vec) k_copy<true><<<g, kBlock, 0, s>>>(n, dst, src);
+  else k_copy<false><<<g, kBlock, 0, s>>>(n, dst, src);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -525,30 +580,68 @@ __global__ void __launch_bounds__(kBlock)
     const double m = block_max(rmax, scratch);
     const double s1 = block_sum(num, scratch);
     const double s2 = block_sum(den, scratch);
-    if (threadIdx.x == 0) {
-      partials[3 * blockIdx.x] = m;
-      partials[3 * blockIdx.x + 1] = s1;
-      partials[3 * blockIdx.x + 2] = s2;
+    if (threadIdx.x == 0) {  // three planes of gridDim.x values: the final pass reads them coalesced
+      partials[blockIdx.x] = m;
+      partials[(size_t)gridDim.x + blockIdx.x] = s1;
+      partials[2 * (size_t)gridDim.x + blockIdx.x] = s2;
     }
   }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(kBlock) k_finalize(int nparts, const double* __restrict__ partials,
-                                                    SolverState* __restrict__ st, int resid_kind, double tol,
-                                                    unsigned max_iters) {
-  __shared__ double scratch[kBlock / 64];
-  if (MODE == X_SOLVE && st->done) return;
-  double rmax = kLowest, num = 0.0, den = 0.0;
+constexpr int kFinalBlock = 1024;  // threads of the single-workgroup final passes
+// ordered reduction of nparts (max, num, den) triples; element (i, k) sits at partials[i * si + k * sk]
+// (block partials: si = 1, sk = nparts; the all-gathered per-rank triples: si = 3, sk = 1)
+__device__ inline void reduce_triples(int nparts, const double* __restrict__ partials, size_t si, size_t sk,
+                                      double* scratch, double& rmax, double& num, double& den) {
+  rmax = kLowest;
+  num = 0.0;
+  den = 0.0;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    const double m = partials[3 * i];
+    const double m = partials[i * si];
     if (m > rmax) rmax = m;
-    num += partials[3 * i + 1];
-    den += partials[3 * i + 2];
+    num += partials[i * si + sk];
+    den += partials[i * si + 2 * sk];
   }
   rmax = block_max(rmax, scratch);
   num = block_sum(num, scratch);
   den = block_sum(den, scratch);
+}
+
+// first level of the final reduction when there are tens of thousands of block partials: workgroup b folds the
+// contiguous slice b of each plane into one triple (fixed slices, fixed order: deterministic)
+constexpr int kFoldGroups = 64;
+__global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, const double* __restrict__ partials,
+                                                         const SolverState* __restrict__ st, int check_done,
+                                                         double* __restrict__ folded) {
+  __shared__ double scratch[kBlock / 64];
+  if (check_done && st->done) return;
+  const int per = (nparts + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = (lo + per < nparts) ? lo + per : nparts;
+  double rmax = kLowest, num = 0.0, den = 0.0;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const double m = partials[i];
+    if (m > rmax) rmax = m;
+    num += partials[(size_t)nparts + i];
+    den += partials[2 * (size_t)nparts + i];
+  }
+  rmax = block_max(rmax, scratch);
+  num = block_sum(num, scratch);
+  den = block_sum(den, scratch);
+  if (threadIdx.x == 0) {
+    folded[blockIdx.x] = rmax;
+    folded[gridDim.x + blockIdx.x] = num;
+    folded[2 * gridDim.x + blockIdx.x] = den;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const double* __restrict__ partials, size_t si,
+                                                         size_t sk, SolverState* __restrict__ st, int resid_kind,
+                                                         double tol, unsigned max_iters) {
+  __shared__ double scratch[kFinalBlock / 64];
+  if (MODE == X_SOLVE && st->done) return;
+  double rmax, num, den;
+  reduce_triples(nparts, partials, si, sk, scratch, rmax, num, den);
   if (threadIdx.x != 0) return;
   const double res = (resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF) ? rmax / kSmallStep : rmax;
   st->residual = res;
@@ -578,21 +671,13 @@ __global__ void __launch_bounds__(kBlock) k_finalize(int nparts, const double* _
 }
 
 // block partials -> one (max, num, den) triple (this rank's contribution to the all-gather of SURVEY 8e step 3)
-__global__ void __launch_bounds__(kBlock) k_reduce_local3(int nparts, const double* __restrict__ partials,
-                                                         const SolverState* __restrict__ st, int check_done,
-                                                         double* __restrict__ out3) {
-  __shared__ double scratch[kBlock / 64];
+__global__ void __launch_bounds__(kFinalBlock) k_reduce_local3(int nparts, const double* __restrict__ partials,
+                                                              const SolverState* __restrict__ st, int check_done,
+                                                              double* __restrict__ out3) {
+  __shared__ double scratch[kFinalBlock / 64];
   if (check_done && st->done) return;
-  double rmax = kLowest, num = 0.0, den = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    const double m = partials[3 * i];
-    if (m > rmax) rmax = m;
-    num += partials[3 * i + 1];
-    den += partials[3 * i + 2];
-  }
-  rmax = block_max(rmax, scratch);
-  num = block_sum(num, scratch);
-  den = block_sum(den, scratch);
+  double rmax, num, den;
+  reduce_triples(nparts, partials, 1, (size_t)nparts, scratch, rmax, num, den);
   if (threadIdx.x == 0) {
     out3[0] = rmax;
     out3[1] = num;
@@ -947,6 +1032,30 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
   return MHIP_SUCCESS;
 }
 
+// block partials of the constraint sweep -> at most kFoldGroups triples (planes) ready for the single-workgroup pass
+inline void fold_partials(unsigned& nparts, double*& parts, const SolverState* st, int check_done, hipStream_t s) {
+  if (nparts <= 4096) return;  // one workgroup reads a few thousand triples as fast as a second launch would
+  double* folded = parts + 3 * (size_t)nparts;
+  k_fold_partials<<<kFoldGroups, kBlock, 0, s>>>((int)nparts, parts, st, check_done, folded);
+  parts = folded;
+  nparts = kFoldGroups;
+}
+// threads of a final pass over n partials: one wave is enough for a handful, 1024 for tens of thousands
+inline unsigned final_block(size_t n) { return n <= 256 ? 64u : (n <= 2048 ? 256u : (unsigned)kFinalBlock); }
+// workgroups of the constraint sweep: one 256-constraint tile each up to the cap (10^6 rods: 29 775), grid-stride
+// beyond; measured 0.145 ms at 2048 workgroups, 0.139 at 8192, 0.131 at one tile per workgroup.  One partial triple
+// per workgroup.
+constexpr int kMaxConstraintGrid = 32768;
+unsigned constraint_grid(size_t C) {
+  static const int cap = [] {
+    const char* e = getenv("MHIP_CONSTRAINT_GRID");
+    const int v = e ? atoi(e) : kMaxConstraintGrid;
+    return v < 8 ? 8 : (v > kMaxConstraintGrid ? kMaxConstraintGrid : v);
+  }();
+  const size_t g = (C + kBlock - 1) / kBlock;
+  return static_cast<unsigned>(g == 0 ? 1 : (g > (size_t)cap ? cap : g));
+}
+
 int check_config(const mhip_pgd_config* cfg) {
   MHIP_REQUIRE(cfg != nullptr, MHIP_ERR_INVALID_ARGUMENT, "config must not be null");
   MHIP_REQUIRE(cfg->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF ||
@@ -1089,7 +1198,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   if (int e = op->cursor.reserve((N + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->inc.reserve((2 * C + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->vel.reserve((6 * N + 2) * sizeof(double))) return bail(e);
-  if (int e = op->partials.reserve((4 * kMaxGrid + 8) * sizeof(double))) return bail(e);
+  if (int e = op->partials.reserve((4 * kMaxConstraintGrid + 3 * kFoldGroups + 8) * sizeof(double))) return bail(e);
   if (int e = op->state.reserve(sizeof(SolverState) + 64)) return bail(e);
   if (int e = op->scanws.reserve(scan_workspace_bytes(N + 1) + 64)) return bail(e);
   {
@@ -1258,7 +1367,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   MHIP_REQUIRE(x != x_tmp && g != g_tmp && x != g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not alias");
   SolverState* st = op->state.as<SolverState>();
   double* parts = op->partials.as<double>();
-  const unsigned cgrid = grid_for(C);
+  const unsigned cgrid = constraint_grid(C);
   const int rk = config->residual_kind;
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   double* P0 = op->iterate.as<double>();
@@ -1266,7 +1375,12 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res   (the pair lands packed in P0)
   if (int e = op_launch_body(op, X_INIT, x, x, nullptr, nullptr, sp, s)) return e;
   if (int e = op_launch_constraint(op, X_INIT, P0, P1, x, nullptr, q, sp, rk, cgrid, s, true)) return e;
-  k_finalize<X_INIT><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
+  {
+    unsigned np = cgrid;
+    double* pp = parts;
+    fold_partials(np, pp, st, 0, s);
+    k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, rk, config->tol, config->max_iters);
+  }
   MHIP_LAUNCH_CHECK();
   unsigned enqueued = 0, chunk = 8, last_todo = 0, iter_before = 0;
   const bool prof = op->profile;
@@ -1300,7 +1414,10 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 1], s));
       if (int e = op_launch_constraint(op, X_SOLVE, P0, P1, nullptr, nullptr, q, sp, rk, cgrid, s, true)) return e;
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
-      k_finalize<X_SOLVE><<<1, kBlock, 0, s>>>((int)cgrid, parts, st, rk, config->tol, config->max_iters);
+      unsigned np = cgrid;
+      double* pp = parts;
+      fold_partials(np, pp, st, 1, s);
+      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, rk, config->tol, config->max_iters);
       MHIP_LAUNCH_CHECK();
     }
     enqueued += todo;
@@ -1455,14 +1572,16 @@ int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, 
   MHIP_REQUIRE(local3 != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local3 is null");
   auto& st = op->stage;
   hipStream_t s = as_stream(stream);
-  const unsigned cgrid = grid_for(op->view.C);
+  const unsigned cgrid = constraint_grid(op->view.C);
   double* P0 = op->iterate.as<double>();
   double* P1 = P0 + 2 * op->view.C;
   if (int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, P0, P1, init ? st.x : nullptr, nullptr, st.q, st.sp,
                                    st.cfg.residual_kind, cgrid, s, true))
     return e;
-  k_reduce_local3<<<1, kBlock, 0, s>>>(op->view.C == 0 ? 0 : (int)cgrid, op->partials.as<double>(),
-                                       op->state.as<SolverState>(), init ? 0 : 1, local3);
+  unsigned np = op->view.C == 0 ? 0u : cgrid;
+  double* pp = op->partials.as<double>();
+  fold_partials(np, pp, op->state.as<SolverState>(), init ? 0 : 1, s);
+  k_reduce_local3<<<1, final_block(np), 0, s>>>((int)np, pp, op->state.as<SolverState>(), init ? 0 : 1, local3);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -1474,11 +1593,11 @@ int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gath
   const auto& cfg = op->stage.cfg;
   SolverState* st = op->state.as<SolverState>();
   if (init)
-    k_finalize<X_INIT><<<1, kBlock, 0, as_stream(stream)>>>(nparts, gathered, st, cfg.residual_kind, cfg.tol,
-                                                            cfg.max_iters);
+    k_finalize<X_INIT><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, 3, 1, st, cfg.residual_kind,
+                                                                         cfg.tol, cfg.max_iters);
   else
-    k_finalize<X_SOLVE><<<1, kBlock, 0, as_stream(stream)>>>(nparts, gathered, st, cfg.residual_kind, cfg.tol,
-                                                             cfg.max_iters);
+    k_finalize<X_SOLVE><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, 3, 1, st,
+                                                                          cfg.residual_kind, cfg.tol, cfg.max_iters);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

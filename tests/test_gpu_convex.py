@@ -43,6 +43,30 @@ def test_vector_kernels(ops, oracle):
         assert ops.bb_step(dev(x), dev(y), dev(x2), dev(y2)) == pytest.approx(oracle.bb_step(x, y, x2, y2), rel=1e-9)
 
 
+def test_vector_kernels_unaligned_views(ops, oracle):
+    # the streaming kernels take 16-byte accesses when they can; views that start on an odd element (8-byte aligned
+    # only) take the scalar path -- same element-wise results either way
+    from gpu_util import assert_bits_equal, dev, host
+    rng = np.random.default_rng(5)
+    for n in (2, 7, 1000, 4097):
+        x, y = rng.normal(size=n + 1), rng.normal(size=n + 1)
+        for ox, oy in ((1, 0), (0, 1), (1, 1)):
+            xs, ys = x[ox:ox + n], y[oy:oy + n]
+            yo = ys.copy()
+            oracle.axpby(0.75, xs, -1.25, yo)
+            dx, dy = dev(x), dev(y)
+            ops.axpby(0.75, dx[ox:ox + n], -1.25, dy[oy:oy + n])
+            assert_bits_equal(host(dy)[oy:oy + n], yo, "axpby on an offset view")
+            assert_bits_equal(host(dy)[:oy], y[:oy], "elements before the view untouched")
+            assert_bits_equal(host(dy)[oy + n:], y[oy + n:], "elements after the view untouched")
+            zo = np.empty(n)
+            oracle.wrapped_axpbyz(1.0, xs, -0.5, ys, zo, (1, 0.0, 0.0))
+            dz = dev(np.full(n + 1, 7.0))
+            ops.wrapped_axpbyz(1.0, dev(x)[ox:ox + n], -0.5, dev(y)[oy:oy + n], dz[1:1 + n], (1, 0.0, 0.0))
+            assert_bits_equal(host(dz)[1:], zo, "wrapped_axpbyz on offset views")
+            assert host(dz)[0] == 7.0
+
+
 A3 = np.array([[2.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 2.0]])
 
 
