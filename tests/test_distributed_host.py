@@ -76,11 +76,18 @@ print("COMM_OK", r)
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:   # a fixed port can still sit in TIME_WAIT from the previous run
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_comm_two_ranks_gloo(tmp_path):
     script = tmp_path / "comm_worker.py"
     script.write_text(WORKER % ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", str(script)]
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert p.stdout.count("COMM_OK") == 2

@@ -12,7 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, port, extra_env=None):
+def _run(world, port=None, extra_env=None):
+    import socket
+    with socket.socket() as sk:   # a fixed port can still sit in TIME_WAIT from an earlier run
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
