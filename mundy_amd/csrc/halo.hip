@@ -1,6 +1,6 @@
 // halo.hip -- stream compaction helpers of the domain-decomposed path: pair filtering by ownership,
-// ghost-candidate selection by box overlap, rank bounding boxes.  Flag -> exclusive scan -> stable scatter, the
-// structure of filter_view (mundy_mesh/GenNeighborLinkers.hpp:141-183).  Integer work, HBM bound.
+// ghost-candidate selection by box overlap, rank bounding boxes.  The compactions do the job of filter_view
+// (mundy_mesh/GenNeighborLinkers.hpp:141-183: PrefixSum + ScatterValid) with wavefront ballots.  Integer work, HBM bound.
 #include "geom_device.hpp"
 
 namespace mhip {
@@ -22,43 +22,122 @@ HaloScratch& halo_scratch() {
   return s;
 }
 
-__global__ void __launch_bounds__(kBlock) k_flag_pairs(size_t c, const int2* __restrict__ pairs, int first, int last,
-                                                      int32_t* __restrict__ flags) {
-  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < c; k += (size_t)gridDim.x * blockDim.x) {
+// ---- order-preserving stream compaction with wavefront ballots -------------------------------------------------------
+// A workgroup owns a tile of kCompactTile consecutive elements, visited in kCompactRounds rounds of 256 (element =
+// tile base + round * 256 + thread), so every wavefront always looks at 64 CONSECUTIVE elements: the ballot of the
+// predicate is that segment's keep-mask, its popcount the segment's size, and a kept element's slot inside the segment
+// is the popcount of the mask below its lane.  Pass 1 stores one count per tile; a scan of the (n / 1024) tile counts
+// gives tile bases; pass 2 re-evaluates the (cheap) predicate and writes the kept elements in order.  No flag or
+// position arrays of length n (the filter_view structure, GenNeighborLinkers.hpp:141-183, needs both).
+constexpr int kCompactRounds = 4;
+constexpr int kCompactTile = kBlock * kCompactRounds;
+constexpr int kCompactSegs = kCompactRounds * (kBlock / 64);  // 64-element segments per tile
+
+struct KeepOwnedPair {  // a pair survives when at least one body is owned (ghost-ghost pairs are dropped)
+  const int2* pairs;
+  int first, last;
+  int2* out;
+  unsigned char* counted;
+  __device__ bool keep(size_t k) const {
     const int2 ij = pairs[k];
-    const bool oi = ij.x >= first && ij.x < last, oj = ij.y >= first && ij.y < last;
-    flags[k] = (oi || oj) ? 1 : 0;
+    return (ij.x >= first && ij.x < last) || (ij.y >= first && ij.y < last);
   }
-}
-__global__ void __launch_bounds__(kBlock)
-    k_scatter_pairs(size_t c, const int2* __restrict__ pairs, const int32_t* __restrict__ flags,
-                    const int32_t* __restrict__ pos, int first, int last, int2* __restrict__ out,
-                    unsigned char* __restrict__ counted) {
-  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < c; k += (size_t)gridDim.x * blockDim.x) {
-    if (!flags[k]) continue;
+  __device__ void emit(size_t k, size_t slot) const {
     const int2 ij = pairs[k];
-    out[pos[k]] = ij;
+    out[slot] = ij;
     if (counted) {
       const int lo = ij.x < ij.y ? ij.x : ij.y;
-      counted[pos[k]] = (lo >= first && lo < last) ? 1 : 0;
+      counted[slot] = (lo >= first && lo < last) ? 1 : 0;
     }
   }
-}
-__global__ void __launch_bounds__(kBlock) k_flag_overlap(size_t n, const double* __restrict__ aabb, double buffer,
-                                                        Box box, int32_t* __restrict__ flags) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+};
+struct KeepBoxOverlap {  // closed interval test of geom::intersects (AABB.hpp:420-431) on the grown box
+  const double* aabb;
+  double buffer;
+  Box box;
+  int32_t* out;
+  __device__ bool keep(size_t i) const {
     const double* b = aabb + 6 * i;
-    // closed interval test of geom::intersects (AABB.hpp:420-431) on the grown box
     const bool disjoint = (b[3] + buffer) < box.lo.x || (b[4] + buffer) < box.lo.y || (b[5] + buffer) < box.lo.z ||
                           box.hi.x < (b[0] - buffer) || box.hi.y < (b[1] - buffer) || box.hi.z < (b[2] - buffer);
-    flags[i] = disjoint ? 0 : 1;
+    return !disjoint;
+  }
+  __device__ void emit(size_t i, size_t slot) const { out[slot] = static_cast<int32_t>(i); }
+};
+
+template <class Op>
+__global__ void __launch_bounds__(kBlock) k_compact_count(size_t n, Op op, int32_t* __restrict__ tile_count) {
+  __shared__ int seg[kCompactSegs];
+  const size_t base = (size_t)blockIdx.x * kCompactTile;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < kCompactRounds; ++r) {
+    const size_t k = base + (size_t)r * kBlock + threadIdx.x;
+    const bool keep = (k < n) && op.keep(k);
+    const unsigned long long mask = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) seg[r * (kBlock / 64) + wave] = __popcll(mask);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int i = 0; i < kCompactSegs; ++i) total += seg[i];
+    tile_count[blockIdx.x] = total;
   }
 }
-__global__ void __launch_bounds__(kBlock) k_scatter_index(size_t n, const int32_t* __restrict__ flags,
-                                                         const int32_t* __restrict__ pos, int32_t* __restrict__ out) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    if (flags[i]) out[pos[i]] = static_cast<int32_t>(i);
+template <class Op>
+__global__ void __launch_bounds__(kBlock) k_compact_emit(size_t n, Op op, const int32_t* __restrict__ tile_base) {
+  __shared__ int seg[kCompactSegs + 1];
+  const size_t base = (size_t)blockIdx.x * kCompactTile;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  bool keep[kCompactRounds];
+  unsigned long long mask[kCompactRounds];
+#pragma unroll
+  for (int r = 0; r < kCompactRounds; ++r) {
+    const size_t k = base + (size_t)r * kBlock + threadIdx.x;
+    keep[r] = (k < n) && op.keep(k);
+    mask[r] = __ballot(keep[r]);
+    if (lane == 0) seg[r * (kBlock / 64) + wave] = __popcll(mask[r]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive prefix over the tile's 16 segments
+    int run = 0;
+    for (int i = 0; i < kCompactSegs; ++i) {
+      const int c = seg[i];
+      seg[i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  const size_t out0 = static_cast<size_t>(tile_base[blockIdx.x]);
+#pragma unroll
+  for (int r = 0; r < kCompactRounds; ++r) {
+    if (!keep[r]) continue;
+    const int below = __popcll(mask[r] & ((1ull << lane) - 1ull));
+    op.emit(base + (size_t)r * kBlock + threadIdx.x, out0 + seg[r * (kBlock / 64) + wave] + below);
+  }
 }
+
+// count, scan of the tile counts, emit; the total lands in host memory after one synchronisation
+template <class Op>
+int compact(size_t n, const Op& op, size_t* count_out, hipStream_t s) {
+  HaloScratch& hs = halo_scratch();
+  const size_t ntiles = (n + kCompactTile - 1) / kCompactTile;
+  if (int e = hs.ensure(ntiles)) return e;
+  int32_t* counts = hs.flags.as<int32_t>();
+  int32_t* bases = hs.pos.as<int32_t>();
+  k_compact_count<<<static_cast<unsigned>(ntiles), kBlock, 0, s>>>(n, op, counts);
+  MHIP_LAUNCH_CHECK();
+  if (int e = exclusive_scan_i32(counts, bases, ntiles, hs.scanws.ptr, s)) return e;
+  k_compact_emit<<<static_cast<unsigned>(ntiles), kBlock, 0, s>>>(n, op, bases);
+  MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipMemcpyAsync(hs.host, bases + ntiles, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  int32_t total = 0;
+  memcpy(&total, hs.host, sizeof(int32_t));
+  *count_out = static_cast<size_t>(total);
+  return MHIP_SUCCESS;
+}
+
 __global__ void __launch_bounds__(kBlock) k_box_bounds(size_t n, const double* __restrict__ aabb, double buffer,
                                                       double* __restrict__ partials) {
   __shared__ double scratch[kBlock / 64];
@@ -109,23 +188,9 @@ int mhip_filter_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, siz
   MHIP_REQUIRE(pairs_in && pairs_out, MHIP_ERR_INVALID_ARGUMENT, "pairs_in / pairs_out is null");
   MHIP_REQUIRE(pairs_in != pairs_out, MHIP_ERR_INVALID_ARGUMENT, "in-place filtering is not supported");
   MHIP_REQUIRE(c < (1u << 31) && first + count < (1u << 31), MHIP_ERR_RUNTIME, "too many pairs / bodies");
-  hipStream_t s = as_stream(stream);
-  HaloScratch& hs = halo_scratch();
-  if (int e = hs.ensure(c)) return e;
-  const int f = static_cast<int>(first), l = static_cast<int>(first + count);
-  const int2* in = reinterpret_cast<const int2*>(pairs_in);
-  k_flag_pairs<<<grid_for(c), kBlock, 0, s>>>(c, in, f, l, hs.flags.as<int32_t>());
-  MHIP_LAUNCH_CHECK();
-  if (int e = exclusive_scan_i32(hs.flags.as<int32_t>(), hs.pos.as<int32_t>(), c, hs.scanws.ptr, s)) return e;
-  k_scatter_pairs<<<grid_for(c), kBlock, 0, s>>>(c, in, hs.flags.as<int32_t>(), hs.pos.as<int32_t>(), f, l,
-                                                reinterpret_cast<int2*>(pairs_out), counted_out);
-  MHIP_LAUNCH_CHECK();
-  int32_t total = 0;
-  MHIP_HIP(hipMemcpyAsync(hs.host, hs.pos.as<int32_t>() + c, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MHIP_HIP(hipStreamSynchronize(s));
-  memcpy(&total, hs.host, sizeof(int32_t));
-  *count_out = static_cast<size_t>(total);
-  return MHIP_SUCCESS;
+  const KeepOwnedPair op{reinterpret_cast<const int2*>(pairs_in), static_cast<int>(first),
+                         static_cast<int>(first + count), reinterpret_cast<int2*>(pairs_out), counted_out};
+  return compact(c, op, count_out, as_stream(stream));
 }
 
 int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const double* box6, int32_t* idx_out,
@@ -135,21 +200,8 @@ int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const 
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(aabb && idx_out, MHIP_ERR_INVALID_ARGUMENT, "aabb / idx_out is null");
   MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
-  hipStream_t s = as_stream(stream);
-  HaloScratch& hs = halo_scratch();
-  if (int e = hs.ensure(n)) return e;
-  const Box box{{box6[0], box6[1], box6[2]}, {box6[3], box6[4], box6[5]}};
-  k_flag_overlap<<<grid_for(n), kBlock, 0, s>>>(n, aabb, buffer, box, hs.flags.as<int32_t>());
-  MHIP_LAUNCH_CHECK();
-  if (int e = exclusive_scan_i32(hs.flags.as<int32_t>(), hs.pos.as<int32_t>(), n, hs.scanws.ptr, s)) return e;
-  k_scatter_index<<<grid_for(n), kBlock, 0, s>>>(n, hs.flags.as<int32_t>(), hs.pos.as<int32_t>(), idx_out);
-  MHIP_LAUNCH_CHECK();
-  int32_t total = 0;
-  MHIP_HIP(hipMemcpyAsync(hs.host, hs.pos.as<int32_t>() + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MHIP_HIP(hipStreamSynchronize(s));
-  memcpy(&total, hs.host, sizeof(int32_t));
-  *count_out = static_cast<size_t>(total);
-  return MHIP_SUCCESS;
+  const KeepBoxOverlap op{aabb, buffer, Box{{box6[0], box6[1], box6[2]}, {box6[3], box6[4], box6[5]}}, idx_out};
+  return compact(n, op, count_out, as_stream(stream));
 }
 
 int mhip_aabb_bounds(size_t n, const double* aabb, double buffer, double* out6, mhip_stream_t stream) {

@@ -71,3 +71,40 @@ def test_nccl_transport_single_rank():
         assert torch.equal(st.lam, ref.lam)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1023, 1024, 1025, 5000, 300_001])
+def test_ballot_compactions_match_numpy(n):
+    # mhip_filter_pairs_owned / mhip_select_aabb_overlap: order-preserving compaction by wavefront ballots, against the
+    # same selections written in numpy (the filter_view step of GenNeighborLinkers.hpp:141-183)
+    import ctypes as C
+    import numpy as np
+    import torch
+    from gpu_util import dev, host
+    from mundy_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(n)
+    nb = max(4, n // 3)
+    pairs = np.sort(rng.integers(0, nb, (n, 2)).astype(np.int32), axis=1)
+    for first, count in ((0, nb), (nb // 4, nb // 2), (nb, 0), (nb // 2, 1)):
+        out = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+        counted = torch.empty(n, dtype=torch.uint8, device="cuda")
+        cnt = C.c_size_t(0)
+        capi.check(lib.mhip_filter_pairs_owned(n, C.c_void_p(dev(pairs).data_ptr()), first, count,
+                                               C.c_void_p(out.data_ptr()), C.c_void_p(counted.data_ptr()),
+                                               C.byref(cnt), None))
+        own = (pairs >= first) & (pairs < first + count)
+        keep = own.any(axis=1)
+        assert cnt.value == int(keep.sum())
+        np.testing.assert_array_equal(host(out)[: cnt.value], pairs[keep])
+        np.testing.assert_array_equal(host(counted)[: cnt.value].astype(bool), own[keep][:, 0])  # lower body = column 0
+    lo = rng.uniform(0, 10, (n, 3))
+    aabb = np.concatenate([lo, lo + rng.uniform(0.1, 1.0, (n, 3))], axis=1)
+    for box, buf in ((np.array([2.0, 2, 2, 6, 6, 6]), 0.25), (np.array([-5.0, -5, -5, -4, -4, -4]), 0.0),
+                     (np.array([-1.0, -1, -1, 12, 12, 12]), 0.0)):
+        idx = torch.empty(n, dtype=torch.int32, device="cuda")
+        cnt = C.c_size_t(0)
+        capi.check(lib.mhip_select_aabb_overlap(n, C.c_void_p(dev(aabb).data_ptr()), buf, (C.c_double * 6)(*box),
+                                                C.c_void_p(idx.data_ptr()), C.byref(cnt), None))
+        disjoint = ((aabb[:, 3:] + buf) < box[:3]).any(axis=1) | (box[3:] < (aabb[:, :3] - buf)).any(axis=1)
+        np.testing.assert_array_equal(host(idx)[: cnt.value], np.nonzero(~disjoint)[0])
