@@ -61,6 +61,11 @@ int mhip_compute_aabb_spherocylinders(size_t n, const double* center, const doub
                                       const double* length, double* aabb, mhip_stream_t stream);
 int mhip_compute_aabb_ellipsoids(size_t n, const double* center, const double* quat, const double* radii,
                                  double* aabb, mhip_stream_t stream);
+/* Build extension, the flagged option of SURVEY row a7: the reference's ellipsoid box (min/max of centre -/+ q*radii)
+ * is exact only for axis-aligned rotations and is NOT conservative in general; this one is the tight box of the
+ * rotated ellipsoid (half extent_k = sqrt(sum_j (r_j (q*e_j)_k)^2)).  No reference implementation: parity unpinned. */
+int mhip_compute_aabb_ellipsoids_conservative(size_t n, const double* center, const double* quat, const double* radii,
+                                              double* aabb, mhip_stream_t stream);
 /* segment records seg[n][8] = (p0 xyz, p1 xyz, radius, 0) */
 int mhip_compute_aabb_segments(size_t n, const double* seg, double* aabb, mhip_stream_t stream);
 int mhip_bounding_radius_spherocylinders(size_t n, const double* radius, const double* length, double* out,

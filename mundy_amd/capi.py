@@ -49,6 +49,7 @@ SIGNATURES = {
     "mhip_compute_aabb_spheres": [_sz, _vp, _vp, _vp, _vp],
     "mhip_compute_aabb_spherocylinders": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_compute_aabb_ellipsoids": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "mhip_compute_aabb_ellipsoids_conservative": [_sz, _vp, _vp, _vp, _vp, _vp],
     "mhip_compute_aabb_segments": [_sz, _vp, _vp, _vp],
     "mhip_bounding_radius_spherocylinders": [_sz, _vp, _vp, _vp, _vp],
     "mhip_bounding_radius_ellipsoids": [_sz, _vp, _vp, _vp],

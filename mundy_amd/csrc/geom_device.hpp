@@ -34,6 +34,26 @@ __device__ inline Box aabb_ellipsoid(V3 c, Quat q, V3 radii) {
   return {{dmin(a.x, b.x), dmin(a.y, b.y), dmin(a.z, b.z)}, {dmax(a.x, b.x), dmax(a.y, b.y), dmax(a.z, b.z)}};
 }
 
+// BUILD EXTENSION (the flagged option of SURVEY row a7): tight conservative box, half extent along lab axis k =
+// sqrt(sum_j (r_j (q * e_j)[k])^2).
+__device__ inline Box aabb_ellipsoid_conservative(V3 c, Quat q, V3 radii) {
+  const V3 a0 = qrot(q, V3{1.0, 0.0, 0.0}), a1 = qrot(q, V3{0.0, 1.0, 0.0}), a2 = qrot(q, V3{0.0, 0.0, 1.0});
+  V3 e;
+  {
+    const double t0 = radii.x * a0.x, t1 = radii.y * a1.x, t2 = radii.z * a2.x;
+    e.x = sqrt(t0 * t0 + (t1 * t1 + t2 * t2));
+  }
+  {
+    const double t0 = radii.x * a0.y, t1 = radii.y * a1.y, t2 = radii.z * a2.y;
+    e.y = sqrt(t0 * t0 + (t1 * t1 + t2 * t2));
+  }
+  {
+    const double t0 = radii.x * a0.z, t1 = radii.y * a1.z, t2 = radii.z * a2.z;
+    e.z = sqrt(t0 * t0 + (t1 * t1 + t2 * t2));
+  }
+  return {c - e, c + e};
+}
+
 // distance(Point, Point, sep)  (mundy_geom/distance/PointPoint.hpp:54-62)
 __device__ inline double dist_point_point(V3 p1, V3 p2, V3& sep) {
   sep = p2 - p1;

@@ -37,6 +37,13 @@ __global__ void __launch_bounds__(kBlock)
     store_box(aabb, i, aabb_ellipsoid(load3(center, i), load4q(quat, i), load3(radii, i)));
 }
 
+__global__ void __launch_bounds__(kBlock)
+    k_aabb_ellipsoids_conservative(size_t n, const double* __restrict__ center, const double* __restrict__ quat,
+                                   const double* __restrict__ radii, double* __restrict__ aabb) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store_box(aabb, i, aabb_ellipsoid_conservative(load3(center, i), load4q(quat, i), load3(radii, i)));
+}
+
 struct SegRec {
   V3 p0, p1;
   double r;
@@ -204,6 +211,15 @@ int mhip_compute_aabb_ellipsoids(size_t n, const double* center, const double* q
   REQ_PTR(center); REQ_PTR(quat); REQ_PTR(radii); REQ_PTR(aabb);
   if (n == 0) return MHIP_SUCCESS;
   k_aabb_ellipsoids<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, center, quat, radii, aabb);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_compute_aabb_ellipsoids_conservative(size_t n, const double* center, const double* quat, const double* radii,
+                                              double* aabb, mhip_stream_t stream) {
+  REQ_PTR(center); REQ_PTR(quat); REQ_PTR(radii); REQ_PTR(aabb);
+  if (n == 0) return MHIP_SUCCESS;
+  k_aabb_ellipsoids_conservative<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, center, quat, radii, aabb);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

@@ -69,6 +69,15 @@ def compute_aabb_ellipsoids(center, quat, radii):
     return out
 
 
+def compute_aabb_ellipsoids_conservative(center, quat, radii):
+    """build extension: tight box of the rotated ellipsoid (the reference's box is not conservative)"""
+    n = center.shape[0]
+    out = _new(center, n, 6)
+    capi.check(capi.load().mhip_compute_aabb_ellipsoids_conservative(n, _ptr(center, cols=3), _ptr(quat, cols=4),
+                                                                     _ptr(radii, cols=3), _ptr(out), _stream()))
+    return out
+
+
 def compute_aabb_segments(seg):
     n = seg.shape[0]
     out = _new(seg, n, 6)

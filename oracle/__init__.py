@@ -75,6 +75,14 @@ def compute_aabb_ellipsoids(center, quat, radii):
     return out
 
 
+def compute_aabb_ellipsoids_conservative(center, quat, radii):
+    """build extension (SURVEY a7's flagged option): tight box of the rotated ellipsoid"""
+    center, quat, radii = _f(center), _f(quat), _f(radii)
+    out = np.empty((len(center), 6))
+    lib().o_compute_aabb_ellipsoids_conservative(C.c_size_t(len(center)), _p(center), _p(quat), _p(radii), _p(out))
+    return out
+
+
 def compute_aabb_segments(p0, p1, radius):
     p0, p1, radius = _f(p0), _f(p1), _f(radius)
     out = np.empty((len(radius), 6))

@@ -137,6 +137,20 @@ inline AABB compute_aabb_ellipsoid(const V3& c, const Quat& q, const V3& radii) 
   }
   return b;
 }
+// BUILD EXTENSION (flagged option of SURVEY row a7, no reference implementation): the tight, conservative box of a
+// rotated ellipsoid.  With the body axes a_j = q * e_j the support of the ellipsoid along lab axis k is
+// sqrt(sum_j (r_j a_j[k])^2); the reference's box above is exact only for axis-aligned rotations and can miss contacts.
+inline AABB compute_aabb_ellipsoid_conservative(const V3& c, const Quat& q, const V3& radii) {
+  const V3 a0 = qrot(q, V3{1.0, 0.0, 0.0}), a1 = qrot(q, V3{0.0, 1.0, 0.0}), a2 = qrot(q, V3{0.0, 0.0, 1.0});
+  AABB b;
+  for (int k = 0; k < 3; ++k) {
+    const double t0 = radii.x * a0[k], t1 = radii.y * a1[k], t2 = radii.z * a2[k];
+    const double e = std::sqrt(t0 * t0 + (t1 * t1 + t2 * t2));
+    b.lo[k] = c[k] - e;
+    b.hi[k] = c[k] + e;
+  }
+  return b;
+}
 // mundy/geom/src/mundy_geom/compute_aabb.hpp:129-143 (SpherocylinderSegment).
 inline AABB compute_aabb_segment(const V3& p0, const V3& p1, double r) {
   AABB b;

@@ -49,6 +49,12 @@ void o_compute_aabb_ellipsoids(size_t n, const double* center, const double* qua
 #pragma omp parallel for
   for (size_t i = 0; i < n; ++i) st_aabb(out, i, compute_aabb_ellipsoid(ld3(center, i), ldq(quat, i), ld3(radii, i)));
 }
+void o_compute_aabb_ellipsoids_conservative(size_t n, const double* center, const double* quat, const double* radii,
+                                            double* out) {
+#pragma omp parallel for
+  for (size_t i = 0; i < n; ++i)
+    st_aabb(out, i, compute_aabb_ellipsoid_conservative(ld3(center, i), ldq(quat, i), ld3(radii, i)));
+}
 void o_compute_aabb_segments(size_t n, const double* p0, const double* p1, const double* radius, double* out) {
 #pragma omp parallel for
   for (size_t i = 0; i < n; ++i) st_aabb(out, i, compute_aabb_segment(ld3(p0, i), ld3(p1, i), radius[i]));

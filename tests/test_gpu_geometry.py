@@ -47,6 +47,8 @@ def test_per_body_kernels_bit_exact(ops, oracle, n):
     assert_bits_equal(host(ops.compute_aabb_spheres(dc, dr)), oracle.compute_aabb_spheres(c, r), "aabb spheres")
     assert_bits_equal(host(ops.compute_aabb_spherocylinders(dc, dq, dr, dL)),
                       oracle.compute_aabb_spherocylinders(c, q, r, L), "aabb rods")
+    assert_bits_equal(host(ops.compute_aabb_ellipsoids_conservative(dc, dq, drad)),
+                      oracle.compute_aabb_ellipsoids_conservative(c, q, radii), "conservative ellipsoid aabb (extension)")
     assert_bits_equal(host(ops.compute_aabb_ellipsoids(dc, dq, drad)), oracle.compute_aabb_ellipsoids(c, q, radii),
                       "aabb ellipsoids")
     seg = ops.spherocylinder_segments(dc, dq, dr, dL)

@@ -280,3 +280,40 @@ def test_triclinic_periodic_metric(oracle):
     sh = oracle.shift_image_triclinic(h, q2, img)
     np.testing.assert_allclose(sh, q2 + (h @ img.T).T, atol=1e-12)
     np.testing.assert_allclose(oracle.periodic_sep_triclinic(h, q1, sh), st, atol=1e-9)
+
+
+def test_conservative_ellipsoid_box(oracle):
+    # build extension (SURVEY a7's flagged option, no reference implementation): the tight box contains every surface
+    # point of the rotated ellipsoid and is touched on all six faces; the reference's box (kept bit for bit elsewhere)
+    # agrees with it on the axis-aligned reference KATs and is NOT conservative for a generic rotation
+    rng = np.random.default_rng(3)
+    n = 200
+    c = rng.uniform(-5, 5, (n, 3))
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    radii = rng.uniform(0.2, 2.0, (n, 3))
+    box = oracle.compute_aabb_ellipsoids_conservative(c, q, radii)
+    ref_box = oracle.compute_aabb_ellipsoids(c, q, radii)
+    # rotation matrices from the quaternions (w, x, y, z)
+    w, x, y, z = q.T
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+    u = rng.normal(size=(4000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    missed = 0
+    for i in range(n):
+        pts = c[i] + (R[i] @ (u * radii[i]).T).T
+        assert np.all(pts >= box[i, :3] - 1e-12) and np.all(pts <= box[i, 3:] + 1e-12)
+        ext = np.sqrt(((R[i] * radii[i]) ** 2).sum(axis=1))           # support of the ellipsoid along x, y, z
+        np.testing.assert_allclose(box[i, 3:] - c[i], ext, rtol=1e-13)
+        np.testing.assert_allclose(c[i] - box[i, :3], ext, rtol=1e-13)
+        missed += np.any(pts < ref_box[i, :3] - 1e-9) or np.any(pts > ref_box[i, 3:] + 1e-9)
+    assert missed > n // 2
+    # axis-aligned KATs of UnitTestComputeAABB.cpp:179-202: both boxes coincide
+    X90 = [1.0 / np.sqrt(2.0), 1.0 / np.sqrt(2.0), 0.0, 0.0]
+    ce = np.array([[1.0, -2, 3], [0, 0, 0]])
+    qe = np.array([[1.0, 0, 0, 0], X90])
+    re_ = np.array([[4.0, 5, 6], [4, 5, 6]])
+    np.testing.assert_allclose(oracle.compute_aabb_ellipsoids_conservative(ce, qe, re_),
+                               oracle.compute_aabb_ellipsoids(ce, qe, re_), atol=1e-12)
