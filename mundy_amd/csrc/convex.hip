@@ -3,15 +3,17 @@
 //
 // Everything here is HBM-bandwidth bound (SpMV-like gathers and streaming vector passes): no MFMA.
 //
-// Fused iteration (mhip_bbpgd_solve_contact), 3 launches, no host round trip:
+// Fused iteration (mhip_bbpgd_solve_contact), 3-4 launches, no host round trip:
 //   k_body        per body:       x_c = Proj(xt_c - step*gt_c) for the incident constraints (fixed order),
 //                                 F = sum -/+ x_c n_c, T = sum -/+ r x (x_c n_c), (U, W) = (mt F, mr T)   [K24+K21+K22]
 //   k_constraint  per constraint: x_c again (bitwise the same), g_c = dt * sdot(U, W) + q_c, store x, g;
 //                                 block partials of max residual, sum dx^2, sum dx dg                       [K23+K14+K17+K16]
+//   k_fold_partials (only above 4096 block partials) 64 workgroups fold contiguous slices of the partials
 //   k_finalize    one workgroup:  ordered reduction of the partials, residual test, BB1 step, iteration count,
 //                                 all kept in a device-resident state block                                  [a26/a27]
-// x/x_tmp and g/g_tmp ping-pong by iteration parity instead of being copied (K20); mhip_bbpgd_solve_* restores the
-// reference's post-conditions (which array holds what) once, at the end.
+// The iterate lives packed as (x, g) pairs in an operator-owned ping-pong pair (K20's deep_copies become a parity
+// flip); mhip_bbpgd_solve_* writes the caller's x, g, x_tmp, g_tmp once at the end with the reference's
+// post-conditions (which array holds what).
 #include <cstdlib>
 #include <vector>
 
@@ -397,10 +399,12 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 }
 
 // Body sweep.  G lanes cooperate on one body: lane `sub` walks the body's half-edge records sub, sub+G, ... (a
-// contiguous, coalesced stream: records are stored in incidence order), then a G-lane butterfly adds the partial sums.
-// The order is fixed (no atomics), so results are bitwise reproducible run to run.
-//   half-edge record e -> (n_c, r_side) gathered once at operator creation: 48 B (24 B translation-only)
-// algorithmic bytes: per half edge 4 (entry) + 48 (record) + 16 (x_tmp, g_tmp gathered); per body 4 + 16 + 48.
+// contiguous, coalesced stream: records are stored in incidence order), U of them at a time, then a G-lane butterfly
+// adds the partial sums.  The order is fixed (no atomics), so results are bitwise reproducible run to run.
+//   half-edge record e, written once at operator creation: (n_c, r_side) 48 B | (n_c, s - 1/2) 32 B for rods |
+//   n_c 24 B translation-only
+// compulsory bytes (rods): per half edge 4 (entry) + 32 (record), 16 per contact for its iterate (gathered by both
+// of its half edges); per body 4 (row pointer) + 16 (mobilities) + 24 (axis) + 48 (velocity row) + 24 (omega).
 template <int MODE, int KIN, int G, int U, bool PACKED>
 __global__ void __launch_bounds__(kBlock)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
