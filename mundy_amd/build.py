@@ -36,7 +36,8 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("MHIP_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds of tuning macros only
+        cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -7,12 +7,19 @@
 namespace mhip {
 
 constexpr int kEllBlock = 64;
+// Register budget: unconstrained, the compiler takes 314-370 VGPRs + AGPRs (one wave per SIMD) and still spills the
+// L-BFGS history (dynamically indexed) to scratch; two waves per SIMD (256 registers) measured +22 % pairs/s, three
+// and four waves spill too much (MI355X, 4*10^5 pairs: 4.6 / 5.6 / 5.3 / 4.5 *10^6 pairs/s for 1 / 2 / 3 / 4 waves).
+#ifndef ELL_WAVES
+#define ELL_WAVES 2
+#endif
+#define ELL_OCC __attribute__((amdgpu_waves_per_eu(ELL_WAVES)))
 
 __device__ inline EllipsoidD load_ellipsoid(const double* c, const double* q, const double* r, size_t i) {
   return {load3(c, i), load4q(q, i), load3(r, i)};
 }
 
-__global__ void __launch_bounds__(kEllBlock)
+__global__ void __launch_bounds__(kEllBlock) ELL_OCC
     k_dist_ellipsoids(size_t n, const double* __restrict__ c1, const double* __restrict__ q1,
                       const double* __restrict__ r1, const double* __restrict__ c2, const double* __restrict__ q2,
                       const double* __restrict__ r2, double* __restrict__ dist, double* __restrict__ cp1,
@@ -27,7 +34,7 @@ __global__ void __launch_bounds__(kEllBlock)
   if (n2) store3(n2, i, V3{-r.n1.x, -r.n1.y, -r.n1.z});
 }
 
-__global__ void __launch_bounds__(kEllBlock)
+__global__ void __launch_bounds__(kEllBlock) ELL_OCC
     k_dist_point_ellipsoid(size_t n, const double* __restrict__ p, const double* __restrict__ c,
                            const double* __restrict__ q, const double* __restrict__ r, double* __restrict__ dist,
                            double* __restrict__ cp, double* __restrict__ nrm) {
@@ -42,7 +49,7 @@ __global__ void __launch_bounds__(kEllBlock)
 
 // contact generation over a neighbour list: sep = shared-normal signed distance, normal = n1 (outward normal of the
 // source ellipsoid), contact points = the two foot points, lever arms about the body centres.
-__global__ void __launch_bounds__(kEllBlock)
+__global__ void __launch_bounds__(kEllBlock) ELL_OCC
     k_contact_ellipsoids(size_t nc, const int2* __restrict__ pairs, const double* __restrict__ center,
                          const double* __restrict__ quat, const double* __restrict__ radii, double* __restrict__ sep,
                          double* __restrict__ normal, double* __restrict__ cp1, double* __restrict__ cp2,

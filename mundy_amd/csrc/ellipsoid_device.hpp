@@ -245,7 +245,9 @@ struct EllipsoidPair {
 
 __device__ inline EllipsoidPair dist_ellipsoid_ellipsoid(const EllipsoidD& e1, const EllipsoidD& e2) {
   auto eval = [&](lbfgs::V2 tp, V3& n1, V3& f1, V3& f2) {
-    const double st = sin(tp.a), ct = cos(tp.a), sp = sin(tp.b), cp = cos(tp.b);
+    double st, ct, sp, cp;  // one argument reduction per angle
+    sincos(tp.a, &st, &ct);
+    sincos(tp.b, &sp, &cp);
     n1 = V3{st * cp, st * sp, ct};
     f1 = normal_to_foot_point(n1, e1);
     f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, e2);
@@ -279,7 +281,9 @@ __device__ inline EllipsoidPair dist_ellipsoid_ellipsoid(const EllipsoidD& e1, c
 // distance(SharedNormalSigned, Point, Ellipsoid, closest, normal) (PointEllipsoid.hpp:94-135)
 __device__ inline double dist_point_ellipsoid(V3 point, const EllipsoidD& el, V3& closest, V3& normal) {
   auto eval = [&](lbfgs::V2 tp, V3& n, V3& f) {
-    const double st = sin(tp.a), ct = cos(tp.a), sp = sin(tp.b), cp = cos(tp.b);
+    double st, ct, sp, cp;  // one argument reduction per angle
+    sincos(tp.a, &st, &ct);
+    sincos(tp.b, &sp, &cp);
     n = V3{st * cp, st * sp, ct};
     f = normal_to_foot_point(n, el);
     V3 sep;

@@ -99,8 +99,9 @@ __device__ inline V3 rod_support(const BodyD& b, V3 n) {
   return (b.c + (sg * h) * a) + b.s.x * n;
 }
 
+// at least two waves per SIMD: the ellipsoid classes would otherwise take every register (see ellipsoid.hip)
 template <int CLS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
     k_contact_class(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
                     const int2* __restrict__ pairs, const int32_t* __restrict__ kind, const double* __restrict__ center,
                     const double* __restrict__ quat, const double* __restrict__ shape, MixedOut out) {
@@ -138,7 +139,9 @@ __global__ void __launch_bounds__(BLOCK)
     } else if (CLS == 4) {  // rod - ellipsoid (extension: shared-normal minimisation with the rod's support map)
       const EllipsoidD el{B.c, B.q, B.s};
       auto eval = [&](lbfgs::V2 tp, V3& n1, V3& f1, V3& f2) {
-        const double st = sin(tp.a), ct = cos(tp.a), sp = sin(tp.b), cp = cos(tp.b);
+        double st, ct, sp, cp;
+        sincos(tp.a, &st, &ct);
+        sincos(tp.b, &sp, &cp);
         n1 = V3{st * cp, st * sp, ct};
         f1 = rod_support(A, n1);
         f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, el);
