@@ -81,6 +81,9 @@ def parse():
     p.add_argument("--no-reorder", dest="reorder", action="store_false", help="skip the per-step Z-order reordering")
     p.add_argument("--reorder-cell", type=float, default=3.0, help="lattice edge of the Morton keys")
     p.add_argument("--cpu-iters", type=int, default=12, help="BBPGD iterations timed on the host cores")
+    p.add_argument("--friction", type=float, default=None,
+                   help="BUILD EXTENSION, parity unpinned: Coulomb coefficient of the cone-complementarity solver "
+                        "(the reference has no frictional solver; default = its frictionless LCP).  N = 1 only.")
     return p.parse_args()
 
 
@@ -120,7 +123,8 @@ def main():
     radius, length = dev(b["radius"]), dev(b["length"])
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
     stepper = pipeline.ContactStepper("spherocylinder", center, radius, quat, length, dt=5e-3, viscosity=1e-3,
-                                      search_buffer=args.buffer, search_kind=ops.SEARCH_AABB, cfg=cfg)
+                                      search_buffer=args.buffer, search_kind=ops.SEARCH_AABB, cfg=cfg,
+                                      friction=args.friction)
     pristine = stepper.snapshot()
     prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 
@@ -131,7 +135,7 @@ def main():
             stepper.reorder_bodies(cell_size=args.reorder_cell, lo=[0.0, 0.0, 0.0])
         stepper.profile_next = timed_kernels
         st = stepper.step(integrate=True, force_rebuild=True, timed=timed_stages)
-        if timed_kernels:
+        if timed_kernels and args.friction is None:
             a, c, k = stepper.op.get_profile()
             prof["body_ms"] += a
             prof["con_ms"] += c
@@ -177,7 +181,7 @@ def main():
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this box's host cores, rank 0 ---------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and args.friction is None:
         cpu = cpu_baseline(b, stepper, args, int(np.mean(iters)))
 
     if rank == 0:
@@ -196,6 +200,11 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
+        if args.friction is not None:  # never the default line: an extension without a reference to pin it on
+            out["metric"] = "timesteps/sec, 10^6 spherocylinders per GPU, FRICTIONAL cone-complementarity contact (build extension)"
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "frictionless LCP", "EXTENSION (parity unpinned): Coulomb friction mu = %g as a cone complementarity "
+                "problem," % args.friction)
         out.update(extra)
         print(json.dumps(out))
     if dist is not None:

@@ -261,6 +261,18 @@ int mhip_bbpgd_solve_dense(size_t n, const double* A, const double* q, const mhi
 int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
                              const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
                              double* g_tmp, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+
+/* BUILD EXTENSION, parity unpinned -- Coulomb friction (BASELINE configs[2] names a "frictional LCP"; the reference has
+ * no frictional solver: SURVEY F2).  The same fused BBPGD iteration on the cone complementarity problem
+ *   p_c in R^3 (world-frame contact impulse),  K_c = { |p - (p.n) n| <= mu (p.n) },
+ *   g_c = dt [(U_j + W_j x rb) - (U_i + W_i x ra)] + sep_c n_c,   p in K, g in K*, p . g = 0
+ * (the convex relaxation of Anitescu / Tasora used by APGD-type solvers; mu = 0 reduces to the frictionless LCP).
+ * op must be the vector-arm operator (mhip_contact_op_create with ra, rb = centre -> CONTACT POINT ON THE SURFACE, and
+ * mob_rot).  p [C][3] is the initial guess on entry (in K; zeros are fine) and the solution on return, g [C][3] its
+ * gradient.  Residual: Linf projected difference over the 3C components (config->residual_kind must say so). */
+int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, double mu,
+                                      const mhip_pgd_config* config /*[host]*/, double* p, double* g,
+                                      mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
 /* Staged form of the same fused iteration for domain-decomposed runs: the host interleaves the halo
  * exchange and the cross-rank reduction between the stages, all asynchronously on `stream`:
  *     begin;  body(init) -> [ghost velocity halo] -> constraint(init, local3) -> [all-gather local3] -> finalize(init)

@@ -942,6 +942,187 @@ __global__ void __launch_bounds__(kBlock) k_assemble_velocity(size_t n, const do
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// BUILD EXTENSION -- Coulomb friction as a cone complementarity problem (BASELINE configs[2] says "frictional LCP"; the
+// reference has no frictional solver at all, SURVEY F2: parity unpinned, flagged wherever it is exposed).
+// The same BBPGD iteration with a per-contact cone projection in place of the 1-D space projection:
+//   unknown       p_c in R^3, the contact impulse in world coordinates (no tangent basis is ever built)
+//   cone          K_c = { p : |p - (p.n) n| <= mu (p.n) }            (mu = 0: the ray lambda n, lambda >= 0)
+//   forces        -p_c on the source body, +p_c on the target, acting at the contact points (lever arms ra, rb)
+//   gradient      g_c = dt * [(U_j + W_j x rb) - (U_i + W_i x ra)] + sep_c n_c      (n . g is the frictionless g)
+//   iteration     p <- Proj_K(p - step g), BB1 step and Linf projected-difference residual over the 3C components
+// This is the convex (associative) relaxation of Coulomb friction used by APGD / BBPGD multibody solvers
+// (Anitescu 2006; Mazhar, Heyn, Negrut, Tasora 2015): p in K, g in K* = { g : mu |g_t| <= g.n }, p . g = 0.
+// The iterate is packed as (p, g), 48 bytes per contact, ping-pong by parity like the frictionless solver.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ inline V3 project_cone(V3 v, V3 n, double mu) {
+  const double a = dot(v, n);
+  const V3 b = v - a * n;
+  const double bn = norm(b);
+  if (a >= 0.0 && bn <= mu * a) return v;        // inside the cone (a >= 0 matters only for mu = 0)
+  if (mu * bn <= -a) return V3{0.0, 0.0, 0.0};   // inside the polar cone
+  const double an = (mu * bn + a) / (mu * mu + 1.0);
+  const V3 t = (bn > 0.0) ? ((mu * an) / bn) * b : V3{0.0, 0.0, 0.0};
+  return an * n + t;
+}
+struct PG {
+  V3 p, g;
+};
+__device__ inline PG load_pg(const double* P, size_t c) {
+  const double2* q = reinterpret_cast<const double2*>(P + 6 * c);
+  const double2 a = q[0], b = q[1], d = q[2];
+  return {{a.x, a.y, b.x}, {b.y, d.x, d.y}};
+}
+__device__ inline void store_pg(double* P, size_t c, V3 p, V3 g) {
+  double2* q = reinterpret_cast<double2*>(P + 6 * c);
+  q[0] = make_double2(p.x, p.y);
+  q[1] = make_double2(p.z, g.x);
+  q[2] = make_double2(g.y, g.z);
+}
+// the impulse a contact carries in this sweep: the given p (INIT) or the projected BB step from the packed iterate
+template <bool INIT>
+__device__ inline V3 friction_iterate(size_t c, const double* __restrict__ Pt, const double* __restrict__ p0, V3 n,
+                                      double mu, double step, bool step_is_zero, V3* p_old, V3* g_old) {
+  if (INIT) return load3(p0, c);
+  const PG s = load_pg(Pt, c);
+  if (p_old) *p_old = s.p;
+  if (g_old) *g_old = s.g;
+  const V3 v = step_is_zero ? s.p : V3{s.p.x + (-step) * s.g.x, s.p.y + (-step) * s.g.y, s.p.z + (-step) * s.g.z};
+  return project_cone(v, n, mu);
+}
+
+// body sweep (48-byte (n, r) half-edge records of the vector-arm operator)
+template <bool INIT, int G, int U>
+__global__ void __launch_bounds__(kBlock)
+    k_body_friction(OpView op, const SolverState* __restrict__ st, const double* __restrict__ P0,
+                    const double* __restrict__ P1, const double* __restrict__ p_init, double mu) {
+  const double* Pt = P0;
+  double step = 0.0;
+  if (!INIT) {
+    if (st->done) return;
+    if (st->flips & 1u) Pt = P1;
+    step = st->step;
+  }
+  const bool step_is_zero = fabs(-step) < kZeroTol;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const int sub = static_cast<int>(t % G);
+  if (t / G >= op.body_count) return;
+  const size_t b = op.body_first + t / G;
+  V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
+  const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
+  for (int32_t k0 = beg + sub; k0 < end; k0 += G * U) {
+    int32_t e[U];
+    double2 h0[U], h1[U], h2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t k = k0 + u * G;
+      e[u] = (k < end) ? op.inc[k] : -1;
+      h0[u] = h1[u] = h2[u] = make_double2(0.0, 0.0);
+      if (k < end) {
+        const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * 6);
+        h0[u] = H2[0];
+        h1[u] = H2[1];
+        h2[u] = H2[2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (e[u] < 0) continue;
+      const V3 n{h0[u].x, h0[u].y, h1[u].x}, r{h1[u].y, h2[u].x, h2[u].y};
+      const V3 p = friction_iterate<INIT>(static_cast<size_t>(e[u] >> 1), Pt, p_init, n, mu, step, step_is_zero,
+                                          nullptr, nullptr);
+      const V3 f = (e[u] & 1) ? p : V3{-p.x, -p.y, -p.z};  // source: -p, target: +p
+      F = F + f;
+      T = T + cross(r, f);
+    }
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) {
+    F.x += __shfl_xor(F.x, off, 64); F.y += __shfl_xor(F.y, off, 64); F.z += __shfl_xor(F.z, off, 64);
+    T.x += __shfl_xor(T.x, off, 64); T.y += __shfl_xor(T.y, off, 64); T.z += __shfl_xor(T.z, off, 64);
+  }
+  if (sub != 0) return;
+  const double mt = op.mt[b], mr = op.mr[b];
+  double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
+  v[0] = make_double2(mt * F.x, mt * F.y);
+  v[1] = make_double2(mt * F.z, mr * T.x);
+  v[2] = make_double2(mr * T.y, mr * T.z);
+}
+
+// constraint sweep: one 256-contact tile per workgroup (grid-stride beyond the cap), block partials as k_constraint
+template <bool INIT>
+__global__ void __launch_bounds__(kBlock)
+    k_constraint_friction(OpView op, const SolverState* __restrict__ st, double* __restrict__ P0,
+                          double* __restrict__ P1, const double* __restrict__ p_init, const double* __restrict__ sep,
+                          double mu, double* __restrict__ partials) {
+  __shared__ double scratch[kBlock / 64];
+  const double* Pt = P0;
+  double* Pn = INIT ? P0 : P1;
+  double step = 0.0;
+  if (!INIT) {
+    if (st->done) return;
+    if (st->flips & 1u) {
+      Pt = P1;
+      Pn = P0;
+    }
+    step = st->step;
+  }
+  const bool step_is_zero = fabs(-step) < kZeroTol;
+  double rmax = kLowest, num = 0.0, den = 0.0;
+  const size_t ntiles = (op.C + kBlock - 1) / kBlock;
+  for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
+    const size_t c = lin * kBlock + threadIdx.x;
+    if (c >= op.C) continue;
+    const int2 ij = op.pairs[c];
+    const V3 n = load3(op.normal, c);
+    V3 p_old{0.0, 0.0, 0.0}, g_old{0.0, 0.0, 0.0};
+    const V3 p = friction_iterate<INIT>(c, Pt, p_init, n, mu, step, step_is_zero, &p_old, &g_old);
+    const double2* vi2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.x);
+    const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
+    const double2 a0 = vi2[0], a1 = vi2[1], a2 = vi2[2], b0 = vj2[0], b1 = vj2[1], b2 = vj2[2];
+    const V3 vi = V3{a0.x, a0.y, a1.x} + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
+    const V3 vj = V3{b0.x, b0.y, b1.x} + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    const double q = sep[c];
+    const V3 g{op.dt * (vj.x - vi.x) + q * n.x, op.dt * (vj.y - vi.y) + q * n.y, op.dt * (vj.z - vi.z) + q * n.z};
+    store_pg(Pn, c, p, g);
+    if (op.counted == nullptr || op.counted[c]) {
+      // Linf projected-difference residual over the three components (the reference's policy, convex.hpp:468-496,
+      // with the cone projection)
+      const V3 w = project_cone(V3{p.x - kSmallStep * g.x, p.y - kSmallStep * g.y, p.z - kSmallStep * g.z}, n, mu);
+      const double r = fmax(fabs(p.x - w.x), fmax(fabs(p.y - w.y), fabs(p.z - w.z)));
+      if (r > rmax) rmax = r;
+      if (!INIT) {
+        const V3 dp = p - p_old, dg = g - g_old;
+        num += dot(dp, dp);
+        den += dot(dp, dg);
+      }
+    }
+  }
+  const double m = block_max(rmax, scratch);
+  const double s1 = block_sum(num, scratch);
+  const double s2 = block_sum(den, scratch);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = m;
+    partials[(size_t)gridDim.x + blockIdx.x] = s1;
+    partials[2 * (size_t)gridDim.x + blockIdx.x] = s2;
+  }
+}
+
+// latest iterate -> caller's p [C][3], g [C][3]
+__global__ void __launch_bounds__(kBlock) k_finish_friction(size_t C, const SolverState* __restrict__ st,
+                                                           const double* __restrict__ P0,
+                                                           const double* __restrict__ P1, double* __restrict__ p,
+                                                           double* __restrict__ g) {
+  const bool odd = st->flips & 1u;
+  // converged at init / never iterated: P0; converged at parity q: the sweep wrote the "new" side; otherwise rolled forward
+  const double* cur = st->converged_at_init ? P0 : (st->converged ? (odd ? P0 : P1) : (odd ? P1 : P0));
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const PG s = load_pg(cur, c);
+    store3(p, c, s.p);
+    store3(g, c, s.g);
+  }
+}
+
 }  // namespace mhip
 
 using namespace mhip;
@@ -1430,6 +1611,76 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   }
   k_finish_packed<<<grid_for(C), kBlock, 0, s>>>(C, st, reinterpret_cast<const double2*>(P0),
                                                  reinterpret_cast<const double2*>(P1), x, g, x_tmp, g_tmp);
+  MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipStreamSynchronize(s));
+  result->num_iters = op->host_state->iter;
+  result->residual = op->host_state->residual;
+  result->converged = op->host_state->converged;
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, double mu,
+                                      const mhip_pgd_config* config, double* p, double* g,
+                                      mhip_solve_result* result, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
+  if (int e = check_config(config)) return e;
+  MHIP_REQUIRE(config->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF, MHIP_ERR_INVALID_ARGUMENT,
+               "the friction extension supports the projected-difference residual only");
+  MHIP_REQUIRE(mu >= 0.0 && mu == mu, MHIP_ERR_INVALID_ARGUMENT, "friction coefficient must be >= 0, got %g", mu);
+  MHIP_REQUIRE(op->kin == KIN_RIGID, MHIP_ERR_INVALID_ARGUMENT,
+               "friction needs the vector-arm operator (mhip_contact_op_create with ra, rb, mob_rot)");
+  const size_t C = op->view.C;
+  hipStream_t s = as_stream(stream);
+  if (C == 0) {
+    result->num_iters = 0;
+    result->residual = kLowest / kSmallStep;
+    result->converged = 1;
+    return MHIP_SUCCESS;
+  }
+  MHIP_REQUIRE(sep && p && g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not be null");
+  MHIP_REQUIRE(p != g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not alias");
+  MHIP_REQUIRE((reinterpret_cast<uintptr_t>(op->view.half) & 15) == 0, MHIP_ERR_RUNTIME, "misaligned records");
+  if (int e = op->iterate.reserve(2 * (6 * C + 2) * sizeof(double))) return e;
+  double* P0 = op->iterate.as<double>();
+  double* P1 = P0 + 6 * C;
+  SolverState* st = op->state.as<SolverState>();
+  double* parts = op->partials.as<double>();
+  const unsigned cgrid = constraint_grid(C);
+  const int G = 8;  // lanes per body of the body sweep, two half-edge chains each
+  const unsigned bgrid = grid_exact(op->view.body_count * (size_t)G);
+  op->last_stream = s;
+  auto finalize = [&](bool init) {
+    unsigned np = cgrid;
+    double* pp = parts;
+    fold_partials(np, pp, st, init ? 0 : 1, s);
+    if (init)
+      k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, config->residual_kind, config->tol,
+                                                       config->max_iters);
+    else
+      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, config->residual_kind, config->tol,
+                                                        config->max_iters);
+  };
+  if (op->view.body_count > 0) k_body_friction<true, 8, 2><<<bgrid, kBlock, 0, s>>>(op->view, st, P0, P1, p, mu);
+  k_constraint_friction<true><<<cgrid, kBlock, 0, s>>>(op->view, st, P0, P1, p, sep, mu, parts);
+  finalize(true);
+  MHIP_LAUNCH_CHECK();
+  unsigned enqueued = 0, chunk = 8;
+  for (;;) {
+    MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    if (op->host_state->done || enqueued >= config->max_iters) break;
+    const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
+    for (unsigned k = 0; k < todo; ++k) {
+      if (op->view.body_count > 0)
+        k_body_friction<false, 8, 2><<<bgrid, kBlock, 0, s>>>(op->view, st, P0, P1, nullptr, mu);
+      k_constraint_friction<false><<<cgrid, kBlock, 0, s>>>(op->view, st, P0, P1, nullptr, sep, mu, parts);
+      finalize(false);
+    }
+    MHIP_LAUNCH_CHECK();
+    enqueued += todo;
+    if (chunk < 64) chunk *= 2;
+  }
+  k_finish_friction<<<grid_for(C), kBlock, 0, s>>>(C, st, P0, P1, p, g);
   MHIP_LAUNCH_CHECK();
   MHIP_HIP(hipStreamSynchronize(s));
   result->num_iters = op->host_state->iter;

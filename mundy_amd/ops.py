@@ -469,6 +469,30 @@ def solve_cqpp(A, q, space, x0, cfg=None, state=None, fused=True):
     return x, g, SolveResult(int(res.num_iters), float(res.residual), bool(res.converged))
 
 
+def solve_friction_contact(A, sep, mu, p0=None, cfg=None):
+    """BUILD EXTENSION, parity unpinned (the reference has no frictional solver): Coulomb friction as a
+    cone complementarity problem on the vector-arm ContactOperator A (lever arms to the contact points ON THE
+    SURFACES), solved by the fused BBPGD iteration with a per-contact cone projection.  Returns (p [C,3] world-frame
+    impulses, g [C,3], SolveResult); mu = 0 reproduces the frictionless LCP (p = lambda n)."""
+    cfg = cfg or PGDConfig()
+    c = sep.shape[0]
+    p = torch.zeros((c, 3), dtype=torch.float64, device=sep.device) if p0 is None else p0.clone()
+    g = torch.empty_like(p)
+    res, pc = capi.SolveResult(), _cfg(cfg)
+    capi.check(capi.load().mhip_bbpgd_solve_contact_friction(A._h, _ptr(sep), float(mu), C.byref(pc), _ptr(p, cols=3),
+                                                             _ptr(g, cols=3), C.byref(res), _stream()))
+    return p, g, SolveResult(int(res.num_iters), float(res.residual), bool(res.converged))
+
+
+def surface_lever_arms(pairs, normal, ra, rb, radius):
+    """lever arms to the contact points on the surfaces of two round-capped bodies (spheres, spherocylinders) from
+    the centreline arms: ra + r_i n, rb - r_j n.  Friction acts there; for a frictionless contact the difference is
+    parallel to the force and drops out of the torque."""
+    ri = radius[pairs[:, 0].long()][:, None]
+    rj = radius[pairs[:, 1].long()][:, None]
+    return (ra + ri * normal).contiguous(), (rb - rj * normal).contiguous()
+
+
 def solve_small_cqpp_batch(A, q, space, x0, cfg=None):
     """make_mundy_math_cqpp + solve_cqpp on a batch of small dense problems, one thread each (convex.hpp:288-350,
     :722-733).  A [b, n, n], q [b, n], x0 [b, n]; returns (x, grad, num_iters, residual, converged) device tensors."""

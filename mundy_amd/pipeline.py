@@ -32,7 +32,7 @@ class ContactStepper:
 
     def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
                  search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
-                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None):
+                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None, friction=None):
         """kind = "sphere" | "spherocylinder" | "mixed".  Mixed systems (BASELINE configs[4]) pass kinds [n] int32
         (0 sphere, 1 spherocylinder, 2 ellipsoid) and shape [n, 3] = (r,-,-) / (r,L,-) / (r1,r2,r3) instead of
         radius / length."""
@@ -44,7 +44,12 @@ class ContactStepper:
             raise ValueError("mixed systems need quat, kinds and shape")
         if kind != "sphere" and periodic_box is not None:
             raise ValueError("periodic boxes are supported for spheres only")
+        if friction is not None and kind != "spherocylinder":
+            raise ValueError("the friction extension is wired for spherocylinders")
         self.kind = kind
+        # BUILD EXTENSION (parity unpinned: the reference has no frictional solver): Coulomb coefficient, None = the
+        # reference's frictionless LCP
+        self.friction = None if friction is None else float(friction)
         self.center, self.radius, self.quat, self.length = center, radius, quat, length
         self.kinds, self.shape = kinds, shape
         self.dt, self.viscosity = float(dt), float(viscosity)
@@ -125,14 +130,22 @@ class ContactStepper:
             self.contacts = ops.contact_mixed(pairs, self.kinds, self.center, self.quat, self.shape)
         else:
             ops.spherocylinder_segments(self.center, self.quat, self.radius, self.length, out=self.seg)
+            rodk = self.rod_kinematics and self.friction is None
             self.contacts = ops.contact_spherocylinders(pairs, self.seg, self.center, want_points=False,
-                                                        arms="arclength" if self.rod_kinematics else "vector")
+                                                        arms="arclength" if rodk else "vector")
         return self.contacts
 
     def resolve_collisions(self, rebuilt):
         c = self.contacts
         if self.op is not None:
             self.op.close()
+        if self.friction is not None:
+            ra, rb = ops.surface_lever_arms(self.links.pairs, c["normal"], c["ra"], c["rb"], self.radius)
+            self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=ra, rb=rb,
+                                          mob_rot=self.mob_rot)
+            p, g, res = ops.solve_friction_contact(self.op, c["sep"], self.friction, cfg=self.cfg)
+            self.impulse, self.lam = p, (p * c["normal"]).sum(dim=1)
+            return res
         if self.kind == "spherocylinder" and self.rod_kinematics:
             self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, mob_rot=self.mob_rot,
                                           rod=(c["s"], c["t"], self.seg))

@@ -350,6 +350,28 @@ def solve_cqpp_contact(pairs, normal, ra, rb, mt, mr, dt, q, x0, space=(LOWER_BO
     return x, g, _result(it, res, conv)
 
 
+def solve_friction_contact(pairs, normal, ra, rb, mt, mr, dt, sep, mu, p0=None, max_iters=10000, tol=1e-5):
+    """BUILD EXTENSION, parity unpinned (the reference has no frictional solver): BBPGD on the cone complementarity
+    problem with world-frame impulses p [C, 3]; returns (p, g, result)."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    normal, ra, rb, mt, mr, sep = _f(normal), _f(ra), _f(rb), _f(mt), _f(mr), _f(sep)
+    c = len(pairs)
+    p = np.zeros((c, 3)) if p0 is None else _f(p0).copy()
+    g = np.zeros((c, 3))
+    it, res, conv = C.c_uint(), C.c_double(), C.c_int()
+    lib().o_solve_friction_contact(C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(normal), _p(ra), _p(rb), _p(mt),
+                                   _p(mr), C.c_double(dt), _p(sep), C.c_double(mu), C.c_uint(max_iters),
+                                   C.c_double(tol), _p(p), _p(g), C.byref(it), C.byref(res), C.byref(conv))
+    return p, g, _result(it, res, conv)
+
+
+def project_cone(v, normal, mu):
+    v, normal = _f(v), _f(normal)
+    out = np.empty_like(v)
+    lib().o_project_cone(C.c_size_t(len(v)), _p(v), _p(normal), C.c_double(mu), _p(out))
+    return out
+
+
 # ---- zmorton / hilbert ------------------------------------------------------------------------------------------
 def float_xor_msb(p, q, single=False):
     L = lib()

@@ -1118,6 +1118,116 @@ struct ContactOp {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// BUILD EXTENSION (no reference implementation; SURVEY F2: the reference has no frictional solver, so everything in
+// this block is "parity unpinned" -- it checks the GPU extension against an independent serial statement of the SAME
+// algorithm, not against MuNDy).  Coulomb friction as a cone complementarity problem solved by the reference's BBPGD
+// iteration (convex.hpp:614-666) with a per-contact cone projection:
+//   p_c in R^3 (world-frame impulse), K_c = { |p - (p.n) n| <= mu (p.n) }, forces -p / +p at the contact points,
+//   g_c = dt [(U_j + W_j x rb) - (U_i + W_i x ra)] + sep_c n_c.
+// ---------------------------------------------------------------------------------------------------------------
+inline V3 project_cone(const V3& v, const V3& n, double mu) {
+  const double a = dot(v, n);
+  const V3 b = v - n * a;
+  const double bn = norm(b);
+  if (a >= 0.0 && bn <= mu * a) return v;  // a >= 0 matters only for mu = 0 (v anti-parallel to n: bn = 0 = mu a)
+  if (mu * bn <= -a) return V3{0.0, 0.0, 0.0};
+  const double an = (mu * bn + a) / (mu * mu + 1.0);
+  if (!(bn > 0.0)) return n * an;
+  return n * an + b * ((mu * an) / bn);
+}
+struct FrictionOp {
+  const int32_t* pairs;
+  const double *normal, *ra, *rb, *mt, *mr, *sep;
+  double dt;
+  size_t C, N;
+  mutable std::vector<double> F, T;
+  // g = A p + q, serial scatter / mobility / gather
+  void gradient(const double* p, double* g) const {
+    F.assign(3 * N, 0.0);
+    T.assign(3 * N, 0.0);
+    for (size_t c = 0; c < C; ++c) {
+      const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
+      const V3 f{p[3 * c], p[3 * c + 1], p[3 * c + 2]};
+      const V3 a{ra[3 * c], ra[3 * c + 1], ra[3 * c + 2]}, b{rb[3 * c], rb[3 * c + 1], rb[3 * c + 2]};
+      const V3 ta = cross(a, f), tb = cross(b, f);
+      for (int k = 0; k < 3; ++k) {
+        F[3 * i + k] += -f[k];
+        F[3 * j + k] += f[k];
+        T[3 * i + k] += -ta[k];
+        T[3 * j + k] += tb[k];
+      }
+    }
+    for (size_t c = 0; c < C; ++c) {
+      const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
+      const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
+      const V3 a{ra[3 * c], ra[3 * c + 1], ra[3 * c + 2]}, b{rb[3 * c], rb[3 * c + 1], rb[3 * c + 2]};
+      const V3 ui{mt[i] * F[3 * i], mt[i] * F[3 * i + 1], mt[i] * F[3 * i + 2]};
+      const V3 uj{mt[j] * F[3 * j], mt[j] * F[3 * j + 1], mt[j] * F[3 * j + 2]};
+      const V3 wi{mr[i] * T[3 * i], mr[i] * T[3 * i + 1], mr[i] * T[3 * i + 2]};
+      const V3 wj{mr[j] * T[3 * j], mr[j] * T[3 * j + 1], mr[j] * T[3 * j + 2]};
+      const V3 vi = ui + cross(wi, a), vj = uj + cross(wj, b);
+      for (int k = 0; k < 3; ++k) g[3 * c + k] = dt * (vj[k] - vi[k]) + sep[c] * n[k];
+    }
+  }
+};
+inline SolveResult solve_friction_contact(const FrictionOp& op, double mu, unsigned max_iters, double tol, double* p,
+                                          double* g) {
+  const size_t C = op.C;
+  std::vector<double> pt(p, p + 3 * C), gt(3 * C);
+  auto nrm = [&](size_t c) { return V3{op.normal[3 * c], op.normal[3 * c + 1], op.normal[3 * c + 2]}; };
+  auto residual = [&](const double* x, const double* gr) {
+    double r = -1.7976931348623157e308;
+    for (size_t c = 0; c < C; ++c) {
+      const V3 pc{x[3 * c], x[3 * c + 1], x[3 * c + 2]}, gc{gr[3 * c], gr[3 * c + 1], gr[3 * c + 2]};
+      const V3 w = project_cone(pc - gc * 1e-6, nrm(c), mu);
+      for (int k = 0; k < 3; ++k) r = std::max(r, std::fabs(pc[k] - w[k]));
+    }
+    return r / 1e-6;
+  };
+  op.gradient(pt.data(), gt.data());
+  SolveResult out{0, residual(pt.data(), gt.data()), false};
+  auto finish = [&](const std::vector<double>& x, const std::vector<double>& gr) {
+    std::copy(x.begin(), x.end(), p);
+    std::copy(gr.begin(), gr.end(), g);
+  };
+  if (out.residual <= tol) {
+    out.converged = true;
+    finish(pt, gt);
+    return out;
+  }
+  double step = 1.0 / out.residual;
+  std::vector<double> pn(3 * C), gn(3 * C);
+  while (out.num_iters < max_iters) {
+    for (size_t c = 0; c < C; ++c) {
+      V3 v;
+      for (int k = 0; k < 3; ++k) v[k] = (std::fabs(-step) < kZeroTol) ? pt[3 * c + k] : pt[3 * c + k] + (-step) * gt[3 * c + k];
+      const V3 w = project_cone(v, nrm(c), mu);
+      for (int k = 0; k < 3; ++k) pn[3 * c + k] = w[k];
+    }
+    op.gradient(pn.data(), gn.data());
+    out.residual = residual(pn.data(), gn.data());
+    if (out.residual <= tol) {
+      out.converged = true;
+      finish(pn, gn);
+      return out;
+    }
+    double num = 0.0, den = 0.0;
+    for (size_t k = 0; k < 3 * C; ++k) {
+      const double dx = pn[k] - pt[k];
+      num += dx * dx;
+      den += dx * (gn[k] - gt[k]);
+    }
+    den += 1e-14 * (std::fabs(den) < 1e-14 ? 1.0 : 0.0);
+    step = num / den;
+    pt.swap(pn);
+    gt.swap(gn);
+    ++out.num_iters;
+  }
+  finish(pt, gt);
+  return out;
+}
+
 // The scrap app's own matrix-free BBPGD (scrap/lcp_spheres/NgpLcp.cpp:558-759, DRY mobility), serial order.
 // Differs from convex.hpp's PGDStrategy: Dai-Fletcher residual with a 1e-12 active-set test (:376-405), strict `<`
 // convergence test, BB1/BB2 alternating by the parity of ite_count with `|b| < 1e-12 -> b += 1e-12` (:716-731),

@@ -1,0 +1,94 @@
+"""BUILD EXTENSION, parity unpinned (the reference has no frictional solver): the fused frictional BBPGD
+on the GPU against the independent serial statement in oracle/, the frictionless (reference-pinned) solve at mu = 0,
+and the cone complementarity conditions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mundy_amd import ops as o
+    return o
+
+
+def _op(ops, P):
+    from gpu_util import dev
+    return ops.ContactOperator(dev(P["pairs"]), dev(P["normal"]), dev(P["mt"]), 5e-3, ra=dev(P["ras"]), rb=dev(P["rbs"]),
+                               mob_rot=dev(P["mr"]))
+
+
+def test_cone_projection_matches_oracle_via_one_step(ops, oracle):
+    # max_iters = 0 returns g0 = sep n; one iteration applies Proj_K(0 - step g0) = 0 or a multiple of n: exercised
+    # through the solver since the projection is not exported on its own
+    from gpu_util import dev, host
+    from test_oracle_friction_ext import _rod_system
+    P = _rod_system(oracle, 800, seed=2)
+    op = _op(ops, P)
+    for mu in (0.0, 0.5):
+        for iters in (0, 1, 3):
+            p, g, r = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=ops.PGDConfig(max_iters=iters, tol=1e-12))
+            po, go, ro = oracle.solve_friction_contact(P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"],
+                                                       5e-3, P["sep"], mu, max_iters=iters, tol=1e-12)
+            assert r.num_iters == ro["num_iters"] == iters and not r.converged
+            np.testing.assert_allclose(host(p), po, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(host(g), go, rtol=1e-9, atol=1e-11)
+            assert r.residual == pytest.approx(ro["residual"], rel=1e-9)
+    op.close()
+
+
+@pytest.mark.parametrize("mu", [0.0, 0.3, 1.0])
+def test_friction_solve_matches_oracle_and_cone_conditions(ops, oracle, mu):
+    from gpu_util import dev, host
+    from test_oracle_friction_ext import _rod_system, cone_checks
+    P = _rod_system(oracle, 2500, seed=13)
+    tol = 1e-6
+    op = _op(ops, P)
+    p, g, r = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=ops.PGDConfig(max_iters=50000, tol=tol))
+    po, go, ro = oracle.solve_friction_contact(P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"], 5e-3,
+                                               P["sep"], mu, max_iters=50000, tol=tol)
+    assert r.converged and ro["converged"] and r.residual <= tol
+    assert 0.5 * ro["num_iters"] <= r.num_iters <= 2.0 * ro["num_iters"] + 10
+    p, g = host(p), host(g)
+    cone_checks(p, g, P["normal"], mu, tol)
+    np.testing.assert_allclose(g, go, atol=40 * tol)          # the gradient is unique, the impulses need not be
+    if mu == 0.0:
+        # the reference-pinned frictionless solve on the same contacts (centreline arms: same torques for forces along n)
+        opn = ops.ContactOperator(dev(P["pairs"]), dev(P["normal"]), dev(P["mt"]), 5e-3, ra=dev(P["ra"]), rb=dev(P["rb"]),
+                                  mob_rot=dev(P["mr"]))
+        x, gl, rl = ops.solve_lcp(opn, dev(P["sep"]), dev(np.zeros(len(P["pairs"]))), ops.PGDConfig(max_iters=50000, tol=tol))
+        assert rl.converged
+        np.testing.assert_allclose((g * P["normal"]).sum(1), host(gl), atol=40 * tol)
+        lam = (p * P["normal"]).sum(1)
+        np.testing.assert_allclose(p, lam[:, None] * P["normal"], atol=1e-12)
+        opn.close()
+    # deterministic: a second solve gives the same bits
+    p2, g2, r2 = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=ops.PGDConfig(max_iters=50000, tol=tol))
+    assert r2.num_iters == r.num_iters and np.array_equal(host(p2), p)
+    op.close()
+
+
+def test_friction_stepper_and_errors(ops, oracle):
+    import torch
+    from gpu_util import dev
+    from mundy_amd import pipeline, synth
+    b = synth.spherocylinders(20_000, volume_fraction=0.3)
+    tol = 1e-5
+    st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]), dev(b["length"]),
+                                 search_buffer=0.1, cfg=ops.PGDConfig(max_iters=30000, tol=tol), friction=0.3)
+    ref = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]),
+                                  dev(b["length"]), search_buffer=0.1, cfg=ops.PGDConfig(max_iters=30000, tol=tol))
+    s, r = st.step(), ref.step()
+    assert s.converged and r.converged and s.num_contacts == r.num_contacts
+    n = st.contacts["normal"]
+    pn = (st.impulse * n).sum(1)
+    pt = (st.impulse - pn[:, None] * n).norm(dim=1)
+    assert float((pt - 0.3 * pn).max()) <= 1e-9 and int((pt > 1e-6).sum()) > 100
+    assert torch.isfinite(st.center).all() and torch.isfinite(st.quat).all()
+    # friction changes the motion (rods pick up spin / tangential drag) but resolves the same overlaps
+    assert float((st.center - ref.center).abs().max()) > 1e-6
+    with pytest.raises(Exception):   # needs the vector-arm operator
+        ops.solve_friction_contact(ref.op, ref.contacts["sep"], 0.3)
+    with pytest.raises(Exception):
+        ops.solve_friction_contact(st.op, st.contacts["sep"], -0.1)
