@@ -291,6 +291,12 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
                            double* g_tmp, mhip_stream_t stream);
 int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream);
 int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream);
+/* the constraint stage in pieces: sweep a sub-range of the constraints (any number of disjoint ranges per iteration,
+ * e.g. interior contacts before the halo has landed, boundary contacts after), then reduce every sweep's partials of
+ * this iteration into local3.  stage_constraint == constraint_range(0, C) + reduce. */
+int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_first, size_t c_count,
+                                      mhip_stream_t stream);
+int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream);
 int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gathered, int nparts,
                               mhip_stream_t stream);
 int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, int* done /*[host]*/,
@@ -333,6 +339,12 @@ int mhip_bbpgd_solve_contact_unfused(mhip_contact_op_t op, const double* q, cons
  * ---------------------------------------------------------------------------------------------------------------- */
 int mhip_filter_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, size_t count, int32_t* pairs_out,
                             unsigned char* counted_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
+/* Same selection, ordered for overlap: first the pairs with BOTH bodies owned (interior), then those with exactly one
+ * (boundary), each block in input order.  interior_out = size of the first block, count_out = total.  The staged solver
+ * sweeps [0, interior) while the ghost-velocity halo that the boundary block needs is still in flight. */
+int mhip_partition_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, size_t count, int32_t* pairs_out,
+                               unsigned char* counted_out, size_t* interior_out /*[host]*/,
+                               size_t* count_out /*[host]*/, mhip_stream_t stream);
 int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const double* box6 /*[host]*/,
                              int32_t* idx_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
 /* min / max corner over n boxes grown by `buffer`: out6 [host] (an empty set gives the inverted box) */

@@ -98,10 +98,13 @@ SIGNATURES = {
     "mhip_bbpgd_stage_begin": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp, _vp],
     "mhip_bbpgd_stage_body": [_vp, _i, _vp],
     "mhip_bbpgd_stage_constraint": [_vp, _i, _vp, _vp],
+    "mhip_bbpgd_stage_constraint_range": [_vp, _i, _sz, _sz, _vp],
+    "mhip_bbpgd_stage_reduce": [_vp, _i, _vp, _vp],
     "mhip_bbpgd_stage_finalize": [_vp, _i, _vp, _i, _vp],
     "mhip_bbpgd_stage_poll": [_vp, C.POINTER(SolveResult), C.POINTER(_i), _vp],
     "mhip_bbpgd_stage_end": [_vp, C.POINTER(SolveResult), _vp],
     "mhip_filter_pairs_owned": [_sz, _vp, _sz, _sz, _vp, _vp, C.POINTER(_sz), _vp],
+    "mhip_partition_pairs_owned": [_sz, _vp, _sz, _sz, _vp, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp],
     "mhip_select_aabb_overlap": [_sz, _vp, _d, C.POINTER(_d), _vp, C.POINTER(_sz), _vp],
     "mhip_aabb_bounds": [_sz, _vp, _d, C.POINTER(_d), _vp],
     "mhip_bbpgd_solve_contact_unfused": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,

@@ -353,6 +353,11 @@ struct OpView {
   const double* axis;           // [N][3] u = p1 - p0
   double* omega;                // [N][3] angular velocity W
   int xcd_aware;  // T of xcd_tile(): consecutive tiles per XCD within a window (performance only; 0 = off)
+  // constraint sweeps over a sub-range [c_first, c_end) (the staged solver sweeps interior contacts while the halo of
+  // the boundary ones is in flight); its block partials go to slots part_offset + blockIdx of planes part_stride apart
+  // (part_stride = 0: one sweep over everything, planes gridDim apart)
+  size_t c_first, c_end;
+  unsigned part_offset, part_stride;
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
@@ -533,10 +538,10 @@ __global__ void __launch_bounds__(kBlock)
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
   double rmax = kLowest, num = 0.0, den = 0.0;
-  const size_t ntiles = (op.C + kBlock - 1) / kBlock;
+  const size_t ntiles = (op.c_end - op.c_first + kBlock - 1) / kBlock;
   for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
-    const size_t c = xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
-    if (c >= op.C) continue;
+    const size_t c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
+    if (c >= op.c_end) continue;
     const int2 ij = op.pairs[c];
     double x_old = 0.0, g_old = 0.0;
     const double xc = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
@@ -584,10 +589,12 @@ __global__ void __launch_bounds__(kBlock)
     const double m = block_max(rmax, scratch);
     const double s1 = block_sum(num, scratch);
     const double s2 = block_sum(den, scratch);
-    if (threadIdx.x == 0) {  // three planes of gridDim.x values: the final pass reads them coalesced
-      partials[blockIdx.x] = m;
-      partials[(size_t)gridDim.x + blockIdx.x] = s1;
-      partials[2 * (size_t)gridDim.x + blockIdx.x] = s2;
+    if (threadIdx.x == 0) {  // three planes of values: the final pass reads them coalesced
+      const size_t stride = op.part_stride ? op.part_stride : gridDim.x;
+      const size_t slot = op.part_offset + blockIdx.x;
+      partials[slot] = m;
+      partials[stride + slot] = s1;
+      partials[2 * stride + slot] = s2;
     }
   }
 }
@@ -614,7 +621,8 @@ __device__ inline void reduce_triples(int nparts, const double* __restrict__ par
 // first level of the final reduction when there are tens of thousands of block partials: workgroup b folds the
 // contiguous slice b of each plane into one triple (fixed slices, fixed order: deterministic)
 constexpr int kFoldGroups = 64;
-__global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, const double* __restrict__ partials,
+__global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, size_t stride,
+                                                         const double* __restrict__ partials,
                                                          const SolverState* __restrict__ st, int check_done,
                                                          double* __restrict__ folded) {
   __shared__ double scratch[kBlock / 64];
@@ -625,8 +633,8 @@ __global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, const doub
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const double m = partials[i];
     if (m > rmax) rmax = m;
-    num += partials[(size_t)nparts + i];
-    den += partials[2 * (size_t)nparts + i];
+    num += partials[stride + i];
+    den += partials[2 * stride + i];
   }
   rmax = block_max(rmax, scratch);
   num = block_sum(num, scratch);
@@ -676,12 +684,12 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
 
 // block partials -> one (max, num, den) triple (this rank's contribution to the all-gather of SURVEY 8e step 3)
 __global__ void __launch_bounds__(kFinalBlock) k_reduce_local3(int nparts, const double* __restrict__ partials,
-                                                              const SolverState* __restrict__ st, int check_done,
-                                                              double* __restrict__ out3) {
+                                                              size_t stride, const SolverState* __restrict__ st,
+                                                              int check_done, double* __restrict__ out3) {
   __shared__ double scratch[kFinalBlock / 64];
   if (check_done && st->done) return;
   double rmax, num, den;
-  reduce_triples(nparts, partials, 1, (size_t)nparts, scratch, rmax, num, den);
+  reduce_triples(nparts, partials, 1, stride, scratch, rmax, num, den);
   if (threadIdx.x == 0) {
     out3[0] = rmax;
     out3[1] = num;
@@ -1144,6 +1152,7 @@ struct mhip_contact_op {
     Space sp{0, 0, 0};
     mhip_pgd_config cfg{0, 0, 0};
     bool active = false;
+    unsigned part_used = 0;  // partial slots written by this iteration's constraint sweeps
   } stage;
   // optional per-kernel timing (mhip_contact_op_set_profiling)
   bool profile = false;
@@ -1218,15 +1227,20 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
 }
 
 // block partials of the constraint sweep -> at most kFoldGroups triples (planes) ready for the single-workgroup pass
-inline void fold_partials(unsigned& nparts, double*& parts, const SolverState* st, int check_done, hipStream_t s) {
+// `stride` is the distance between the three planes on entry and on return
+inline void fold_partials(unsigned& nparts, size_t& stride, double*& parts, const SolverState* st, int check_done,
+                          hipStream_t s) {
   if (nparts <= 4096) return;  // one workgroup reads a few thousand triples as fast as a second launch would
-  double* folded = parts + 3 * (size_t)nparts;
-  k_fold_partials<<<kFoldGroups, kBlock, 0, s>>>((int)nparts, parts, st, check_done, folded);
+  double* folded = parts + 3 * stride;
+  k_fold_partials<<<kFoldGroups, kBlock, 0, s>>>((int)nparts, stride, parts, st, check_done, folded);
   parts = folded;
   nparts = kFoldGroups;
+  stride = kFoldGroups;
 }
 // threads of a final pass over n partials: one wave is enough for a handful, 1024 for tens of thousands
 inline unsigned final_block(size_t n) { return n <= 256 ? 64u : (n <= 2048 ? 256u : (unsigned)kFinalBlock); }
+// plane distance of the staged solver's partials: up to two range sweeps per iteration share one set of planes
+constexpr unsigned kStageStride = 2 * 32768;
 // workgroups of the constraint sweep: one 256-constraint tile each up to the cap (10^6 rods: 29 775), grid-stride
 // beyond; measured 0.145 ms at 2048 workgroups, 0.139 at 8192, 0.131 at one tile per workgroup.  One partial triple
 // per workgroup.
@@ -1383,7 +1397,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   if (int e = op->cursor.reserve((N + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->inc.reserve((2 * C + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->vel.reserve((6 * N + 2) * sizeof(double))) return bail(e);
-  if (int e = op->partials.reserve((4 * kMaxConstraintGrid + 3 * kFoldGroups + 8) * sizeof(double))) return bail(e);
+  if (int e = op->partials.reserve((6 * kMaxConstraintGrid + 3 * kFoldGroups + 64) * sizeof(double))) return bail(e);
   if (int e = op->state.reserve(sizeof(SolverState) + 64)) return bail(e);
   if (int e = op->scanws.reserve(scan_workspace_bytes(N + 1) + 64)) return bail(e);
   {
@@ -1448,7 +1462,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
-                    op->axis.as<double>(), op->omega.as<double>(), 0};
+                    op->axis.as<double>(), op->omega.as<double>(), 0, 0, C, 0, 0};
   if (const char* xe = getenv("MHIP_XCD_TILE")) {  // A/B runs; clamped so a window stays a few thousand tiles
     const int t = atoi(xe);
     op->view.xcd_aware = t < 0 ? 0 : (t > 4096 ? 4096 : t);
@@ -1562,9 +1576,10 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   if (int e = op_launch_constraint(op, X_INIT, P0, P1, x, nullptr, q, sp, rk, cgrid, s, true)) return e;
   {
     unsigned np = cgrid;
+    size_t ps = cgrid;
     double* pp = parts;
-    fold_partials(np, pp, st, 0, s);
-    k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, rk, config->tol, config->max_iters);
+    fold_partials(np, ps, pp, st, 0, s);
+    k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters);
   }
   MHIP_LAUNCH_CHECK();
   unsigned enqueued = 0, chunk = 8, last_todo = 0, iter_before = 0;
@@ -1600,9 +1615,10 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       if (int e = op_launch_constraint(op, X_SOLVE, P0, P1, nullptr, nullptr, q, sp, rk, cgrid, s, true)) return e;
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       unsigned np = cgrid;
+      size_t ps = cgrid;
       double* pp = parts;
-      fold_partials(np, pp, st, 1, s);
-      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, rk, config->tol, config->max_iters);
+      fold_partials(np, ps, pp, st, 1, s);
+      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters);
       MHIP_LAUNCH_CHECK();
     }
     enqueued += todo;
@@ -1651,13 +1667,14 @@ int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, d
   op->last_stream = s;
   auto finalize = [&](bool init) {
     unsigned np = cgrid;
+    size_t ps = cgrid;
     double* pp = parts;
-    fold_partials(np, pp, st, init ? 0 : 1, s);
+    fold_partials(np, ps, pp, st, init ? 0 : 1, s);
     if (init)
-      k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, config->residual_kind, config->tol,
+      k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, config->residual_kind, config->tol,
                                                        config->max_iters);
     else
-      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, np, st, config->residual_kind, config->tol,
+      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, config->residual_kind, config->tol,
                                                         config->max_iters);
   };
   if (op->view.body_count > 0) k_body_friction<true, 8, 2><<<bgrid, kBlock, 0, s>>>(op->view, st, P0, P1, p, mu);
@@ -1808,6 +1825,7 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.sp = sp;
   op->stage.cfg = *config;
   op->stage.active = true;
+  op->stage.part_used = 0;
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   MHIP_HIP(hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState), as_stream(stream)));
   return MHIP_SUCCESS;
@@ -1822,23 +1840,51 @@ int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream) 
   return op_launch_body(op, X_SOLVE, P0, P1, nullptr, nullptr, st.sp, as_stream(stream), true);
 }
 
-int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
+int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_first, size_t c_count,
+                                      mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
-  MHIP_REQUIRE(local3 != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local3 is null");
+  MHIP_REQUIRE(c_first + c_count <= op->view.C, MHIP_ERR_INVALID_ARGUMENT,
+               "constraint range [%zu, %zu) exceeds the %zu constraints", c_first, c_first + c_count, op->view.C);
+  if (c_count == 0) return MHIP_SUCCESS;
   auto& st = op->stage;
-  hipStream_t s = as_stream(stream);
-  const unsigned cgrid = constraint_grid(op->view.C);
+  const unsigned grid = constraint_grid(c_count);
+  MHIP_REQUIRE(st.part_used + grid <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
   double* P0 = op->iterate.as<double>();
   double* P1 = P0 + 2 * op->view.C;
-  if (int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, P0, P1, init ? st.x : nullptr, nullptr, st.q, st.sp,
-                                   st.cfg.residual_kind, cgrid, s, true))
-    return e;
-  unsigned np = op->view.C == 0 ? 0u : cgrid;
-  double* pp = op->partials.as<double>();
-  fold_partials(np, pp, op->state.as<SolverState>(), init ? 0 : 1, s);
-  k_reduce_local3<<<1, final_block(np), 0, s>>>((int)np, pp, op->state.as<SolverState>(), init ? 0 : 1, local3);
-  MHIP_LAUNCH_CHECK();
+  op->view.c_first = c_first;
+  op->view.c_end = c_first + c_count;
+  op->view.part_offset = st.part_used;
+  op->view.part_stride = kStageStride;
+  const int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, P0, P1, init ? st.x : nullptr, nullptr, st.q, st.sp,
+                                     st.cfg.residual_kind, grid, as_stream(stream), true);
+  op->view.c_first = 0;
+  op->view.c_end = op->view.C;
+  op->view.part_offset = 0;
+  op->view.part_stride = 0;
+  if (e) return e;
+  st.part_used += grid;
   return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  MHIP_REQUIRE(local3 != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local3 is null");
+  hipStream_t s = as_stream(stream);
+  unsigned np = op->stage.part_used;
+  size_t ps = kStageStride;
+  double* pp = op->partials.as<double>();
+  fold_partials(np, ps, pp, op->state.as<SolverState>(), init ? 0 : 1, s);
+  k_reduce_local3<<<1, final_block(np), 0, s>>>((int)np, pp, ps, op->state.as<SolverState>(), init ? 0 : 1, local3);
+  MHIP_LAUNCH_CHECK();
+  op->stage.part_used = 0;
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  op->stage.part_used = 0;
+  if (int e = mhip_bbpgd_stage_constraint_range(op, init, 0, op->view.C, stream)) return e;
+  return mhip_bbpgd_stage_reduce(op, init, local3, stream);
 }
 
 int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gathered, int nparts,

@@ -51,6 +51,28 @@ struct KeepOwnedPair {  // a pair survives when at least one body is owned (ghos
     }
   }
 };
+// the two classes of the staged solver's constraint sweep: both bodies owned (interior: its body rows are final as
+// soon as this rank's body sweep ends) / exactly one owned (boundary: needs the ghost's row from the velocity halo)
+template <bool INTERIOR>
+struct KeepPairClass {
+  const int2* pairs;
+  int first, last;
+  int2* out;
+  unsigned char* counted;
+  __device__ bool keep(size_t k) const {
+    const int2 ij = pairs[k];
+    const bool oi = ij.x >= first && ij.x < last, oj = ij.y >= first && ij.y < last;
+    return INTERIOR ? (oi && oj) : (oi != oj);
+  }
+  __device__ void emit(size_t k, size_t slot) const {
+    const int2 ij = pairs[k];
+    out[slot] = ij;
+    if (counted) {
+      const int lo = ij.x < ij.y ? ij.x : ij.y;
+      counted[slot] = (lo >= first && lo < last) ? 1 : 0;
+    }
+  }
+};
 struct KeepBoxOverlap {  // closed interval test of geom::intersects (AABB.hpp:420-431) on the grown box
   const double* aabb;
   double buffer;
@@ -191,6 +213,29 @@ int mhip_filter_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, siz
   const KeepOwnedPair op{reinterpret_cast<const int2*>(pairs_in), static_cast<int>(first),
                          static_cast<int>(first + count), reinterpret_cast<int2*>(pairs_out), counted_out};
   return compact(c, op, count_out, as_stream(stream));
+}
+
+int mhip_partition_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, size_t count, int32_t* pairs_out,
+                               unsigned char* counted_out, size_t* interior_out, size_t* count_out,
+                               mhip_stream_t stream) {
+  MHIP_REQUIRE(count_out != nullptr && interior_out != nullptr, MHIP_ERR_INVALID_ARGUMENT, "count outputs are null");
+  *count_out = 0;
+  *interior_out = 0;
+  if (c == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(pairs_in && pairs_out, MHIP_ERR_INVALID_ARGUMENT, "pairs_in / pairs_out is null");
+  MHIP_REQUIRE(pairs_in != pairs_out, MHIP_ERR_INVALID_ARGUMENT, "in-place filtering is not supported");
+  MHIP_REQUIRE(c < (1u << 31) && first + count < (1u << 31), MHIP_ERR_RUNTIME, "too many pairs / bodies");
+  const int2* in = reinterpret_cast<const int2*>(pairs_in);
+  const int f = static_cast<int>(first), l = static_cast<int>(first + count);
+  size_t n_int = 0, n_bnd = 0;
+  const KeepPairClass<true> interior{in, f, l, reinterpret_cast<int2*>(pairs_out), counted_out};
+  if (int e = compact(c, interior, &n_int, as_stream(stream))) return e;
+  const KeepPairClass<false> boundary{in, f, l, reinterpret_cast<int2*>(pairs_out) + n_int,
+                                      counted_out ? counted_out + n_int : nullptr};
+  if (int e = compact(c, boundary, &n_bnd, as_stream(stream))) return e;
+  *interior_out = n_int;
+  *count_out = n_int + n_bnd;
+  return MHIP_SUCCESS;
 }
 
 int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const double* box6, int32_t* idx_out,

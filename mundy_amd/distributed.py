@@ -150,9 +150,16 @@ class Comm:
         return p2p
 
     def run_plan(self, plan):
-        if plan:
-            for w in dist.batch_isend_irecv(plan):
-                w.wait()
+        self.finish_plan(self.start_plan(plan))
+
+    def start_plan(self, plan):
+        """enqueues the grouped send/recv (it starts once the work already on the current stream is done) and returns
+        the handles; kernels launched before finish_plan() overlap with the transfers"""
+        return dist.batch_isend_irecv(plan) if plan else []
+
+    def finish_plan(self, works):
+        for w in works:
+            w.wait()  # orders the current stream after the transfer; no host block with nccl
 
     def exchange(self, send, recv):
         """send / recv: {peer: contiguous tensor}; recv tensors are filled in place."""
@@ -289,16 +296,24 @@ class DistributedContactStepper:
         self._vrecv = {p: self.vel[a:b] for p, (a, b) in self.vel_recv.items()}
         self._vplan = self.comm.make_plan(self._vsend, self._vrecv)
 
-    def _halo_velocity(self):
+    def _halo_velocity_start(self):
+        """packs the owned boundary rows and starts the grouped send/recv; returns what _halo_velocity_finish waits on"""
         if self.comm.world == 1:
-            return
+            return None
         if self._vsend_buf is not None:
             capi.check(capi.load().mhip_gather_rows(self._vsend_buf.shape[0], 6, _p(self.vel_send_idx), _p(self.vel),
                                                     _p(self._vsend_buf), _stream()))
         if self._vplan is not None:
-            self.comm.run_plan(self._vplan)
-        else:
+            return self.comm.start_plan(self._vplan)   # nccl: transfers run on RCCL's stream from here on
+        return "staged"
+
+    def _halo_velocity_finish(self, pending):
+        if pending is None:
+            return
+        if pending == "staged":                        # gloo (tests): blocking, staged through the host
             self.comm.exchange(self._vsend, self._vrecv)
+        else:
+            self.comm.finish_plan(pending)             # the compute stream waits for the transfers here
 
     # -- one step -------------------------------------------------------------------------------------------------------------
     def step(self, integrate=True):
@@ -312,9 +327,10 @@ class DistributedContactStepper:
         pairs = torch.empty((c_all, 2), dtype=torch.int32, device=dev)
         counted = torch.empty(c_all, dtype=torch.uint8, device=dev)
         cnt = C.c_size_t(0)
-        capi.check(lib.mhip_filter_pairs_owned(c_all, _p(self.links.pairs), self.n_lo, self.n, _p(pairs), _p(counted),
-                                               C.byref(cnt), _stream()))
-        nc = int(cnt.value)
+        n_int = C.c_size_t(0)  # interior contacts (both bodies owned) first, boundary contacts (one ghost) after
+        capi.check(lib.mhip_partition_pairs_owned(c_all, _p(self.links.pairs), self.n_lo, self.n, _p(pairs),
+                                                  _p(counted), C.byref(n_int), C.byref(cnt), _stream()))
+        nc, nci = int(cnt.value), int(n_int.value)
         pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
         mt, mr = self._synth.dry_mobility(brad.cpu().numpy(), viscosity=self.viscosity)
         mob_t, mob_r = torch.from_numpy(mt).to(dev), torch.from_numpy(mr).to(dev)
@@ -361,9 +377,13 @@ class DistributedContactStepper:
             e0 = mark() if prof else None
             capi.check(lib.mhip_bbpgd_stage_body(h, init, stream))
             e1 = mark() if prof else None
-            self._halo_velocity()
+            # the interior contacts only need this rank's own rows: swept while the ghost rows are in flight
+            pending = self._halo_velocity_start()
             e2 = mark() if prof else None
-            capi.check(lib.mhip_bbpgd_stage_constraint(h, init, p_local3, stream))
+            capi.check(lib.mhip_bbpgd_stage_constraint_range(h, init, 0, nci, stream))
+            self._halo_velocity_finish(pending)
+            capi.check(lib.mhip_bbpgd_stage_constraint_range(h, init, nci, nc - nci, stream))
+            capi.check(lib.mhip_bbpgd_stage_reduce(h, init, p_local3, stream))
             e3 = mark() if prof else None
             comm.all_gather_into(gathered, local3)
             capi.check(lib.mhip_bbpgd_stage_finalize(h, init, p_gathered, comm.world, stream))

@@ -98,6 +98,19 @@ def test_ballot_compactions_match_numpy(n):
         assert cnt.value == int(keep.sum())
         np.testing.assert_array_equal(host(out)[: cnt.value], pairs[keep])
         np.testing.assert_array_equal(host(counted)[: cnt.value].astype(bool), own[keep][:, 0])  # lower body = column 0
+        # the same selection split for overlap: interior pairs (both owned) first, boundary pairs (one owned) after
+        out2 = torch.empty((n, 2), dtype=torch.int32, device="cuda")
+        counted2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+        n_int, cnt2 = C.c_size_t(0), C.c_size_t(0)
+        capi.check(lib.mhip_partition_pairs_owned(n, C.c_void_p(dev(pairs).data_ptr()), first, count,
+                                                  C.c_void_p(out2.data_ptr()), C.c_void_p(counted2.data_ptr()),
+                                                  C.byref(n_int), C.byref(cnt2), None))
+        both = own.all(axis=1)
+        assert cnt2.value == cnt.value and n_int.value == int(both.sum())
+        np.testing.assert_array_equal(host(out2)[: n_int.value], pairs[both])
+        np.testing.assert_array_equal(host(out2)[n_int.value: cnt2.value], pairs[keep & ~both])
+        np.testing.assert_array_equal(host(counted2)[: cnt2.value].astype(bool),
+                                      np.concatenate([own[both][:, 0], own[keep & ~both][:, 0]]))
     lo = rng.uniform(0, 10, (n, 3))
     aabb = np.concatenate([lo, lo + rng.uniform(0.1, 1.0, (n, 3))], axis=1)
     for box, buf in ((np.array([2.0, 2, 2, 6, 6, 6]), 0.25), (np.array([-5.0, -5, -5, -4, -4, -4]), 0.0),
