@@ -190,8 +190,8 @@ def main():
             "value": round(value, 4), "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: 1M spherocylinders r=0.5 L=2 at 40%% volume fraction, random packing, "
-                                   "AABB+%.2g neighbour list, frictionless LCP tol %.0e" % (args.buffer, args.tol),
+            "config": {"workload": "configs[2]: %.3gM spherocylinders r=0.5 L=2 at 40%% volume fraction, random packing, "
+                                   "AABB+%.2g neighbour list, frictionless LCP tol %.0e" % (n / 1e6, args.buffer, args.tol),
                        "bodies_per_gpu": n, "contacts_per_gpu": contacts, "bbpgd_iters_per_step": iters,
                        "converged": [bool(s.converged) for s in stats],
                        "parallelism": "single GPU (N > 1: hilbert domain decomposition with RCCL halo)"},
@@ -265,9 +265,9 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
             "value": round(world * args.steps / elapsed, 4), "unit": "timesteps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[3]: %dM spherocylinders r=0.5 L=2 at 40%% volume fraction, one system "
+            "config": {"workload": "configs[3]: %.3gM spherocylinders r=0.5 L=2 at 40%% volume fraction, one system "
                                    "Hilbert-partitioned over %d GPUs, AABB+%.2g neighbour list, frictionless LCP tol %.0e"
-                                   % (world, world, args.buffer, args.tol),
+                                   % (n_total / 1e6, world, args.buffer, args.tol),
                        "bodies_per_gpu": n, "bodies_total": n_total, "contacts_total": contacts_global,
                        "ghost_bodies_total": ghosts_global, "bbpgd_iters_per_step": iters,
                        "converged": [bool(s["converged"]) for s in stats],
