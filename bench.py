@@ -268,7 +268,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                                              st.prof["body_ms"] / st.prof["iters"], st.prof["iters"], ", rank 0")
     if rank == 0:
         out = {
-            "metric": "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",
+            "metric": ("timesteps/sec, one %.3g-spherocylinder system over all GPUs, frictionless LCP contact (BBPGD)" % n_total)
+            if args.strong else "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",
             # weak: world x (10^6-rod workloads per second); strong: timesteps per second of the one fixed-size system
             "value": round((1 if args.strong else world) * args.steps / elapsed, 4), "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
