@@ -358,6 +358,16 @@ struct OpView {
   // (part_stride = 0: one sweep over everything, planes gridDim apart)
   size_t c_first, c_end;
   unsigned part_offset, part_stride;
+  // Activity masks (packed LCP solves): bit p of body_mask[b] is 0 iff the contact behind the p-th incidence entry of
+  // body b has x == 0 and 0 <= g < inf in the iterate the constraint sweep wrote last.  For any finite step >= 0 such
+  // a contact's next iterate is Proj(0 - step g) = 0 exactly, i.e. it adds +/-0 to the body's sums -- the body sweep
+  // walks only the set bits and never touches the entry, iterate or record of the others (two thirds of the list at
+  // 10^6 rods).  The constraint sweep keeps the masks current: it knows the old state (from the iterate it read) and
+  // the new one (from the iterate it writes) and flips the two bits with atomicXor when they differ, which after the
+  // first few iterations is rare.  A set bit only means "evaluate": stale ones are harmless, and a clear bit is never
+  // stale because every contact is re-evaluated every iteration.  Entries beyond the 64th of a body are always walked.
+  unsigned long long* body_mask;  // [N]
+  const unsigned char* pos;       // [2C]: slot of (c, side) in its body's incidence list, 255 if >= 64
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
@@ -436,28 +446,25 @@ __global__ void __launch_bounds__(kBlock)
   V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
-  // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight (entries k, k+G, ...),
-  // every level's U loads issued back to back before the first use.
-  for (int32_t k0 = beg + sub; k0 < end; k0 += G * U) {
+  // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
+  // issued back to back before the first use.  kk[u] = incidence slot or -1.
+  auto process = [&](const int32_t* kk) {
     int32_t e[U];
     double lam[U];
     double2 h0[U], h1[U], h2[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int32_t k = k0 + u * G;
-      e[u] = (k < end) ? op.inc[k] : -1;
-    }
+    for (int u = 0; u < U; ++u) e[u] = (kk[u] >= 0) ? op.inc[kk[u]] : -1;
 #pragma unroll
     for (int u = 0; u < U; ++u)
       lam[u] = (e[u] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(e[u] >> 1), xt, gt, step, step_is_zero, sp)
                            : 0.0;
-    // an inactive contact (lam == 0: most of a neighbour list) adds +/-0 to the sums, which leaves them bit for bit
-    // unchanged -- so its record is never fetched
+    // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so its record
+    // is never fetched
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       h0[u] = h1[u] = h2[u] = make_double2(0.0, 0.0);
       if (lam[u] != 0.0) {
-        const size_t k = static_cast<size_t>(k0 + u * G);
+        const size_t k = static_cast<size_t>(kk[u]);
         if (KIN == KIN_TRANS) {
           const double* H = op.half + k * HW;
           h0[u] = make_double2(H[0], H[1]);
@@ -480,6 +487,41 @@ __global__ void __launch_bounds__(kBlock)
       if (KIN == KIN_RIGID) T = T + cross(V3{h1[u].y, h2[u].x, h2[u].y}, f);  // torque r x (+/- lam n)
       if (KIN == KIN_ROD) T = T + h1[u].y * f;  // S = sum coef f; the torque is u x S, formed once per body below
     }
+  };
+  // activity masks apply when Proj(0 - step g) == 0 is guaranteed for g >= 0: LCP space, finite non-negative step
+  const bool masked = PACKED && MODE == X_SOLVE && op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND &&
+                      sp.lo == 0.0 && step >= 0.0 && step <= 1.7976931348623157e308;
+  int32_t full_from = beg;  // incidence slots from here on are walked unconditionally
+  if (masked) {
+    const int32_t head = (end - beg < 64) ? end - beg : 64;
+    unsigned long long mm = op.body_mask[b];
+    if (head < 64) mm &= (1ull << head) - 1ull;
+    int32_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kk[u] = -1;
+    int rank = 0, nm = 0;
+    while (mm) {  // the lane takes every G-th set bit (in slot order), U at a time
+      const int bit = __ffsll(static_cast<long long>(mm)) - 1;
+      mm &= mm - 1ull;
+      if ((rank++ & (G - 1)) != sub) continue;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (nm == u) kk[u] = beg + bit;
+      if (++nm == U) {
+        process(kk);
+        nm = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) kk[u] = -1;
+      }
+    }
+    if (nm) process(kk);
+    full_from = beg + head;
+  }
+  for (int32_t k0 = full_from + sub; k0 < end; k0 += G * U) {
+    int32_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kk[u] = (k0 + u * G < end) ? k0 + u * G : -1;
+    process(kk);
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
@@ -570,6 +612,16 @@ __global__ void __launch_bounds__(kBlock)
       const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
       if (PACKED) {
         reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
+        if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
+          // masks start all-ones (every contact "active"); flip this contact's two bits when its state changes
+          const bool was = (MODE == X_INIT) ? true : !(x_old == 0.0 && g_old >= 0.0 && g_old <= 1.7976931348623157e308);
+          const bool now = !(xc == 0.0 && g >= 0.0 && g <= 1.7976931348623157e308);
+          if (was != now) {
+            const unsigned pi = op.pos[2 * c], pj = op.pos[2 * c + 1];
+            if (pi < 64u) atomicXor(&op.body_mask[ij.x], 1ull << pi);
+            if (pj < 64u) atomicXor(&op.body_mask[ij.y], 1ull << pj);
+          }
+        }
       } else {
         gn[c] = g;
         if (MODE == X_SOLVE) xn[c] = xc;
@@ -933,6 +985,18 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// slot of every (contact, side) in its body's incidence list, for the activity masks
+__global__ void __launch_bounds__(kBlock) k_pos_build(size_t N, const int32_t* __restrict__ inc_ptr,
+                                                     const int32_t* __restrict__ inc, unsigned char* __restrict__ pos) {
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x) {
+    const int32_t beg = inc_ptr[b], end = inc_ptr[b + 1];
+    for (int32_t k = beg; k < end; ++k) {
+      const int32_t e = inc[k];
+      const int32_t slot = k - beg;
+      pos[2 * static_cast<size_t>(e >> 1) + (e & 1)] = static_cast<unsigned char>(slot < 255 ? slot : 255);
+    }
+  }
+}
 // rod axes u = p1 - p0 from the 64-byte segment records
 __global__ void __launch_bounds__(kBlock) k_rod_axes(size_t n, const double* __restrict__ seg, double* __restrict__ axis) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1142,6 +1206,7 @@ struct mhip_contact_op {
   hipStream_t last_stream = nullptr;
   DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half, axis, omega, vel_out;
   DeviceBuffer iterate;  // packed (x, g) ping-pong pair of the fused / staged solvers: 2 x C x 16 bytes
+  DeviceBuffer body_mask, pos;  // activity masks of the packed LCP solves (see OpView)
   int lanes_per_body = 8;
   int body_unroll = 1;  // independent half-edge chains per lane (k_body's U)
   SolverState* host_state = nullptr;  // pinned
@@ -1181,7 +1246,12 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
 #define BODY(M, R)                                    \
   do {                                                \
     const int lay = G * 10 + op->body_unroll;         \
-    if (lay == 41) BODY4(M, R, 4, 1);                 \
+    if (lay == 14) BODY4(M, R, 1, 4);                 \
+    else if (lay == 18) BODY4(M, R, 1, 8);            \
+    else if (lay == 24) BODY4(M, R, 2, 4);            \
+    else if (lay == 28) BODY4(M, R, 2, 8);            \
+    else if (lay == 48) BODY4(M, R, 4, 8);            \
+    else if (lay == 41) BODY4(M, R, 4, 1);            \
     else if (lay == 44) BODY4(M, R, 4, 4);            \
     else if (lay == 81) BODY4(M, R, 8, 1);            \
     else if (lay == 82) BODY4(M, R, 8, 2);            \
@@ -1449,20 +1519,33 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "half-edge build failed: %s", hipGetErrorString(he)));
   {
-    // G lanes per body, each keeping U half-edge chains in flight: G * U ~ twice the mean degree, so most bodies are
-    // done in one pass.  Measured at 10^6 rods (mean degree 15.2, MI355X): (16,1) 0.198 ms, (8,1) 0.164, (8,2) 0.154,
-    // (4,4) 0.157, (8,4) 0.150 per sweep.
+    // G lanes per body, each keeping U half-edge chains in flight.  Measured at 10^6 rods (mean degree 15.2, a third
+    // of it active; MI355X), walking every entry: (16,1) 0.198 ms, (8,1) 0.164, (8,2) 0.154, (4,4) 0.157, (8,4) 0.150
+    // per sweep; walking only the entries the activity masks flag: (8,4) 0.144, (4,4) 0.137, (2,8) 0.142, (1,8) 0.156.
     const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
     const char* env = getenv("MHIP_LANES_PER_BODY");
-    op->lanes_per_body = env ? atoi(env) : (mean_deg <= 8.0 ? 4 : 8);
+    op->lanes_per_body = env ? atoi(env) : (mean_deg <= 24.0 ? 4 : 8);
     op->body_unroll = 4;
-    if (op->lanes_per_body != 4 && op->lanes_per_body != 8 && op->lanes_per_body != 16 && op->lanes_per_body != 32)
+    if (op->lanes_per_body != 1 && op->lanes_per_body != 2 && op->lanes_per_body != 4 && op->lanes_per_body != 8 &&
+        op->lanes_per_body != 16 && op->lanes_per_body != 32)
       op->lanes_per_body = 8;
     if (const char* ue = getenv("MHIP_BODY_UNROLL")) op->body_unroll = atoi(ue);
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
-                    op->axis.as<double>(), op->omega.as<double>(), 0, 0, C, 0, 0};
+                    op->axis.as<double>(), op->omega.as<double>(), 0, 0, C, 0, 0, nullptr, nullptr};
+  if (int e = op->body_mask.reserve((N + 2) * sizeof(unsigned long long))) return bail(e);
+  if (int e = op->pos.reserve(2 * C + 16)) return bail(e);
+  if (N > 0 && C > 0) {
+    k_pos_build<<<grid_for(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
+                                              op->pos.as<unsigned char>());
+    he = hipGetLastError();
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "slot table build failed: %s", hipGetErrorString(he)));
+  }
+  op->view.body_mask = op->body_mask.as<unsigned long long>();
+  op->view.pos = op->pos.as<unsigned char>();
+  if (const char* me = getenv("MHIP_BODY_MASKS"))  // A/B runs
+    if (atoi(me) == 0) op->view.body_mask = nullptr;
   if (const char* xe = getenv("MHIP_XCD_TILE")) {  // A/B runs; clamped so a window stays a few thousand tiles
     const int t = atoi(xe);
     op->view.xcd_aware = t < 0 ? 0 : (t > 4096 ? 4096 : t);
@@ -1495,7 +1578,7 @@ int mhip_contact_op_destroy(mhip_contact_op_t op) {
   if (!op) return MHIP_SUCCESS;
   op->inc_ptr.release(); op->inc.release(); op->cursor.release(); op->vel.release();
   op->partials.release(); op->state.release(); op->scanws.release(); op->half.release();
-  op->axis.release(); op->omega.release(); op->vel_out.release(); op->iterate.release();
+  op->axis.release(); op->omega.release(); op->vel_out.release(); op->iterate.release(); op->body_mask.release(); op->pos.release();
   if (op->host_state) (void)hipHostFree(op->host_state);
   for (auto& ev : op->events) (void)hipEventDestroy(ev);
   delete op;
@@ -1571,6 +1654,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   double* P0 = op->iterate.as<double>();
   double* P1 = P0 + 2 * C;
+  if (op->view.body_mask) MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), s));
   // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res   (the pair lands packed in P0)
   if (int e = op_launch_body(op, X_INIT, x, x, nullptr, nullptr, sp, s)) return e;
   if (int e = op_launch_constraint(op, X_INIT, P0, P1, x, nullptr, q, sp, rk, cgrid, s, true)) return e;
@@ -1826,6 +1910,8 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.cfg = *config;
   op->stage.active = true;
   op->stage.part_used = 0;
+  if (op->view.body_mask)
+    MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), as_stream(stream)));
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   MHIP_HIP(hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState), as_stream(stream)));
   return MHIP_SUCCESS;
