@@ -285,6 +285,74 @@ inline SegmentSegmentResult distance(SharedNormalSigned, const std::vector<LineS
   return r;
 }
 
+// ---- periodic metrics (mundy_geom/periodicity.hpp) -------------------------------------------------------------------
+namespace detail {
+inline std::vector<double> flatten(const std::vector<Point<double>>& p) {
+  std::vector<double> h;
+  h.reserve(3 * p.size());
+  for (const auto& x : p) push3(h, x);
+  return h;
+}
+inline std::vector<Point<double>> to_points(const std::vector<double>& h) {
+  std::vector<Point<double>> p(h.size() / 3);
+  for (size_t i = 0; i < p.size(); ++i) p[i] = Point<double>(h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+  return p;
+}
+}  // namespace detail
+
+/// PeriodicScaledMetric (periodicity.hpp:743-841): orthorhombic cell of edge lengths `cell`; batch sep / wrap.
+class PeriodicScaledMetric {
+ public:
+  explicit PeriodicScaledMetric(const Point<double>& cell) : cell_{cell[0], cell[1], cell[2]} {}
+  std::vector<Point<double>> sep(const std::vector<Point<double>>& p1, const std::vector<Point<double>>& p2) const {
+    if (p1.size() != p2.size()) throw std::invalid_argument("sep: list sizes differ");
+    DeviceVector a(detail::flatten(p1)), b(detail::flatten(p2)), out(3 * p1.size());
+    check(mhip_periodic_sep(p1.size(), cell_, a.data(), b.data(), out.data(), nullptr));
+    return detail::to_points(out.download());
+  }
+  std::vector<Point<double>> wrap(const std::vector<Point<double>>& p) const {
+    DeviceVector a(detail::flatten(p));
+    check(mhip_wrap_rigid(p.size(), cell_, a.data(), nullptr));
+    return detail::to_points(a.download());
+  }
+  const double* cell() const { return cell_; }
+
+ private:
+  double cell_[3];
+};
+/// PeriodicMetric (periodicity.hpp:233-332): general unit cell h (row-major 3x3, lattice vectors as columns).
+class PeriodicMetric {
+ public:
+  explicit PeriodicMetric(const double (&h)[9]) {
+    for (int i = 0; i < 9; ++i) h_[i] = h[i];
+    check(mhip_unit_cell_inverse(h_, h_inv_));
+  }
+  std::vector<Point<double>> sep(const std::vector<Point<double>>& p1, const std::vector<Point<double>>& p2) const {
+    if (p1.size() != p2.size()) throw std::invalid_argument("sep: list sizes differ");
+    DeviceVector a(detail::flatten(p1)), b(detail::flatten(p2)), out(3 * p1.size());
+    check(mhip_periodic_sep_triclinic(p1.size(), h_, a.data(), b.data(), out.data(), nullptr));
+    return detail::to_points(out.download());
+  }
+  std::vector<Point<double>> wrap(const std::vector<Point<double>>& p) const {
+    DeviceVector a(detail::flatten(p));
+    check(mhip_wrap_rigid_triclinic(p.size(), h_, a.data(), nullptr));
+    return detail::to_points(a.download());
+  }
+  const double* direct_lattice_vectors() const { return h_; }
+  const double* inverse() const { return h_inv_; }
+
+ private:
+  double h_[9], h_inv_[9];
+};
+/// periodic_metric_from_unit_cell / periodic_scaled_metric_from_unit_cell (periodicity.hpp:848-855, :871-875)
+inline PeriodicMetric periodic_metric_from_unit_cell(const Point<double>& cell) {
+  const double h[9] = {cell[0], 0, 0, 0, cell[1], 0, 0, 0, cell[2]};
+  return PeriodicMetric(h);
+}
+inline PeriodicScaledMetric periodic_scaled_metric_from_unit_cell(const Point<double>& cell) {
+  return PeriodicScaledMetric(cell);
+}
+
 }  // namespace geom
 
 // ---- neighbour links ------------------------------------------------------------------------------------------------------

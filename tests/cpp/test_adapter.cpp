@@ -233,6 +233,44 @@ static void test_two_coincident_spheres() {  // UnitTestGenNeighborLinks.cpp:73-
   EXPECT_TRUE((p[0] == 0 && p[1] == 1) || (p[0] == 1 && p[1] == 0));
 }
 
+static void test_periodic_metrics() {  // UnitTestPeriodicity.cpp:623-660 (MinImageDirectVsPeriodic), restated
+  const geom::Point<double> cell(100.0, 100.0, 100.0);
+  const auto metric = geom::periodic_metric_from_unit_cell(cell);
+  const auto scaled = geom::periodic_scaled_metric_from_unit_cell(cell);
+  std::vector<geom::Point<double>> p1, p2;
+  unsigned long long state = 1234;
+  auto uniform = [&state]() {  // splitmix64 -> [0, 100)
+    state += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = state;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return 100.0 * static_cast<double>(z >> 11) / 9007199254740992.0;
+  };
+  for (int i = 0; i < 2000; ++i) {
+    p1.emplace_back(uniform(), uniform(), uniform());
+    p2.emplace_back(uniform(), uniform(), uniform());
+  }
+  const auto s1 = metric.sep(p1, p2), s2 = scaled.sep(p1, p2);
+  for (size_t i = 0; i < p1.size(); ++i) {
+    double best = 1e300;
+    for (int a = -1; a <= 1; ++a)
+      for (int b = -1; b <= 1; ++b)
+        for (int c = -1; c <= 1; ++c) {
+          const double dx = p2[i][0] + 100.0 * a - p1[i][0], dy = p2[i][1] + 100.0 * b - p1[i][1],
+                       dz = p2[i][2] + 100.0 * c - p1[i][2];
+          best = std::min(best, std::sqrt(dx * dx + dy * dy + dz * dz));
+        }
+    const double n1 = std::sqrt(s1[i][0] * s1[i][0] + s1[i][1] * s1[i][1] + s1[i][2] * s1[i][2]);
+    const double n2 = std::sqrt(s2[i][0] * s2[i][0] + s2[i][1] * s2[i][1] + s2[i][2] * s2[i][2]);
+    EXPECT_TRUE(std::fabs(n1 - best) <= 1e-8);  // get_relaxed_zero_tolerance<double>()
+    EXPECT_TRUE(std::fabs(n2 - best) <= 1e-8);
+  }
+  const auto w = metric.wrap({geom::Point<double>(950.0, -10.0, 100.0)});
+  EXPECT_TRUE(std::fabs(w[0][0] - 50.0) <= 1e-8 && std::fabs(w[0][1] - 90.0) <= 1e-8 && std::fabs(w[0][2]) <= 1e-8);
+  EXPECT_TRUE(metric.inverse()[0] == 0.01 && metric.inverse()[4] == 0.01 && metric.inverse()[1] == 0.0);
+}
+
 int main() {
   int count = 0;
   char arch[128];
@@ -244,6 +282,7 @@ int main() {
   test_compute_aabb_hard_coded();
   test_segment_kats();
   test_two_coincident_spheres();
+  test_periodic_metrics();
   std::printf("%s (%d failed checks)\n", g_failures ? "FAILED" : "ALL PASSED", g_failures);
   return g_failures;
 }
