@@ -350,3 +350,44 @@ def test_full_size_lcp_properties_1M_rods(ops):
     # symmetry: <z, A x> == <x, A z>
     a, bb = float((z * y).sum()), float((lam * st.op.apply(z)).sum())
     assert abs(a - bb) <= 1e-9 * max(1.0, abs(a))
+
+
+@pytest.mark.parametrize("rigid", [False, True])
+def test_high_degree_bodies_beyond_the_activity_mask(ops, oracle, rigid):
+    # a few big spheres each touched by ~150 small ones: incidence lists longer than the 64 slots the per-body activity
+    # masks cover (the tail is always walked), next to ordinary low-degree bodies
+    from gpu_util import dev, host
+    from mundy_amd import synth
+    rng = np.random.default_rng(8)
+    big = np.array([[0.0, 0.0, 0.0], [14.0, 0.0, 0.0], [0.0, 14.0, 3.0]])
+    centers, radii = [big], [np.full(3, 5.0)]
+    for b in big:
+        d = rng.normal(size=(150, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        centers.append(b + d * (5.0 + 0.3 - rng.uniform(0.0, 0.08, (150, 1))))   # small spheres pressed into the big one
+        radii.append(np.full(150, 0.3))
+    c, r = np.concatenate(centers), np.concatenate(radii)
+    n = len(c)
+    lo, hi, R = oracle.grow(oracle.compute_aabb_spheres(c, r), r, 0.2)
+    pairs = oracle.search(0, lo, hi, c, R)
+    deg = np.bincount(pairs.ravel(), minlength=n)
+    assert deg.max() > 100 and np.median(deg) < 20
+    sep, nrm = oracle.contact_spheres(pairs, c, r)
+    mt, mr = synth.dry_mobility(r)
+    ra = rb = None
+    if rigid:   # surface lever arms: torques vanish for central forces, the 6-DOF kernels still run
+        ra, rb = r[pairs[:, 0]][:, None] * nrm, -r[pairs[:, 1]][:, None] * nrm
+    C = len(pairs)
+    tol = 1e-7
+    opt = lambda a: None if a is None else dev(a)  # noqa: E731
+    op = ops.ContactOperator(dev(pairs), dev(nrm), dev(mt), 5e-3, ra=opt(ra), rb=opt(rb), mob_rot=dev(mr) if rigid else None)
+    x, g, res = ops.solve_lcp(op, dev(sep), dev(np.zeros(C)), ops.PGDConfig(max_iters=20000, tol=tol))
+    xo, go, ro = oracle.solve_cqpp_contact(pairs, nrm, ra, rb, mt, mr if rigid else None, 5e-3, sep, np.zeros(C),
+                                           max_iters=20000, tol=tol)
+    assert res.converged and ro["converged"]
+    np.testing.assert_allclose(host(g), go, atol=20 * tol)
+    x = host(x)
+    assert x.min() >= 0 and np.abs(np.minimum(x, host(g))).max() <= 10 * tol
+    # g is A x + q for the returned x: checks the body sweep of the final iterate against the plain apply
+    np.testing.assert_allclose(host(op.apply(dev(x))) + sep, host(g), atol=1e-10)
+    op.close()
