@@ -380,9 +380,9 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
   bool is_concretized() const { return concretized_; }
   /// \return true if the search was performed, false if no regeneration was necessary (:510-543)
   bool generate(size_t n, const double* aabb, const double* center, const double* bounding_radius,
-                mhip_stream_t stream = nullptr) {
+                mhip_stream_t stream = nullptr, bool force = false) {
     if (!concretized_) throw std::runtime_error("Cannot generate links before concretization.");
-    if (generated_) {
+    if (generated_ && !force) {
       int flag = 0;
       check(mhip_broadphase_needs_rebuild(h_, n, center, &flag, stream));
       if (!flag) return false;

@@ -1,0 +1,101 @@
+// stepper.hpp -- the per-timestep contact hot path for spherocylinders as a C++ host loop over the C ABI: what a
+// MundyMech-style timestep loop would hold (the reference's only such loops are its scrap apps,
+// scrap/lcp_spheres/NgpLcp.cpp:835-920; scrap/.../Bacteria.cpp:1013-1110).  Host code only sequences kernels:
+//   [Z-order reorder] -> compute_aabb -> GenNeighborLinks::generate -> segment records -> contact_spherocylinders
+//   -> ContactOperator (rod-compressed) -> solve_lcp (fused BBPGD) -> body velocities -> Euler + quaternion update
+// All arrays stay on the device; the only host reads are the pair count and the solver's convergence polls.
+#pragma once
+#include <chrono>
+
+#include "mundy_hip/adapter.hpp"
+
+namespace mundy_hip {
+namespace mech {
+
+struct StepStats {
+  size_t num_contacts = 0;
+  unsigned num_iters = 0;
+  double residual = 0.0;
+  bool converged = false, rebuilt = false;
+};
+
+class SpherocylinderStepper {
+ public:
+  /// host arrays: center [n][3], quat [n][4] (w, x, y, z), radius [n], length [n], mob_trans [n], mob_rot [n]
+  SpherocylinderStepper(const std::vector<double>& center, const std::vector<double>& quat,
+                        const std::vector<double>& radius, const std::vector<double>& length,
+                        const std::vector<double>& mob_trans, const std::vector<double>& mob_rot, double dt,
+                        double search_buffer, convex::PGDConfig<double> cfg)
+      : n_(radius.size()), dt_(dt), cfg_(cfg), center_(center), quat_(quat), radius_(radius), length_(length),
+        mob_t_(mob_trans), mob_r_(mob_rot), brad_(n_), aabb_(6 * n_), seg_(8 * n_), tmp_(4 * n_), perm_(n_) {
+    check(mhip_bounding_radius_spherocylinders(n_, radius_.data(), length_.data(), brad_.data(), nullptr));
+    links_.set_search_buffer(search_buffer).set_search_kind(MHIP_SEARCH_AABB).concretize();
+  }
+
+  /// Z-order permutation of every per-body array by centre
+  void reorder_bodies(double cell_size, const double lo[3]) {
+    check(mhip_morton_order(n_, center_.data(), lo, cell_size, perm_.data(), nullptr));
+    gather(center_, 3);
+    gather(quat_, 4);
+    gather(radius_, 1);
+    gather(length_, 1);
+    gather(brad_, 1);
+    gather(mob_t_, 1);
+    gather(mob_r_, 1);
+  }
+
+  StepStats step(bool integrate = true, bool force_rebuild = false) {
+    StepStats st;
+    check(mhip_compute_aabb_spherocylinders(n_, center_.data(), quat_.data(), radius_.data(), length_.data(),
+                                            aabb_.data(), nullptr));
+    st.rebuilt = links_.generate(n_, aabb_.data(), center_.data(), brad_.data(), nullptr, force_rebuild);
+    if (st.rebuilt) pairs_ = links_.links();
+    const size_t C = links_.num_links();
+    st.num_contacts = C;
+    check(mhip_spherocylinder_segments(n_, center_.data(), quat_.data(), radius_.data(), length_.data(), seg_.data(),
+                                       nullptr));
+    DeviceVector sep(C), normal(3 * C), s(C), t(C);
+    check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep.data(), normal.data(), nullptr,
+                                       nullptr, nullptr, nullptr, s.data(), t.data(), nullptr));
+    ContactOperator op(C, n_, pairs_.data(), normal.data(), ContactOperator::Rods{s.data(), t.data(), seg_.data()},
+                       mob_t_.data(), mob_r_.data(), dt_);
+    DeviceVector x(std::vector<double>(C, 0.0)), g(C), x_tmp(C), g_tmp(C);  // lambda = 0 (NgpLcp.cpp:890-891)
+    const mhip_space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
+    const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};
+    mhip_solve_result res{};
+    check(mhip_bbpgd_solve_contact(op.handle(), sep.data(), &lcp, &pc, x.data(), g.data(), x_tmp.data(), g_tmp.data(),
+                                   &res, nullptr));
+    st.num_iters = res.num_iters;
+    st.residual = res.residual;
+    st.converged = res.converged != 0;
+    if (integrate) {
+      const double* vel = nullptr;
+      check(mhip_contact_op_body_velocity(op.handle(), &vel));
+      check(mhip_integrate_euler(n_, dt_, vel, center_.data(), quat_.data(), nullptr));
+    }
+    check(mhip_stream_synchronize(nullptr));
+    lambda_ = std::move(x);
+    return st;
+  }
+
+  size_t num_bodies() const { return n_; }
+  const DeviceVector& center() const { return center_; }
+  const DeviceVector& quat() const { return quat_; }
+  const DeviceVector& lambda() const { return lambda_; }
+  const DeviceArray<int32_t>& pairs() const { return pairs_; }
+
+ private:
+  void gather(DeviceVector& a, size_t width) {
+    check(mhip_gather_rows(n_, width, perm_.data(), a.data(), tmp_.data(), nullptr));
+    check(mhip_deep_copy(width * n_, a.data(), tmp_.data(), nullptr));
+  }
+  size_t n_;
+  double dt_;
+  convex::PGDConfig<double> cfg_;
+  DeviceVector center_, quat_, radius_, length_, mob_t_, mob_r_, brad_, aabb_, seg_, tmp_, lambda_;
+  DeviceArray<int32_t> perm_, pairs_;
+  mesh::GenNeighborLinks links_;
+};
+
+}  // namespace mech
+}  // namespace mundy_hip
