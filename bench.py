@@ -292,13 +292,28 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     dist.destroy_process_group()
 
 
+def host_core_share(omp_max):
+    """Cores this job may actually use: the cgroup CPU quota when there is one (the GPU boxes give a 16-core share of a
+    256-thread host; 128 OpenMP threads on that quota ran the baseline at half the speed of 16), else the affinity
+    mask -- never more than OpenMP's own maximum."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(round(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, omp_max))
+
+
 def cpu_baseline(b, stepper, args, gpu_iters):
     """Times the CPU oracle (kind "port") on a bounded sample of the same workload: the full AABB / neighbour search /
-    narrow phase once at full size, and `--cpu-iters` BBPGD iterations of the full-size LCP on all host threads; the
+    narrow phase once at full size, and `--cpu-iters` BBPGD iterations of the full-size LCP on this job's host cores; the
     solve is extrapolated to the iteration count the GPU needed.  Reported, never the target."""
     import oracle
     oracle.build()
-    threads = oracle.num_threads()
+    threads = host_core_share(oracle.num_threads())
+    oracle.set_num_threads(threads)
     t = {}
     t0 = time.perf_counter()
     aabb = oracle.compute_aabb_spherocylinders(b["center"], b["quat"], b["radius"], b["length"], fast=True)

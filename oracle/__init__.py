@@ -52,6 +52,10 @@ def num_threads(fast=True):
     return int(lib(fast).o_num_threads())
 
 
+def set_num_threads(n, fast=True):
+    lib(fast).o_set_num_threads(C.c_int(int(n)))
+
+
 # ---- per-body geometry ------------------------------------------------------------------------------------------
 def compute_aabb_spheres(center, radius, fast=False):
     center, radius = _f(center), _f(radius)

@@ -32,6 +32,7 @@ std::vector<int32_t> g_pairs;
 extern "C" {
 
 int o_num_threads() { return omp_get_max_threads(); }
+void o_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 // ---- per-body geometry ------------------------------------------------------------------------------------------
 void o_compute_aabb_spheres(size_t n, const double* center, const double* radius, double* out) {
