@@ -385,6 +385,9 @@ int mhip_contact_spheres_triclinic(size_t c, const int32_t* pairs, const double*
  * Body reordering: Z-order (Morton) permutation of bodies by centre, z most significant as
  * zorder_knn::Less (mundy/math/src/mundy_math/zmort.hpp:195-220) orders non-negative lattice coordinates.
  * perm[k] = index of the body that goes to position k.  Deterministic (ties broken by index).
+ * The lattice has 2^b cells per axis, b = the largest of 4..8 with 8^b <= 8 n (the code space stays within 8 codes per
+ * body: 128 cells per axis at 10^6 bodies); lattice coordinates floor((c - lo) / cell_size) are clamped to
+ * [0, 2^b - 1], so bodies outside that cube share the boundary cells (a locality heuristic there, exact Z-order inside).
  * ---------------------------------------------------------------------------------------------------------------- */
 int mhip_morton_order(size_t n, const double* center, const double* lo /*[host] 3*/, double cell_size, int32_t* perm,
                       mhip_stream_t stream);

@@ -186,6 +186,14 @@ def contact_spherocylinders(pairs, seg, center, fast=False):
     return out
 
 
+def integrate_euler(dt, vel, center, quat=None):
+    """x += dt U; q <- rotate_quaternion(q, W, dt); returns new (center, quat)"""
+    vel, c = _f(vel), _f(center).copy()
+    q = None if quat is None else _f(quat).copy()
+    lib().o_integrate_euler(C.c_size_t(len(c)), C.c_double(dt), _p(vel), _p(c), _p(q))
+    return c, q
+
+
 # ---- periodicity --------------------------------------------------------------------------------------------------
 def periodic_sep(box, p1, p2):
     box, p1, p2 = _f(box), _f(p1), _f(p2)

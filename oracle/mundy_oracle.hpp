@@ -172,6 +172,24 @@ inline double bounding_radius_ellipsoid(const V3& radii) { return std::max(radii
 inline double bounding_radius_spherocylinder(double r, double length) { return 0.5 * length + r; }
 inline double bounding_radius_segment(const V3& p0, const V3& p1, double r) { return 0.5 * norm(p1 - p0) + r; }
 
+// mundy/math/src/mundy_math/Quaternion.hpp:1366-1383 (rotate_quaternion: Delong 2015 App. A eq. 1, then normalize()
+// :409-417 with norm :1233-1235, a left-to-right sum of squares).
+inline Quat rotate_quaternion(const Quat& q, const V3& omega, double dt) {
+  const double w = norm(omega);
+  if (w < kZeroTol) return q;
+  const double winv = 1.0 / w;
+  const double sw = std::sin(0.5 * w * dt), cw = std::cos(0.5 * w * dt);
+  const double s = q.w;
+  const V3 p{q.x, q.y, q.z};
+  const V3 cr = cross(omega, p);
+  const double a = s * sw, b = sw * winv;
+  const V3 xyz{a * omega.x * winv + cw * p.x + b * cr.x, a * omega.y * winv + cw * p.y + b * cr.y,
+               a * omega.z * winv + cw * p.z + b * cr.z};
+  const double qw = s * cw - dot(omega, p) * sw * winv;
+  const double inv = 1.0 / std::sqrt(qw * qw + xyz.x * xyz.x + xyz.y * xyz.y + xyz.z * xyz.z);
+  return Quat{qw * inv, xyz.x * inv, xyz.y * inv, xyz.z * inv};
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // mundy::geom -- periodicity (PeriodicScaledMetric only)
 // ---------------------------------------------------------------------------------------------------------------

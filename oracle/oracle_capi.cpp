@@ -236,6 +236,17 @@ void o_contact_mixed(size_t C, const int32_t* pairs, const int32_t* kind, const 
   }
 }
 
+// ---- time integration (scrap/lcp_spheres/NgpLcp.cpp:898 + Quaternion.hpp:1366-1383) -------------------------------
+void o_integrate_euler(size_t n, double dt, const double* vel, double* center, double* quat) {
+  for (size_t i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) center[3 * i + k] = dt * vel[6 * i + k] + 1.0 * center[3 * i + k];
+    if (quat) {
+      const Quat q = rotate_quaternion(ldq(quat, i), V3{vel[6 * i + 3], vel[6 * i + 4], vel[6 * i + 5]}, dt);
+      quat[4 * i] = q.w; quat[4 * i + 1] = q.x; quat[4 * i + 2] = q.y; quat[4 * i + 3] = q.z;
+    }
+  }
+}
+
 // ---- periodicity --------------------------------------------------------------------------------------------------
 void o_periodic_sep(size_t n, const double* box, const double* p1, const double* p2, double* out) {
   const PeriodicScaledMetric pm(V3{box[0], box[1], box[2]});
