@@ -391,3 +391,52 @@ def test_high_degree_bodies_beyond_the_activity_mask(ops, oracle, rigid):
     # g is A x + q for the returned x: checks the body sweep of the final iterate against the plain apply
     np.testing.assert_allclose(host(op.apply(dev(x))) + sep, host(g), atol=1e-10)
     op.close()
+
+
+def test_staged_api_whole_range_equals_fused_solve(ops, oracle):
+    # the staged entry points driven by hand on one rank, with the whole-range mhip_bbpgd_stage_constraint wrapper:
+    # same kernels in the same order as the fused driver -> identical iterates
+    import ctypes as C
+    import torch
+    from gpu_util import dev, host
+    from mundy_amd import capi
+    lib = capi.load()
+    P = _rod_problem_arclength(oracle, 3000, seed=17)
+    nc = len(P["pairs"])
+    cfg = ops.PGDConfig(max_iters=5000, tol=1e-6)
+    op = _gpu_op(ops, P)
+    x_ref, g_ref, r_ref = ops.solve_lcp(op, dev(P["sep"]), dev(np.zeros(nc)), cfg)
+    sep = dev(P["sep"])
+    x, g, xt, gt = (torch.zeros(nc, dtype=torch.float64, device="cuda") for _ in range(4))
+    local3 = torch.empty(3, dtype=torch.float64, device="cuda")
+    sp = capi.Space(ops.SPACE_LOWER_BOUND, 0.0, 0.0)
+    pc = capi.PgdConfig(cfg.max_iters, cfg.tol, cfg.residual_kind)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    capi.check(lib.mhip_bbpgd_stage_begin(op._h, p(sep), C.byref(sp), C.byref(pc), p(x), p(g), p(xt), p(gt), None))
+    res, done = capi.SolveResult(), C.c_int(0)
+    for it in range(cfg.max_iters + 1):
+        init = 1 if it == 0 else 0
+        capi.check(lib.mhip_bbpgd_stage_body(op._h, init, None))
+        capi.check(lib.mhip_bbpgd_stage_constraint(op._h, init, p(local3), None))
+        capi.check(lib.mhip_bbpgd_stage_finalize(op._h, init, p(local3), 1, None))   # one rank: its own triple
+        capi.check(lib.mhip_bbpgd_stage_poll(op._h, C.byref(res), C.byref(done), None))
+        if done.value:
+            break
+    capi.check(lib.mhip_bbpgd_stage_end(op._h, C.byref(res), None))
+    assert res.converged and res.num_iters == r_ref.num_iters and res.residual == r_ref.residual
+    assert np.array_equal(host(x), host(x_ref)) and np.array_equal(host(g), host(g_ref))
+    op.close()
+
+
+def test_fill_and_deep_copy(ops):
+    import ctypes as C
+    import torch
+    from mundy_amd import capi
+    lib = capi.load()
+    for n in (0, 1, 1000, 1_000_001):
+        t = torch.full((n + 2,), -1.0, dtype=torch.float64, device="cuda")
+        capi.check(lib.mhip_fill(n, C.c_void_p(t.data_ptr() + 8), 2.5, None))
+        assert bool((t[1:n + 1] == 2.5).all()) and float(t[0]) == -1.0 and float(t[-1]) == -1.0
+        u = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+        capi.check(lib.mhip_deep_copy(n, C.c_void_p(u.data_ptr() + 8), C.c_void_p(t.data_ptr() + 8), None))
+        assert torch.equal(u[1:n + 1], t[1:n + 1]) and float(u[0]) == 0.0 and float(u[-1]) == 0.0
