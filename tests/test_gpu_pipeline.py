@@ -131,3 +131,26 @@ def test_mixed_shape_stepper(mods):
     st.compute_aabb()
     st.generate_neighbor_links(force=True)
     assert float(st.compute_contacts()["sep"].min()) > worst0
+
+
+@pytest.mark.parametrize("kind", ["sphere", "spherocylinder"])
+def test_steps_with_no_contacts_and_single_bodies(mods, kind):
+    # dilute systems: an empty neighbour list (nothing to solve: zero iterations, converged, bodies do not move), one
+    # body, and two far bodies -- every stage must accept C = 0
+    import torch
+    from gpu_util import dev
+    ops, pipeline, synth = mods
+    for n in (1, 2, 300):
+        if kind == "sphere":
+            s = synth.spheres(n, volume_fraction=1e-4)
+            st = pipeline.ContactStepper("sphere", dev(s["center"]), dev(s["radius"]), search_buffer=0.1)
+        else:
+            b = synth.spherocylinders(n, volume_fraction=1e-4)
+            st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]),
+                                         dev(b["length"]), search_buffer=0.1)
+        c0 = st.center.clone()
+        for _ in range(2):
+            r = st.step()
+            assert r.num_contacts == 0 and r.converged and r.num_iters == 0
+        assert torch.equal(st.center, c0)
+        assert st.op.body_velocity().abs().max().item() == 0.0 if n else True
