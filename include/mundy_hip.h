@@ -219,12 +219,15 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
  * ra, rb, mob_rot may all be NULL (translation only, the sphere app).  The handle keeps views of the caller's
  * arrays (they must outlive it) and owns a body->constraint incidence index, so sums run in a fixed order (bitwise
  * reproducible, no atomics).
+ * priority [C] or NULL: a locality hint for that index only (never the result beyond summation-order rounding) -- each
+ * body lists the contacts with priority < 0 first.  Pass the signed separations: the contacts that overlap at the
+ * start of the step are the ones that will carry impulses, and the body sweep of the LCP solver only walks those.
  * ---------------------------------------------------------------------------------------------------------------- */
 typedef struct mhip_contact_op* mhip_contact_op_t;
 
 int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
                            const double* normal, const double* ra, const double* rb, const double* mob_trans,
-                           const double* mob_rot, double dt, mhip_stream_t stream);
+                           const double* mob_rot, double dt, const double* priority, mhip_stream_t stream);
 /* Spherocylinders: the same operator with rod-compressed kinematics.  A rod's contact point lies on its centreline,
  * cp = c + (s - 1/2)(p1 - p0), so each lever arm is one scalar; the sweeps stream (s, t) [16 B per contact] instead of
  * (ra, rb) [48 B] and 32-byte instead of 48-byte half-edge records (-18 % bytes per BBPGD iteration).  arc_s / arc_t
@@ -233,7 +236,7 @@ int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, si
 int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies,
                                 const int32_t* pairs, const double* normal, const double* arc_s, const double* arc_t,
                                 const double* seg, const double* mob_trans, const double* mob_rot, double dt,
-                                mhip_stream_t stream);
+                                const double* priority, mhip_stream_t stream);
 int mhip_contact_op_destroy(mhip_contact_op_t handle);
 int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, mhip_stream_t stream);
 /* Per-kernel timing of the fused solver (measurement support, no effect on results): when enabled,

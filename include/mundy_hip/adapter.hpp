@@ -417,9 +417,9 @@ class ContactOperator {
  public:
   ContactOperator(size_t num_constraints, size_t num_bodies, const int32_t* pairs, const double* normal,
                   const double* ra, const double* rb, const double* mob_trans, const double* mob_rot, double dt,
-                  mhip_stream_t stream = nullptr) {
+                  mhip_stream_t stream = nullptr, const double* priority = nullptr) {
     check(mhip_contact_op_create(&h_, num_constraints, num_bodies, pairs, normal, ra, rb, mob_trans, mob_rot, dt,
-                                 stream));
+                                 priority, stream));
   }
   /// Spherocylinders: lever arms as arclengths (s, t) along the rods' segments (mhip_contact_op_create_rods).
   struct Rods {
@@ -428,9 +428,10 @@ class ContactOperator {
     const double* segments;  // [num_bodies][8] from mhip_spherocylinder_segments
   };
   ContactOperator(size_t num_constraints, size_t num_bodies, const int32_t* pairs, const double* normal, Rods rods,
-                  const double* mob_trans, const double* mob_rot, double dt, mhip_stream_t stream = nullptr) {
+                  const double* mob_trans, const double* mob_rot, double dt, mhip_stream_t stream = nullptr,
+                  const double* priority = nullptr) {
     check(mhip_contact_op_create_rods(&h_, num_constraints, num_bodies, pairs, normal, rods.arc_s, rods.arc_t,
-                                      rods.segments, mob_trans, mob_rot, dt, stream));
+                                      rods.segments, mob_trans, mob_rot, dt, priority, stream));
   }
   ~ContactOperator() { mhip_contact_op_destroy(h_); }
   ContactOperator(const ContactOperator&) = delete;

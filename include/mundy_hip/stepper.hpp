@@ -58,7 +58,7 @@ class SpherocylinderStepper {
     check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep.data(), normal.data(), nullptr,
                                        nullptr, nullptr, nullptr, s.data(), t.data(), nullptr));
     ContactOperator op(C, n_, pairs_.data(), normal.data(), ContactOperator::Rods{s.data(), t.data(), seg_.data()},
-                       mob_t_.data(), mob_r_.data(), dt_);
+                       mob_t_.data(), mob_r_.data(), dt_, nullptr, /*priority=*/sep.data());
     DeviceVector x(std::vector<double>(C, 0.0)), g(C), x_tmp(C), g_tmp(C);  // lambda = 0 (NgpLcp.cpp:890-891)
     const mhip_space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
     const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};

@@ -78,8 +78,8 @@ SIGNATURES = {
     "mhip_residual": [_sz, _i, _vp, _vp, C.POINTER(Space), C.POINTER(_d), _vp],
     "mhip_bb_step": [_sz, _vp, _vp, _vp, _vp, C.POINTER(_d), _vp],
     "mhip_gemv": [_sz, _vp, _vp, _vp, _vp],
-    "mhip_contact_op_create": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp],
-    "mhip_contact_op_create_rods": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp],
+    "mhip_contact_op_create": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp],
+    "mhip_contact_op_create_rods": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp],
     "mhip_contact_op_destroy": [_vp],
     "mhip_contact_op_apply": [_vp, _vp, _vp, _vp],
     "mhip_contact_op_body_velocity": [_vp, C.POINTER(_vp)],

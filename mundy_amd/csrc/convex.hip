@@ -947,21 +947,30 @@ __global__ void __launch_bounds__(kBlock) k_inc_fill(size_t C, const int2* __res
     inc[atomicAdd(&cursor[ij.y], 1)] = static_cast<int32_t>((c << 1) | 1);
   }
 }
-// each body's list sorted ascending => sums run in constraint order whatever order the atomics arrived in
+// Each body's list in a fixed order whatever order the atomics arrived in: ascending (constraint, side) -- or, given a
+// priority array, the contacts with priority < 0 first (ascending), then the others (ascending).  With priority = the
+// signed separation the contacts that overlap at the start of the step, i.e. nearly all that will carry an impulse,
+// sit together at the head of the list, so the entries and records the masked body sweep touches share sectors.
 __global__ void __launch_bounds__(kBlock) k_inc_sort(size_t N, const int32_t* __restrict__ inc_ptr,
-                                                    int32_t* __restrict__ inc) {
+                                                    int32_t* __restrict__ inc, const double* __restrict__ priority) {
   const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (b >= N) return;
   const int32_t beg = inc_ptr[b], end = inc_ptr[b + 1];
+  unsigned* u = reinterpret_cast<unsigned*>(inc);
+  if (priority)  // entries use 31 bits: bit 31 marks the second class while sorting
+    for (int32_t i = beg; i < end; ++i)
+      if (!(priority[u[i] >> 1] < 0.0)) u[i] |= 0x80000000u;
   for (int32_t i = beg + 1; i < end; ++i) {
-    const int32_t v = inc[i];
+    const unsigned v = u[i];
     int32_t j = i - 1;
-    while (j >= beg && inc[j] > v) {
-      inc[j + 1] = inc[j];
+    while (j >= beg && u[j] > v) {
+      u[j + 1] = u[j];
       --j;
     }
-    inc[j + 1] = v;
+    u[j + 1] = v;
   }
+  if (priority)
+    for (int32_t i = beg; i < end; ++i) u[i] &= 0x7fffffffu;
 }
 
 // half-edge records in incidence order: the body sweep then streams them instead of gathering normals / arms
@@ -1448,7 +1457,7 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
 static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_constraints, size_t num_bodies,
                              const int32_t* pairs, const double* normal, const double* ra, const double* rb,
                              const double* arc_s, const double* arc_t, const double* seg, const double* mob_trans,
-                             const double* mob_rot, double dt, mhip_stream_t stream) {
+                             const double* mob_rot, double dt, const double* priority, mhip_stream_t stream) {
   MHIP_REQUIRE(handle != nullptr, MHIP_ERR_INVALID_ARGUMENT, "handle is null");
   *handle = nullptr;
   const size_t C = num_constraints, N = num_bodies;
@@ -1495,7 +1504,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
   if (C > 0) {
     k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>());
-    k_inc_sort<<<grid_exact(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>());
+    k_inc_sort<<<grid_exact(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(), priority);
   }
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "incidence build failed: %s", hipGetErrorString(he)));
@@ -1556,22 +1565,22 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
 
 int mhip_contact_op_create(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies, const int32_t* pairs,
                            const double* normal, const double* ra, const double* rb, const double* mob_trans,
-                           const double* mob_rot, double dt, mhip_stream_t stream) {
+                           const double* mob_rot, double dt, const double* priority, mhip_stream_t stream) {
   const int nrot = (ra != nullptr) + (rb != nullptr) + (mob_rot != nullptr);
   MHIP_REQUIRE(nrot == 0 || nrot == 3, MHIP_ERR_INVALID_ARGUMENT,
                "ra, rb and mob_rot must be given together (rigid bodies) or all be null (translation only)");
   return create_contact_op(handle, nrot == 3 ? KIN_RIGID : KIN_TRANS, num_constraints, num_bodies, pairs, normal, ra,
-                           rb, nullptr, nullptr, nullptr, mob_trans, mob_rot, dt, stream);
+                           rb, nullptr, nullptr, nullptr, mob_trans, mob_rot, dt, priority, stream);
 }
 
 int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraints, size_t num_bodies,
                                 const int32_t* pairs, const double* normal, const double* arc_s, const double* arc_t,
                                 const double* seg, const double* mob_trans, const double* mob_rot, double dt,
-                                mhip_stream_t stream) {
+                                const double* priority, mhip_stream_t stream) {
   MHIP_REQUIRE(num_constraints == 0 || (arc_s && arc_t), MHIP_ERR_INVALID_ARGUMENT, "arclength arrays must not be null");
   MHIP_REQUIRE(num_bodies == 0 || (seg && mob_rot), MHIP_ERR_INVALID_ARGUMENT, "seg / mob_rot must not be null");
   return create_contact_op(handle, KIN_ROD, num_constraints, num_bodies, pairs, normal, nullptr, nullptr, arc_s, arc_t,
-                           seg, mob_trans, mob_rot, dt, stream);
+                           seg, mob_trans, mob_rot, dt, priority, stream);
 }
 
 int mhip_contact_op_destroy(mhip_contact_op_t op) {

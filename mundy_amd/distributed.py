@@ -340,14 +340,14 @@ class DistributedContactStepper:
             seg = None
             con = ops.contact_mixed(pairs, L["kind"], L["center"], L["quat"], L["shape"])
             op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, ra=con["ra"], rb=con["rb"],
-                                               mob_rot=mob_r)
+                                               mob_rot=mob_r, priority=con["sep"])
         else:
             seg = ops.spherocylinder_segments(L["center"], L["quat"], L["shape"][:, 0].contiguous(),
                                               L["shape"][:, 1].contiguous())
             con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False, arms="arclength")
             # rod-compressed kinematics: velocity rows (and the halo) carry (U, W x u); (U, W) = body_velocity()
             op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
-                                               rod=(con["s"], con["t"], seg))
+                                               rod=(con["s"], con["t"], seg), priority=con["sep"])
         self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
         self._keep = (pairs, counted, con, mob_t, mob_r, seg)
         capi.check(lib.mhip_contact_op_set_partition(op._h, self.n_lo, self.n, _p(counted), _p(self.vel)))

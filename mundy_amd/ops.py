@@ -386,22 +386,25 @@ def gemv(A, x):
 class ContactOperator:
     """Matrix-free A = dt D^T M D over a neighbour list (the LinearOp of seam S2; apply(x, y) as convex.hpp:133-136)."""
 
-    def __init__(self, pairs, normal, mob_trans, dt, ra=None, rb=None, mob_rot=None, rod=None):
-        """rod = (arc_s, arc_t, seg): spherocylinders with rod-compressed lever arms (mhip_contact_op_create_rods)."""
+    def __init__(self, pairs, normal, mob_trans, dt, ra=None, rb=None, mob_rot=None, rod=None, priority=None):
+        """rod = (arc_s, arc_t, seg): spherocylinders with rod-compressed lever arms (mhip_contact_op_create_rods).
+        priority [C] (optional, e.g. the signed separations): locality hint -- each body lists the contacts with
+        priority < 0 first; changes nothing but the summation order."""
         self.num_constraints = pairs.shape[0]
         self.num_bodies = mob_trans.shape[0]
-        self._keep = (pairs, normal, ra, rb, mob_trans, mob_rot, rod)  # the handle holds views of these
+        self._keep = (pairs, normal, ra, rb, mob_trans, mob_rot, rod, priority)  # the handle holds views of these
+        prio = _ptr(priority, allow_none=True, name="priority")
         h = C.c_void_p()
         if rod is not None:
             arc_s, arc_t, seg = rod
             capi.check(capi.load().mhip_contact_op_create_rods(
                 C.byref(h), self.num_constraints, self.num_bodies, _ptr(pairs, torch.int32, 2), _ptr(normal, cols=3),
-                _ptr(arc_s), _ptr(arc_t), _ptr(seg, cols=8), _ptr(mob_trans), _ptr(mob_rot), float(dt), _stream()))
+                _ptr(arc_s), _ptr(arc_t), _ptr(seg, cols=8), _ptr(mob_trans), _ptr(mob_rot), float(dt), prio, _stream()))
         else:
             capi.check(capi.load().mhip_contact_op_create(
                 C.byref(h), self.num_constraints, self.num_bodies, _ptr(pairs, torch.int32, 2), _ptr(normal, cols=3),
                 _ptr(ra, allow_none=True, name="ra"), _ptr(rb, allow_none=True, name="rb"), _ptr(mob_trans),
-                _ptr(mob_rot, allow_none=True, name="mob_rot"), float(dt), _stream()))
+                _ptr(mob_rot, allow_none=True, name="mob_rot"), float(dt), prio, _stream()))
         self._h = h
         self._device = normal.device
 

@@ -148,10 +148,10 @@ class ContactStepper:
             return res
         if self.kind == "spherocylinder" and self.rod_kinematics:
             self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, mob_rot=self.mob_rot,
-                                          rod=(c["s"], c["t"], self.seg))
+                                          rod=(c["s"], c["t"], self.seg), priority=c["sep"])
         else:
             self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c.get("ra"),
-                                          rb=c.get("rb"), mob_rot=self.mob_rot)
+                                          rb=c.get("rb"), mob_rot=self.mob_rot, priority=c["sep"])
         if getattr(self, "profile_next", False):
             self.op.set_profiling(True)  # per-kernel HIP-event timing of the fused iteration (bench.py roofline)
         nc = self.links.num_pairs

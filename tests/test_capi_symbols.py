@@ -71,7 +71,7 @@ def test_validation_before_any_hip_call(lib):
     # rigid-body operator needs ra, rb and mob_rot together
     op = C.c_void_p()
     with pytest.raises(ValueError, match="given together"):
-        capi.check(lib.mhip_contact_op_create(C.byref(op), 0, 0, None, None, C.c_void_p(8), None, None, None, 1.0, None))
+        capi.check(lib.mhip_contact_op_create(C.byref(op), 0, 0, None, None, C.c_void_p(8), None, None, None, 1.0, None, None))
 
 
 def test_gen_neighbor_links_builder_misuse():
