@@ -21,6 +21,7 @@ torch.distributed carries the messages; with the gloo backend (tests, several ra
 staged through the host.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -200,7 +201,7 @@ class DistributedContactStepper:
     Rod systems use the rod-compressed operator; a mixed system (kind / shape given) bins its contacts by shape class
     (mhip_contact_mixed) and uses the vector-arm operator."""
 
-    RECORD = 12  # gid, centre 3, quat 4, shape 3 (r,L,- for rods), kind
+    RECORD = 14  # gid, centre 3, quat 4, shape 3 (r,L,- for rods), kind, translational and rotational mobility
 
     def __init__(self, center, quat, radius, length, gid_first, *, comm=None, dt=5e-3, viscosity=1e-3,
                  search_buffer=0.1, cfg=None, poll_every=16, kind=None, shape=None):
@@ -216,6 +217,11 @@ class DistributedContactStepper:
             self.shape = torch.stack([radius, length, torch.zeros_like(radius)], dim=1).contiguous()
         self.center, self.quat = center, quat
         self.n = center.shape[0]
+        # dry local-drag mobilities of the owned bodies, once (they travel with the ghost records)
+        brad0 = self._aabb(center, quat, self.shape, self.kind)[1] if self.n else torch.zeros(0, dtype=torch.float64)
+        mt0, mr0 = synth.dry_mobility(brad0.cpu().numpy(), viscosity=float(viscosity))
+        self.mob_t = torch.from_numpy(mt0).to(center.device)
+        self.mob_r = torch.from_numpy(mr0).to(center.device)
         self.gid_first = int(gid_first)
         self.dt, self.viscosity, self.buffer = float(dt), float(viscosity), float(search_buffer)
         self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)
@@ -256,7 +262,8 @@ class DistributedContactStepper:
         # records of the owned bodies, gathered per peer
         gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
         kcol = self.kind.to(torch.float64)[:, None] if self.mixed else torch.ones((n, 1), dtype=torch.float64, device=dev)
-        rec = torch.cat([gid[:, None], self.center, self.quat, self.shape, kcol], dim=1)
+        rec = torch.cat([gid[:, None], self.center, self.quat, self.shape, kcol, self.mob_t[:, None],
+                         self.mob_r[:, None]], dim=1)
         send = {p: ops.gather_rows(send_idx[p], rec) if send_cnt[p] else rec[:0] for p in send_idx}
         recv = {p: torch.empty((recv_cnt[p], self.RECORD), dtype=torch.float64, device=dev)
                 for p in range(comm.world) if p != comm.rank}
@@ -267,7 +274,8 @@ class DistributedContactStepper:
         self.n_lo, self.n_hi, self.n_local = n_lo, n_hi, local.shape[0]
         self.local = dict(gid=local[:, 0].contiguous(), center=local[:, 1:4].contiguous(),
                           quat=local[:, 4:8].contiguous(), shape=local[:, 8:11].contiguous(),
-                          kind=local[:, 11].to(torch.int32).contiguous())
+                          kind=local[:, 11].to(torch.int32).contiguous(), mob_t=local[:, 12].contiguous(),
+                          mob_r=local[:, 13].contiguous())
         # velocity halo plan: what I send each iteration (owned rows, as local indices) and where receives land
         order = [p for p in range(comm.world) if p != comm.rank and send_cnt[p]]
         self.vel_send_peers = order
@@ -318,11 +326,24 @@ class DistributedContactStepper:
     # -- one step -------------------------------------------------------------------------------------------------------------
     def step(self, integrate=True):
         lib, comm = capi.load(), self.comm
+        self.phase_ms = {}
+        t_last = [time.perf_counter()]
+
+        def tick(name):   # host wall time per phase, with a device sync, only when profiling
+            if self.profile:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                self.phase_ms[name] = self.phase_ms.get(name, 0.0) + 1e3 * (now - t_last[0])
+                t_last[0] = now
+
+        tick("start")
         self._exchange_ghosts()
+        tick("ghost_exchange")
         L, dev = self.local, self.center.device
         nl = self.n_local
         aabb, brad = self._aabb(L["center"], L["quat"], L["shape"], L["kind"])
         self.links.generate(aabb, L["center"], brad, force=True)
+        tick("aabb_neighbour_list")
         c_all = self.links.num_pairs
         pairs = torch.empty((c_all, 2), dtype=torch.int32, device=dev)
         counted = torch.empty(c_all, dtype=torch.uint8, device=dev)
@@ -332,8 +353,8 @@ class DistributedContactStepper:
                                                   _p(counted), C.byref(n_int), C.byref(cnt), _stream()))
         nc, nci = int(cnt.value), int(n_int.value)
         pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
-        mt, mr = self._synth.dry_mobility(brad.cpu().numpy(), viscosity=self.viscosity)
-        mob_t, mob_r = torch.from_numpy(mt).to(dev), torch.from_numpy(mr).to(dev)
+        tick("partition_pairs")
+        mob_t, mob_r = L["mob_t"], L["mob_r"]
         if self.op is not None:
             self.op.close()
         if self.mixed:
@@ -348,6 +369,7 @@ class DistributedContactStepper:
             # rod-compressed kinematics: velocity rows (and the halo) carry (U, W x u); (U, W) = body_velocity()
             op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
                                                rod=(con["s"], con["t"], seg), priority=con["sep"])
+        tick("narrow_phase_operator")
         self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
         self._keep = (pairs, counted, con, mob_t, mob_r, seg)
         capi.check(lib.mhip_contact_op_set_partition(op._h, self.n_lo, self.n, _p(counted), _p(self.vel)))
@@ -411,6 +433,7 @@ class DistributedContactStepper:
                 iteration(0)
             enq += todo
         capi.check(lib.mhip_bbpgd_stage_end(op._h, C.byref(res), _stream()))
+        tick("solve")
         self.lam, self.grad, self.contacts, self.pairs, self.counted = x, g, con, pairs, counted
         if integrate:
             a, b = self.n_lo, self.n_lo + self.n
@@ -418,6 +441,7 @@ class DistributedContactStepper:
             ops.integrate_euler(self.dt, op.body_velocity()[a:b], own_c, own_q)
             self.center.copy_(own_c)
             self.quat.copy_(own_q)
+        tick("integrate")
         owned_contacts = int(counted.sum().item()) if nc else 0
         self.stats.update(local_bodies=nl, local_contacts=nc, owned_contacts=owned_contacts,
                           num_iters=int(res.num_iters), residual=float(res.residual), converged=bool(res.converged))

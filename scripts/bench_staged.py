@@ -24,4 +24,5 @@ st.prof.update(body_ms=0.0, con_ms=0.0, iters=0)
 out = st.step(integrate=False)
 print("staged sampled sweeps: k_body %.4f ms, k_constraint+local3 %.4f ms over %d iterations; stats %s"
       % (st.prof["body_ms"] / max(1, st.prof["iters"]), st.prof["con_ms"] / max(1, st.prof["iters"]), st.prof["iters"], out))
+print("staged phases (ms, with syncs):", {k: round(v, 2) for k, v in st.phase_ms.items()})
 dist.destroy_process_group()
