@@ -403,14 +403,16 @@ class DistributedContactStepper:
             pending = self._halo_velocity_start()
             e2 = mark() if prof else None
             capi.check(lib.mhip_bbpgd_stage_constraint_range(h, init, 0, nci, stream))
+            e2b = mark() if prof else None
             self._halo_velocity_finish(pending)
+            e2c = mark() if prof else None     # the wait for the halo is not part of the sweep's time
             capi.check(lib.mhip_bbpgd_stage_constraint_range(h, init, nci, nc - nci, stream))
             capi.check(lib.mhip_bbpgd_stage_reduce(h, init, p_local3, stream))
             e3 = mark() if prof else None
             comm.all_gather_into(gathered, local3)
             capi.check(lib.mhip_bbpgd_stage_finalize(h, init, p_gathered, comm.world, stream))
             if prof:
-                events.append((self._it_count - 1, e0, e1, e2, e3))
+                events.append((self._it_count - 1, e0, e1, e2, e2b, e2c, e3))
 
         self._it_count = 0
         iteration(1)
@@ -420,10 +422,10 @@ class DistributedContactStepper:
             capi.check(lib.mhip_bbpgd_stage_poll(op._h, C.byref(res), C.byref(done), _stream()))
             if events:  # only iterations that did work: index (1-based after init) <= iterations actually run
                 ran = int(res.num_iters) + (1 if res.converged else 0)
-                for k, e0, e1, e2, e3 in events:
+                for k, e0, e1, e2, e2b, e2c, e3 in events:
                     if k <= ran:
                         self.prof["body_ms"] += e0.elapsed_time(e1)
-                        self.prof["con_ms"] += e2.elapsed_time(e3)
+                        self.prof["con_ms"] += e2.elapsed_time(e2b) + e2c.elapsed_time(e3)
                         self.prof["iters"] += 1
                 events.clear()
             if done.value or enq >= self.cfg.max_iters:
