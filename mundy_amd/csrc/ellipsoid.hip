@@ -1,17 +1,20 @@
-// ellipsoid.hip -- ellipsoid narrow phase: batch and neighbour-list entry points over
-// ellipsoid_device.hpp.  One thread per pair; 64-thread workgroups keep the divergent L-BFGS loops of different
-// pairs on as many SIMDs as possible.  Compute/latency bound (fp64 vector + transcendental), priced against the
-// fp64 vector peak, not HBM.
-#include "ellipsoid_device.hpp"
+// ellipsoid.hip -- ellipsoid narrow phase: batch and neighbour-list entry points.
+// One lane per pair; the multistart L-BFGS runs as a per-lane state machine so that the objective evaluations of a
+// wavefront stay converged and lanes refill from a global counter (ellipsoid_lockstep.hpp).  Compute bound (fp64
+// vector + transcendental), priced against the fp64 vector peak, not HBM.
+#include <cstdlib>
+
+#include "ellipsoid_lockstep.hpp"
 
 namespace mhip {
 
 constexpr int kEllBlock = 64;
-// Register budget: unconstrained, the compiler takes 314-370 VGPRs + AGPRs (one wave per SIMD) and still spills the
-// L-BFGS history (dynamically indexed) to scratch; two waves per SIMD (256 registers) measured +22 % pairs/s, three
-// and four waves spill too much (MI355X, 4*10^5 pairs: 4.6 / 5.6 / 5.3 / 4.5 *10^6 pairs/s for 1 / 2 / 3 / 4 waves).
+// Register budget of the lockstep kernel (10^6 pairs, MI355X): with the minimiser's state -- L-BFGS history included --
+// in registers under compile-time indices it needs one wave per SIMD's worth of registers and no scratch memory:
+// 9.9 * 10^6 pairs/s; forced to two waves it spills 236 B per lane (8.9), to three 632 B (3.3).  (The nested-loop
+// kernels below, kept as the bit-for-bit cross-check, ran 4.6 / 5.6 / 5.3 / 4.5 * 10^6 pairs/s at 1 / 2 / 3 / 4 waves.)
 #ifndef ELL_WAVES
-#define ELL_WAVES 2
+#define ELL_WAVES 1
 #endif
 #define ELL_OCC __attribute__((amdgpu_waves_per_eu(ELL_WAVES)))
 
@@ -67,6 +70,96 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
   if (rb) store3(rb, c, r.cp2 - e2.c);
 }
 
+// ---- lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one lane per pair, objective evaluations converged
+struct EEInput {  // where a lane finds pair k
+  const int2* pairs;                            // neighbour-list form: both ellipsoids come from one body table ...
+  const double *c1, *q1, *r1, *c2, *q2, *r2;    // ... or element-wise over two tables (pairs == nullptr)
+};
+struct EEOutput {
+  double *dist, *cp1, *cp2, *n1, *n2, *ra, *rb;  // any may be null
+};
+__global__ void __launch_bounds__(kEllBlock) ELL_OCC
+    k_ellipsoid_pairs_lockstep(size_t n, EEInput in, EEOutput out, unsigned long long* __restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  lockstep::Machine m;
+  m.phase = lockstep::PH_IDLE;
+  EllipsoidD e1{}, e2{};
+  size_t k = 0;
+  bool active = false, need = true;
+  for (;;) {
+    // lanes without a pair take the next ones from the global counter (one atomic per wave)
+    const unsigned long long want = __ballot(need);
+    if (want) {
+      const int leader = __ffsll(static_cast<long long>(want)) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(want)));
+      base = __shfl(base, leader, 64);
+      if (need) {
+        k = base + __popcll(want & ((1ull << lane) - 1ull));
+        need = false;
+        active = k < n;
+        if (active) {
+          if (in.pairs) {
+            const int2 ij = in.pairs[k];
+            e1 = load_ellipsoid(in.c1, in.q1, in.r1, ij.x);
+            e2 = load_ellipsoid(in.c1, in.q1, in.r1, ij.y);
+          } else {
+            e1 = load_ellipsoid(in.c1, in.q1, in.r1, k);
+            e2 = load_ellipsoid(in.c2, in.q2, in.r2, k);
+          }
+          lockstep::begin_pair(m);
+        }
+      }
+    }
+    if (!__any(active)) break;  // every lane of the wave has run out of pairs
+    // the objective for all lanes at once (EllipsoidEllipsoid.hpp:118-129): the converged part of the loop
+    V3 n1{0, 0, 0}, f1{0, 0, 0}, f2{0, 0, 0};
+    double fv = 0.0;
+    if (active) {
+      const lbfgs::V2 tp = lockstep::query_point(m);
+      double st, ct, sp, cp;
+      sincos(tp.a, &st, &ct);
+      sincos(tp.b, &sp, &cp);
+      n1 = V3{st * cp, st * sp, ct};
+      f1 = normal_to_foot_point(n1, e1);
+      f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, e2);
+      V3 sep;
+      fv = dist_point_point(f1, f2, sep);
+    }
+    // each lane's minimiser consumes its value (the diverging part: a few dozen flops)
+    if (active && lockstep::advance(m, fv)) {  // that was the evaluation at the best of the nine starts
+      if (out.dist) out.dist[k] = dot(f2 - f1, n1);
+      if (out.n1) store3(out.n1, k, n1);
+      if (out.n2) store3(out.n2, k, V3{-n1.x, -n1.y, -n1.z});
+      if (out.cp1) store3(out.cp1, k, f1);
+      if (out.cp2) store3(out.cp2, k, f2);
+      if (out.ra) store3(out.ra, k, f1 - e1.c);
+      if (out.rb) store3(out.rb, k, f2 - e2.c);
+      active = false;
+      need = true;
+    }
+  }
+}
+
+struct EllipsoidScratch {
+  DeviceBuffer counter;
+};
+EllipsoidScratch& ellipsoid_scratch() {
+  thread_local EllipsoidScratch s;
+  return s;
+}
+// persistent grid: every CU gets its waves, each lane keeps pulling pairs until the counter passes n
+int launch_ellipsoid_lockstep(size_t n, const EEInput& in, const EEOutput& out, hipStream_t s) {
+  EllipsoidScratch& es = ellipsoid_scratch();
+  if (int e = es.counter.reserve(64)) return e;
+  MHIP_HIP(hipMemsetAsync(es.counter.ptr, 0, sizeof(unsigned long long), s));
+  const size_t waves = (n + 63) / 64;
+  const unsigned grid = static_cast<unsigned>(waves < 4096 ? waves : 4096);  // 256 CUs x 4 SIMDs x up to 4 waves
+  k_ellipsoid_pairs_lockstep<<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
 }  // namespace mhip
 
 using namespace mhip;
@@ -78,10 +171,14 @@ int mhip_distance_ellipsoid_ellipsoid(size_t n, const double* c1, const double* 
                                       double* cp2, double* n1, double* n2, mhip_stream_t stream) {
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(c1 && q1 && r1 && c2 && q2 && r2, MHIP_ERR_INVALID_ARGUMENT, "ellipsoid arrays must not be null");
-  k_dist_ellipsoids<<<grid_exact(n, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(n, c1, q1, r1, c2, q2, r2, dist,
-                                                                                   cp1, cp2, n1, n2);
-  MHIP_LAUNCH_CHECK();
-  return MHIP_SUCCESS;
+  if (getenv("MHIP_ELLIPSOID_NESTED")) {  // the nested-loop form, kept for A/B and as the bit-for-bit cross-check
+    k_dist_ellipsoids<<<grid_exact(n, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(n, c1, q1, r1, c2, q2, r2, dist,
+                                                                                     cp1, cp2, n1, n2);
+    MHIP_LAUNCH_CHECK();
+    return MHIP_SUCCESS;
+  }
+  return launch_ellipsoid_lockstep(n, EEInput{nullptr, c1, q1, r1, c2, q2, r2},
+                                   EEOutput{dist, cp1, cp2, n1, n2, nullptr, nullptr}, as_stream(stream));
 }
 
 int mhip_distance_point_ellipsoid(size_t n, const double* p, const double* c, const double* q, const double* r,
@@ -99,10 +196,15 @@ int mhip_contact_ellipsoids(size_t c, const int32_t* pairs, const double* center
                             double* rb, mhip_stream_t stream) {
   if (c == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(pairs && center && quat && radii, MHIP_ERR_INVALID_ARGUMENT, "pairs / ellipsoid arrays must not be null");
-  k_contact_ellipsoids<<<grid_exact(c, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(
-      c, reinterpret_cast<const int2*>(pairs), center, quat, radii, sep, normal, cp1, cp2, ra, rb);
-  MHIP_LAUNCH_CHECK();
-  return MHIP_SUCCESS;
+  if (getenv("MHIP_ELLIPSOID_NESTED")) {
+    k_contact_ellipsoids<<<grid_exact(c, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(
+        c, reinterpret_cast<const int2*>(pairs), center, quat, radii, sep, normal, cp1, cp2, ra, rb);
+    MHIP_LAUNCH_CHECK();
+    return MHIP_SUCCESS;
+  }
+  return launch_ellipsoid_lockstep(c, EEInput{reinterpret_cast<const int2*>(pairs), center, quat, radii, nullptr,
+                                              nullptr, nullptr},
+                                   EEOutput{sep, cp1, cp2, normal, nullptr, ra, rb}, as_stream(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,347 @@
+// ellipsoid_lockstep.hpp -- the multistart L-BFGS of ellipsoid_device.hpp run in lockstep across a wavefront.
+//
+// One lane still owns one pair, and performs exactly the arithmetic of lbfgs::find_min / line_search in exactly their
+// order -- but the control flow is turned inside out.  Each lane carries the minimiser as an explicit state machine
+// whose only externally visible act is "evaluate the objective at this point".  The wave's loop is then
+//     evaluate the objective for all lanes at once  ->  every lane feeds the value to its own machine
+// so the expensive part (two sincos, four quaternion rotations, two foot-point maps: ~95 % of the instructions) runs
+// with all lanes converged whatever line-search branch, L-BFGS iteration, start point or pair each lane is in; only
+// the few dozen flops of minimiser logic diverge.  A lane that finishes a pair takes the next one from a global
+// counter, so no lane waits for the slowest pair of its wave either.  (One thread per pair with the minimiser called
+// as ordinary nested loops spends most of its time with lanes masked off: pairs need 577...1640 objective
+// evaluations, and lanes are in different loops at any moment.)
+//
+// Results are bit-identical to the nested-loop form: the same evaluations at the same points in the same order per
+// lane (checked in the tests).
+#pragma once
+#include "ellipsoid_device.hpp"
+
+namespace mhip {
+namespace lockstep {
+
+using lbfgs::kEps;
+using lbfgs::M;
+using lbfgs::V2;
+
+enum Phase : int {
+  PH_COST_INIT = 0,  // f(x) at the start point
+  PH_G0P, PH_G0M, PH_G1P, PH_G1M,  // central differences: x.a +/- eps, x.b +/- eps
+  PH_COST_AFTER,     // f(x) after a line search
+  PH_LS1_VAL, PH_LS1_DP, PH_LS1_DM,  // bracketing loop of the line search: phi(a), phi(a + eps), phi(a - eps)
+  PH_LS2_VAL, PH_LS2_DP, PH_LS2_DM,  // sectioning loop
+  PH_FINAL,          // re-evaluation at the best point of the nine starts (outputs)
+  PH_IDLE
+};
+
+struct Machine {
+  // find_min (minimize_impl.hpp:407-605 with the defaults of minimize.hpp:42-51)
+  V2 x, g, prev_x, prev_g, dir;
+  double cost, prev_val;
+  bool been_used, stop_used, after_ls;
+  V2 hs[M], hy[M];
+  double hrho[M];
+  int current_size;
+  // line_search (minimize_impl.hpp:233-405)
+  double f0, d0, mu, alpha, last_alpha, last_val, last_val_der, a, b, a_val, b_val, a_val_der, b_val_der, thresh;
+  double ls_first, ls_last, val, fp;
+  int itr;
+  // multistart (EllipsoidEllipsoid.hpp:106-151)
+  int start;
+  double best;
+  V2 best_tp;
+  int phase;
+};
+
+constexpr double kMinDelta = 1e-7, kDerivEps = 1e-7, kMinCost = 1e-8 /* get_relaxed_zero_tolerance<double>() */;
+constexpr double kRho = 0.01, kSigma = 0.9;
+constexpr int kLsMaxIter = 100;
+
+__device__ inline V2 start_point(int s) {
+  const double pi = 3.141592653589793;
+  const double theta_guesses[3] = {0.0, 0.5 * pi, pi};
+  const double phi_guesses[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
+  return V2{theta_guesses[s / 3], phi_guesses[s % 3]};
+}
+
+__device__ inline void begin_start(Machine& m) {
+  m.x = start_point(m.start);
+  m.current_size = 0;
+  m.been_used = false;
+  m.stop_used = false;
+  m.after_ls = false;
+  m.prev_x = V2{0, 0};
+  m.prev_g = V2{0, 0};
+  m.prev_val = 0;
+  m.phase = PH_COST_INIT;
+}
+__device__ inline void begin_pair(Machine& m) {
+  m.start = 0;
+  m.best = __builtin_huge_val();
+  m.best_tp = V2{0.0, 0.0};
+  begin_start(m);
+}
+
+// the point the lane wants evaluated in its current phase
+__device__ inline V2 query_point(const Machine& m) {
+  const double eps = kDerivEps;
+  switch (m.phase) {
+    case PH_COST_INIT:
+    case PH_COST_AFTER: return m.x;
+    case PH_G0P: return V2{m.x.a + eps, m.x.b};
+    case PH_G0M: return V2{m.x.a - eps, m.x.b};
+    case PH_G1P: return V2{m.x.a, m.x.b + eps};
+    case PH_G1M: return V2{m.x.a, m.x.b - eps};
+    case PH_LS1_VAL:
+    case PH_LS2_VAL: return V2{m.x.a + m.alpha * m.dir.a, m.x.b + m.alpha * m.dir.b};
+    case PH_LS1_DP:
+    case PH_LS2_DP: return V2{m.x.a + (m.alpha + eps) * m.dir.a, m.x.b + (m.alpha + eps) * m.dir.b};
+    case PH_LS1_DM:
+    case PH_LS2_DM: return V2{m.x.a + (m.alpha - eps) * m.dir.a, m.x.b + (m.alpha - eps) * m.dir.b};
+    case PH_FINAL: return m.best_tp;
+    default: return V2{0.0, 0.0};
+  }
+}
+
+// top of the sectioning loop (minimize_impl.hpp line_search, second while): next trial alpha
+__device__ inline void sectioning_top(Machine& m) {
+  const double tau2 = 1.0 / 10.0, tau3 = 1.0 / 2.0;
+  ++m.itr;
+  m.ls_first = m.a + tau2 * (m.b - m.a);
+  m.ls_last = m.b - tau3 * (m.b - m.a);
+  m.alpha = m.a + (m.b - m.a) * lbfgs::poly_min_extrap(m.a_val, m.a_val_der, m.b_val, m.b_val_der, 1.0);
+  m.alpha = lbfgs::clampd(m.ls_first, m.ls_last, m.alpha);
+  m.phase = PH_LS2_VAL;
+}
+
+// the line search returned `alpha`: take the step, then gradient and cost at the new point
+__device__ inline void line_search_done(Machine& m, double alpha) {
+  m.x = V2{alpha * m.dir.a + m.x.a, alpha * m.dir.b + m.x.b};
+  m.after_ls = true;
+  m.phase = PH_G0P;
+}
+
+// one start is finished: keep it if it is the best so far, go to the next start or to the final evaluation
+__device__ inline void finish_start(Machine& m) {
+  if (m.cost < m.best) {
+    m.best = m.cost;
+    m.best_tp = m.x;
+  }
+  ++m.start;
+  if (m.start < 9)
+    begin_start(m);
+  else
+    m.phase = PH_FINAL;
+}
+
+// head of find_min's loop: stop tests, L-BFGS direction, line-search set-up (no objective evaluation in here)
+__device__ inline void iteration_head(Machine& m) {
+  if (m.stop_used && fabs(m.cost - m.prev_val) < kMinDelta) return finish_start(m);
+  m.stop_used = true;
+  m.prev_val = m.cost;
+  if (!(m.cost > kMinCost)) return finish_start(m);
+  V2 dir{-m.g.a, -m.g.b};
+  if (!m.been_used) {
+    m.been_used = true;
+  } else {
+    const V2 s{m.x.a - m.prev_x.a, m.x.b - m.prev_x.b}, y{m.g.a - m.prev_g.a, m.g.b - m.prev_g.b};
+    const double temp = lbfgs::dot2(s, y);
+    // Every history access below uses a compile-time index under a predicate: a run-time index would send the
+    // arrays -- and with them the whole machine -- to scratch memory, and the wave would spend its time waiting for it.
+    if (fabs(temp) > kEps) {
+      if (m.current_size < M) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+          if (i == m.current_size) {
+            m.hs[i] = s; m.hy[i] = y; m.hrho[i] = 1.0 / temp;
+          }
+        ++m.current_size;
+      } else {
+#pragma unroll
+        for (int i = 1; i < M; ++i) {
+          m.hs[i - 1] = m.hs[i]; m.hy[i - 1] = m.hy[i]; m.hrho[i - 1] = m.hrho[i];
+        }
+        m.hs[M - 1] = s; m.hy[M - 1] = y; m.hrho[M - 1] = 1.0 / temp;
+      }
+    } else {
+      m.current_size = 0;
+    }
+    if (m.current_size > 0) {
+      double halpha[M];
+      double rho_last = 0.0;
+      V2 y_last{0.0, 0.0};
+#pragma unroll
+      for (int i = M - 1; i >= 0; --i) {
+        halpha[i] = 0.0;
+        if (i < m.current_size) {
+          halpha[i] = m.hrho[i] * lbfgs::dot2(m.hs[i], dir);
+          dir = V2{dir.a - halpha[i] * m.hy[i].a, dir.b - halpha[i] * m.hy[i].b};
+          if (i == m.current_size - 1) {
+            rho_last = m.hrho[i];
+            y_last = m.hy[i];
+          }
+        }
+      }
+      double H0 = 1.0 / rho_last / lbfgs::dot2(y_last, y_last);
+      H0 = lbfgs::clampd(0.001, 1000.0, H0);
+      dir = V2{H0 * dir.a, H0 * dir.b};
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+        if (i < m.current_size) {
+          const double beta = m.hrho[i] * lbfgs::dot2(m.hy[i], dir);
+          dir = V2{dir.a + (halpha[i] - beta) * m.hs[i].a, dir.b + (halpha[i] - beta) * m.hs[i].b};
+        }
+    }
+  }
+  m.dir = dir;
+  m.prev_x = m.x;
+  m.prev_g = m.g;
+  // line_search(f, x, dir, cost, dot(g, dir), 0.01, 0.9, min_allowable_cost, 100, eps): the part before its first loop
+  m.f0 = m.cost;
+  m.d0 = lbfgs::dot2(m.g, dir);
+  if (fabs(m.d0) <= fabs(m.f0) * kEps) return line_search_done(m, 0);
+  if (m.f0 <= kMinCost) return line_search_done(m, 0);
+  m.mu = (kMinCost - m.f0) / (kRho * m.d0);
+  double alpha = 1;
+  if (m.mu < 0) alpha = -alpha;
+  m.alpha = lbfgs::clampd(0.0, 0.65 * m.mu, alpha);
+  m.last_alpha = 0;
+  m.last_val = m.f0;
+  m.last_val_der = m.d0;
+  m.thresh = fabs(kSigma * m.d0);
+  m.itr = 1;  // ++itr at the top of the first loop
+  m.phase = PH_LS1_VAL;
+}
+
+// feeds the objective value at query_point(m) to the machine; returns true when the pair is complete (PH_FINAL done)
+__device__ inline bool advance(Machine& m, double fv) {
+  const double eps = kDerivEps;
+  switch (m.phase) {
+    case PH_COST_INIT:
+      m.cost = fv;
+      m.phase = PH_G0P;
+      return false;
+    case PH_G0P:
+      m.fp = fv;
+      m.phase = PH_G0M;
+      return false;
+    case PH_G0M:
+      m.g.a = (m.fp - fv) / ((m.x.a + eps) - (m.x.a - eps));
+      m.phase = PH_G1P;
+      return false;
+    case PH_G1P:
+      m.fp = fv;
+      m.phase = PH_G1M;
+      return false;
+    case PH_G1M:
+      m.g.b = (m.fp - fv) / ((m.x.b + eps) - (m.x.b - eps));
+      if (m.after_ls) {
+        m.phase = PH_COST_AFTER;
+      } else {
+        iteration_head(m);
+      }
+      return false;
+    case PH_COST_AFTER:
+      m.cost = fv;
+      iteration_head(m);
+      return false;
+    case PH_LS1_VAL:
+    case PH_LS2_VAL:
+      m.val = fv;
+      m.phase += 1;
+      return false;
+    case PH_LS1_DP:
+    case PH_LS2_DP:
+      m.fp = fv;
+      m.phase += 1;
+      return false;
+    case PH_LS1_DM: {
+      const double val = m.val, alpha = m.alpha;
+      const double val_der = (m.fp - fv) / ((alpha + eps) - (alpha - eps));
+      const double tau1a = 1.4, tau1b = 9;
+      if (val <= kMinCost) {
+        line_search_done(m, alpha);
+        return false;
+      }
+      if (val > m.f0 + kRho * alpha * m.d0 || val >= m.last_val) {
+        m.a_val = m.last_val; m.a_val_der = m.last_val_der; m.b_val = val; m.b_val_der = val_der;
+        m.a = m.last_alpha; m.b = alpha;
+        sectioning_top(m);
+        return false;
+      }
+      if (fabs(val_der) <= m.thresh) {
+        line_search_done(m, alpha);
+        return false;
+      }
+      if (m.last_alpha == alpha || m.itr >= kLsMaxIter) {
+        line_search_done(m, alpha);
+        return false;
+      }
+      if (val_der >= 0) {
+        m.a_val = val; m.a_val_der = val_der; m.b_val = m.last_val; m.b_val_der = m.last_val_der;
+        m.a = alpha; m.b = m.last_alpha;
+        sectioning_top(m);
+        return false;
+      }
+      const double temp = alpha;
+      double first, last;
+      if (m.mu > 0) {
+        first = dmin(m.mu, alpha + tau1a * (alpha - m.last_alpha));
+        last = dmin(m.mu, alpha + tau1b * (alpha - m.last_alpha));
+      } else {
+        first = dmax(m.mu, alpha + tau1a * (alpha - m.last_alpha));
+        last = dmax(m.mu, alpha + tau1b * (alpha - m.last_alpha));
+      }
+      double na;
+      if (m.last_alpha < alpha)
+        na = m.last_alpha + (alpha - m.last_alpha) * lbfgs::poly_min_extrap(m.last_val, m.last_val_der, val, val_der, 1e10);
+      else
+        na = alpha + (m.last_alpha - alpha) * lbfgs::poly_min_extrap(val, val_der, m.last_val, m.last_val_der, 1e10);
+      m.alpha = lbfgs::clampd(first, last, na);
+      m.last_alpha = temp;
+      m.last_val = val;
+      m.last_val_der = val_der;
+      ++m.itr;
+      m.phase = PH_LS1_VAL;
+      return false;
+    }
+    case PH_LS2_DM: {
+      const double val = m.val, alpha = m.alpha;
+      const double val_der = (m.fp - fv) / ((alpha + eps) - (alpha - eps));
+      if (val <= kMinCost || m.itr >= kLsMaxIter) {
+        line_search_done(m, alpha);
+        return false;
+      }
+      if (m.a == m.ls_first || m.b == m.ls_last) {
+        line_search_done(m, m.b);
+        return false;
+      }
+      const double max_possible_alpha = dmax(fabs(m.a), fabs(m.b));
+      if (fabs(max_possible_alpha * m.d0) <= fabs(m.f0) * kEps) {
+        line_search_done(m, alpha);
+        return false;
+      }
+      if (val > m.f0 + kRho * alpha * m.d0 || val >= m.a_val) {
+        m.b = alpha; m.b_val = val; m.b_val_der = val_der;
+      } else {
+        if (fabs(val_der) <= m.thresh) {
+          line_search_done(m, alpha);
+          return false;
+        }
+        if ((m.b - m.a) * val_der >= 0) {
+          m.b = m.a; m.b_val = m.a_val; m.b_val_der = m.a_val_der;
+        }
+        m.a = alpha; m.a_val = val; m.a_val_der = val_der;
+      }
+      sectioning_top(m);
+      return false;
+    }
+    case PH_FINAL:
+      m.phase = PH_IDLE;
+      return true;
+    default:
+      return false;
+  }
+}
+
+}  // namespace lockstep
+}  // namespace mhip

@@ -1,5 +1,5 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0, ".")
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mundy_amd import ops
 rng = np.random.default_rng(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
