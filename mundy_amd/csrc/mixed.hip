@@ -8,7 +8,9 @@
 // S-E and R-E have no reference implementation (empty stubs SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp): build
 // extensions, parity unpinned (see the oracle).  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
 // (r,-,-) / (r,L,-) / (r1,r2,r3).
-#include "ellipsoid_device.hpp"
+#include <cstdlib>
+
+#include "ellipsoid_lockstep.hpp"
 
 namespace mhip {
 
@@ -175,8 +177,87 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   }
 }
 
+// The three minimisation classes (S-E, R-E, E-E) in lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one
+// lane per pair of the class, objective evaluations converged, lanes refilled from a per-class counter.  Same
+// arithmetic per lane as the nested-loop branches of k_contact_class above, which stay as the cross-check.
+template <int CLS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
+    k_contact_class_lockstep(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
+                             const int2* __restrict__ pairs, const int32_t* __restrict__ kind,
+                             const double* __restrict__ center, const double* __restrict__ quat,
+                             const double* __restrict__ shape, MixedOut out, unsigned long long* __restrict__ counter) {
+  static_assert(CLS == 2 || CLS == 4 || CLS == 5, "lockstep kernels exist for the minimisation classes only");
+  const int32_t beg = class_start[CLS], end = class_start[CLS + 1];
+  const size_t n = static_cast<size_t>(end - beg);
+  const int lane = threadIdx.x & 63;
+  lockstep::Machine m;
+  m.phase = lockstep::PH_IDLE;
+  BodyD A{}, B{};
+  bool swapped = false;
+  size_t k = 0;
+  bool active = false, need = true;
+  for (;;) {
+    const unsigned long long want = __ballot(need);
+    if (want) {
+      const int leader = __ffsll(static_cast<long long>(want)) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(want)));
+      base = __shfl(base, leader, 64);
+      if (need) {
+        const size_t idx = base + __popcll(want & ((1ull << lane) - 1ull));
+        need = false;
+        active = idx < n;
+        if (active) {
+          k = static_cast<size_t>(order[beg + idx]);
+          const int2 ij = pairs[k];
+          const BodyD bi = load_body(kind, center, quat, shape, ij.x), bj = load_body(kind, center, quat, shape, ij.y);
+          swapped = bi.kind > bj.kind;
+          A = swapped ? bj : bi;
+          B = swapped ? bi : bj;
+          lockstep::begin_pair(m);
+        }
+      }
+    }
+    if (!__any(active)) break;
+    V3 n1{0, 0, 0}, f1{0, 0, 0}, f2{0, 0, 0};
+    double fv = 0.0;
+    if (active) {
+      const lbfgs::V2 tp = lockstep::query_point(m);
+      double st, ct, sp, cp;
+      sincos(tp.a, &st, &ct);
+      sincos(tp.b, &sp, &cp);
+      n1 = V3{st * cp, st * sp, ct};
+      const EllipsoidD elB{B.c, B.q, B.s};
+      V3 sv;
+      if (CLS == 2) {         // point - ellipsoid: n1 is the ellipsoid's outward normal, f1 its foot point
+        f1 = normal_to_foot_point(n1, elB);
+        fv = dist_point_point(f1, A.c, sv);
+      } else if (CLS == 4) {  // rod support point against the ellipsoid's foot point for the opposite normal
+        f1 = rod_support(A, n1);
+        f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, elB);
+        fv = dist_point_point(f1, f2, sv);
+      } else {                // ellipsoid - ellipsoid
+        f1 = normal_to_foot_point(n1, EllipsoidD{A.c, A.q, A.s});
+        f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, elB);
+        fv = dist_point_point(f1, f2, sv);
+      }
+    }
+    if (active && lockstep::advance(m, fv)) {
+      const V3 ci = swapped ? B.c : A.c, cj = swapped ? A.c : B.c;  // centres in the list's (i, j) order
+      if (CLS == 2) {
+        const double d = dot(A.c - f1, n1);
+        store_contact(out, k, swapped, d - A.s.x, V3{-n1.x, -n1.y, -n1.z}, A.c, f1, ci, cj);
+      } else {
+        store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, ci, cj);
+      }
+      active = false;
+      need = true;
+    }
+  }
+}
+
 struct MixedScratch {
-  DeviceBuffer cls, flags, pos, order, start, scanws;
+  DeviceBuffer cls, flags, pos, order, start, scanws, counters;
   int32_t* host = nullptr;
 };
 MixedScratch& mixed_scratch() {
@@ -237,9 +318,19 @@ int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, cons
   CLASS(0, kBlock, gs);
   CLASS(1, kBlock, gs);
   CLASS(3, kBlock, gs);
-  CLASS(2, 64, ge);
-  CLASS(4, 64, ge);
-  CLASS(5, 64, ge);
+  if (getenv("MHIP_ELLIPSOID_NESTED")) {  // nested-loop minimisers: A/B and bit-for-bit cross-check
+    CLASS(2, 64, ge);
+    CLASS(4, 64, ge);
+    CLASS(5, 64, ge);
+  } else {
+    if (int e = ms.counters.reserve(64)) return e;
+    unsigned long long* cnt = ms.counters.as<unsigned long long>();
+    MHIP_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), s));
+    const unsigned gl = static_cast<unsigned>(c / 64 + 1 > 2048 ? 2048 : c / 64 + 1);  // persistent waves
+    k_contact_class_lockstep<2><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 0);
+    k_contact_class_lockstep<4><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 1);
+    k_contact_class_lockstep<5><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 2);
+  }
 #undef CLASS
   MHIP_LAUNCH_CHECK();
   if (class_counts) {

@@ -78,3 +78,28 @@ def test_extension_classes_on_sphere_like_bodies(ops):
         np.testing.assert_allclose(host(out["sep"]), dist - rs - re, atol=1e-4, rtol=0)
         nexp = (c[n:] - c[:n]) / dist[:, None]
         np.testing.assert_allclose(host(out["normal"]), nexp, atol=5e-3)
+
+
+def test_mixed_lockstep_classes_are_bitwise_the_nested_minimisers(ops):
+    # S-E, R-E and E-E contacts come from lockstep state-machine kernels; the nested-loop branches stay in the library
+    # behind MHIP_ELLIPSOID_NESTED as the cross-check: identical bits for every output of every pair
+    import os
+    import torch
+    from gpu_util import dev
+    from mundy_amd import synth
+    b = synth.mixed_bodies(9000, volume_fraction=0.3, seed=5)
+    dk, dc, dq, ds = dev(b["kind"]), dev(b["center"]), dev(b["quat"]), dev(b["shape"])
+    aabb, brad = ops.compute_aabb_mixed(dk, dc, dq, ds)
+    links = ops.GenNeighborLinks().set_search_kind(ops.SEARCH_AABB).set_search_buffer(0.1).concretize()
+    links.generate(aabb, dc, brad)
+    os.environ["MHIP_ELLIPSOID_NESTED"] = "1"
+    try:
+        nested = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True)
+    finally:
+        os.environ.pop("MHIP_ELLIPSOID_NESTED", None)
+    lock = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True)
+    assert nested["class_counts"] == lock["class_counts"]
+    assert min(lock["class_counts"][k] for k in ("SE", "RE", "EE")) > 300
+    for key in ("sep", "normal", "cp1", "cp2", "ra", "rb"):
+        assert torch.equal(nested[key], lock[key]), key
+    links.close()
