@@ -74,10 +74,13 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
 struct EEInput {  // where a lane finds pair k
   const int2* pairs;                            // neighbour-list form: both ellipsoids come from one body table ...
   const double *c1, *q1, *r1, *c2, *q2, *r2;    // ... or element-wise over two tables (pairs == nullptr)
+  const double* point;                          // POINT problems: point k against ellipsoid k of (c1, q1, r1)
 };
 struct EEOutput {
   double *dist, *cp1, *cp2, *n1, *n2, *ra, *rb;  // any may be null
 };
+// POINT = false: ellipsoid-ellipsoid (EllipsoidEllipsoid.hpp:106-151); true: point-ellipsoid (PointEllipsoid.hpp:94-135)
+template <bool POINT>
 __global__ void __launch_bounds__(kEllBlock) ELL_OCC
     k_ellipsoid_pairs_lockstep(size_t n, EEInput in, EEOutput out, unsigned long long* __restrict__ counter) {
   const int lane = threadIdx.x & 63;
@@ -99,7 +102,10 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
         need = false;
         active = k < n;
         if (active) {
-          if (in.pairs) {
+          if (POINT) {
+            e1 = load_ellipsoid(in.c1, in.q1, in.r1, k);
+            e2.c = load3(in.point, k);  // the point rides in e2's centre
+          } else if (in.pairs) {
             const int2 ij = in.pairs[k];
             e1 = load_ellipsoid(in.c1, in.q1, in.r1, ij.x);
             e2 = load_ellipsoid(in.c1, in.q1, in.r1, ij.y);
@@ -122,13 +128,13 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
       sincos(tp.b, &sp, &cp);
       n1 = V3{st * cp, st * sp, ct};
       f1 = normal_to_foot_point(n1, e1);
-      f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, e2);
+      f2 = POINT ? e2.c : normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, e2);
       V3 sep;
       fv = dist_point_point(f1, f2, sep);
     }
     // each lane's minimiser consumes its value (the diverging part: a few dozen flops)
     if (active && lockstep::advance(m, fv)) {  // that was the evaluation at the best of the nine starts
-      if (out.dist) out.dist[k] = dot(f2 - f1, n1);
+      if (out.dist) out.dist[k] = dot(f2 - f1, n1);  // POINT: dot(point - closest, normal)
       if (out.n1) store3(out.n1, k, n1);
       if (out.n2) store3(out.n2, k, V3{-n1.x, -n1.y, -n1.z});
       if (out.cp1) store3(out.cp1, k, f1);
@@ -155,7 +161,10 @@ int launch_ellipsoid_lockstep(size_t n, const EEInput& in, const EEOutput& out, 
   MHIP_HIP(hipMemsetAsync(es.counter.ptr, 0, sizeof(unsigned long long), s));
   const size_t waves = (n + 63) / 64;
   const unsigned grid = static_cast<unsigned>(waves < 4096 ? waves : 4096);  // 256 CUs x 4 SIMDs x up to 4 waves
-  k_ellipsoid_pairs_lockstep<<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
+  if (in.point)
+    k_ellipsoid_pairs_lockstep<true><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
+  else
+    k_ellipsoid_pairs_lockstep<false><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -177,7 +186,7 @@ int mhip_distance_ellipsoid_ellipsoid(size_t n, const double* c1, const double* 
     MHIP_LAUNCH_CHECK();
     return MHIP_SUCCESS;
   }
-  return launch_ellipsoid_lockstep(n, EEInput{nullptr, c1, q1, r1, c2, q2, r2},
+  return launch_ellipsoid_lockstep(n, EEInput{nullptr, c1, q1, r1, c2, q2, r2, nullptr},
                                    EEOutput{dist, cp1, cp2, n1, n2, nullptr, nullptr}, as_stream(stream));
 }
 
@@ -185,10 +194,15 @@ int mhip_distance_point_ellipsoid(size_t n, const double* p, const double* c, co
                                   double* dist, double* cp, double* normal, mhip_stream_t stream) {
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(p && c && q && r, MHIP_ERR_INVALID_ARGUMENT, "point / ellipsoid arrays must not be null");
-  k_dist_point_ellipsoid<<<grid_exact(n, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(n, p, c, q, r, dist, cp,
-                                                                                        normal);
-  MHIP_LAUNCH_CHECK();
-  return MHIP_SUCCESS;
+  if (getenv("MHIP_ELLIPSOID_NESTED")) {
+    k_dist_point_ellipsoid<<<grid_exact(n, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(n, p, c, q, r, dist, cp,
+                                                                                          normal);
+    MHIP_LAUNCH_CHECK();
+    return MHIP_SUCCESS;
+  }
+  // closest point = the ellipsoid's foot point (cp1 slot), normal = its outward normal there (n1 slot)
+  return launch_ellipsoid_lockstep(n, EEInput{nullptr, c, q, r, nullptr, nullptr, nullptr, p},
+                                   EEOutput{dist, cp, nullptr, normal, nullptr, nullptr, nullptr}, as_stream(stream));
 }
 
 int mhip_contact_ellipsoids(size_t c, const int32_t* pairs, const double* center, const double* quat,

@@ -103,6 +103,12 @@ def test_lockstep_kernel_is_bitwise_the_nested_loop_minimiser(ops):
         nested, lock = both(lambda: ops.distance_ellipsoid_ellipsoid(*a, *b))
         for key in nested:
             assert torch.equal(nested[key], lock[key]), (n, key)
+    for n in (1, 100, 30_011):   # distance(Point, Ellipsoid) through the same machine
+        e = ell(n)
+        pts = dev(rng.uniform(-1, 5, (n, 3)))
+        nested, lock = both(lambda: ops.distance_point_ellipsoid(pts, *e))
+        for x, y in zip(nested, lock):
+            assert torch.equal(x, y), n
     c, q, r = ell(3000)
     pairs = dev(np.stack([rng.integers(0, 3000, 20000), rng.integers(0, 3000, 20000)], 1).astype(np.int32))
     nested, lock = both(lambda: ops.contact_ellipsoids(pairs, c, q, r))
