@@ -9,10 +9,10 @@
 namespace mhip {
 
 constexpr int kEllBlock = 64;
-// Register budget of the lockstep kernel (10^6 pairs, MI355X): with the minimiser's state -- L-BFGS history included --
-// in registers under compile-time indices it needs one wave per SIMD's worth of registers and no scratch memory:
-// 9.9 * 10^6 pairs/s; forced to two waves it spills 236 B per lane (8.9), to three 632 B (3.3).  (The nested-loop
-// kernels below, kept as the bit-for-bit cross-check, ran 4.6 / 5.6 / 5.3 / 4.5 * 10^6 pairs/s at 1 / 2 / 3 / 4 waves.)
+// Resources of the lockstep kernel (10^6 pairs, MI355X): ~200 VGPRs, no scratch, 30 KB of LDS per wave for the L-BFGS
+// history ring (five waves per CU): 1.2 * 10^7 pairs/s.  With the history in registers under compile-time indices:
+// 9.9 * 10^6 at one wave per SIMD, 8.9 at two (236 B of spills), 3.3 at three.  (The nested-loop kernels below, kept as
+// the bit-for-bit cross-check, ran 4.6 / 5.6 / 5.3 / 4.5 * 10^6 pairs/s at 1 / 2 / 3 / 4 waves.)
 #ifndef ELL_WAVES
 #define ELL_WAVES 1
 #endif
@@ -84,6 +84,8 @@ template <bool POINT>
 __global__ void __launch_bounds__(kEllBlock) ELL_OCC
     k_ellipsoid_pairs_lockstep(size_t n, EEInput in, EEOutput out, unsigned long long* __restrict__ counter) {
   const int lane = threadIdx.x & 63;
+  __shared__ double history_tile[lockstep::kHistorySlots][64];  // one column per lane (workgroup = one wave)
+  const lockstep::History hist{&history_tile[0][threadIdx.x & 63]};
   lockstep::Machine m;
   m.phase = lockstep::PH_IDLE;
   EllipsoidD e1{}, e2{};
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
       fv = dist_point_point(f1, f2, sep);
     }
     // each lane's minimiser consumes its value (the diverging part: a few dozen flops)
-    if (active && lockstep::advance(m, fv)) {  // that was the evaluation at the best of the nine starts
+    if (active && lockstep::advance(m, hist, fv)) {  // that was the evaluation at the best of the nine starts
       if (out.dist) out.dist[k] = dot(f2 - f1, n1);  // POINT: dot(point - closest, normal)
       if (out.n1) store3(out.n1, k, n1);
       if (out.n2) store3(out.n2, k, V3{-n1.x, -n1.y, -n1.z});

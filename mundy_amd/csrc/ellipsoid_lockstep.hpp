@@ -38,9 +38,7 @@ struct Machine {
   V2 x, g, prev_x, prev_g, dir;
   double cost, prev_val;
   bool been_used, stop_used, after_ls;
-  V2 hs[M], hy[M];
-  double hrho[M];
-  int current_size;
+  int current_size, ring_head;  // the L-BFGS history itself lives in LDS (History below), as a ring buffer
   // line_search (minimize_impl.hpp:233-405)
   double f0, d0, mu, alpha, last_alpha, last_val, last_val_der, a, b, a_val, b_val, a_val_der, b_val_der, thresh;
   double ls_first, ls_last, val, fp;
@@ -50,6 +48,21 @@ struct Machine {
   double best;
   V2 best_tp;
   int phase;
+};
+
+// The lane's column of the workgroup's history tile: M entries of (s.a, s.b, y.a, y.b, rho) plus the alpha_i scratch
+// of the two-loop recursion, laid out [slot][lane] so a wave's access to one slot is conflict-free.  Kept in LDS
+// rather than registers because it is indexed at run time (a ring buffer): with compile-time indices under predicates
+// the bookkeeping cost ~1000 instructions per round, executed by the wave whenever ANY lane was in that phase.
+constexpr int kHistorySlots = 6 * M;
+struct History {
+  double* col;  // &tile[0][lane]
+  __device__ double& sa(int i) const { return col[(0 * M + i) * 64]; }
+  __device__ double& sb(int i) const { return col[(1 * M + i) * 64]; }
+  __device__ double& ya(int i) const { return col[(2 * M + i) * 64]; }
+  __device__ double& yb(int i) const { return col[(3 * M + i) * 64]; }
+  __device__ double& rho(int i) const { return col[(4 * M + i) * 64]; }
+  __device__ double& alpha(int i) const { return col[(5 * M + i) * 64]; }
 };
 
 constexpr double kMinDelta = 1e-7, kDerivEps = 1e-7, kMinCost = 1e-8 /* get_relaxed_zero_tolerance<double>() */;
@@ -66,6 +79,7 @@ __device__ inline V2 start_point(int s) {
 __device__ inline void begin_start(Machine& m) {
   m.x = start_point(m.start);
   m.current_size = 0;
+  m.ring_head = 0;
   m.been_used = false;
   m.stop_used = false;
   m.after_ls = false;
@@ -134,7 +148,7 @@ __device__ inline void finish_start(Machine& m) {
 }
 
 // head of find_min's loop: stop tests, L-BFGS direction, line-search set-up (no objective evaluation in here)
-__device__ inline void iteration_head(Machine& m) {
+__device__ inline void iteration_head(Machine& m, const History& h) {
   if (m.stop_used && fabs(m.cost - m.prev_val) < kMinDelta) return finish_start(m);
   m.stop_used = true;
   m.prev_val = m.cost;
@@ -145,51 +159,43 @@ __device__ inline void iteration_head(Machine& m) {
   } else {
     const V2 s{m.x.a - m.prev_x.a, m.x.b - m.prev_x.b}, y{m.g.a - m.prev_g.a, m.g.b - m.prev_g.b};
     const double temp = lbfgs::dot2(s, y);
-    // Every history access below uses a compile-time index under a predicate: a run-time index would send the
-    // arrays -- and with them the whole machine -- to scratch memory, and the wave would spend its time waiting for it.
+    // logical entry i (0 = oldest) sits in ring slot (ring_head + i) mod M
     if (fabs(temp) > kEps) {
+      int slot;
       if (m.current_size < M) {
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-          if (i == m.current_size) {
-            m.hs[i] = s; m.hy[i] = y; m.hrho[i] = 1.0 / temp;
-          }
+        slot = m.ring_head + m.current_size;
+        if (slot >= M) slot -= M;
         ++m.current_size;
-      } else {
-#pragma unroll
-        for (int i = 1; i < M; ++i) {
-          m.hs[i - 1] = m.hs[i]; m.hy[i - 1] = m.hy[i]; m.hrho[i - 1] = m.hrho[i];
-        }
-        m.hs[M - 1] = s; m.hy[M - 1] = y; m.hrho[M - 1] = 1.0 / temp;
+      } else {  // full: the oldest entry is overwritten and the ring advances (the reference shifts the arrays)
+        slot = m.ring_head;
+        m.ring_head = (m.ring_head + 1 == M) ? 0 : m.ring_head + 1;
       }
+      h.sa(slot) = s.a; h.sb(slot) = s.b; h.ya(slot) = y.a; h.yb(slot) = y.b; h.rho(slot) = 1.0 / temp;
     } else {
       m.current_size = 0;
+      m.ring_head = 0;
     }
     if (m.current_size > 0) {
-      double halpha[M];
-      double rho_last = 0.0;
-      V2 y_last{0.0, 0.0};
-#pragma unroll
-      for (int i = M - 1; i >= 0; --i) {
-        halpha[i] = 0.0;
-        if (i < m.current_size) {
-          halpha[i] = m.hrho[i] * lbfgs::dot2(m.hs[i], dir);
-          dir = V2{dir.a - halpha[i] * m.hy[i].a, dir.b - halpha[i] * m.hy[i].b};
-          if (i == m.current_size - 1) {
-            rho_last = m.hrho[i];
-            y_last = m.hy[i];
-          }
-        }
+      for (int i = m.current_size - 1; i >= 0; --i) {
+        int p = m.ring_head + i;
+        if (p >= M) p -= M;
+        const double al = h.rho(p) * lbfgs::dot2(V2{h.sa(p), h.sb(p)}, dir);
+        h.alpha(i) = al;
+        dir = V2{dir.a - al * h.ya(p), dir.b - al * h.yb(p)};
       }
-      double H0 = 1.0 / rho_last / lbfgs::dot2(y_last, y_last);
+      int pl = m.ring_head + m.current_size - 1;
+      if (pl >= M) pl -= M;
+      const V2 y_last{h.ya(pl), h.yb(pl)};
+      double H0 = 1.0 / h.rho(pl) / lbfgs::dot2(y_last, y_last);
       H0 = lbfgs::clampd(0.001, 1000.0, H0);
       dir = V2{H0 * dir.a, H0 * dir.b};
-#pragma unroll
-      for (int i = 0; i < M; ++i)
-        if (i < m.current_size) {
-          const double beta = m.hrho[i] * lbfgs::dot2(m.hy[i], dir);
-          dir = V2{dir.a + (halpha[i] - beta) * m.hs[i].a, dir.b + (halpha[i] - beta) * m.hs[i].b};
-        }
+      for (int i = 0; i < m.current_size; ++i) {
+        int p = m.ring_head + i;
+        if (p >= M) p -= M;
+        const double beta = h.rho(p) * lbfgs::dot2(V2{h.ya(p), h.yb(p)}, dir);
+        const double al = h.alpha(i);
+        dir = V2{dir.a + (al - beta) * h.sa(p), dir.b + (al - beta) * h.sb(p)};
+      }
     }
   }
   m.dir = dir;
@@ -213,7 +219,7 @@ __device__ inline void iteration_head(Machine& m) {
 }
 
 // feeds the objective value at query_point(m) to the machine; returns true when the pair is complete (PH_FINAL done)
-__device__ inline bool advance(Machine& m, double fv) {
+__device__ inline bool advance(Machine& m, const History& h, double fv) {
   const double eps = kDerivEps;
   switch (m.phase) {
     case PH_COST_INIT:
@@ -237,12 +243,12 @@ __device__ inline bool advance(Machine& m, double fv) {
       if (m.after_ls) {
         m.phase = PH_COST_AFTER;
       } else {
-        iteration_head(m);
+        iteration_head(m, h);
       }
       return false;
     case PH_COST_AFTER:
       m.cost = fv;
-      iteration_head(m);
+      iteration_head(m, h);
       return false;
     case PH_LS1_VAL:
     case PH_LS2_VAL:

@@ -190,6 +190,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
   const int32_t beg = class_start[CLS], end = class_start[CLS + 1];
   const size_t n = static_cast<size_t>(end - beg);
   const int lane = threadIdx.x & 63;
+  __shared__ double history_tile[lockstep::kHistorySlots][64];  // one column per lane (workgroup = one wave)
+  const lockstep::History hist{&history_tile[0][threadIdx.x & 63]};
   lockstep::Machine m;
   m.phase = lockstep::PH_IDLE;
   BodyD A{}, B{};
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
         fv = dist_point_point(f1, f2, sv);
       }
     }
-    if (active && lockstep::advance(m, fv)) {
+    if (active && lockstep::advance(m, hist, fv)) {
       const V3 ci = swapped ? B.c : A.c, cj = swapped ? A.c : B.c;  // centres in the list's (i, j) order
       if (CLS == 2) {
         const double d = dot(A.c - f1, n1);
