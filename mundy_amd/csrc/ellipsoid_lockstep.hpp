@@ -65,6 +65,31 @@ struct History {
   __device__ double& alpha(int i) const { return col[(5 * M + i) * 64]; }
 };
 
+// Per-pair constants of the objective, hoisted out of the ~900 evaluations a pair needs.  qrot(q, v) computes
+// 1 / |q|^2 and the inverse quaternion on every call; both depend on the body only.  The values below are produced by
+// the very expressions qrot uses, so the framed foot-point map returns the same bits as normal_to_foot_point.
+struct Frame {
+  Quat q, q_inv;    // lab <- body:  (q (0, v)) q_inv
+  Quat qc, qc_inv;  // body <- lab:  (conj(q) (0, v)) conj(q)_inv
+};
+__device__ inline Frame make_frame(const Quat& q) {
+  const double inv_n2 = 1.0 / (q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  const Quat qc{q.w, -q.x, -q.y, -q.z};
+  const double inv_n2c = 1.0 / (qc.w * qc.w + qc.x * qc.x + qc.y * qc.y + qc.z * qc.z);
+  return Frame{q, Quat{q.w * inv_n2, -q.x * inv_n2, -q.y * inv_n2, -q.z * inv_n2}, qc,
+               Quat{qc.w * inv_n2c, -qc.x * inv_n2c, -qc.y * inv_n2c, -qc.z * inv_n2c}};
+}
+__device__ inline V3 qrot_framed(const Quat& q, const Quat& q_inv, V3 v) {
+  const Quat vq{0.0, v.x, v.y, v.z};
+  const Quat r = qmul(qmul(q, vq), q_inv);
+  return {r.x, r.y, r.z};
+}
+// map_surface_normal_to_foot_point_on_ellipsoid (Ellipsoid.hpp:462-468) with the frame precomputed
+__device__ inline V3 normal_to_foot_point_framed(V3 lab_n, const EllipsoidD& el, const Frame& f) {
+  const V3 body_n = qrot_framed(f.qc, f.qc_inv, lab_n);
+  return qrot_framed(f.q, f.q_inv, body_normal_to_foot(body_n, el)) + el.c;
+}
+
 constexpr double kMinDelta = 1e-7, kDerivEps = 1e-7, kMinCost = 1e-8 /* get_relaxed_zero_tolerance<double>() */;
 constexpr double kRho = 0.01, kSigma = 0.9;
 constexpr int kLsMaxIter = 100;

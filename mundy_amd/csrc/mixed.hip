@@ -195,6 +195,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
   lockstep::Machine m;
   m.phase = lockstep::PH_IDLE;
   BodyD A{}, B{};
+  lockstep::Frame frA{}, frB{};  // per-pair constants of the objective (see ellipsoid_lockstep.hpp)
+  V3 rod_axis{0, 0, 0};
   bool swapped = false;
   size_t k = 0;
   bool active = false, need = true;
@@ -216,6 +218,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
           swapped = bi.kind > bj.kind;
           A = swapped ? bj : bi;
           B = swapped ? bi : bj;
+          frB = lockstep::make_frame(B.q);
+          if (CLS == 5) frA = lockstep::make_frame(A.q);
+          if (CLS == 4) rod_axis = qrot(A.q, V3{0.0, 0.0, 1.0});  // what rod_support recomputes on every call
           lockstep::begin_pair(m);
         }
       }
@@ -232,15 +237,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
       const EllipsoidD elB{B.c, B.q, B.s};
       V3 sv;
       if (CLS == 2) {         // point - ellipsoid: n1 is the ellipsoid's outward normal, f1 its foot point
-        f1 = normal_to_foot_point(n1, elB);
+        f1 = lockstep::normal_to_foot_point_framed(n1, elB, frB);
         fv = dist_point_point(f1, A.c, sv);
       } else if (CLS == 4) {  // rod support point against the ellipsoid's foot point for the opposite normal
-        f1 = rod_support(A, n1);
-        f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, elB);
+        const double h = 0.5 * A.s.y;  // rod_support(A, n1) with the axis hoisted
+        const double sg = copysign(1.0, dot(n1, rod_axis));
+        f1 = (A.c + (sg * h) * rod_axis) + A.s.x * n1;
+        f2 = lockstep::normal_to_foot_point_framed(V3{-n1.x, -n1.y, -n1.z}, elB, frB);
         fv = dist_point_point(f1, f2, sv);
       } else {                // ellipsoid - ellipsoid
-        f1 = normal_to_foot_point(n1, EllipsoidD{A.c, A.q, A.s});
-        f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, elB);
+        f1 = lockstep::normal_to_foot_point_framed(n1, EllipsoidD{A.c, A.q, A.s}, frA);
+        f2 = lockstep::normal_to_foot_point_framed(V3{-n1.x, -n1.y, -n1.z}, elB, frB);
         fv = dist_point_point(f1, f2, sv);
       }
     }
