@@ -2,7 +2,7 @@
 used; this shows whether another count would have been a fairer (faster) baseline."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from mundy_amd import ops, pipeline, synth
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()

@@ -1,9 +1,10 @@
 """Randomised parity sweep (not part of the test-suite; run on the GPU box): rod systems of varied size / density / buffer /
 dt through the stepper, every stage against the oracle -- neighbour list, separations, normals bit for bit; LCP
 gradient to 20 tol."""
+import os
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from mundy_amd import ops, pipeline, synth
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()

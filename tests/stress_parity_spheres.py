@@ -1,8 +1,9 @@
 """Randomised parity sweep for sphere systems (free space and periodic boxes, bounding-sphere and AABB searches):
 every stage of the stepper against the oracle.  Not part of the test-suite; run on the GPU box."""
+import os
 import sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from mundy_amd import ops, pipeline, synth
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
