@@ -257,6 +257,60 @@ inline std::vector<double> distance(SharedNormalSigned, const std::vector<Sphere
   return dist.download();
 }
 
+struct EllipsoidEllipsoidResult {
+  std::vector<double> distance;
+  std::vector<Point<double>> closest_point1, closest_point2, shared_normal1, shared_normal2;
+};
+// distance(SharedNormalSigned, Ellipsoid, Ellipsoid, cp1, cp2, n1, n2) (EllipsoidEllipsoid.hpp:62-151), element-wise
+inline EllipsoidEllipsoidResult distance(SharedNormalSigned, const std::vector<Ellipsoid<double>>& a,
+                                         const std::vector<Ellipsoid<double>>& b) {
+  if (a.size() != b.size()) throw std::invalid_argument("distance: list sizes differ");
+  const size_t n = a.size();
+  std::vector<double> c1, q1, r1, c2, q2, r2;
+  for (size_t i = 0; i < n; ++i) {
+    detail::push3(c1, a[i].center()); detail::push3(r1, a[i].radii());
+    detail::push3(c2, b[i].center()); detail::push3(r2, b[i].radii());
+    for (int k = 0; k < 4; ++k) { q1.push_back(a[i].orientation()[k]); q2.push_back(b[i].orientation()[k]); }
+  }
+  DeviceVector dc1(c1), dq1(q1), dr1(r1), dc2(c2), dq2(q2), dr2(r2), dist(n), cp1(3 * n), cp2(3 * n), n1(3 * n), n2(3 * n);
+  check(mhip_distance_ellipsoid_ellipsoid(n, dc1.data(), dq1.data(), dr1.data(), dc2.data(), dq2.data(), dr2.data(),
+                                          dist.data(), cp1.data(), cp2.data(), n1.data(), n2.data(), nullptr));
+  auto to_pts = [n](const std::vector<double>& h) {
+    std::vector<Point<double>> p(n);
+    for (size_t i = 0; i < n; ++i) p[i] = Point<double>(h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+    return p;
+  };
+  EllipsoidEllipsoidResult r;
+  r.distance = dist.download();
+  r.closest_point1 = to_pts(cp1.download()); r.closest_point2 = to_pts(cp2.download());
+  r.shared_normal1 = to_pts(n1.download()); r.shared_normal2 = to_pts(n2.download());
+  return r;
+}
+// distance(SharedNormalSigned, Point, Ellipsoid, closest, normal) (PointEllipsoid.hpp:94-135), element-wise
+inline std::vector<double> distance(SharedNormalSigned, const std::vector<Point<double>>& p,
+                                    const std::vector<Ellipsoid<double>>& e,
+                                    std::vector<Point<double>>* closest = nullptr,
+                                    std::vector<Point<double>>* normal = nullptr) {
+  if (p.size() != e.size()) throw std::invalid_argument("distance: list sizes differ");
+  const size_t n = p.size();
+  std::vector<double> pp, c, q, r;
+  for (size_t i = 0; i < n; ++i) {
+    detail::push3(pp, p[i]); detail::push3(c, e[i].center()); detail::push3(r, e[i].radii());
+    for (int k = 0; k < 4; ++k) q.push_back(e[i].orientation()[k]);
+  }
+  DeviceVector dp(pp), dc(c), dq(q), dr(r), dist(n), cp(3 * n), nrm(3 * n);
+  check(mhip_distance_point_ellipsoid(n, dp.data(), dc.data(), dq.data(), dr.data(), dist.data(), cp.data(),
+                                      nrm.data(), nullptr));
+  auto fill = [n](std::vector<Point<double>>* dst, const std::vector<double>& h) {
+    if (!dst) return;
+    dst->resize(n);
+    for (size_t i = 0; i < n; ++i) (*dst)[i] = Point<double>(h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+  };
+  fill(closest, cp.download());
+  fill(normal, nrm.download());
+  return dist.download();
+}
+
 struct SegmentSegmentResult {
   std::vector<double> distance, arch_length1, arch_length2;
   std::vector<Point<double>> closest_point1, closest_point2, sep;

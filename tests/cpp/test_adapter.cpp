@@ -233,6 +233,42 @@ static void test_two_coincident_spheres() {  // UnitTestGenNeighborLinks.cpp:73-
   EXPECT_TRUE((p[0] == 0 && p[1] == 1) || (p[0] == 1 && p[1] == 0));
 }
 
+static void test_ellipsoid_sphere_cases() {
+  // SharedNormalDistanceBetweenEllipsoids.AnalyticalSphereTestCases and ...EllipsoidAndPoint.AnalyticalSphereTestCases
+  // (UnitTestEllipsoidEllipsoid.cpp:65-145): ellipsoids with three equal radii are spheres, tolerance 1e-4
+  std::mt19937_64 rng(7);
+  std::uniform_real_distribution<double> pos(-10.0, 10.0), rad(0.1, 10.0);
+  std::normal_distribution<double> gauss(0.0, 1.0);
+  auto sphere_like = [&]() {
+    double q[4] = {gauss(rng), gauss(rng), gauss(rng), gauss(rng)};
+    const double nn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double r = rad(rng);
+    return geom::Ellipsoid<double>(geom::Point<double>(pos(rng), pos(rng), pos(rng)),
+                                   geom::Quaternion<double>(q[0] / nn, q[1] / nn, q[2] / nn, q[3] / nn),
+                                   geom::Point<double>(r, r, r));
+  };
+  std::vector<geom::Ellipsoid<double>> a, b;
+  std::vector<geom::Point<double>> pts;
+  for (int i = 0; i < 500; ++i) {
+    a.push_back(sphere_like());
+    b.push_back(sphere_like());
+    pts.emplace_back(pos(rng), pos(rng), pos(rng));
+  }
+  const auto r = geom::distance(geom::SharedNormalSigned{}, a, b);
+  std::vector<geom::Point<double>> closest, normal;
+  const auto dp = geom::distance(geom::SharedNormalSigned{}, pts, a, &closest, &normal);
+  for (size_t i = 0; i < a.size(); ++i) {
+    auto len = [](double x, double y, double z) { return std::sqrt(x * x + y * y + z * z); };
+    const auto &ca = a[i].center(), &cb = b[i].center();
+    const double expect = len(cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]) - a[i].radii()[0] - b[i].radii()[0];
+    EXPECT_TRUE(std::fabs(r.distance[i] - expect) <= 1e-4);
+    EXPECT_TRUE(std::fabs(len(r.shared_normal1[i][0], r.shared_normal1[i][1], r.shared_normal1[i][2]) - 1.0) <= 1e-12);
+    EXPECT_TRUE(r.shared_normal2[i][0] == -r.shared_normal1[i][0]);
+    const double expect_p = len(pts[i][0] - ca[0], pts[i][1] - ca[1], pts[i][2] - ca[2]) - a[i].radii()[0];
+    EXPECT_TRUE(std::fabs(dp[i] - expect_p) <= 1e-4);
+  }
+}
+
 static void test_periodic_metrics() {  // UnitTestPeriodicity.cpp:623-660 (MinImageDirectVsPeriodic), restated
   const geom::Point<double> cell(100.0, 100.0, 100.0);
   const auto metric = geom::periodic_metric_from_unit_cell(cell);
@@ -283,6 +319,7 @@ int main() {
   test_segment_kats();
   test_two_coincident_spheres();
   test_periodic_metrics();
+  test_ellipsoid_sphere_cases();
   std::printf("%s (%d failed checks)\n", g_failures ? "FAILED" : "ALL PASSED", g_failures);
   return g_failures;
 }
