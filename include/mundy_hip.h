@@ -394,6 +394,13 @@ int mhip_contact_spheres_triclinic(size_t c, const int32_t* pairs, const double*
  * ---------------------------------------------------------------------------------------------------------------- */
 int mhip_morton_order(size_t n, const double* center, const double* lo /*[host] 3*/, double cell_size, int32_t* perm,
                       mhip_stream_t stream);
+/* The same reordering along any lattice curve given as a table: key_table [device, (2^level)^3 int32, indexed
+ * [ix][iy][iz]] = visiting index of the cell.  With the table of mundy::math::hilbert_3d (mundy/math/src/mundy_math/
+ * Hilbert.hpp:48-83; mundy_amd.distributed.hilbert_key_table generates it with that recursion) this is the Hilbert
+ * order used for the domain decomposition.  Cells: floor((c - lo) / (hi - lo) * 2^level) clamped to the lattice;
+ * ties by index.  level <= 8. */
+int mhip_curve_order(size_t n, const double* center, const double* lo /*[host] 3*/, const double* hi /*[host] 3*/,
+                     int level, const int32_t* key_table, int32_t* perm, mhip_stream_t stream);
 /* dst[k][0..width) = src[perm[k]][0..width)  for rows of `width` doubles */
 int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst, mhip_stream_t stream);
 

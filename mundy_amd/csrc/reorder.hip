@@ -38,6 +38,26 @@ __global__ void __launch_bounds__(kBlock)
     atomicAdd(&hist[m], 1);
   }
 }
+// curve order by table: code = key_table[ix][iy][iz] on a (2^bits)^3 lattice (the Hilbert visiting index of the cell,
+// generated on the host by the recursion of mundy_math/Hilbert.hpp:48-83)
+__global__ void __launch_bounds__(kBlock)
+    k_table_count(size_t n, const double* __restrict__ center, V3 lo, V3 span, int bits,
+                  const int32_t* __restrict__ key_table, unsigned* __restrict__ code, int32_t* __restrict__ hist) {
+  const int ns = 1 << bits, maxc = ns - 1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const V3 c = load3(center, i);
+    const double nsd = static_cast<double>(ns);  // ((c - lo) / span) * ns, the host partitioner's expression
+    double fx = floor((c.x - lo.x) / span.x * nsd), fy = floor((c.y - lo.y) / span.y * nsd),
+           fz = floor((c.z - lo.z) / span.z * nsd);
+    fx = fx < 0.0 ? 0.0 : (fx > maxc ? (double)maxc : fx);  // clamp before the integer conversion
+    fy = fy < 0.0 ? 0.0 : (fy > maxc ? (double)maxc : fy);
+    fz = fz < 0.0 ? 0.0 : (fz > maxc ? (double)maxc : fz);
+    const int ix = static_cast<int>(fx), iy = static_cast<int>(fy), iz = static_cast<int>(fz);
+    const unsigned m = static_cast<unsigned>(key_table[((size_t)ix * ns + iy) * ns + iz]);
+    code[i] = m;
+    atomicAdd(&hist[m], 1);
+  }
+}
 __global__ void __launch_bounds__(kBlock) k_morton_scatter(size_t n, const unsigned* __restrict__ code,
                                                           int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -160,6 +180,36 @@ int mhip_morton_order(size_t n, const double* center, const double* lo, double c
   const V3 l{lo[0], lo[1], lo[2]};
   k_morton_count<<<grid_for(n), kBlock, 0, s>>>(n, center, l, 1.0 / cell_size, bits, rs.code.as<unsigned>(),
                                                rs.hist.as<int32_t>());
+  MHIP_LAUNCH_CHECK();
+  if (int e = exclusive_scan_i32(rs.hist.as<int32_t>(), rs.ptr.as<int32_t>(), ncodes, rs.scanws.ptr, s)) return e;
+  MHIP_HIP(hipMemcpyAsync(rs.hist.ptr, rs.ptr.ptr, (ncodes + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  k_morton_scatter<<<grid_for(n), kBlock, 0, s>>>(n, rs.code.as<unsigned>(), rs.hist.as<int32_t>(), perm);
+  MHIP_LAUNCH_CHECK();
+  k_segment_sort<<<grid_for(ncodes), kBlock, 0, s>>>(ncodes, rs.ptr.as<int32_t>(), perm);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_curve_order(size_t n, const double* center, const double* lo, const double* hi, int level,
+                     const int32_t* key_table, int32_t* perm, mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (center && perm), MHIP_ERR_INVALID_ARGUMENT, "center / perm is null");
+  MHIP_REQUIRE(lo != nullptr && hi != nullptr && key_table != nullptr, MHIP_ERR_INVALID_ARGUMENT,
+               "lo / hi / key_table is null");
+  MHIP_REQUIRE(level >= 1 && level <= 8, MHIP_ERR_INVALID_ARGUMENT, "level must be in [1, 8], got %d", level);
+  MHIP_REQUIRE(hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2], MHIP_ERR_INVALID_ARGUMENT, "empty domain");
+  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
+  if (n == 0) return MHIP_SUCCESS;
+  hipStream_t s = as_stream(stream);
+  const size_t ncodes = size_t(1) << (3 * level);
+  ReorderScratch& rs = reorder_scratch();
+  if (int e = rs.code.reserve(n * sizeof(unsigned))) return e;
+  if (int e = rs.hist.reserve((ncodes + 2) * sizeof(int32_t))) return e;
+  if (int e = rs.ptr.reserve((ncodes + 2) * sizeof(int32_t))) return e;
+  if (int e = rs.scanws.reserve(scan_workspace_bytes(ncodes + 2) + 64)) return e;
+  MHIP_HIP(hipMemsetAsync(rs.hist.ptr, 0, (ncodes + 1) * sizeof(int32_t), s));
+  const V3 l{lo[0], lo[1], lo[2]}, span{hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  k_table_count<<<grid_for(n), kBlock, 0, s>>>(n, center, l, span, level, key_table, rs.code.as<unsigned>(),
+                                              rs.hist.as<int32_t>());
   MHIP_LAUNCH_CHECK();
   if (int e = exclusive_scan_i32(rs.hist.as<int32_t>(), rs.ptr.as<int32_t>(), ncodes, rs.scanws.ptr, s)) return e;
   MHIP_HIP(hipMemcpyAsync(rs.hist.ptr, rs.ptr.ptr, (ncodes + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));

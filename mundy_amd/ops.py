@@ -548,6 +548,18 @@ def morton_order(center, lo, cell_size):
     return perm
 
 
+def curve_order(center, lo, hi, level, key_table):
+    """permutation along a lattice curve given by key_table [2^level]^3 (device int32), e.g. the Hilbert table of
+    mundy_amd.distributed.hilbert_key_table; ties by index"""
+    n = center.shape[0]
+    perm = torch.empty(n, dtype=torch.int32, device=center.device)
+    lop = (C.c_double * 3)(*[float(v) for v in lo])
+    hip = (C.c_double * 3)(*[float(v) for v in hi])
+    capi.check(capi.load().mhip_curve_order(n, _ptr(center, cols=3), lop, hip, int(level),
+                                            _ptr(key_table.reshape(-1), torch.int32), _ptr(perm, torch.int32), _stream()))
+    return perm
+
+
 def gather_rows(perm, src):
     src2 = src if src.dim() == 2 else src.unsqueeze(1)
     dst = torch.empty((perm.shape[0], src2.shape[1]), dtype=src2.dtype, device=src2.device)

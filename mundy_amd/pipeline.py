@@ -94,15 +94,26 @@ class ContactStepper:
         for k, v in snap.items():
             getattr(self, k).copy_(v)
 
-    def reorder_bodies(self, cell_size=None, lo=None):
-        """Z-order (Morton) permutation of all per-body arrays by centre (what the reference's
-        zmorton helpers are advertised for): neighbours in space become neighbours in memory, so every gather of
-        the contact sweeps hits nearby lines.  Returns the permutation (new position k holds old body perm[k])."""
-        if cell_size is None:
-            cell_size = 2.0 * float(self.bounding_radius.max())
+    def reorder_bodies(self, cell_size=None, lo=None, curve="morton", hi=None, level=7):
+        """Space-filling-curve permutation of all per-body arrays by centre (what the reference's zmorton /
+        Hilbert helpers are advertised for): neighbours in space become neighbours in memory, so every gather of the
+        contact sweeps hits nearby lines.  curve = "morton" (lattice of edge cell_size anchored at lo) or "hilbert"
+        (the hilbert_3d order of a (2^level)^3 lattice over [lo, hi]; both give the same sweep times).  Returns the
+        permutation (new position k holds old body perm[k])."""
         if lo is None:
             lo = self.center.min(dim=0).values.tolist() if self.box is None else [0.0, 0.0, 0.0]
-        perm = ops.morton_order(self.center, lo, cell_size)
+        if curve == "hilbert":
+            from . import distributed
+            if hi is None:
+                hi = self.center.max(dim=0).values.tolist() if self.box is None else list(self.box)
+            table = torch.from_numpy(distributed.hilbert_key_table(level).astype("int32")).to(self.center.device)
+            perm = ops.curve_order(self.center, lo, hi, level, table)
+        elif curve == "morton":
+            if cell_size is None:
+                cell_size = 2.0 * float(self.bounding_radius.max())
+            perm = ops.morton_order(self.center, lo, cell_size)
+        else:
+            raise ValueError("curve must be 'morton' or 'hilbert'")
         for name in self._BODY_ARRAYS:
             t = getattr(self, name, None)
             if t is not None:

@@ -154,3 +154,37 @@ def test_steps_with_no_contacts_and_single_bodies(mods, kind):
             assert r.num_contacts == 0 and r.converged and r.num_iters == 0
         assert torch.equal(st.center, c0)
         assert st.op.body_velocity().abs().max().item() == 0.0 if n else True
+
+
+def test_reordering_leaves_the_physics_unchanged(mods, oracle):
+    # Morton and Hilbert reordering are permutations of the bodies: the same contacts (as a set of body pairs mapped
+    # back through the permutation), the same LCP solution to solver tolerance, the same step
+    import torch
+    from gpu_util import dev, host
+    ops, pipeline, synth = mods
+    b = synth.spherocylinders(20_000, seed=3)
+    tol = 1e-6
+
+    def run(curve):
+        st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]),
+                                     dev(b["length"]), search_buffer=0.1, cfg=ops.PGDConfig(max_iters=20000, tol=tol))
+        perm = None
+        if curve:
+            perm = host(st.reorder_bodies(cell_size=3.0, lo=[0.0, 0.0, 0.0], curve=curve, hi=[b["box"]] * 3, level=6))
+        s = st.step()
+        assert s.converged
+        ids = np.arange(20_000) if perm is None else perm.astype(np.int64)
+        p = ids[host(st.links.pairs).astype(np.int64)]
+        p.sort(axis=1)
+        order = np.lexsort((p[:, 1], p[:, 0]))
+        g = host(st.op.apply(st.lam) + st.contacts["sep"])
+        centers = np.empty((20_000, 3))
+        centers[ids] = host(st.center)
+        return p[order], g[order], centers
+
+    p0, g0, c0 = run(None)
+    for curve in ("morton", "hilbert"):
+        p, g, c = run(curve)
+        np.testing.assert_array_equal(p, p0)
+        np.testing.assert_allclose(g, g0, atol=20 * tol)
+        np.testing.assert_allclose(c, c0, atol=1e-4)
