@@ -40,6 +40,9 @@ enum {
 
 const char* mhip_last_error(void);
 int mhip_version(void);
+/* roctx ranges around the stages of the path, named after the reference's functions / Kokkos kernel labels (visible to
+ * rocprofv3 --marker-trace).  Off by default; MHIP_TRACE=1 in the environment enables it too. */
+int mhip_set_tracing(int enable);
 /* Fails with MHIP_ERR_NO_DEVICE when no GPU is visible. [host] out pointers. */
 int mhip_device_info(int* device_count, char* arch_name, size_t arch_name_len);
 

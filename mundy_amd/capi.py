@@ -118,6 +118,7 @@ SIGNATURES = {
     "mhip_contact_spheres_triclinic": [_sz, _vp, _vp, _vp, C.POINTER(_d), _vp, _vp, _vp],
     "mhip_integrate_euler": [_sz, _d, _vp, _vp, _vp, _vp],
     "mhip_morton_order": [_sz, _vp, C.POINTER(_d), _d, _vp, _vp],
+    "mhip_set_tracing": [_i],
     "mhip_curve_order": [_sz, _vp, C.POINTER(_d), C.POINTER(_d), _i, _vp, _vp, _vp],
     "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],
 }

@@ -329,6 +329,7 @@ int mhip_broadphase_destroy(mhip_broadphase_t h) {
 int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* config, size_t n, const double* aabb,
                           const double* center, const double* bounding_radius, size_t* num_pairs,
                           mhip_stream_t stream) {
+  TraceRange trace_range("GenNeighborLinks::generate");
   MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
   MHIP_REQUIRE(config != nullptr && num_pairs != nullptr, MHIP_ERR_INVALID_ARGUMENT, "config / num_pairs is null");
   MHIP_REQUIRE(config->search_kind == MHIP_SEARCH_SPHERES || config->search_kind == MHIP_SEARCH_AABB,

@@ -1458,6 +1458,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
                              const int32_t* pairs, const double* normal, const double* ra, const double* rb,
                              const double* arc_s, const double* arc_t, const double* seg, const double* mob_trans,
                              const double* mob_rot, double dt, const double* priority, mhip_stream_t stream) {
+  TraceRange trace_range("ContactOperator::build");
   MHIP_REQUIRE(handle != nullptr, MHIP_ERR_INVALID_ARGUMENT, "handle is null");
   *handle = nullptr;
   const size_t C = num_constraints, N = num_bodies;
@@ -1642,6 +1643,7 @@ int mhip_contact_op_body_velocity(mhip_contact_op_t op, const double** velocity)
 int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_space* space,
                              const mhip_pgd_config* config, double* x, double* g, double* x_tmp, double* g_tmp,
                              mhip_solve_result* result, mhip_stream_t stream) {
+  TraceRange trace_range("solve_cqpp (fused BBPGD)");
   MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
   if (int e = check_config(config)) return e;
   Space sp;
@@ -1731,6 +1733,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
 int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, double mu,
                                       const mhip_pgd_config* config, double* p, double* g,
                                       mhip_solve_result* result, mhip_stream_t stream) {
+  TraceRange trace_range("solve_friction_contact (extension)");
   MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
   if (int e = check_config(config)) return e;
   MHIP_REQUIRE(config->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF, MHIP_ERR_INVALID_ARGUMENT,
@@ -1820,6 +1823,7 @@ int mhip_solve_small_cqpp_batch(size_t batch, int n, const double* A, const doub
 int mhip_scrap_bbpgd_solve_contact(mhip_contact_op_t op, const double* sep, double max_allowable_overlap,
                                    unsigned max_iterations, double* lam, double* lam_tmp, double* g, double* g_tmp,
                                    mhip_solve_result* result, double* max_speed, mhip_stream_t stream) {
+  TraceRange trace_range("resolve_collisions");
   MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
   const size_t C = op->view.C;
   hipStream_t s = as_stream(stream);

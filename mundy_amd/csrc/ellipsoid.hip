@@ -210,6 +210,7 @@ int mhip_distance_point_ellipsoid(size_t n, const double* p, const double* c, co
 int mhip_contact_ellipsoids(size_t c, const int32_t* pairs, const double* center, const double* quat,
                             const double* radii, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                             double* rb, mhip_stream_t stream) {
+  TraceRange trace_range("distance(Ellipsoid, Ellipsoid)");
   if (c == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(pairs && center && quat && radii, MHIP_ERR_INVALID_ARGUMENT, "pairs / ellipsoid arrays must not be null");
   if (getenv("MHIP_ELLIPSOID_NESTED")) {

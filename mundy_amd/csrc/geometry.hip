@@ -199,6 +199,7 @@ int mhip_compute_aabb_spheres(size_t n, const double* center, const double* radi
 
 int mhip_compute_aabb_spherocylinders(size_t n, const double* center, const double* quat, const double* radius,
                                       const double* length, double* aabb, mhip_stream_t stream) {
+  TraceRange trace_range("compute_aabb");
   REQ_PTR(center); REQ_PTR(quat); REQ_PTR(radius); REQ_PTR(length); REQ_PTR(aabb);
   if (n == 0) return MHIP_SUCCESS;
   k_aabb_spherocylinders<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, center, quat, radius, length, aabb);
@@ -290,6 +291,7 @@ int mhip_distance_segment_segment(size_t n, const double* a0, const double* a1, 
 
 int mhip_contact_spheres(size_t c, const int32_t* pairs, const double* center, const double* radius,
                          const double* box, double* sep, double* normal, mhip_stream_t stream) {
+  TraceRange trace_range("contact_spheres");
   const size_t n = c;
   REQ_PTR(pairs); REQ_PTR(center); REQ_PTR(radius);
   if (c == 0) return MHIP_SUCCESS;
@@ -322,6 +324,7 @@ int mhip_contact_spheres_triclinic(size_t c, const int32_t* pairs, const double*
 int mhip_contact_spherocylinders(size_t c, const int32_t* pairs, const double* seg, const double* center, double* sep,
                                  double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
                                  double* t, mhip_stream_t stream) {
+  TraceRange trace_range("contact_spherocylinders");
   const size_t n = c;
   REQ_PTR(pairs); REQ_PTR(seg);
   MHIP_REQUIRE(center != nullptr || (ra == nullptr && rb == nullptr), MHIP_ERR_INVALID_ARGUMENT,

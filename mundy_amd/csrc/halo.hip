@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_emit(size_t n, Op op, const 
 // count, scan of the tile counts, emit; the total lands in host memory after one synchronisation
 template <class Op>
 int compact(size_t n, const Op& op, size_t* count_out, hipStream_t s) {
+  TraceRange trace_range("filter_view (PrefixSum + ScatterValid)");
   HaloScratch& hs = halo_scratch();
   const size_t ntiles = (n + kCompactTile - 1) / kCompactTile;
   if (int e = hs.ensure(ntiles)) return e;

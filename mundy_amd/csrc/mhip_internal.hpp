@@ -196,6 +196,18 @@ inline int to_space(const mhip_space* s, Space* out) {
 
 // exclusive scan of n int32 counts into out[0..n] (out[n] = total); workspace >= scan_workspace_bytes(n)
 size_t scan_workspace_bytes(size_t n);
+// Host-side trace ranges around the stages of the path (the reference labels its kernels for Kokkos Tools, e.g.
+// "PrefixSum" / "ScatterValid" GenNeighborLinkers.hpp:148,164, "axpby" / "diff_dot" / "reduce_max" convex.hpp:208-283):
+// roctx ranges with the reference's names, visible to rocprofv3 --marker-trace.  Off unless MHIP_TRACE=1 or
+// mhip_set_tracing(1); libroctx64 is looked up at run time, so there is no link dependency.
+struct TraceRange {
+  explicit TraceRange(const char* name);
+  ~TraceRange();
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+  bool pushed;
+};
+
 int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, void* workspace, hipStream_t stream);
 
 }  // namespace mhip

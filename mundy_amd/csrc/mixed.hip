@@ -292,6 +292,7 @@ int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center,
 int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
                        const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                        double* rb, size_t* class_counts, mhip_stream_t stream) {
+  TraceRange trace_range("contact_mixed");
   if (class_counts)
     for (int k = 0; k < 6; ++k) class_counts[k] = 0;
   if (c == 0) return MHIP_SUCCESS;

@@ -161,6 +161,7 @@ extern "C" {
 
 int mhip_morton_order(size_t n, const double* center, const double* lo, double cell_size, int32_t* perm,
                       mhip_stream_t stream) {
+  TraceRange trace_range("zmorton reorder");
   MHIP_REQUIRE(n == 0 || (center && perm), MHIP_ERR_INVALID_ARGUMENT, "center / perm is null");
   MHIP_REQUIRE(lo != nullptr, MHIP_ERR_INVALID_ARGUMENT, "lo is null");
   MHIP_REQUIRE(cell_size > 0.0, MHIP_ERR_INVALID_ARGUMENT, "cell_size must be positive");
@@ -192,6 +193,7 @@ int mhip_morton_order(size_t n, const double* center, const double* lo, double c
 
 int mhip_curve_order(size_t n, const double* center, const double* lo, const double* hi, int level,
                      const int32_t* key_table, int32_t* perm, mhip_stream_t stream) {
+  TraceRange trace_range("hilbert reorder");
   MHIP_REQUIRE(n == 0 || (center && perm), MHIP_ERR_INVALID_ARGUMENT, "center / perm is null");
   MHIP_REQUIRE(lo != nullptr && hi != nullptr && key_table != nullptr, MHIP_ERR_INVALID_ARGUMENT,
                "lo / hi / key_table is null");
@@ -290,6 +292,7 @@ int mhip_shift_image_triclinic(size_t n, const double* cell, const double* p, co
 
 int mhip_integrate_euler(size_t n, double dt, const double* velocity, double* center, double* quat,
                          mhip_stream_t stream) {
+  TraceRange trace_range("integrate");
   MHIP_REQUIRE(n == 0 || (velocity && center), MHIP_ERR_INVALID_ARGUMENT, "velocity / center is null");
   if (n == 0) return MHIP_SUCCESS;
   k_integrate<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, dt, velocity, center, quat);

@@ -1,4 +1,9 @@
 // runtime.hip -- error state, device discovery, plain memory helpers and the shared exclusive scan.
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <initializer_list>
+
 #include "mhip_internal.hpp"
 
 namespace mhip {
@@ -126,6 +131,46 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, void* workspac
   return MHIP_SUCCESS;
 }
 
+struct TraceState {
+  int enabled = -1;  // -1: not decided yet (MHIP_TRACE)
+  void* lib = nullptr;
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+};
+TraceState& trace_state() {
+  static TraceState t;
+  return t;
+}
+TraceRange::TraceRange(const char* name) : pushed(false) {
+  TraceState& t = trace_state();
+  if (t.enabled < 0) {
+    const char* e = getenv("MHIP_TRACE");
+    t.enabled = (e && atoi(e)) ? 1 : 0;
+  }
+  if (!t.enabled) return;
+  if (!t.tried) {
+    t.tried = true;
+    // rocprofv3 listens to the rocprofiler-sdk flavour of roctx; the roctracer one is the fallback
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so",
+                             "libroctx64.so", "/opt/rocm/lib/libroctx64.so"}) {
+      t.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (t.lib) break;
+    }
+    if (t.lib) {
+      t.push = reinterpret_cast<int (*)(const char*)>(dlsym(t.lib, "roctxRangePushA"));
+      t.pop = reinterpret_cast<int (*)()>(dlsym(t.lib, "roctxRangePop"));
+    }
+  }
+  if (t.push && t.pop) {
+    t.push(name);
+    pushed = true;
+  }
+}
+TraceRange::~TraceRange() {
+  if (pushed) trace_state().pop();
+}
+
 }  // namespace mhip
 
 using namespace mhip;
@@ -133,6 +178,10 @@ using namespace mhip;
 extern "C" {
 
 const char* mhip_last_error(void) { return last_error_storage().c_str(); }
+int mhip_set_tracing(int enable) {
+  trace_state().enabled = enable ? 1 : 0;
+  return MHIP_SUCCESS;
+}
 int mhip_version(void) { return 100; }
 
 int mhip_device_info(int* device_count, char* arch_name, size_t arch_name_len) {
