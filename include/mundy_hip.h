@@ -246,6 +246,8 @@ int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, 
  * mhip_bbpgd_solve_contact brackets the k_body / k_constraint launches of every 8th iteration with HIP events on
  * `stream` and accumulates their device durations.  get_profile returns the totals in milliseconds and the number of timed iterations
  * (sampled launches of each kernel) since profiling was enabled.  All out pointers [host]. */
+/* sizes the operator was created with (either pointer may be NULL) */
+int mhip_contact_op_sizes(mhip_contact_op_t handle, size_t* num_constraints, size_t* num_bodies);
 int mhip_contact_op_set_profiling(mhip_contact_op_t handle, int enable);
 int mhip_contact_op_get_profile(mhip_contact_op_t handle, double* body_ms, double* constraint_ms, size_t* iterations);
 /* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate (valid in stream order after
@@ -406,6 +408,82 @@ int mhip_curve_order(size_t n, const double* center, const double* lo /*[host] 3
                      int level, const int32_t* key_table, int32_t* perm, mhip_stream_t stream);
 /* dst[k][0..width) = src[perm[k]][0..width)  for rows of `width` doubles */
 int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst, mhip_stream_t stream);
+
+
+/* ----------------------------------------------------------------------------------------------------------------
+ * Multi-GPU transport and the domain-decomposed solve driven from C++.
+ *
+ * Replaces, on the reference side: the MPI communicator handed to stk::search::coarse_search and change_ghosting
+ * (mundy/mesh/src/mundy_mesh/GenNeighborLinkers.hpp:658, :687-711), and per BBPGD iteration stk::all_reduce_max +
+ * 3 x stk::all_reduce_sum (scrap/lcp_spheres/NGPSpheresLCP.cpp:371, :450-452) and the ghost field refresh left as a
+ * TODO at :1057.
+ *
+ * A communicator is one rank's end of a group of `world` ranks, one rank per GPU.  Two transports:
+ *   - RCCL (mhip_comm_create_rccl): grouped ncclSend / ncclRecv and ncclAllGather over xGMI, issued on a stream the
+ *     communicator owns and ordered against the caller's stream with events, so an exchange started after one kernel
+ *     overlaps the kernels launched before mhip_comm_exchange_finish.  librccl is looked up at run time (dlopen of
+ *     the already loaded librccl.so.1 or the one on the library path): no link dependency.  The 128-byte unique id
+ *     is made by rank 0 (mhip_comm_unique_id) and handed to the other ranks by the launcher (MPI_Bcast in an MPI
+ *     host, the torch.distributed store in bench.py).
+ *   - host callbacks (mhip_comm_create_host): the same calls forwarded to two functions of the host program after a
+ *     stream synchronisation (device pointers are passed through).  For hosts that bring their own message layer and
+ *     for tests where several ranks share one GPU, which RCCL refuses.
+ * All buffers are DEVICE pointers to doubles; counts are in doubles.  Handles are not thread-safe.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mhip_comm* mhip_comm_t;
+#define MHIP_COMM_ID_BYTES 128
+typedef int (*mhip_comm_exchange_fn)(void* user, int nsend, const int* send_peer, const double* const* send_buf,
+                                     const size_t* send_count, int nrecv, const int* recv_peer, double* const* recv_buf,
+                                     const size_t* recv_count); /* returns 0 when every message has landed */
+typedef int (*mhip_comm_all_gather_fn)(void* user, const double* send, size_t count, double* recv /*[world][count]*/);
+
+int mhip_comm_unique_id(unsigned char* id /*[host] MHIP_COMM_ID_BYTES*/);
+int mhip_comm_create_rccl(mhip_comm_t* comm, const unsigned char* id /*[host]*/, int rank, int world);
+int mhip_comm_create_host(mhip_comm_t* comm, int rank, int world, mhip_comm_exchange_fn exchange,
+                          mhip_comm_all_gather_fn all_gather, void* user);
+int mhip_comm_destroy(mhip_comm_t comm);
+int mhip_comm_info(mhip_comm_t comm, int* rank, int* world, int* is_rccl);
+/* recv[r][0..count) = rank r's send[0..count); later work on `stream` sees recv */
+int mhip_comm_all_gather(mhip_comm_t comm, const double* send, size_t count, double* recv, mhip_stream_t stream);
+/* One grouped point-to-point exchange: message k goes to send_peer[k] / comes from recv_peer[k]; empty messages are
+ * skipped on both sides.  start: the transfers begin once the work already on `stream` is done; finish: later work on
+ * `stream` waits for them.  The peer / pointer / count arrays are host arrays and are read during start only. */
+int mhip_comm_exchange_start(mhip_comm_t comm, int nsend, const int* send_peer, const double* const* send_buf,
+                             const size_t* send_count, int nrecv, const int* recv_peer, double* const* recv_buf,
+                             const size_t* recv_count, mhip_stream_t stream);
+int mhip_comm_exchange_finish(mhip_comm_t comm, mhip_stream_t stream);
+
+/* Ghost-velocity halo of one rank, fixed between neighbour-list rebuilds.  velocity = the [num_local_bodies][6] array
+ * given to mhip_contact_op_set_partition.  Rows send_index[...] (DEVICE, local body indices, peer after peer in the
+ * order of send_peer, send_rows[k] of them for peer k) go out each iteration; rows [recv_first_row[k],
+ * recv_first_row[k] + recv_rows[k]) are filled from recv_peer[k]. */
+typedef struct mhip_velocity_halo {
+  double* velocity;
+  int num_send_peers;
+  const int* send_peer;       /* [host] */
+  const size_t* send_rows;    /* [host] */
+  const int32_t* send_index;  /* [device] sum(send_rows) */
+  int num_recv_peers;
+  const int* recv_peer;            /* [host] */
+  const size_t* recv_first_row;    /* [host] */
+  const size_t* recv_rows;         /* [host] */
+} mhip_velocity_halo;
+typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that did work, summed */
+  double body_ms, constraint_ms, halo_wait_ms;
+  size_t timed_iterations;
+} mhip_dist_profile;
+/* The domain-decomposed BBPGD solve, whole loop on the host side of this library (no interpreter between the stages):
+ *   begin;  per iteration: body sweep of the owned bodies -> pack + start the velocity halo -> constraint sweep of the
+ *   interior contacts [0, interior_contacts) while the halo is in flight -> finish halo -> sweep of the boundary
+ *   contacts -> local (max, sum dx^2, sum dx dg) -> all-gather -> every rank reduces the triples in rank order (bit-
+ *   identical steps) ;  convergence polled every poll_every iterations (0: 32) ;  end.
+ * Same iterates as the mhip_bbpgd_stage_* sequence driven by hand.  op must carry mhip_contact_op_set_partition; the
+ * four solver vectors are caller owned as in mhip_bbpgd_solve_contact.  profile may be NULL. */
+int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t comm, const mhip_velocity_halo* halo,
+                                         size_t interior_contacts, const double* q, const mhip_space* space /*[host]*/,
+                                         const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
+                                         double* g_tmp, unsigned poll_every, mhip_solve_result* result /*[host]*/,
+                                         mhip_dist_profile* profile /*[host]*/, mhip_stream_t stream);
 
 #ifdef __cplusplus
 }

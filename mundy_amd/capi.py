@@ -35,6 +35,26 @@ class SolveResult(C.Structure):
     _fields_ = [("num_iters", C.c_uint), ("residual", C.c_double), ("converged", C.c_int)]
 
 
+class VelocityHalo(C.Structure):
+    """mhip_velocity_halo: the per-iteration ghost-velocity exchange of one rank (host lists + one device index list)"""
+    _fields_ = [("velocity", C.c_void_p), ("num_send_peers", C.c_int), ("send_peer", C.POINTER(C.c_int)),
+                ("send_rows", C.POINTER(C.c_size_t)), ("send_index", C.c_void_p), ("num_recv_peers", C.c_int),
+                ("recv_peer", C.POINTER(C.c_int)), ("recv_first_row", C.POINTER(C.c_size_t)),
+                ("recv_rows", C.POINTER(C.c_size_t))]
+
+
+class DistProfile(C.Structure):
+    _fields_ = [("body_ms", C.c_double), ("constraint_ms", C.c_double), ("halo_wait_ms", C.c_double),
+                ("timed_iterations", C.c_size_t)]
+
+
+# host-callback transport (mhip_comm_create_host): device pointers arrive as integers
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_size_t))
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+COMM_ID_BYTES = 128
+
 _vp, _sz, _d, _i = C.c_void_p, C.c_size_t, C.c_double, C.c_int
 
 # name -> argtypes; every function returns int status.  Must list every symbol include/mundy_hip.h declares
@@ -121,6 +141,19 @@ SIGNATURES = {
     "mhip_set_tracing": [_i],
     "mhip_curve_order": [_sz, _vp, C.POINTER(_d), C.POINTER(_d), _i, _vp, _vp, _vp],
     "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],
+    "mhip_contact_op_sizes": [_vp, C.POINTER(_sz), C.POINTER(_sz)],
+    "mhip_comm_unique_id": [C.c_char_p],
+    "mhip_comm_create_rccl": [C.POINTER(_vp), C.c_char_p, _i, _i],
+    "mhip_comm_create_host": [C.POINTER(_vp), _i, _i, EXCHANGE_FN, ALL_GATHER_FN, _vp],
+    "mhip_comm_destroy": [_vp],
+    "mhip_comm_info": [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "mhip_comm_all_gather": [_vp, _vp, _sz, _vp, _vp],
+    "mhip_comm_exchange_start": [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i),
+                                 C.POINTER(_vp), C.POINTER(_sz), _vp],
+    "mhip_comm_exchange_finish": [_vp, _vp],
+    "mhip_bbpgd_solve_contact_distributed": [_vp, _vp, C.POINTER(VelocityHalo), _sz, _vp, C.POINTER(Space),
+                                             C.POINTER(PgdConfig), _vp, _vp, _vp, _vp, C.c_uint,
+                                             C.POINTER(SolveResult), C.POINTER(DistProfile), _vp],
 }
 OTHER_SYMBOLS = {"mhip_last_error": ([], C.c_char_p), "mhip_version": ([], C.c_int)}
 

@@ -1606,6 +1606,13 @@ int mhip_contact_op_apply(mhip_contact_op_t op, const double* x, double* y, mhip
                               grid_for(op->view.C), s);
 }
 
+int mhip_contact_op_sizes(mhip_contact_op_t op, size_t* num_constraints, size_t* num_bodies) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  if (num_constraints) *num_constraints = op->view.C;
+  if (num_bodies) *num_bodies = op->view.N;
+  return MHIP_SUCCESS;
+}
+
 int mhip_contact_op_set_profiling(mhip_contact_op_t op, int enable) {
   MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
   op->profile = enable != 0;

@@ -1,0 +1,377 @@
+// dist.hip -- multi-GPU transport (RCCL over xGMI, or host callbacks) and the domain-decomposed BBPGD solve driven
+// from C++.  Host code only: the kernels it sequences live in convex.hip / reorder.hip and are reached
+// through the public stage entry points, so this loop and a host that drives the stages by hand produce the same
+// iterates.
+//
+// Reference counterparts: the MPI communicator of stk::search::coarse_search / change_ghosting
+// (mundy_mesh/GenNeighborLinkers.hpp:658, :687-711); per iteration stk::all_reduce_max + 3 x stk::all_reduce_sum
+// (scrap/lcp_spheres/NGPSpheresLCP.cpp:371, :450-452) and the ghost refresh left as a TODO at :1057.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time
+
+#include <vector>
+
+#include "mhip_internal.hpp"
+
+namespace mhip {
+
+struct RcclApi {
+  void* lib = nullptr;
+  bool tried = false;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok() const {
+    return GetUniqueId && CommInitRank && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd &&
+           GetErrorString;
+  }
+};
+
+static RcclApi& rccl() {
+  static RcclApi api;
+  if (api.tried) return api;
+  api.tried = true;
+  // a process that already carries an RCCL (PyTorch ships its own librccl.so.1) must keep using that one
+  api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+    if (api.lib) break;
+    api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  }
+  if (!api.lib) return api;
+#define MHIP_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name))
+  MHIP_SYM(GetUniqueId, "ncclGetUniqueId");
+  MHIP_SYM(CommInitRank, "ncclCommInitRank");
+  MHIP_SYM(CommDestroy, "ncclCommDestroy");
+  MHIP_SYM(AllGather, "ncclAllGather");
+  MHIP_SYM(Send, "ncclSend");
+  MHIP_SYM(Recv, "ncclRecv");
+  MHIP_SYM(GroupStart, "ncclGroupStart");
+  MHIP_SYM(GroupEnd, "ncclGroupEnd");
+  MHIP_SYM(GetErrorString, "ncclGetErrorString");
+#undef MHIP_SYM
+  return api;
+}
+
+#define MHIP_RCCL(call)                                                                                         \
+  do {                                                                                                          \
+    ncclResult_t r_ = (call);                                                                                   \
+    if (r_ != ncclSuccess)                                                                                      \
+      return ::mhip::fail(MHIP_ERR_RUNTIME, "%s failed: %s (%s:%d)", #call, rccl().GetErrorString(r_), __FILE__, \
+                          __LINE__);                                                                            \
+  } while (0)
+
+}  // namespace mhip
+
+using namespace mhip;
+
+struct mhip_comm {
+  int rank = 0, world = 1;
+  bool is_rccl = false;
+  // RCCL transport: everything RCCL does runs on comm_stream; `ready` carries the caller's stream into it, `done`
+  // carries it back
+  ncclComm_t nccl = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+  bool in_flight = false;
+  // host-callback transport: the exchange is kept until finish (the callbacks block)
+  mhip_comm_exchange_fn xfn = nullptr;
+  mhip_comm_all_gather_fn gfn = nullptr;
+  void* user = nullptr;
+  std::vector<int> send_peer, recv_peer;
+  std::vector<const double*> send_buf;
+  std::vector<double*> recv_buf;
+  std::vector<size_t> send_count, recv_count;
+  // work buffers of the distributed solve
+  DeviceBuffer send_rows, triples;
+  std::vector<hipEvent_t> events;
+};
+
+extern "C" {
+
+int mhip_comm_unique_id(unsigned char* id) {
+  MHIP_REQUIRE(id != nullptr, MHIP_ERR_INVALID_ARGUMENT, "id is null");
+  static_assert(sizeof(ncclUniqueId) == MHIP_COMM_ID_BYTES, "unique id size");
+  MHIP_REQUIRE(rccl().ok(), MHIP_ERR_RUNTIME, "librccl.so.1 could not be loaded: %s", dlerror());
+  ncclUniqueId u;
+  MHIP_RCCL(rccl().GetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_create_rccl(mhip_comm_t* comm, const unsigned char* id, int rank, int world) {
+  MHIP_REQUIRE(comm != nullptr && id != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(world >= 1 && rank >= 0 && rank < world, MHIP_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, world);
+  MHIP_REQUIRE(rccl().ok(), MHIP_ERR_RUNTIME, "librccl.so.1 could not be loaded: %s", dlerror());
+  mhip_comm* c = new mhip_comm();
+  c->rank = rank;
+  c->world = world;
+  c->is_rccl = true;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclResult_t r = rccl().CommInitRank(&c->nccl, world, u, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return fail(MHIP_ERR_RUNTIME, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl().GetErrorString(r));
+  }
+  hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    mhip_comm_destroy(c);
+    return fail(MHIP_ERR_HIP, "communicator stream / events: %s", hipGetErrorString(e));
+  }
+  *comm = c;
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_create_host(mhip_comm_t* comm, int rank, int world, mhip_comm_exchange_fn exchange,
+                          mhip_comm_all_gather_fn all_gather, void* user) {
+  MHIP_REQUIRE(comm != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(world >= 1 && rank >= 0 && rank < world, MHIP_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, world);
+  MHIP_REQUIRE(world == 1 || (exchange && all_gather), MHIP_ERR_INVALID_ARGUMENT,
+               "a host transport of more than one rank needs both callbacks");
+  mhip_comm* c = new mhip_comm();
+  c->rank = rank;
+  c->world = world;
+  c->xfn = exchange;
+  c->gfn = all_gather;
+  c->user = user;
+  *comm = c;
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_destroy(mhip_comm_t c) {
+  if (!c) return MHIP_SUCCESS;
+  for (auto ev : c->events) (void)hipEventDestroy(ev);
+  c->send_rows.release();
+  c->triples.release();
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+  if (c->ready) (void)hipEventDestroy(c->ready);
+  if (c->done) (void)hipEventDestroy(c->done);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  delete c;
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_info(mhip_comm_t c, int* rank, int* world, int* is_rccl) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (is_rccl) *is_rccl = c->is_rccl ? 1 : 0;
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_all_gather(mhip_comm_t c, const double* send, size_t count, double* recv, mhip_stream_t stream) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  MHIP_REQUIRE(!c->in_flight, MHIP_ERR_RUNTIME, "an exchange is in flight: call mhip_comm_exchange_finish first");
+  if (count == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(send != nullptr && recv != nullptr, MHIP_ERR_INVALID_ARGUMENT, "all_gather buffers are null");
+  hipStream_t s = as_stream(stream);
+  if (c->is_rccl) {
+    MHIP_HIP(hipEventRecord(c->ready, s));
+    MHIP_HIP(hipStreamWaitEvent(c->comm_stream, c->ready, 0));
+    MHIP_RCCL(rccl().AllGather(send, recv, count, ncclDouble, c->nccl, c->comm_stream));
+    MHIP_HIP(hipEventRecord(c->done, c->comm_stream));
+    MHIP_HIP(hipStreamWaitEvent(s, c->done, 0));
+    return MHIP_SUCCESS;
+  }
+  if (c->world == 1) {
+    MHIP_HIP(hipMemcpyAsync(recv, send, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return MHIP_SUCCESS;
+  }
+  MHIP_HIP(hipStreamSynchronize(s));
+  const int e = c->gfn(c->user, send, count, recv);
+  MHIP_REQUIRE(e == 0, MHIP_ERR_RUNTIME, "the host all_gather callback returned %d", e);
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_exchange_start(mhip_comm_t c, int nsend, const int* send_peer, const double* const* send_buf,
+                             const size_t* send_count, int nrecv, const int* recv_peer, double* const* recv_buf,
+                             const size_t* recv_count, mhip_stream_t stream) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  MHIP_REQUIRE(!c->in_flight, MHIP_ERR_RUNTIME, "an exchange is already in flight");
+  MHIP_REQUIRE(nsend >= 0 && nrecv >= 0, MHIP_ERR_INVALID_ARGUMENT, "negative message count");
+  MHIP_REQUIRE(nsend == 0 || (send_peer && send_buf && send_count), MHIP_ERR_INVALID_ARGUMENT, "send lists are null");
+  MHIP_REQUIRE(nrecv == 0 || (recv_peer && recv_buf && recv_count), MHIP_ERR_INVALID_ARGUMENT, "recv lists are null");
+  for (int k = 0; k < nsend; ++k) {
+    // RCCL delivers a message to oneself as a local copy; the host transport does not loop back
+    MHIP_REQUIRE(send_peer[k] >= 0 && send_peer[k] < c->world && (c->is_rccl || send_peer[k] != c->rank),
+                 MHIP_ERR_INVALID_ARGUMENT, "send peer %d is not another rank of this %d-rank group", send_peer[k],
+                 c->world);
+    MHIP_REQUIRE(send_count[k] == 0 || send_buf[k], MHIP_ERR_INVALID_ARGUMENT, "send buffer %d is null", k);
+  }
+  for (int k = 0; k < nrecv; ++k) {
+    MHIP_REQUIRE(recv_peer[k] >= 0 && recv_peer[k] < c->world && (c->is_rccl || recv_peer[k] != c->rank),
+                 MHIP_ERR_INVALID_ARGUMENT, "recv peer %d is not another rank of this %d-rank group", recv_peer[k],
+                 c->world);
+    MHIP_REQUIRE(recv_count[k] == 0 || recv_buf[k], MHIP_ERR_INVALID_ARGUMENT, "recv buffer %d is null", k);
+  }
+  hipStream_t s = as_stream(stream);
+  if (c->is_rccl) {
+    MHIP_HIP(hipEventRecord(c->ready, s));
+    MHIP_HIP(hipStreamWaitEvent(c->comm_stream, c->ready, 0));
+    MHIP_RCCL(rccl().GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int k = 0; k < nrecv && bad == ncclSuccess; ++k)
+      if (recv_count[k]) bad = rccl().Recv(recv_buf[k], recv_count[k], ncclDouble, recv_peer[k], c->nccl, c->comm_stream);
+    for (int k = 0; k < nsend && bad == ncclSuccess; ++k)
+      if (send_count[k]) bad = rccl().Send(send_buf[k], send_count[k], ncclDouble, send_peer[k], c->nccl, c->comm_stream);
+    ncclResult_t end = rccl().GroupEnd();  // always closes the group, even after a failed enqueue
+    MHIP_RCCL(bad);
+    MHIP_RCCL(end);
+    MHIP_HIP(hipEventRecord(c->done, c->comm_stream));
+    c->in_flight = true;
+    return MHIP_SUCCESS;
+  }
+  c->send_peer.assign(send_peer, send_peer + nsend);
+  c->send_buf.assign(send_buf, send_buf + nsend);
+  c->send_count.assign(send_count, send_count + nsend);
+  c->recv_peer.assign(recv_peer, recv_peer + nrecv);
+  c->recv_buf.assign(recv_buf, recv_buf + nrecv);
+  c->recv_count.assign(recv_count, recv_count + nrecv);
+  c->in_flight = true;
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_exchange_finish(mhip_comm_t c, mhip_stream_t stream) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  MHIP_REQUIRE(c->in_flight, MHIP_ERR_RUNTIME, "no exchange in flight");
+  c->in_flight = false;
+  hipStream_t s = as_stream(stream);
+  if (c->is_rccl) {
+    MHIP_HIP(hipStreamWaitEvent(s, c->done, 0));
+    return MHIP_SUCCESS;
+  }
+  if (c->world == 1 || (c->send_peer.empty() && c->recv_peer.empty())) return MHIP_SUCCESS;
+  MHIP_HIP(hipStreamSynchronize(s));
+  const int e = c->xfn(c->user, (int)c->send_peer.size(), c->send_peer.data(), c->send_buf.data(), c->send_count.data(),
+                       (int)c->recv_peer.size(), c->recv_peer.data(), c->recv_buf.data(), c->recv_count.data());
+  MHIP_REQUIRE(e == 0, MHIP_ERR_RUNTIME, "the host exchange callback returned %d", e);
+  return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, const mhip_velocity_halo* halo,
+                                         size_t interior_contacts, const double* q, const mhip_space* space,
+                                         const mhip_pgd_config* config, double* x, double* g, double* x_tmp,
+                                         double* g_tmp, unsigned poll_every, mhip_solve_result* result,
+                                         mhip_dist_profile* profile, mhip_stream_t stream) {
+  TraceRange trace_range("solve_cqpp (domain-decomposed BBPGD)");
+  MHIP_REQUIRE(op != nullptr && c != nullptr && halo != nullptr && result != nullptr && config != nullptr,
+               MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(halo->num_send_peers >= 0 && halo->num_recv_peers >= 0, MHIP_ERR_INVALID_ARGUMENT,
+               "negative peer count");
+  if (poll_every == 0) poll_every = 32;
+  hipStream_t s = as_stream(stream);
+  // message lists of the velocity halo (rows of 6 doubles)
+  size_t send_total = 0;
+  for (int k = 0; k < halo->num_send_peers; ++k) send_total += halo->send_rows[k];
+  MHIP_REQUIRE(send_total == 0 || (halo->send_index && halo->velocity), MHIP_ERR_INVALID_ARGUMENT,
+               "velocity halo without send_index / velocity");
+  if (int e = c->send_rows.reserve((6 * send_total + 2) * sizeof(double))) return e;
+  if (int e = c->triples.reserve((3 + 3 * (size_t)c->world) * sizeof(double))) return e;
+  double* local3 = c->triples.as<double>();
+  double* gathered = local3 + 3;
+  std::vector<const double*> sbuf(halo->num_send_peers);
+  std::vector<size_t> scount(halo->num_send_peers);
+  {
+    size_t off = 0;
+    for (int k = 0; k < halo->num_send_peers; ++k) {
+      sbuf[k] = c->send_rows.as<double>() + 6 * off;
+      scount[k] = 6 * halo->send_rows[k];
+      off += halo->send_rows[k];
+    }
+  }
+  std::vector<double*> rbuf(halo->num_recv_peers);
+  std::vector<size_t> rcount(halo->num_recv_peers);
+  for (int k = 0; k < halo->num_recv_peers; ++k) {
+    MHIP_REQUIRE(halo->recv_rows[k] == 0 || halo->velocity, MHIP_ERR_INVALID_ARGUMENT, "velocity halo without velocity");
+    rbuf[k] = halo->velocity + 6 * halo->recv_first_row[k];
+    rcount[k] = 6 * halo->recv_rows[k];
+  }
+  const bool has_halo = c->world > 1 && (halo->num_send_peers > 0 || halo->num_recv_peers > 0);
+
+  if (int e = mhip_bbpgd_stage_begin(op, q, space, config, x, g, x_tmp, g_tmp, stream)) return e;
+  size_t C = 0;
+  if (int e = mhip_contact_op_sizes(op, &C, nullptr)) return e;
+  MHIP_REQUIRE(interior_contacts <= C, MHIP_ERR_INVALID_ARGUMENT, "interior_contacts %zu exceeds the %zu constraints",
+               interior_contacts, C);
+
+  // sampled timing: every kStride-th iteration of a chunk is bracketed by events
+  constexpr unsigned kStride = 8, kEv = 6;
+  const bool prof = profile != nullptr;
+  const unsigned slots = (poll_every + kStride - 1) / kStride;
+  if (prof && c->events.size() < (size_t)kEv * slots) {
+    const size_t old = c->events.size();
+    c->events.resize((size_t)kEv * slots);
+    for (size_t k = old; k < c->events.size(); ++k) MHIP_HIP(hipEventCreate(&c->events[k]));
+  }
+  if (prof) *profile = mhip_dist_profile{0.0, 0.0, 0.0, 0};
+
+  auto iteration = [&](int init, hipEvent_t* ev) -> int {
+    if (ev) MHIP_HIP(hipEventRecord(ev[0], s));
+    if (int e = mhip_bbpgd_stage_body(op, init, stream)) return e;
+    if (ev) MHIP_HIP(hipEventRecord(ev[1], s));
+    if (has_halo) {
+      if (send_total)
+        if (int e = mhip_gather_rows(send_total, 6, halo->send_index, halo->velocity, c->send_rows.as<double>(), stream))
+          return e;
+      if (int e = mhip_comm_exchange_start(c, halo->num_send_peers, halo->send_peer, sbuf.data(), scount.data(),
+                                           halo->num_recv_peers, halo->recv_peer, rbuf.data(), rcount.data(), stream))
+        return e;
+    }
+    if (ev) MHIP_HIP(hipEventRecord(ev[2], s));
+    // interior contacts need only this rank's own rows: swept while the ghost rows are in flight
+    if (int e = mhip_bbpgd_stage_constraint_range(op, init, 0, interior_contacts, stream)) return e;
+    if (ev) MHIP_HIP(hipEventRecord(ev[3], s));
+    if (has_halo)
+      if (int e = mhip_comm_exchange_finish(c, stream)) return e;
+    if (ev) MHIP_HIP(hipEventRecord(ev[4], s));
+    if (int e = mhip_bbpgd_stage_constraint_range(op, init, interior_contacts, C - interior_contacts, stream)) return e;
+    if (int e = mhip_bbpgd_stage_reduce(op, init, local3, stream)) return e;
+    if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
+    if (int e = mhip_comm_all_gather(c, local3, 3, gathered, stream)) return e;
+    return mhip_bbpgd_stage_finalize(op, init, gathered, c->world, stream);
+  };
+
+  if (int e = iteration(1, nullptr)) return e;
+  unsigned enqueued = 0, last_todo = 0, iter_before = 0;
+  int done = 0;
+  for (;;) {
+    if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
+    if (prof && last_todo) {
+      unsigned eff = result->num_iters - iter_before + ((result->converged && result->num_iters < config->max_iters) ? 1u : 0u);
+      if (eff > last_todo) eff = last_todo;
+      for (unsigned k = 0; k < eff; k += kStride) {
+        hipEvent_t* ev = &c->events[(size_t)kEv * (k / kStride)];
+        float a = 0.f, b = 0.f, w = 0.f, d = 0.f;
+        MHIP_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
+        MHIP_HIP(hipEventElapsedTime(&b, ev[2], ev[3]));
+        MHIP_HIP(hipEventElapsedTime(&w, ev[3], ev[4]));
+        MHIP_HIP(hipEventElapsedTime(&d, ev[4], ev[5]));
+        profile->body_ms += a;
+        profile->constraint_ms += b + d;  // the wait for the halo is not part of the sweep's time
+        profile->halo_wait_ms += w;
+        profile->timed_iterations += 1;
+      }
+    }
+    if (done || enqueued >= config->max_iters) break;
+    iter_before = result->num_iters;
+    const unsigned todo = (config->max_iters - enqueued < poll_every) ? config->max_iters - enqueued : poll_every;
+    for (unsigned k = 0; k < todo; ++k) {
+      hipEvent_t* ev = (prof && k % kStride == 0) ? &c->events[(size_t)kEv * (k / kStride)] : nullptr;
+      if (int e = iteration(0, ev)) return e;
+    }
+    enqueued += todo;
+    last_todo = todo;
+  }
+  return mhip_bbpgd_stage_end(op, result, stream);
+}
+
+}  // extern "C"

@@ -108,79 +108,124 @@ def halo_layout(count_matrix, rank):
 
 # ---- communication ------------------------------------------------------------------------------------------------------
 class Comm:
-    """Thin wrapper over torch.distributed: P2P halo + small all-gathers.  nccl: device buffers go straight to RCCL;
-    any other backend (gloo in the tests): staged through host memory."""
+    """One rank's communicator of the C library (mhip_comm_*, csrc/dist.hip).  torch.distributed is only the launcher:
+    it carries the RCCL unique id from rank 0 to the others, and, when the process group is not nccl (gloo in the
+    tests, where several ranks share one GPU and RCCL refuses duplicate devices), it is the message layer behind the
+    library's host-callback transport.  All halo traffic and reductions of the step go through the library."""
 
     def __init__(self, group=None):
+        lib = capi.load()
         self.group = group
         self.enabled = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.direct = self.enabled and dist.get_backend(group) == "nccl"
-
-    def all_gather(self, t):
-        """t: 1-D tensor (device or host) -> [world, len] tensor on the same device"""
-        if self.world == 1 and not self.direct:
-            return t.reshape(1, -1).clone()
-        if self.direct:  # RCCL moves device memory only: host scalars (boxes, counts) ride through the GPU
-            src = t.contiguous() if t.is_cuda else t.cuda()
-            out = torch.empty((self.world, src.numel()), dtype=src.dtype, device=src.device)
-            dist.all_gather_into_tensor(out.reshape(-1), src, group=self.group)
-            return out if t.is_cuda else out.cpu()
-        src = t.detach().cpu().contiguous()
-        parts = [torch.empty_like(src) for _ in range(self.world)]
-        dist.all_gather(parts, src, group=self.group)
-        return torch.stack(parts).to(t.device)
-
-    def all_gather_into(self, out, t):
-        """device fast path: out [world, len] and t [len] are preallocated device tensors (no allocation per call)"""
+        self._h = C.c_void_p()
+        self._callbacks = None
         if self.direct:
-            dist.all_gather_into_tensor(out.view(-1), t, group=self.group)
-        elif self.world == 1:
-            out.copy_(t.view(1, -1))
+            ident = C.create_string_buffer(capi.COMM_ID_BYTES)
+            if self.rank == 0:
+                capi.check(lib.mhip_comm_unique_id(ident))
+            t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).cuda()
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), capi.COMM_ID_BYTES)
+            capi.check(lib.mhip_comm_create_rccl(C.byref(self._h), ident, self.rank, self.world))
         else:
-            out.copy_(self.all_gather(t))
-        return out
+            self._callbacks = (capi.EXCHANGE_FN(self._exchange_cb), capi.ALL_GATHER_FN(self._all_gather_cb))
+            capi.check(lib.mhip_comm_create_host(C.byref(self._h), self.rank, self.world, self._callbacks[0],
+                                                 self._callbacks[1], None))
 
-    def make_plan(self, send, recv):
-        """Pre-builds the grouped send/recv of a halo whose buffers do not change between calls (nccl only)."""
-        if not self.direct or self.world == 1:
-            return None
-        p2p = [dist.P2POp(dist.irecv, t, p, group=self.group) for p, t in sorted(recv.items()) if t.numel()]
-        p2p += [dist.P2POp(dist.isend, t, p, group=self.group) for p, t in sorted(send.items()) if t.numel()]
-        return p2p
+    def close(self):
+        if self._h:
+            capi.check(capi.load().mhip_comm_destroy(self._h))
+            self._h = C.c_void_p()
 
-    def run_plan(self, plan):
-        self.finish_plan(self.start_plan(plan))
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
-    def start_plan(self, plan):
-        """enqueues the grouped send/recv (it starts once the work already on the current stream is done) and returns
-        the handles; kernels launched before finish_plan() overlap with the transfers"""
-        return dist.batch_isend_irecv(plan) if plan else []
-
-    def finish_plan(self, works):
-        for w in works:
-            w.wait()  # orders the current stream after the transfer; no host block with nccl
-
-    def exchange(self, send, recv):
-        """send / recv: {peer: contiguous tensor}; recv tensors are filled in place."""
-        if self.world == 1 or (not send and not recv):
-            return
-        if self.direct:
-            p2p = [dist.P2POp(dist.irecv, t, p, group=self.group) for p, t in sorted(recv.items()) if t.numel()]
-            p2p += [dist.P2POp(dist.isend, t, p, group=self.group) for p, t in sorted(send.items()) if t.numel()]
-            if p2p:
-                for w in dist.batch_isend_irecv(p2p):
-                    w.wait()  # orders the current stream after the transfer; no host block with nccl
-            return
-        stage_r = {p: torch.empty(t.shape, dtype=t.dtype) for p, t in recv.items() if t.numel()}
-        works = [dist.irecv(b, src=p, group=self.group) for p, b in sorted(stage_r.items())]
-        works += [dist.isend(t.detach().cpu().contiguous(), dst=p, group=self.group)
-                  for p, t in sorted(send.items()) if t.numel()]
+    # -- message layer of the host-callback transport: host tensors through the process group -----------------------
+    def host_exchange(self, send, recv):
+        """send / recv: {peer: contiguous float64 HOST tensor}; one message per (peer, direction); recv filled in place"""
+        works = [dist.irecv(t, src=self._global(p), group=self.group) for p, t in sorted(recv.items()) if t.numel()]
+        works += [dist.isend(t, dst=self._global(p), group=self.group) for p, t in sorted(send.items()) if t.numel()]
         for w in works:
             w.wait()
-        for p, b in stage_r.items():
-            recv[p].copy_(b)
+
+    def host_all_gather(self, t):
+        """t: 1-D float64 HOST tensor -> [world, len] host tensor"""
+        if self.world == 1:
+            return t.reshape(1, -1).clone()
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.stack(parts)
+
+    # -- the callbacks the library calls (after synchronising the stream): device pointers in, staged through the host
+    def _exchange_cb(self, _user, nsend, send_peer, send_buf, send_count, nrecv, recv_peer, recv_buf, recv_count):
+        try:
+            lib = capi.load()
+            send, recv, where = {}, {}, {}
+            for k in range(nrecv):
+                if recv_count[k]:
+                    recv[recv_peer[k]] = torch.empty(recv_count[k], dtype=torch.float64)
+                    where[recv_peer[k]] = recv_buf[k]
+            for k in range(nsend):
+                if send_count[k]:
+                    b = send[send_peer[k]] = torch.empty(send_count[k], dtype=torch.float64)
+                    capi.check(lib.mhip_memcpy_d2h(b.data_ptr(), send_buf[k], 8 * b.numel(), None))
+            self.host_exchange(send, recv)
+            for p, b in recv.items():
+                capi.check(lib.mhip_memcpy_h2d(where[p], b.data_ptr(), 8 * b.numel(), None))
+            return 0
+        except Exception:  # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _all_gather_cb(self, _user, send, count, recv):
+        try:
+            lib = capi.load()
+            src = torch.empty(count, dtype=torch.float64)
+            capi.check(lib.mhip_memcpy_d2h(src.data_ptr(), send, 8 * count, None))
+            out = self.host_all_gather(src).contiguous()
+            capi.check(lib.mhip_memcpy_h2d(recv, out.data_ptr(), 8 * out.numel(), None))
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _global(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    # -- what the stepper calls ----------------------------------------------------------------------------------------
+    def all_gather(self, t):
+        """t: 1-D float64 tensor (device or host) -> [world, len] tensor on the same device"""
+        src = (t if t.is_cuda else t.cuda()).to(torch.float64).contiguous()
+        out = torch.empty((self.world, src.numel()), dtype=torch.float64, device=src.device)
+        capi.check(capi.load().mhip_comm_all_gather(self._h, _p(src), src.numel(), _p(out), _stream()))
+        return out if t.is_cuda else out.cpu()
+
+    def exchange(self, send, recv):
+        """send / recv: {peer: contiguous float64 device tensor}; recv tensors are filled in place."""
+        lib = capi.load()
+        sp = [p for p, t in sorted(send.items()) if t.numel()]
+        rp = [p for p, t in sorted(recv.items()) if t.numel()]
+        if not sp and not rp:
+            return
+        for p in sp:
+            assert send[p].is_contiguous() and send[p].dtype == torch.float64
+        for p in rp:
+            assert recv[p].is_contiguous() and recv[p].dtype == torch.float64
+        arr_i, arr_p, arr_z = C.c_int * len(sp), C.c_void_p * len(sp), C.c_size_t * len(sp)
+        brr_i, brr_p, brr_z = C.c_int * len(rp), C.c_void_p * len(rp), C.c_size_t * len(rp)
+        capi.check(lib.mhip_comm_exchange_start(
+            self._h, len(sp), arr_i(*sp), arr_p(*[send[p].data_ptr() for p in sp]), arr_z(*[send[p].numel() for p in sp]),
+            len(rp), brr_i(*rp), brr_p(*[recv[p].data_ptr() for p in rp]), brr_z(*[recv[p].numel() for p in rp]),
+            _stream()))
+        capi.check(lib.mhip_comm_exchange_finish(self._h, _stream()))
 
 
 # ---- the distributed stepper ----------------------------------------------------------------------------------------------
@@ -257,7 +302,7 @@ class DistributedContactStepper:
             pb = (C.c_double * 6)(*boxes[p])
             capi.check(lib.mhip_select_aabb_overlap(n, _p(aabb), self.buffer, pb, _p(idx), C.byref(cnt), _stream()))
             send_idx[p], send_cnt[p] = idx[: cnt.value], int(cnt.value)
-        counts = comm.all_gather(torch.tensor(send_cnt, dtype=torch.int64)).tolist()  # counts[s][d]
+        counts = comm.all_gather(torch.tensor(send_cnt, dtype=torch.float64)).to(torch.int64).tolist()  # counts[s][d]
         recv_cnt, n_lo, n_hi, _ = halo_layout(counts, comm.rank)
         # records of the owned bodies, gathered per peer
         gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
@@ -292,36 +337,22 @@ class DistributedContactStepper:
             off += recv_cnt[p]
         self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=sum(send_cnt))
 
-    def _prepare_velocity_halo(self):
-        """fixed send buffer + receive views into self.vel, and (nccl) a reusable grouped send/recv plan"""
-        self._vsend, self._vsend_buf = {}, None
-        if self.vel_send_idx is not None:
-            self._vsend_buf = torch.empty((self.vel_send_idx.shape[0], 6), dtype=torch.float64, device=self.vel.device)
-            off = 0
-            for p, k in zip(self.vel_send_peers, self.vel_send_split):
-                self._vsend[p] = self._vsend_buf[off:off + k]
-                off += k
-        self._vrecv = {p: self.vel[a:b] for p, (a, b) in self.vel_recv.items()}
-        self._vplan = self.comm.make_plan(self._vsend, self._vrecv)
-
-    def _halo_velocity_start(self):
-        """packs the owned boundary rows and starts the grouped send/recv; returns what _halo_velocity_finish waits on"""
-        if self.comm.world == 1:
-            return None
-        if self._vsend_buf is not None:
-            capi.check(capi.load().mhip_gather_rows(self._vsend_buf.shape[0], 6, _p(self.vel_send_idx), _p(self.vel),
-                                                    _p(self._vsend_buf), _stream()))
-        if self._vplan is not None:
-            return self.comm.start_plan(self._vplan)   # nccl: transfers run on RCCL's stream from here on
-        return "staged"
-
-    def _halo_velocity_finish(self, pending):
-        if pending is None:
-            return
-        if pending == "staged":                        # gloo (tests): blocking, staged through the host
-            self.comm.exchange(self._vsend, self._vrecv)
-        else:
-            self.comm.finish_plan(pending)             # the compute stream waits for the transfers here
+    def _velocity_halo(self):
+        """mhip_velocity_halo of this rank for the current ghost layout: which owned rows go to whom, where the
+        ghosts' rows land (host lists; the row indices stay on the device)"""
+        sp, sr = self.vel_send_peers, self.vel_send_split
+        rp = sorted(self.vel_recv)
+        h = capi.VelocityHalo()
+        h.velocity = self.vel.data_ptr()
+        h.num_send_peers = len(sp)
+        h.send_peer = (C.c_int * max(1, len(sp)))(*sp)
+        h.send_rows = (C.c_size_t * max(1, len(sp)))(*sr)
+        h.send_index = self.vel_send_idx.data_ptr() if self.vel_send_idx is not None else None
+        h.num_recv_peers = len(rp)
+        h.recv_peer = (C.c_int * max(1, len(rp)))(*rp)
+        h.recv_first_row = (C.c_size_t * max(1, len(rp)))(*[self.vel_recv[p][0] for p in rp])
+        h.recv_rows = (C.c_size_t * max(1, len(rp)))(*[self.vel_recv[p][1] - self.vel_recv[p][0] for p in rp])
+        return h
 
     # -- one step -------------------------------------------------------------------------------------------------------------
     def step(self, integrate=True):
@@ -378,63 +409,19 @@ class DistributedContactStepper:
         g, x_tmp, g_tmp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         sp = capi.Space(ops.SPACE_LOWER_BOUND, 0.0, 0.0)
         pc = capi.PgdConfig(int(self.cfg.max_iters), float(self.cfg.tol), int(self.cfg.residual_kind))
-        local3 = torch.empty(3, dtype=torch.float64, device=dev)
-        gathered = torch.empty((comm.world, 3), dtype=torch.float64, device=dev)
-        self._prepare_velocity_halo()
-        h, stream = op._h, _stream()
-        p_local3, p_gathered = _p(local3), _p(gathered)
-        capi.check(lib.mhip_bbpgd_stage_begin(op._h, _p(con["sep"]), C.byref(sp), C.byref(pc), _p(x), _p(g),
-                                              _p(x_tmp), _p(g_tmp), _stream()))
-
-        events = []
-
-        def mark():
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            return e
-
-        def iteration(init):
-            prof = self.profile and not init and (self._it_count % 8 == 0)  # sampled: event records are not free
-            self._it_count += 1
-            e0 = mark() if prof else None
-            capi.check(lib.mhip_bbpgd_stage_body(h, init, stream))
-            e1 = mark() if prof else None
-            # the interior contacts only need this rank's own rows: swept while the ghost rows are in flight
-            pending = self._halo_velocity_start()
-            e2 = mark() if prof else None
-            capi.check(lib.mhip_bbpgd_stage_constraint_range(h, init, 0, nci, stream))
-            e2b = mark() if prof else None
-            self._halo_velocity_finish(pending)
-            e2c = mark() if prof else None     # the wait for the halo is not part of the sweep's time
-            capi.check(lib.mhip_bbpgd_stage_constraint_range(h, init, nci, nc - nci, stream))
-            capi.check(lib.mhip_bbpgd_stage_reduce(h, init, p_local3, stream))
-            e3 = mark() if prof else None
-            comm.all_gather_into(gathered, local3)
-            capi.check(lib.mhip_bbpgd_stage_finalize(h, init, p_gathered, comm.world, stream))
-            if prof:
-                events.append((self._it_count - 1, e0, e1, e2, e2b, e2c, e3))
-
-        self._it_count = 0
-        iteration(1)
-        res, done = capi.SolveResult(), C.c_int(0)
-        enq = 0
-        while True:
-            capi.check(lib.mhip_bbpgd_stage_poll(op._h, C.byref(res), C.byref(done), _stream()))
-            if events:  # only iterations that did work: index (1-based after init) <= iterations actually run
-                ran = int(res.num_iters) + (1 if res.converged else 0)
-                for k, e0, e1, e2, e2b, e2c, e3 in events:
-                    if k <= ran:
-                        self.prof["body_ms"] += e0.elapsed_time(e1)
-                        self.prof["con_ms"] += e2.elapsed_time(e2b) + e2c.elapsed_time(e3)
-                        self.prof["iters"] += 1
-                events.clear()
-            if done.value or enq >= self.cfg.max_iters:
-                break
-            todo = min(self.poll_every, self.cfg.max_iters - enq)
-            for _ in range(todo):
-                iteration(0)
-            enq += todo
-        capi.check(lib.mhip_bbpgd_stage_end(op._h, C.byref(res), _stream()))
+        # the whole staged loop runs inside the library (csrc/dist.hip): body sweep -> velocity halo in flight during
+        # the interior sweep -> boundary sweep -> 3-double all-gather -> finalize, polled every poll_every iterations
+        halo = self._velocity_halo()
+        res = capi.SolveResult()
+        dprof = capi.DistProfile()
+        capi.check(lib.mhip_bbpgd_solve_contact_distributed(
+            op._h, comm._h, C.byref(halo), nci, _p(con["sep"]), C.byref(sp), C.byref(pc), _p(x), _p(g), _p(x_tmp),
+            _p(g_tmp), self.poll_every, C.byref(res), C.byref(dprof) if self.profile else None, _stream()))
+        if self.profile:
+            self.prof["body_ms"] += dprof.body_ms
+            self.prof["con_ms"] += dprof.constraint_ms
+            self.prof["halo_wait_ms"] = self.prof.get("halo_wait_ms", 0.0) + dprof.halo_wait_ms
+            self.prof["iters"] += int(dprof.timed_iterations)
         tick("solve")
         self.lam, self.grad, self.contacts, self.pairs, self.counted = x, g, con, pairs, counted
         if integrate:

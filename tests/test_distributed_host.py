@@ -55,22 +55,33 @@ def test_halo_layout():
 
 
 WORKER = r'''
-import os, sys, torch, torch.distributed as dist
+import os, sys, ctypes as C, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 dist.init_process_group(backend="gloo")
-from mundy_amd import distributed as D
-comm = D.Comm()
+from mundy_amd import capi, distributed as D
+comm = D.Comm()            # host-callback transport of the C library; its message layer is what runs here (no GPU)
 r, w = comm.rank, comm.world
 assert w == 2 and not comm.direct
-g = comm.all_gather(torch.tensor([float(r), 10.0 + r, 20.0 + r], dtype=torch.float64))
+rank, world, is_rccl = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+capi.check(capi.load().mhip_comm_info(comm._h, C.byref(rank), C.byref(world), C.byref(is_rccl)))
+assert (rank.value, world.value, is_rccl.value) == (r, 2, 0)
+g = comm.host_all_gather(torch.tensor([float(r), 10.0 + r, 20.0 + r], dtype=torch.float64))
 assert g.tolist() == [[0.0, 10.0, 20.0], [1.0, 11.0, 21.0]], g
 send = {1 - r: torch.full((3 + r, 6), float(r), dtype=torch.float64)}
 recv = {1 - r: torch.empty((4 - r, 6), dtype=torch.float64)}
-comm.exchange(send, recv)
+comm.host_exchange(send, recv)
 assert torch.all(recv[1 - r] == float(1 - r))
-comm.exchange({}, {})
-counts = comm.all_gather(torch.tensor([0, 5] if r == 0 else [3, 0], dtype=torch.int64)).tolist()
+comm.host_exchange({}, {})
+# the ghost bookkeeping both sides derive from the all-gathered count matrix agrees: what r sends is what 1-r expects
+counts = comm.host_all_gather(torch.tensor([0.0, 5.0] if r == 0 else [3.0, 0.0], dtype=torch.float64)).to(torch.int64).tolist()
 assert counts == [[0, 5], [3, 0]]
+rc, n_lo, n_hi, off = D.halo_layout(counts, r)
+assert rc[1 - r] == counts[1 - r][r] and n_lo + n_hi == counts[1 - r][r]
+# argument validation of the exchange that needs no device: a rank cannot message itself
+one_i, one_p, one_z = (C.c_int * 1)(r), (C.c_void_p * 1)(8), (C.c_size_t * 1)(1)
+st = capi.load().mhip_comm_exchange_start(comm._h, 1, one_i, one_p, one_z, 0, None, None, None, None)
+assert st == capi.ERR_INVALID_ARGUMENT and b"not another rank" in capi.load().mhip_last_error()
+comm.close()
 dist.destroy_process_group()
 print("COMM_OK", r)
 '''

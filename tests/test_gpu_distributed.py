@@ -1,7 +1,8 @@
 """Domain-decomposed path on real kernels: W ranks share the one GPU of the test box (gloo staging), each owning a
 Hilbert range of one rod system; the distributed solve must reproduce the single-rank solve (same neighbour list,
-same LCP gradient to 20 tol, bit-identical duplicated contacts).  The nccl transport differs only inside
-mundy_amd.distributed.Comm (exercised with world_size 1 here)."""
+same LCP gradient to 20 tol, bit-identical duplicated contacts).  The whole iteration loop runs in the library
+(mhip_bbpgd_solve_contact_distributed); gloo is only the message layer behind its host-callback transport.  The RCCL
+transport is exercised with world_size 1 (self-addressed messages, all-gather, the full step)."""
 import os
 import subprocess
 import sys
@@ -46,7 +47,8 @@ def test_nccl_transport_single_rank():
     import torch.distributed as dist
     from gpu_util import dev
     import numpy as np
-    from mundy_amd import distributed as D, ops, pipeline, synth
+    import ctypes as C
+    from mundy_amd import capi, distributed as D, ops, pipeline, synth
     if not dist.is_initialized():
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
@@ -55,8 +57,31 @@ def test_nccl_transport_single_rank():
         assert comm.direct and comm.world == 1
         t = torch.arange(3, dtype=torch.float64, device="cuda")
         assert torch.equal(comm.all_gather(t), t.reshape(1, 3))
-        h = torch.tensor([4, 5], dtype=torch.int64)          # host scalars ride through the GPU with nccl
-        assert comm.all_gather(h).tolist() == [[4, 5]] and not comm.all_gather(h).is_cuda
+        h = torch.tensor([4.0, 5.0], dtype=torch.float64)    # host scalars ride through the GPU
+        assert comm.all_gather(h).tolist() == [[4.0, 5.0]] and not comm.all_gather(h).is_cuda
+        # grouped ncclSend / ncclRecv with the stream hand-over, on the one rank there is: RCCL delivers a message to
+        # oneself as a local copy.  Producer and consumer are ordinary stream work right before / after the exchange.
+        for n in (1, 6 * 1000, 6 * 250_000):
+            src = torch.zeros(n, dtype=torch.float64, device="cuda")
+            dst = torch.full((n,), -1.0, dtype=torch.float64, device="cuda")
+            for rep in range(3):
+                src.copy_(torch.arange(n, dtype=torch.float64, device="cuda") + rep)   # producer on the stream
+                comm.exchange({0: src}, {0: dst})
+                got = dst.clone()                                                       # consumer on the stream
+                src.zero_()                                                             # must not overtake the send
+                assert torch.equal(got, torch.arange(n, dtype=torch.float64, device="cuda") + rep)
+        a, b = torch.ones(12, dtype=torch.float64, device="cuda"), torch.full((18,), 2.0, dtype=torch.float64, device="cuda")
+        ra, rb = torch.empty_like(a), torch.empty_like(b)
+        lib, i2, p2, z2 = capi.load(), C.c_int * 2, C.c_void_p * 2, C.c_size_t * 2
+        capi.check(lib.mhip_comm_exchange_start(comm._h, 2, i2(0, 0), p2(a.data_ptr(), b.data_ptr()), z2(12, 18),
+                                                2, i2(0, 0), p2(ra.data_ptr(), rb.data_ptr()), z2(12, 18), None))
+        with pytest.raises(RuntimeError, match="in flight"):
+            comm.all_gather(t)
+        capi.check(lib.mhip_comm_exchange_finish(comm._h, None))
+        torch.cuda.synchronize()
+        assert torch.equal(ra, a) and torch.equal(rb, b)      # two messages between the same pair keep their order
+        with pytest.raises(RuntimeError, match="no exchange in flight"):
+            capi.check(lib.mhip_comm_exchange_finish(comm._h, None))
         b = synth.spherocylinders(8000, seed=3)
         cfg = ops.PGDConfig(max_iters=20000, tol=1e-6)
         st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), 0,
@@ -69,6 +94,7 @@ def test_nccl_transport_single_rank():
         assert torch.equal(st.pairs, ref.links.pairs)
         assert s["num_iters"] == r.num_iters            # one rank: identical arithmetic to the fused driver
         assert torch.equal(st.lam, ref.lam)
+        comm.close()
     finally:
         dist.destroy_process_group()
 
