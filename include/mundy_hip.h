@@ -468,6 +468,24 @@ typedef struct mhip_velocity_halo {
   const size_t* recv_first_row;    /* [host] */
   const size_t* recv_rows;         /* [host] */
 } mhip_velocity_halo;
+/* Ghost bodies of one neighbour-list rebuild (replaces coarse_search(comm) + change_ghosting,
+ * GenNeighborLinkers.hpp:658, :687-711).  Ranks own contiguous, increasing ranges of the global (curve-ordered) ids.
+ *   plan:     all-gather of the rank boxes (owned AABBs grown by `buffer`), per peer the owned bodies whose grown box
+ *             meets the peer's box (closed test, ascending order), all-gather of the count matrix.  Fills `layout`:
+ *             local index order = ghosts of lower ranks (peer order), the n owned bodies, ghosts of higher ranks --
+ *             also global-id order, so local pairs (i < j) keep their global orientation; and the velocity halo of
+ *             this layout (lists owned by the communicator, valid until the next plan; halo.velocity is left NULL).
+ *   exchange: moves rows of `width` doubles with that plan: local[num_ghost_lo + i] = records[i] for the owned rows,
+ *             ghost rows filled from their owners.  Any number of record sets per plan. */
+typedef struct mhip_ghost_layout {
+  size_t num_ghost_lo, num_owned, num_ghost_hi;
+  size_t num_sent; /* owned bodies that are ghosts somewhere, counted once per receiving rank */
+  mhip_velocity_halo halo;
+} mhip_ghost_layout;
+int mhip_ghost_plan(mhip_comm_t comm, size_t n, const double* aabb, double buffer,
+                    mhip_ghost_layout* layout /*[host] out*/, mhip_stream_t stream);
+int mhip_ghost_exchange(mhip_comm_t comm, size_t width, const double* records /*[n][width]*/,
+                        double* local /*[num_ghost_lo + n + num_ghost_hi][width]*/, mhip_stream_t stream);
 typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that did work, summed */
   double body_ms, constraint_ms, halo_wait_ms;
   size_t timed_iterations;

@@ -43,6 +43,11 @@ class VelocityHalo(C.Structure):
                 ("recv_rows", C.POINTER(C.c_size_t))]
 
 
+class GhostLayout(C.Structure):
+    _fields_ = [("num_ghost_lo", C.c_size_t), ("num_owned", C.c_size_t), ("num_ghost_hi", C.c_size_t),
+                ("num_sent", C.c_size_t), ("halo", VelocityHalo)]
+
+
 class DistProfile(C.Structure):
     _fields_ = [("body_ms", C.c_double), ("constraint_ms", C.c_double), ("halo_wait_ms", C.c_double),
                 ("timed_iterations", C.c_size_t)]
@@ -151,6 +156,8 @@ SIGNATURES = {
     "mhip_comm_exchange_start": [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i),
                                  C.POINTER(_vp), C.POINTER(_sz), _vp],
     "mhip_comm_exchange_finish": [_vp, _vp],
+    "mhip_ghost_plan": [_vp, _sz, _vp, _d, C.POINTER(GhostLayout), _vp],
+    "mhip_ghost_exchange": [_vp, _sz, _vp, _vp, _vp],
     "mhip_bbpgd_solve_contact_distributed": [_vp, _vp, C.POINTER(VelocityHalo), _sz, _vp, C.POINTER(Space),
                                              C.POINTER(PgdConfig), _vp, _vp, _vp, _vp, C.c_uint,
                                              C.POINTER(SolveResult), C.POINTER(DistProfile), _vp],

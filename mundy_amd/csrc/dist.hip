@@ -90,7 +90,37 @@ struct mhip_comm {
   // work buffers of the distributed solve
   DeviceBuffer send_rows, triples;
   std::vector<hipEvent_t> events;
+  // ghost plan of the last mhip_ghost_plan: who gets which owned rows, where the ghosts' rows land
+  struct GhostPlan {
+    bool valid = false;
+    size_t n = 0, n_lo = 0, n_hi = 0, total_send = 0;
+    std::vector<int> send_peer, recv_peer;
+    std::vector<size_t> send_rows, recv_first_row, recv_rows;
+    DeviceBuffer send_index;        // owned indices (0-based in the owned block), peer after peer
+    DeviceBuffer send_index_local;  // the same as local indices (+ n_lo): what the velocity halo gathers
+    DeviceBuffer stage;             // boxes / counts on their way through the all-gather; packed send rows
+  } ghost;
 };
+
+namespace mhip {
+__global__ void __launch_bounds__(kBlock) k_offset_i32(size_t n, const int32_t* __restrict__ in, int32_t off,
+                                                      int32_t* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[i] + off;
+}
+// all-gather of a few host doubles through the communicator: out [world][count]
+static int host_all_gather(mhip_comm* c, const double* in, size_t count, std::vector<double>& out, hipStream_t s) {
+  const size_t w = (size_t)c->world;
+  if (int e = c->ghost.stage.reserve((count + w * count + 2) * sizeof(double))) return e;
+  double* d_in = c->ghost.stage.as<double>();
+  double* d_out = d_in + count;
+  MHIP_HIP(hipMemcpyAsync(d_in, in, count * sizeof(double), hipMemcpyHostToDevice, s));
+  if (int e = mhip_comm_all_gather(c, d_in, count, d_out, reinterpret_cast<mhip_stream_t>(s))) return e;
+  out.resize(w * count);
+  MHIP_HIP(hipMemcpyAsync(out.data(), d_out, w * count * sizeof(double), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  return MHIP_SUCCESS;
+}
+}  // namespace mhip
 
 extern "C" {
 
@@ -151,6 +181,9 @@ int mhip_comm_destroy(mhip_comm_t c) {
   for (auto ev : c->events) (void)hipEventDestroy(ev);
   c->send_rows.release();
   c->triples.release();
+  c->ghost.send_index.release();
+  c->ghost.send_index_local.release();
+  c->ghost.stage.release();
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   if (c->ready) (void)hipEventDestroy(c->ready);
@@ -254,6 +287,121 @@ int mhip_comm_exchange_finish(mhip_comm_t c, mhip_stream_t stream) {
                        (int)c->recv_peer.size(), c->recv_peer.data(), c->recv_buf.data(), c->recv_count.data());
   MHIP_REQUIRE(e == 0, MHIP_ERR_RUNTIME, "the host exchange callback returned %d", e);
   return MHIP_SUCCESS;
+}
+
+int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, mhip_ghost_layout* layout,
+                    mhip_stream_t stream) {
+  TraceRange trace_range("ghost plan (coarse_search(comm) + change_ghosting)");
+  MHIP_REQUIRE(c != nullptr && layout != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(n == 0 || aabb != nullptr, MHIP_ERR_INVALID_ARGUMENT, "aabb is null");
+  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
+  hipStream_t s = as_stream(stream);
+  auto& gp = c->ghost;
+  gp.valid = false;
+  const int W = c->world, R = c->rank;
+  // rank boxes
+  double box[6];
+  if (int e = mhip_aabb_bounds(n, aabb, buffer, box, stream)) return e;
+  std::vector<double> boxes;
+  if (int e = host_all_gather(c, box, 6, boxes, s)) return e;
+  // per peer: the owned bodies whose grown box meets the peer's box
+  if (int e = gp.send_index.reserve(((size_t)(W > 1 ? W - 1 : 1) * n + 2) * sizeof(int32_t))) return e;
+  std::vector<double> send_cnt((size_t)W, 0.0);
+  size_t off = 0;
+  for (int p = 0; p < W; ++p) {
+    if (p == R || n == 0) continue;
+    size_t cnt = 0;
+    if (int e = mhip_select_aabb_overlap(n, aabb, buffer, &boxes[6 * (size_t)p], gp.send_index.as<int32_t>() + off, &cnt,
+                                         stream))
+      return e;
+    send_cnt[(size_t)p] = (double)cnt;
+    off += cnt;
+  }
+  gp.total_send = off;
+  std::vector<double> counts;  // counts[s][d] = bodies rank s sends to rank d
+  if (int e = host_all_gather(c, send_cnt.data(), (size_t)W, counts, s)) return e;
+  gp.n = n;
+  gp.n_lo = gp.n_hi = 0;
+  gp.send_peer.clear(); gp.send_rows.clear(); gp.recv_peer.clear(); gp.recv_first_row.clear(); gp.recv_rows.clear();
+  for (int p = 0; p < W; ++p) {
+    if (p == R) continue;
+    const size_t sc = (size_t)send_cnt[(size_t)p];
+    if (sc) {
+      gp.send_peer.push_back(p);
+      gp.send_rows.push_back(sc);
+    }
+    const size_t rc = (size_t)counts[(size_t)p * W + R];
+    if (p < R) gp.n_lo += rc; else gp.n_hi += rc;
+  }
+  size_t row = 0;
+  for (int p = 0; p < W; ++p) {
+    if (p == R) {
+      row = gp.n_lo + n;  // ghosts of higher ranks sit after the owned block
+      continue;
+    }
+    const size_t rc = (size_t)counts[(size_t)p * W + R];
+    if (rc) {
+      gp.recv_peer.push_back(p);
+      gp.recv_first_row.push_back(row);
+      gp.recv_rows.push_back(rc);
+    }
+    row += rc;
+  }
+  MHIP_REQUIRE(gp.n_lo + n + gp.n_hi < (1u << 31), MHIP_ERR_RUNTIME, "too many local bodies");
+  if (int e = gp.send_index_local.reserve((gp.total_send + 2) * sizeof(int32_t))) return e;
+  if (gp.total_send) {
+    k_offset_i32<<<grid_for(gp.total_send), kBlock, 0, s>>>(gp.total_send, gp.send_index.as<int32_t>(), (int32_t)gp.n_lo,
+                                                           gp.send_index_local.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+  }
+  gp.valid = true;
+  layout->num_ghost_lo = gp.n_lo;
+  layout->num_owned = n;
+  layout->num_ghost_hi = gp.n_hi;
+  layout->num_sent = gp.total_send;
+  layout->halo = mhip_velocity_halo{nullptr,
+                                    (int)gp.send_peer.size(), gp.send_peer.data(), gp.send_rows.data(),
+                                    gp.send_index_local.as<int32_t>(),
+                                    (int)gp.recv_peer.size(), gp.recv_peer.data(), gp.recv_first_row.data(),
+                                    gp.recv_rows.data()};
+  return MHIP_SUCCESS;
+}
+
+int mhip_ghost_exchange(mhip_comm_t c, size_t width, const double* records, double* local, mhip_stream_t stream) {
+  TraceRange trace_range("ghost exchange");
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  auto& gp = c->ghost;
+  MHIP_REQUIRE(gp.valid, MHIP_ERR_RUNTIME, "mhip_ghost_plan has not been called");
+  MHIP_REQUIRE(width >= 1, MHIP_ERR_INVALID_ARGUMENT, "width must be at least 1");
+  const size_t n_local = gp.n_lo + gp.n + gp.n_hi;
+  MHIP_REQUIRE(n_local == 0 || local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local is null");
+  MHIP_REQUIRE(gp.n == 0 || records != nullptr, MHIP_ERR_INVALID_ARGUMENT, "records is null");
+  hipStream_t s = as_stream(stream);
+  if (gp.n)
+    MHIP_HIP(hipMemcpyAsync(local + gp.n_lo * width, records, gp.n * width * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (gp.send_peer.empty() && gp.recv_peer.empty()) return MHIP_SUCCESS;
+  if (int e = gp.stage.reserve((gp.total_send * width + 2) * sizeof(double))) return e;
+  double* packed = gp.stage.as<double>();
+  if (gp.total_send)
+    if (int e = mhip_gather_rows(gp.total_send, width, gp.send_index.as<int32_t>(), records, packed, stream)) return e;
+  std::vector<const double*> sbuf(gp.send_peer.size());
+  std::vector<size_t> scount(gp.send_peer.size());
+  size_t off = 0;
+  for (size_t k = 0; k < gp.send_peer.size(); ++k) {
+    sbuf[k] = packed + off * width;
+    scount[k] = gp.send_rows[k] * width;
+    off += gp.send_rows[k];
+  }
+  std::vector<double*> rbuf(gp.recv_peer.size());
+  std::vector<size_t> rcount(gp.recv_peer.size());
+  for (size_t k = 0; k < gp.recv_peer.size(); ++k) {
+    rbuf[k] = local + gp.recv_first_row[k] * width;
+    rcount[k] = gp.recv_rows[k] * width;
+  }
+  if (int e = mhip_comm_exchange_start(c, (int)sbuf.size(), gp.send_peer.data(), sbuf.data(), scount.data(),
+                                       (int)rbuf.size(), gp.recv_peer.data(), rbuf.data(), rcount.data(), stream))
+    return e;
+  return mhip_comm_exchange_finish(c, stream);
 }
 
 int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, const mhip_velocity_halo* halo,

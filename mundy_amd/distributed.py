@@ -287,72 +287,26 @@ class DistributedContactStepper:
 
     # -- ghost halo -----------------------------------------------------------------------------------------------------
     def _exchange_ghosts(self):
+        """ghost plan + body-record exchange, both inside the library (mhip_ghost_plan / mhip_ghost_exchange)"""
         lib, comm = capi.load(), self.comm
         n, dev = self.n, self.center.device
         aabb, _ = self._aabb(self.center, self.quat, self.shape, self.kind)
-        box = (C.c_double * 6)()
-        capi.check(lib.mhip_aabb_bounds(n, _p(aabb), self.buffer, box, _stream()))
-        boxes = comm.all_gather(torch.tensor(list(box), dtype=torch.float64)).tolist()
-        send_idx, send_cnt = {}, [0] * comm.world
-        for p in range(comm.world):
-            if p == comm.rank:
-                continue
-            idx = torch.empty(n, dtype=torch.int32, device=dev)
-            cnt = C.c_size_t(0)
-            pb = (C.c_double * 6)(*boxes[p])
-            capi.check(lib.mhip_select_aabb_overlap(n, _p(aabb), self.buffer, pb, _p(idx), C.byref(cnt), _stream()))
-            send_idx[p], send_cnt[p] = idx[: cnt.value], int(cnt.value)
-        counts = comm.all_gather(torch.tensor(send_cnt, dtype=torch.float64)).to(torch.int64).tolist()  # counts[s][d]
-        recv_cnt, n_lo, n_hi, _ = halo_layout(counts, comm.rank)
-        # records of the owned bodies, gathered per peer
+        lay = self._layout = capi.GhostLayout()
+        capi.check(lib.mhip_ghost_plan(comm._h, n, _p(aabb), self.buffer, C.byref(lay), _stream()))
+        n_lo, n_hi = int(lay.num_ghost_lo), int(lay.num_ghost_hi)
+        # records of the owned bodies: gid, centre, quaternion, shape, kind, mobilities
         gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
         kcol = self.kind.to(torch.float64)[:, None] if self.mixed else torch.ones((n, 1), dtype=torch.float64, device=dev)
         rec = torch.cat([gid[:, None], self.center, self.quat, self.shape, kcol, self.mob_t[:, None],
-                         self.mob_r[:, None]], dim=1)
-        send = {p: ops.gather_rows(send_idx[p], rec) if send_cnt[p] else rec[:0] for p in send_idx}
-        recv = {p: torch.empty((recv_cnt[p], self.RECORD), dtype=torch.float64, device=dev)
-                for p in range(comm.world) if p != comm.rank}
-        comm.exchange(send, recv)
-        lo = [recv[p] for p in range(comm.rank) if recv_cnt[p]]
-        hi = [recv[p] for p in range(comm.rank + 1, comm.world) if recv_cnt[p]]
-        local = torch.cat(lo + [rec] + hi, dim=0).contiguous()
+                         self.mob_r[:, None]], dim=1).contiguous()
+        local = torch.empty((n_lo + n + n_hi, self.RECORD), dtype=torch.float64, device=dev)
+        capi.check(lib.mhip_ghost_exchange(comm._h, self.RECORD, _p(rec), _p(local), _stream()))
         self.n_lo, self.n_hi, self.n_local = n_lo, n_hi, local.shape[0]
         self.local = dict(gid=local[:, 0].contiguous(), center=local[:, 1:4].contiguous(),
                           quat=local[:, 4:8].contiguous(), shape=local[:, 8:11].contiguous(),
                           kind=local[:, 11].to(torch.int32).contiguous(), mob_t=local[:, 12].contiguous(),
                           mob_r=local[:, 13].contiguous())
-        # velocity halo plan: what I send each iteration (owned rows, as local indices) and where receives land
-        order = [p for p in range(comm.world) if p != comm.rank and send_cnt[p]]
-        self.vel_send_peers = order
-        self.vel_send_idx = (torch.cat([send_idx[p] for p in order]) + n_lo).to(torch.int32) if order else None
-        self.vel_send_split = [send_cnt[p] for p in order]
-        self.vel_recv = {}
-        off = 0
-        for p in range(comm.world):
-            if p == comm.rank:
-                off = n_lo + n  # ghosts of higher ranks sit after the owned block
-                continue
-            if recv_cnt[p]:
-                self.vel_recv[p] = (off, off + recv_cnt[p])
-            off += recv_cnt[p]
-        self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=sum(send_cnt))
-
-    def _velocity_halo(self):
-        """mhip_velocity_halo of this rank for the current ghost layout: which owned rows go to whom, where the
-        ghosts' rows land (host lists; the row indices stay on the device)"""
-        sp, sr = self.vel_send_peers, self.vel_send_split
-        rp = sorted(self.vel_recv)
-        h = capi.VelocityHalo()
-        h.velocity = self.vel.data_ptr()
-        h.num_send_peers = len(sp)
-        h.send_peer = (C.c_int * max(1, len(sp)))(*sp)
-        h.send_rows = (C.c_size_t * max(1, len(sp)))(*sr)
-        h.send_index = self.vel_send_idx.data_ptr() if self.vel_send_idx is not None else None
-        h.num_recv_peers = len(rp)
-        h.recv_peer = (C.c_int * max(1, len(rp)))(*rp)
-        h.recv_first_row = (C.c_size_t * max(1, len(rp)))(*[self.vel_recv[p][0] for p in rp])
-        h.recv_rows = (C.c_size_t * max(1, len(rp)))(*[self.vel_recv[p][1] - self.vel_recv[p][0] for p in rp])
-        return h
+        self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=int(lay.num_sent))
 
     # -- one step -------------------------------------------------------------------------------------------------------------
     def step(self, integrate=True):
@@ -411,7 +365,8 @@ class DistributedContactStepper:
         pc = capi.PgdConfig(int(self.cfg.max_iters), float(self.cfg.tol), int(self.cfg.residual_kind))
         # the whole staged loop runs inside the library (csrc/dist.hip): body sweep -> velocity halo in flight during
         # the interior sweep -> boundary sweep -> 3-double all-gather -> finalize, polled every poll_every iterations
-        halo = self._velocity_halo()
+        halo = self._layout.halo   # the velocity halo of the ghost layout (lists owned by the communicator)
+        halo.velocity = self.vel.data_ptr()
         res = capi.SolveResult()
         dprof = capi.DistProfile()
         capi.check(lib.mhip_bbpgd_solve_contact_distributed(
