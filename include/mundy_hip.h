@@ -408,6 +408,10 @@ int mhip_curve_order(size_t n, const double* center, const double* lo /*[host] 3
                      int level, const int32_t* key_table, int32_t* perm, mhip_stream_t stream);
 /* dst[k][0..width) = src[perm[k]][0..width)  for rows of `width` doubles */
 int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst, mhip_stream_t stream);
+/* dst[k * dst_stride + c] = src[k * src_stride + c], c < width (strides in doubles): packs per-body fields into
+ * interleaved records for the ghost exchange and unpacks them again */
+int mhip_copy_strided(size_t n, size_t width, const double* src, size_t src_stride, double* dst, size_t dst_stride,
+                      mhip_stream_t stream);
 
 
 /* ----------------------------------------------------------------------------------------------------------------

@@ -97,5 +97,119 @@ class SpherocylinderStepper {
   mesh::GenNeighborLinks links_;
 };
 
+// One rank's share of a spherocylinder system cut along a space-filling curve: this rank owns the bodies
+// with global ids [gid_first, gid_first + n), ranks own increasing ranges.  step() =
+//   compute_aabb(owned) -> ghost plan + body-record exchange (coarse_search(comm) + change_ghosting,
+//   GenNeighborLinkers.hpp:658, :687-711) -> neighbour list over owned + ghosts, ghost-ghost pairs dropped, interior
+//   contacts first -> contacts -> rod operator with the owned range -> domain-decomposed BBPGD (velocity halo + 3-double
+//   all-gather per iteration, NGPSpheresLCP.cpp:371, :450-452) -> Euler update of the owned bodies.
+// The communicator is the caller's (mhip_comm_create_rccl with an id the launcher hands round, or a host transport).
+class DistributedSpherocylinderStepper {
+ public:
+  static constexpr size_t kRecord = 12;  // gid, centre 3, quaternion 4, radius, length, translational / rotational mobility
+
+  DistributedSpherocylinderStepper(mhip_comm_t comm, size_t gid_first, const std::vector<double>& center,
+                                   const std::vector<double>& quat, const std::vector<double>& radius,
+                                   const std::vector<double>& length, const std::vector<double>& mob_trans,
+                                   const std::vector<double>& mob_rot, double dt, double search_buffer,
+                                   convex::PGDConfig<double> cfg)
+      : comm_(comm), n_(radius.size()), dt_(dt), buffer_(search_buffer), cfg_(cfg), center_(center), quat_(quat),
+        radius_(radius), length_(length), mob_t_(mob_trans), mob_r_(mob_rot), aabb_(6 * n_), rec_(kRecord * n_) {
+    std::vector<double> gid(n_);
+    for (size_t i = 0; i < n_; ++i) gid[i] = static_cast<double>(gid_first + i);
+    gid_ = DeviceVector(gid);
+    links_.set_search_buffer(search_buffer).set_search_kind(MHIP_SEARCH_AABB).concretize();
+  }
+
+  struct DistStats : StepStats {
+    size_t ghosts = 0, local_contacts = 0, interior_contacts = 0, owned_contacts = 0;
+  };
+
+  DistStats step(bool integrate = true) {
+    DistStats st;
+    check(mhip_compute_aabb_spherocylinders(n_, center_.data(), quat_.data(), radius_.data(), length_.data(),
+                                            aabb_.data(), nullptr));
+    mhip_ghost_layout lay{};
+    check(mhip_ghost_plan(comm_, n_, aabb_.data(), buffer_, &lay, nullptr));
+    const size_t n_lo = lay.num_ghost_lo, nl = n_lo + n_ + lay.num_ghost_hi;
+    st.ghosts = nl - n_;
+    // interleave the owned fields into records, exchange, split the local records into fields again
+    const struct { const DeviceVector* v; size_t w; } fields[] = {{&gid_, 1}, {&center_, 3}, {&quat_, 4}, {&radius_, 1},
+                                                                  {&length_, 1}, {&mob_t_, 1}, {&mob_r_, 1}};
+    size_t col = 0;
+    for (const auto& f : fields) {
+      check(mhip_copy_strided(n_, f.w, f.v->data(), f.w, rec_.data() + col, kRecord, nullptr));
+      col += f.w;
+    }
+    DeviceVector local(kRecord * nl);
+    check(mhip_ghost_exchange(comm_, kRecord, rec_.data(), local.data(), nullptr));
+    DeviceVector l_gid(nl), l_center(3 * nl), l_quat(4 * nl), l_radius(nl), l_length(nl), l_mt(nl), l_mr(nl);
+    DeviceVector* out[] = {&l_gid, &l_center, &l_quat, &l_radius, &l_length, &l_mt, &l_mr};
+    col = 0;
+    for (size_t k = 0; k < 7; ++k) {
+      check(mhip_copy_strided(nl, fields[k].w, local.data() + col, kRecord, out[k]->data(), fields[k].w, nullptr));
+      col += fields[k].w;
+    }
+    // neighbour list over owned + ghosts; ghost-ghost pairs dropped, interior contacts first
+    DeviceVector l_aabb(6 * nl), l_brad(nl), seg(8 * nl);
+    check(mhip_compute_aabb_spherocylinders(nl, l_center.data(), l_quat.data(), l_radius.data(), l_length.data(),
+                                            l_aabb.data(), nullptr));
+    check(mhip_bounding_radius_spherocylinders(nl, l_radius.data(), l_length.data(), l_brad.data(), nullptr));
+    links_.generate(nl, l_aabb.data(), l_center.data(), l_brad.data(), nullptr, /*force=*/true);
+    const DeviceArray<int32_t> all_pairs = links_.links();
+    const size_t c_all = links_.num_links();
+    DeviceArray<int32_t> pairs(2 * c_all + 2);
+    DeviceArray<unsigned char> counted(c_all + 1);
+    size_t n_int = 0, C = 0;
+    check(mhip_partition_pairs_owned(c_all, all_pairs.data(), n_lo, n_, pairs.data(), counted.data(), &n_int, &C, nullptr));
+    st.num_contacts = st.local_contacts = C;
+    st.interior_contacts = n_int;
+    check(mhip_spherocylinder_segments(nl, l_center.data(), l_quat.data(), l_radius.data(), l_length.data(), seg.data(),
+                                       nullptr));
+    DeviceVector sep(C), normal(3 * C), s(C), t(C);
+    check(mhip_contact_spherocylinders(C, pairs.data(), seg.data(), nullptr, sep.data(), normal.data(), nullptr, nullptr,
+                                       nullptr, nullptr, s.data(), t.data(), nullptr));
+    ContactOperator op(C, nl, pairs.data(), normal.data(), ContactOperator::Rods{s.data(), t.data(), seg.data()},
+                       l_mt.data(), l_mr.data(), dt_, nullptr, /*priority=*/sep.data());
+    DeviceVector vel(std::vector<double>(6 * nl, 0.0));
+    check(mhip_contact_op_set_partition(op.handle(), n_lo, n_, counted.data(), vel.data()));
+    lay.halo.velocity = vel.data();
+    DeviceVector x(std::vector<double>(C, 0.0)), g(C), x_tmp(C), g_tmp(C);
+    const mhip_space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
+    const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};
+    mhip_solve_result res{};
+    check(mhip_bbpgd_solve_contact_distributed(op.handle(), comm_, &lay.halo, n_int, sep.data(), &lcp, &pc, x.data(),
+                                               g.data(), x_tmp.data(), g_tmp.data(), /*poll_every=*/32, &res, nullptr,
+                                               nullptr));
+    st.num_iters = res.num_iters;
+    st.residual = res.residual;
+    st.converged = res.converged != 0;
+    st.rebuilt = true;
+    if (integrate) {
+      const double* v = nullptr;
+      check(mhip_contact_op_body_velocity(op.handle(), &v));
+      check(mhip_integrate_euler(n_, dt_, v + 6 * n_lo, l_center.data() + 3 * n_lo, l_quat.data() + 4 * n_lo, nullptr));
+      check(mhip_deep_copy(3 * n_, center_.data(), l_center.data() + 3 * n_lo, nullptr));
+      check(mhip_deep_copy(4 * n_, quat_.data(), l_quat.data() + 4 * n_lo, nullptr));
+    }
+    check(mhip_stream_synchronize(nullptr));
+    lambda_ = std::move(x);
+    return st;
+  }
+
+  size_t num_bodies() const { return n_; }
+  const DeviceVector& center() const { return center_; }
+  const DeviceVector& quat() const { return quat_; }
+  const DeviceVector& lambda() const { return lambda_; }
+
+ private:
+  mhip_comm_t comm_;
+  size_t n_;
+  double dt_, buffer_;
+  convex::PGDConfig<double> cfg_;
+  DeviceVector center_, quat_, radius_, length_, mob_t_, mob_r_, aabb_, rec_, gid_, lambda_;
+  mesh::GenNeighborLinks links_;
+};
+
 }  // namespace mech
 }  // namespace mundy_hip

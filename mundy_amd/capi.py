@@ -146,6 +146,7 @@ SIGNATURES = {
     "mhip_set_tracing": [_i],
     "mhip_curve_order": [_sz, _vp, C.POINTER(_d), C.POINTER(_d), _i, _vp, _vp, _vp],
     "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],
+    "mhip_copy_strided": [_sz, _sz, _vp, _sz, _vp, _sz, _vp],
     "mhip_contact_op_sizes": [_vp, C.POINTER(_sz), C.POINTER(_sz)],
     "mhip_comm_unique_id": [C.c_char_p],
     "mhip_comm_create_rccl": [C.POINTER(_vp), C.c_char_p, _i, _i],

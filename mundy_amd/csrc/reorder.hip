@@ -233,6 +233,17 @@ int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* 
   return MHIP_SUCCESS;
 }
 
+int mhip_copy_strided(size_t n, size_t width, const double* src, size_t src_stride, double* dst, size_t dst_stride,
+                      mhip_stream_t stream) {
+  MHIP_REQUIRE(width > 0 && src_stride >= width && dst_stride >= width, MHIP_ERR_INVALID_ARGUMENT,
+               "strides (%zu, %zu) must be at least the width %zu", src_stride, dst_stride, width);
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(src && dst, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_HIP(hipMemcpy2DAsync(dst, dst_stride * sizeof(double), src, src_stride * sizeof(double), width * sizeof(double), n,
+                            hipMemcpyDeviceToDevice, as_stream(stream)));
+  return MHIP_SUCCESS;
+}
+
 int mhip_periodic_sep(size_t n, const double* box, const double* p1, const double* p2, double* out,
                       mhip_stream_t stream) {
   MHIP_REQUIRE(box != nullptr && box[0] > 0 && box[1] > 0 && box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
