@@ -9,6 +9,7 @@
 //                              sort the row -> pairs sorted by (i, j) without a global sort
 // The predicate is evaluated with the lower body index first, exactly as the CPU oracle does, so pair sets are
 // bit-identical.  Integer/comparison work only: HBM/L2-bound, no MFMA.
+#include <cstdlib>
 #include <initializer_list>
 
 #include "geom_device.hpp"
@@ -274,6 +275,97 @@ __global__ void __launch_bounds__(kBlock)
   for (int a = 0; a < cnt; ++a) pairs[base + a] = make_int2(i, col[base + a]);
 }
 
+// The same search with the candidates staged through LDS (free boundaries; the periodic search keeps k_pairs, whose
+// wrapped stencil is not a linear cell range).  A workgroup owns 256 consecutive slots of the cell-ordered records, i.e.
+// the bodies of cells c_first..c_last.  Cells are numbered x-fastest, so for each of the 9 (dz, dy) rows of the stencil
+// the candidates of ALL its bodies lie in the linear cell range [c_first + off - 1, c_last + off + 1], off = (dz ny +
+// dy) nx -- one contiguous run of 64-byte records (at a row end the run also holds a few cells that are nobody's
+// neighbours; they are staged but never tested).  The run is copied to LDS in tiles of kPairTile records with
+// coalesced 16-byte loads, and every lane then walks only its own three x-cells inside the tile.  Global memory
+// sees each candidate record once per workgroup instead of once per lane; the tests, their operand order and the
+// row sort are those of k_pairs, so the lists are identical.
+constexpr int kPairTile = 512;  // records per tile: 32 KB of LDS, 4 workgroups per CU
+template <bool FILL>
+__global__ void __launch_bounds__(kBlock)
+    k_pairs_lds(size_t n, BpArgs A, const GridParams* __restrict__ gpp, const SearchRec* __restrict__ recs,
+                const int32_t* __restrict__ slot_cell, const int32_t* __restrict__ cell_ptr,
+                int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ col,
+                int2* __restrict__ pairs) {
+  __shared__ __attribute__((aligned(16))) SearchRec tile[kPairTile];
+  const GridParams gp = *gpp;
+  const size_t s0 = blockIdx.x * (size_t)kBlock;
+  const size_t s = s0 + threadIdx.x;
+  const bool live = s < n;
+  SearchRec me{};
+  int i = -1, cx = 0, cy = 0, cz = 0;
+  if (live) {
+    me = recs[s];
+    i = static_cast<int>(me.id);
+    const int cid = slot_cell[s];
+    cx = cid % gp.nc[0];
+    cy = (cid / gp.nc[0]) % gp.nc[1];
+    cz = cid / (gp.nc[0] * gp.nc[1]);
+  }
+  const int c_first = slot_cell[s0];
+  const int c_last = slot_cell[(s0 + kBlock <= n ? s0 + kBlock : n) - 1];
+  int cnt = 0;
+  const int32_t base = (FILL && live) ? row_ptr[i] : 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy) {
+      const long long off = (static_cast<long long>(dz) * gp.nc[1] + dy) * gp.nc[0];
+      long long lo = c_first + off - 1, hi = c_last + off + 1;
+      if (lo < 0) lo = 0;
+      if (hi > gp.ncell - 1) hi = gp.ncell - 1;
+      if (hi < lo) continue;  // the same for every thread of the workgroup
+      const int32_t run_beg = cell_ptr[lo], run_end = cell_ptr[hi + 1];
+      int32_t my_beg = 0, my_end = 0;  // this lane's candidates in the row: its cells x-1 .. x+1
+      const int z = cz + dz, y = cy + dy;
+      if (live && z >= 0 && z < gp.nc[2] && y >= 0 && y < gp.nc[1]) {
+        const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < gp.nc[0] ? cx + 1 : gp.nc[0] - 1;
+        const int row = (z * gp.nc[1] + y) * gp.nc[0];
+        my_beg = cell_ptr[row + x0];
+        my_end = cell_ptr[row + x1 + 1];
+      }
+      for (int32_t t0 = run_beg; t0 < run_end; t0 += kPairTile) {
+        const int32_t t1 = t0 + kPairTile < run_end ? t0 + kPairTile : run_end;
+        __syncthreads();  // everyone is done with the previous tile
+        {
+          const double2* __restrict__ src = reinterpret_cast<const double2*>(recs + t0);
+          double2* dst = reinterpret_cast<double2*>(tile);
+          const int nq = (t1 - t0) * 4;
+          for (int q = threadIdx.x; q < nq; q += kBlock) dst[q] = src[q];
+        }
+        __syncthreads();
+        const int32_t b = my_beg > t0 ? my_beg : t0, e = my_end < t1 ? my_end : t1;
+        for (int32_t t = b; t < e; ++t) {
+          const SearchRec& o = tile[t - t0];
+          const int j = static_cast<int>(o.id);
+          if (j == i || (!A.symmetric && j < i)) continue;
+          const bool hit = (i < j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
+          if (hit) {
+            if (FILL) col[base + cnt] = j;
+            ++cnt;
+          }
+        }
+      }
+    }
+  if (!live) return;
+  if (!FILL) {
+    counts[i] = cnt;
+    return;
+  }
+  for (int a = 1; a < cnt; ++a) {  // sort the row ascending (rows are short), then emit (i, j)
+    const int32_t v = col[base + a];
+    int b = a - 1;
+    while (b >= 0 && col[base + b] > v) {
+      col[base + b + 1] = col[base + b];
+      --b;
+    }
+    col[base + b + 1] = v;
+  }
+  for (int a = 0; a < cnt; ++a) pairs[base + a] = make_int2(i, col[base + a]);
+}
+
 // GenNeighborLinkers.hpp:603-615: moved iff sqrt(dx^2+dy^2+dz^2) > 0.5 * buffer (plain left-to-right sum there)
 __global__ void __launch_bounds__(kBlock) k_moved(size_t n, const double* __restrict__ c_new,
                                                  const double* __restrict__ c_old, double buffer,
@@ -401,8 +493,18 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
                                      h->cursor.as<int32_t>(), h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>());
   MHIP_LAUNCH_CHECK();
   const unsigned gb = grid_exact(n);
-  k_pairs<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                      h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, nullptr, nullptr);
+  static const bool use_lds = [] {
+    const char* e = getenv("MHIP_PAIRS_LDS");  // A/B switch of the LDS-staged search (default on)
+    return !(e && atoi(e) == 0);
+  }();
+  const bool lds = use_lds && !A.periodic;
+  if (lds)
+    k_pairs_lds<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                            h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, nullptr,
+                                            nullptr);
+  else
+    k_pairs<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                        h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, nullptr, nullptr);
   MHIP_LAUNCH_CHECK();
   if (int e = exclusive_scan_i32(h->counts.as<int32_t>(), h->row_ptr.as<int32_t>(), n, h->scanws.ptr, s)) return e;
   MHIP_HIP(hipMemcpyAsync(h->host_scalar, h->row_ptr.as<int32_t>() + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -412,9 +514,14 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   h->num_pairs = static_cast<size_t>(total);
   if (int e = h->col.reserve((h->num_pairs + 2) * sizeof(int32_t))) return e;
   if (int e = h->pairs.reserve((h->num_pairs + 2) * sizeof(int2))) return e;
-  k_pairs<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                     h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(),
-                                     h->col.as<int32_t>(), h->pairs.as<int2>());
+  if (lds)
+    k_pairs_lds<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                           h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(),
+                                           h->col.as<int32_t>(), h->pairs.as<int2>());
+  else
+    k_pairs<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                       h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(),
+                                       h->col.as<int32_t>(), h->pairs.as<int2>());
   MHIP_LAUNCH_CHECK();
   MHIP_HIP(hipMemcpyAsync(h->old_center.ptr, center, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
   *num_pairs = h->num_pairs;
