@@ -14,8 +14,9 @@ Every step starts from the same pristine input (restored by a device copy inside
 identical work.  Inputs are resident in HBM before the timed region starts.
 
 N > 1 (weak scaling): ONE system of N x 10^6 spherocylinders in a box grown to keep the 40 % volume fraction, cut along
-a Hilbert curve into N contiguous ranges, one per GPU (mundy_amd/distributed.py): ghost-body halo at the neighbour-list
-build, and per BBPGD iteration a ghost-velocity halo (RCCL send/recv) + one 3-double all-gather.
+a Hilbert curve into N contiguous ranges, one per GPU: ghost-body halo at the neighbour-list build, and per BBPGD
+iteration a ghost-velocity halo (RCCL send/recv) + one 3-double all-gather.  The iteration loop and the transport are
+C++ inside libmundy_hip (csrc/dist.hip); torch.distributed only launches (RCCL id broadcast, barrier, max over ranks).
 `value` = timesteps of 10^6-spherocylinder shards completed per second over all ranks (= N x global timesteps/s).
 The BBPGD iteration count grows with the system (767 iterations at 10^6 rods, ~960 at 2*10^6, ~1430 at 8*10^6 on this
 packing), so weak-scaling efficiency is bounded by that growth before any communication cost.
@@ -232,8 +233,10 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     del centers
     b = synth.spherocylinders(len(mine), seed=1234, n_total=n_total, indices=mine)
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
+    comm = D.Comm()
+    comm.self_check()  # pairwise messages + all-gather with known contents, before anything is timed
     st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
-                                     comm=D.Comm(), search_buffer=args.buffer, cfg=cfg, poll_every=32)
+                                     comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=32)
     pristine_c, pristine_q = st.center.clone(), st.quat.clone()
 
     def one_step(profile):

@@ -208,6 +208,24 @@ class Comm:
         capi.check(capi.load().mhip_comm_all_gather(self._h, _p(src), src.numel(), _p(out), _stream()))
         return out if t.is_cuda else out.cpu()
 
+    def self_check(self):
+        """Every rank messages every other rank a pattern only that pair knows and all-gathers a rank-stamped triple;
+        raises on any rank that sees something else.  bench.py runs it once before the timed region, so a transport
+        that misroutes fails loudly instead of timing wrong physics."""
+        dev, r, w = torch.device("cuda", torch.cuda.current_device()), self.rank, self.world
+        pattern = lambda src, dst, n: torch.arange(n, dtype=torch.float64, device=dev) + 1000.0 * src + 7.0 * dst  # noqa: E731
+        size = lambda src, dst: 6 * (1 + (3 * src + 5 * dst) % 11)  # noqa: E731
+        send = {p: pattern(r, p, size(r, p)) for p in range(w) if p != r}
+        recv = {p: torch.full((size(p, r),), -1.0, dtype=torch.float64, device=dev) for p in range(w) if p != r}
+        self.exchange(send, recv)
+        for p, t in recv.items():
+            if not torch.equal(t, pattern(p, r, size(p, r))):
+                raise RuntimeError("rank %d: the message from rank %d arrived damaged" % (r, p))
+        g = self.all_gather(torch.tensor([r, 2.0 * r, -1.0 * r], dtype=torch.float64, device=dev))
+        want = torch.tensor([[q, 2.0 * q, -1.0 * q] for q in range(w)], dtype=torch.float64, device=dev)
+        if not torch.equal(g, want):
+            raise RuntimeError("rank %d: all_gather returned %s" % (r, g.tolist()))
+
     def exchange(self, send, recv):
         """send / recv: {peer: contiguous float64 device tensor}; recv tensors are filled in place."""
         lib = capi.load()

@@ -28,6 +28,7 @@ def main():
     g_center, g_quat = b["center"][order], b["quat"][order]
     a, e = int(starts[rank]), int(starts[rank + 1])
     cfg = ops.PGDConfig(max_iters=20000, tol=tol)
+    D.Comm().self_check()
     if mixed:
         g_kind, g_shape = b["kind"][order], b["shape"][order]
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), None, None, a, comm=D.Comm(),

@@ -57,6 +57,7 @@ def test_nccl_transport_single_rank():
         assert comm.direct and comm.world == 1
         t = torch.arange(3, dtype=torch.float64, device="cuda")
         assert torch.equal(comm.all_gather(t), t.reshape(1, 3))
+        comm.self_check()
         h = torch.tensor([4.0, 5.0], dtype=torch.float64)    # host scalars ride through the GPU
         assert comm.all_gather(h).tolist() == [[4.0, 5.0]] and not comm.all_gather(h).is_cuda
         # grouped ncclSend / ncclRecv with the stream hand-over, on the one rank there is: RCCL delivers a message to
