@@ -205,6 +205,8 @@ def main():
                        "parallelism": "single GPU (N > 1: hilbert domain decomposition with RCCL halo)"},
             "contact_pairs_per_sec": round(world * contacts * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(world * sum(iters) / elapsed, 1),
+            # contacts x iterations per second: the rate that stays comparable when the iteration count changes
+            "constraint_updates_per_sec": round(world * contacts * sum(iters) / elapsed, 1),
             "roofline": roof, "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         }
@@ -288,6 +290,10 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                                       "iteration ghost-velocity send/recv + 3-double all-gather (RCCL)" % world},
             "contact_pairs_per_sec": round(contacts_global * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
+            # contacts x iterations per second over all ranks: separates the growth of the BBPGD iteration count with
+            # the system size (algorithmic) from what the halo and the all-gather cost per iteration
+            "constraint_updates_per_sec": round(contacts_global * sum(iters) / elapsed, 1),
+            "halo_wait_ms_per_iteration": round(st.prof.get("halo_wait_ms", 0.0) / max(1, st.prof["iters"]), 4),
             "roofline": roof, "cpu_baseline": None,
         }
         out.update(extra)
