@@ -486,6 +486,13 @@ typedef struct mhip_ghost_layout {
   size_t num_sent; /* owned bodies that are ghosts somewhere, counted once per receiving rank */
   mhip_velocity_halo halo;
 } mhip_ghost_layout;
+/* The bookkeeping of the plan on its own (host arithmetic only, no device): counts[s * world + d] = bodies rank s sends
+ * to rank d.  Peer lists are filled in ascending rank order, empty messages left out; the lists must hold `world`
+ * entries.  recv_first_row = first local row of each peer's ghosts. */
+int mhip_ghost_layout_from_counts(int world, int rank, size_t n_owned, const size_t* counts /*[host]*/,
+                                  size_t* num_ghost_lo, size_t* num_ghost_hi, int* num_send, int* send_peer,
+                                  size_t* send_rows, int* num_recv, int* recv_peer, size_t* recv_first_row,
+                                  size_t* recv_rows);
 int mhip_ghost_plan(mhip_comm_t comm, size_t n, const double* aabb, double buffer,
                     mhip_ghost_layout* layout /*[host] out*/, mhip_stream_t stream);
 int mhip_ghost_exchange(mhip_comm_t comm, size_t width, const double* records /*[n][width]*/,

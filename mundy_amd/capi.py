@@ -157,6 +157,9 @@ SIGNATURES = {
     "mhip_comm_exchange_start": [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i),
                                  C.POINTER(_vp), C.POINTER(_sz), _vp],
     "mhip_comm_exchange_finish": [_vp, _vp],
+    "mhip_ghost_layout_from_counts": [_i, _i, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i),
+                                      C.POINTER(_i), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz),
+                                      C.POINTER(_sz)],
     "mhip_ghost_plan": [_vp, _sz, _vp, _d, C.POINTER(GhostLayout), _vp],
     "mhip_ghost_exchange": [_vp, _sz, _vp, _vp, _vp],
     "mhip_bbpgd_solve_contact_distributed": [_vp, _vp, C.POINTER(VelocityHalo), _sz, _vp, C.POINTER(Space),

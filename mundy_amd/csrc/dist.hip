@@ -289,6 +289,46 @@ int mhip_comm_exchange_finish(mhip_comm_t c, mhip_stream_t stream) {
   return MHIP_SUCCESS;
 }
 
+int mhip_ghost_layout_from_counts(int world, int rank, size_t n_owned, const size_t* counts, size_t* num_ghost_lo,
+                                  size_t* num_ghost_hi, int* num_send, int* send_peer, size_t* send_rows, int* num_recv,
+                                  int* recv_peer, size_t* recv_first_row, size_t* recv_rows) {
+  MHIP_REQUIRE(world >= 1 && rank >= 0 && rank < world, MHIP_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, world);
+  MHIP_REQUIRE(counts && num_ghost_lo && num_ghost_hi && num_send && num_recv, MHIP_ERR_INVALID_ARGUMENT,
+               "null argument");
+  MHIP_REQUIRE(world == 1 || (send_peer && send_rows && recv_peer && recv_first_row && recv_rows),
+               MHIP_ERR_INVALID_ARGUMENT, "peer lists are null");
+  const size_t W = (size_t)world, R = (size_t)rank;
+  size_t n_lo = 0, n_hi = 0;
+  int ns = 0, nr = 0;
+  for (size_t p = 0; p < W; ++p) {
+    if (p == R) continue;
+    if (const size_t sc = counts[R * W + p]) {
+      send_peer[ns] = (int)p;
+      send_rows[ns++] = sc;
+    }
+    (p < R ? n_lo : n_hi) += counts[p * W + R];
+  }
+  size_t row = 0;
+  for (size_t p = 0; p < W; ++p) {
+    if (p == R) {
+      row = n_lo + n_owned;  // ghosts of higher ranks sit after the owned block
+      continue;
+    }
+    const size_t rc = counts[p * W + R];
+    if (rc) {
+      recv_peer[nr] = (int)p;
+      recv_first_row[nr] = row;
+      recv_rows[nr++] = rc;
+    }
+    row += rc;
+  }
+  *num_ghost_lo = n_lo;
+  *num_ghost_hi = n_hi;
+  *num_send = ns;
+  *num_recv = nr;
+  return MHIP_SUCCESS;
+}
+
 int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, mhip_ghost_layout* layout,
                     mhip_stream_t stream) {
   TraceRange trace_range("ghost plan (coarse_search(comm) + change_ghosting)");
@@ -321,31 +361,18 @@ int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, 
   std::vector<double> counts;  // counts[s][d] = bodies rank s sends to rank d
   if (int e = host_all_gather(c, send_cnt.data(), (size_t)W, counts, s)) return e;
   gp.n = n;
-  gp.n_lo = gp.n_hi = 0;
-  gp.send_peer.clear(); gp.send_rows.clear(); gp.recv_peer.clear(); gp.recv_first_row.clear(); gp.recv_rows.clear();
-  for (int p = 0; p < W; ++p) {
-    if (p == R) continue;
-    const size_t sc = (size_t)send_cnt[(size_t)p];
-    if (sc) {
-      gp.send_peer.push_back(p);
-      gp.send_rows.push_back(sc);
-    }
-    const size_t rc = (size_t)counts[(size_t)p * W + R];
-    if (p < R) gp.n_lo += rc; else gp.n_hi += rc;
-  }
-  size_t row = 0;
-  for (int p = 0; p < W; ++p) {
-    if (p == R) {
-      row = gp.n_lo + n;  // ghosts of higher ranks sit after the owned block
-      continue;
-    }
-    const size_t rc = (size_t)counts[(size_t)p * W + R];
-    if (rc) {
-      gp.recv_peer.push_back(p);
-      gp.recv_first_row.push_back(row);
-      gp.recv_rows.push_back(rc);
-    }
-    row += rc;
+  {
+    std::vector<size_t> cm(counts.size());
+    for (size_t k = 0; k < counts.size(); ++k) cm[k] = (size_t)counts[k];
+    gp.send_peer.assign((size_t)W, 0); gp.send_rows.assign((size_t)W, 0);
+    gp.recv_peer.assign((size_t)W, 0); gp.recv_first_row.assign((size_t)W, 0); gp.recv_rows.assign((size_t)W, 0);
+    int ns = 0, nr = 0;
+    if (int e = mhip_ghost_layout_from_counts(W, R, n, cm.data(), &gp.n_lo, &gp.n_hi, &ns, gp.send_peer.data(),
+                                              gp.send_rows.data(), &nr, gp.recv_peer.data(), gp.recv_first_row.data(),
+                                              gp.recv_rows.data()))
+      return e;
+    gp.send_peer.resize((size_t)ns); gp.send_rows.resize((size_t)ns);
+    gp.recv_peer.resize((size_t)nr); gp.recv_first_row.resize((size_t)nr); gp.recv_rows.resize((size_t)nr);
   }
   MHIP_REQUIRE(gp.n_lo + n + gp.n_hi < (1u << 31), MHIP_ERR_RUNTIME, "too many local bodies");
   if (int e = gp.send_index_local.reserve((gp.total_send + 2) * sizeof(int32_t))) return e;

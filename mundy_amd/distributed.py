@@ -91,21 +91,6 @@ def partition_ranges(n_total, world):
     return np.concatenate([[0], np.cumsum(counts)])
 
 
-def halo_layout(count_matrix, rank):
-    """Pure bookkeeping of the ghost halo.  count_matrix[s][d] = number of bodies rank s sends to rank d.
-    Returns (recv_counts per peer, ghosts_lo, ghosts_hi, recv_offsets): ghosts from lower ranks come first in the
-    local index space, then the owned bodies, then ghosts from higher ranks (peer order within each group)."""
-    world = len(count_matrix)
-    recv = [int(count_matrix[p][rank]) if p != rank else 0 for p in range(world)]
-    n_lo = sum(recv[:rank])
-    n_hi = sum(recv[rank + 1:])
-    offsets, acc = [], 0
-    for p in range(world):
-        offsets.append(acc)
-        acc += recv[p]
-    return recv, n_lo, n_hi, offsets
-
-
 # ---- communication ------------------------------------------------------------------------------------------------------
 class Comm:
     """One rank's communicator of the C library (mhip_comm_*, csrc/dist.hip).  torch.distributed is only the launcher:

@@ -45,13 +45,61 @@ def test_hilbert_order_and_partition():
     assert (q.max(axis=0) - q.min(axis=0)).min() < 7.0
 
 
-def test_halo_layout():
-    from mundy_amd import distributed as D
+def _halo_layout(count_matrix, rank):
+    """independent restatement of the ghost bookkeeping: ghosts of lower ranks, owned, ghosts of higher ranks"""
+    world = len(count_matrix)
+    recv = [int(count_matrix[p][rank]) if p != rank else 0 for p in range(world)]
+    return recv, sum(recv[:rank]), sum(recv[rank + 1:])
+
+
+def _c_layout(counts, rank, n_owned):
+    import ctypes as C
+    from mundy_amd import capi
+    lib = capi.load()
+    w = len(counts)
+    flat = (C.c_size_t * (w * w))(*[counts[s][d] for s in range(w) for d in range(w)])
+    lo, hi, ns, nr = C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int()
+    sp, sr = (C.c_int * w)(), (C.c_size_t * w)()
+    rp, rf, rr = (C.c_int * w)(), (C.c_size_t * w)(), (C.c_size_t * w)()
+    capi.check(lib.mhip_ghost_layout_from_counts(w, rank, n_owned, flat, C.byref(lo), C.byref(hi), C.byref(ns), sp, sr,
+                                                 C.byref(nr), rp, rf, rr))
+    return dict(n_lo=lo.value, n_hi=hi.value, send=[(sp[k], sr[k]) for k in range(ns.value)],
+                recv=[(rp[k], rf[k], rr[k]) for k in range(nr.value)])
+
+
+def test_ghost_layout_bookkeeping():
+    # the host arithmetic of mhip_ghost_plan (C++, no device needed) against the restatement above
     counts = [[0, 5, 0, 2], [3, 0, 7, 0], [0, 4, 0, 1], [6, 0, 8, 0]]
-    recv, n_lo, n_hi, off = D.halo_layout(counts, 2)
-    assert recv == [0, 7, 0, 8] and n_lo == 7 and n_hi == 8 and off == [0, 0, 7, 7]
-    recv, n_lo, n_hi, off = D.halo_layout(counts, 0)
-    assert recv == [0, 3, 0, 6] and n_lo == 0 and n_hi == 9
+    lay = _c_layout(counts, 2, 100)
+    assert lay["n_lo"] == 7 and lay["n_hi"] == 8
+    assert lay["send"] == [(1, 4), (3, 1)]
+    assert lay["recv"] == [(1, 0, 7), (3, 107, 8)]          # lower ghosts from row 0, higher ones after lo + owned
+    lay = _c_layout(counts, 0, 10)
+    assert (lay["n_lo"], lay["n_hi"]) == (0, 9) and lay["recv"] == [(1, 10, 3), (3, 13, 6)] and lay["send"] == [(1, 5), (3, 2)]
+    rng = np.random.default_rng(5)
+    for w in (1, 2, 3, 5, 8):
+        cm = rng.integers(0, 4, (w, w)) * rng.integers(0, 50, (w, w))
+        np.fill_diagonal(cm, 0)
+        cm = cm.tolist()
+        lays = [_c_layout(cm, r, 1000 + r) for r in range(w)]
+        for r in range(w):
+            recv, n_lo, n_hi = _halo_layout(cm, r)
+            assert (lays[r]["n_lo"], lays[r]["n_hi"]) == (n_lo, n_hi)
+            # rows are contiguous, in peer order, with the owned block between the lower and the higher ghosts
+            row = 0
+            want = []
+            for p in range(w):
+                if p == r:
+                    row = n_lo + 1000 + r
+                    continue
+                if recv[p]:
+                    want.append((p, row, recv[p]))
+                row += recv[p]
+            assert lays[r]["recv"] == want
+            # what r sends to p is what p expects from r
+            for p, rows in lays[r]["send"]:
+                assert (r, rows) in [(q, k) for q, _, k in lays[p]["recv"]]
+            assert sum(k for _, k in lays[r]["send"]) == sum(cm[r])
 
 
 WORKER = r'''
@@ -75,8 +123,14 @@ comm.host_exchange({}, {})
 # the ghost bookkeeping both sides derive from the all-gathered count matrix agrees: what r sends is what 1-r expects
 counts = comm.host_all_gather(torch.tensor([0.0, 5.0] if r == 0 else [3.0, 0.0], dtype=torch.float64)).to(torch.int64).tolist()
 assert counts == [[0, 5], [3, 0]]
-rc, n_lo, n_hi, off = D.halo_layout(counts, r)
-assert rc[1 - r] == counts[1 - r][r] and n_lo + n_hi == counts[1 - r][r]
+import ctypes as C2
+flat = (C2.c_size_t * 4)(*[counts[s][d] for s in range(2) for d in range(2)])
+lo, hi, ns, nr = C2.c_size_t(), C2.c_size_t(), C2.c_int(), C2.c_int()
+sp, sr, rp, rf, rr = (C2.c_int * 2)(), (C2.c_size_t * 2)(), (C2.c_int * 2)(), (C2.c_size_t * 2)(), (C2.c_size_t * 2)()
+capi.check(capi.load().mhip_ghost_layout_from_counts(2, r, 100, flat, C2.byref(lo), C2.byref(hi), C2.byref(ns), sp, sr,
+                                                     C2.byref(nr), rp, rf, rr))
+assert lo.value + hi.value == counts[1 - r][r] and (sp[0], sr[0]) == (1 - r, counts[r][1 - r])
+assert (rp[0], rr[0]) == (1 - r, counts[1 - r][r]) and rf[0] == (0 if r == 1 else 100)
 # argument validation of the exchange that needs no device: a rank cannot message itself
 one_i, one_p, one_z = (C.c_int * 1)(r), (C.c_void_p * 1)(8), (C.c_size_t * 1)(1)
 st = capi.load().mhip_comm_exchange_start(comm._h, 1, one_i, one_p, one_z, 0, None, None, None, None)
