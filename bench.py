@@ -109,6 +109,9 @@ def main():
     torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
+        # a transport that stalls must end the run, not sit on the node: dump the stacks and exit after the limit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("MUNDY_BENCH_WATCHDOG_S", "900")), exit=True)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
