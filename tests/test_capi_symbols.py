@@ -74,6 +74,30 @@ def test_validation_before_any_hip_call(lib):
         capi.check(lib.mhip_contact_op_create(C.byref(op), 0, 0, None, None, C.c_void_p(8), None, None, None, 1.0, None, None))
 
 
+def test_communicator_validation_before_any_hip_call(lib):
+    from mundy_amd import capi
+    h = C.c_void_p()
+    no_x, no_g = capi.EXCHANGE_FN(0), capi.ALL_GATHER_FN(0)
+    with pytest.raises(ValueError, match="rank 2 of 2"):
+        capi.check(lib.mhip_comm_create_host(C.byref(h), 2, 2, no_x, no_g, None))
+    with pytest.raises(ValueError, match="needs both callbacks"):
+        capi.check(lib.mhip_comm_create_host(C.byref(h), 0, 2, no_x, no_g, None))
+    capi.check(lib.mhip_comm_create_host(C.byref(h), 0, 1, no_x, no_g, None))   # one rank needs no message layer
+    rank, world, is_rccl = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    capi.check(lib.mhip_comm_info(h, C.byref(rank), C.byref(world), C.byref(is_rccl)))
+    assert (rank.value, world.value, is_rccl.value) == (0, 1, 0)
+    with pytest.raises(RuntimeError, match="mhip_ghost_plan has not been called"):
+        capi.check(lib.mhip_ghost_exchange(h, 12, None, None, None))
+    with pytest.raises(RuntimeError, match="no exchange in flight"):
+        capi.check(lib.mhip_comm_exchange_finish(h, None))
+    with pytest.raises(ValueError, match="null argument"):
+        capi.check(lib.mhip_bbpgd_solve_contact_distributed(None, h, None, 0, None, None, None, None, None, None, None,
+                                                            32, None, None, None))
+    capi.check(lib.mhip_comm_destroy(h))
+    with pytest.raises(ValueError, match="strides"):
+        capi.check(lib.mhip_copy_strided(4, 3, None, 2, None, 3, None))
+
+
 def test_gen_neighbor_links_builder_misuse():
     # the builder's error behaviour (GenNeighborLinkers.hpp:401-511): std::runtime_error on misuse
     from mundy_amd import build, ops
