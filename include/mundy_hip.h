@@ -241,6 +241,9 @@ int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraint
                                 const double* seg, const double* mob_trans, const double* mob_rot, double dt,
                                 const double* priority, mhip_stream_t stream);
 int mhip_contact_op_destroy(mhip_contact_op_t handle);
+/* A destroyed operator leaves its device workspaces in one process-wide spare set that the next create adopts (no
+ * allocation in the steady state of a time loop); this frees that set. */
+int mhip_release_cached_workspaces(void);
 int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, mhip_stream_t stream);
 /* Per-kernel timing of the fused solver (measurement support, no effect on results): when enabled,
  * mhip_bbpgd_solve_contact brackets the k_body / k_constraint launches of every 8th iteration with HIP events on

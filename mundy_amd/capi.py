@@ -166,7 +166,8 @@ SIGNATURES = {
                                              C.POINTER(PgdConfig), _vp, _vp, _vp, _vp, C.c_uint,
                                              C.POINTER(SolveResult), C.POINTER(DistProfile), _vp],
 }
-OTHER_SYMBOLS = {"mhip_last_error": ([], C.c_char_p), "mhip_version": ([], C.c_int)}
+OTHER_SYMBOLS = {"mhip_last_error": ([], C.c_char_p), "mhip_version": ([], C.c_int),
+                 "mhip_release_cached_workspaces": ([], C.c_int)}
 
 _lib = None
 
