@@ -127,8 +127,11 @@ def test_contact_lcp_matches_dense_and_threaded(oracle):
                                            max_iters=5000, tol=1e-6, threads=True)
     assert rt["converged"]
     # the LCP solution (g, and the net body forces D x) is unique even when x is not
-    # (tol 1e-6: at |x| ~ 60 the projected-diff residual is quantised in steps of ulp(x)/1e-6 ~ 7e-9)
-    np.testing.assert_allclose(gt, g, atol=1e-5)
+    # (tol 1e-6: at |x| ~ 60 the projected-diff residual is quantised in steps of ulp(x)/1e-6 ~ 7e-9).  The threaded
+    # solve sums forces with atomics, so its path -- 414 to 641 iterations over 200 runs against 514 serial -- and the
+    # point inside the tolerance ball where it stops change from run to run: max |dg| was 3e-6 in the median and
+    # 1.5e-5 at worst over those runs, hence 40 tol here (the GPU tests hold 20 tol against deterministic sums)
+    np.testing.assert_allclose(gt, g, atol=4e-5)
 
 
 def test_mundy_math_backend_problems(oracle):
