@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); must be in the
+# environment before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
@@ -300,7 +304,10 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
             "roofline": roof, "cpu_baseline": None,
         }
         out.update(extra)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    st.op.close()
+    comm.close()   # the library's RCCL communicator goes before the launcher's process group
+    dist.barrier()
     dist.destroy_process_group()
 
 
