@@ -358,6 +358,15 @@ int mhip_partition_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, 
                                size_t* count_out /*[host]*/, mhip_stream_t stream);
 int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const double* box6 /*[host]*/,
                              int32_t* idx_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
+/* A rank's region as several boxes: bodies [k * ceil(n / nchunks), ...) form chunk k (the owned bodies are in curve
+ * order, so a chunk is a compact blob); boxes [device, (nchunks + 1)][6] receives the bounds of each chunk's boxes grown
+ * by `buffer` and, last, their union.  select_aabb_overlap_any keeps the bodies whose grown box meets ANY of the first
+ * nboxes boxes (boxes [device, (nboxes + 1)][6], the last one the union, used as a quick reject) -- the ghost
+ * candidates for a rank described that way; ascending order.  No host round trip in chunk_bounds. */
+int mhip_aabb_chunk_bounds(size_t n, const double* aabb, double buffer, int nchunks, double* boxes,
+                           mhip_stream_t stream);
+int mhip_select_aabb_overlap_any(size_t n, const double* aabb, double buffer, int nboxes, const double* boxes,
+                                 int32_t* idx_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
 /* min / max corner over n boxes grown by `buffer`: out6 [host] (an empty set gives the inverted box) */
 int mhip_aabb_bounds(size_t n, const double* aabb, double buffer, double* out6 /*[host]*/, mhip_stream_t stream);
 
@@ -477,8 +486,9 @@ typedef struct mhip_velocity_halo {
 } mhip_velocity_halo;
 /* Ghost bodies of one neighbour-list rebuild (replaces coarse_search(comm) + change_ghosting,
  * GenNeighborLinkers.hpp:658, :687-711).  Ranks own contiguous, increasing ranges of the global (curve-ordered) ids.
- *   plan:     all-gather of the rank boxes (owned AABBs grown by `buffer`), per peer the owned bodies whose grown box
- *             meets the peer's box (closed test, ascending order), all-gather of the count matrix.  Fills `layout`:
+ *   plan:     all-gather of the rank regions (64 chunk boxes per rank, mhip_aabb_chunk_bounds), per peer the owned bodies
+ *             whose grown box meets any of the peer's boxes (closed test, ascending order), all-gather of the count
+ *             matrix.  The owned bodies should be in curve order (any order is correct, only looser).  Fills `layout`:
  *             local index order = ghosts of lower ranks (peer order), the n owned bodies, ghosts of higher ranks --
  *             also global-id order, so local pairs (i < j) keep their global orientation; and the velocity halo of
  *             this layout (lists owned by the communicator, valid until the next plan; halo.velocity is left NULL).

@@ -131,6 +131,8 @@ SIGNATURES = {
     "mhip_filter_pairs_owned": [_sz, _vp, _sz, _sz, _vp, _vp, C.POINTER(_sz), _vp],
     "mhip_partition_pairs_owned": [_sz, _vp, _sz, _sz, _vp, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp],
     "mhip_select_aabb_overlap": [_sz, _vp, _d, C.POINTER(_d), _vp, C.POINTER(_sz), _vp],
+    "mhip_aabb_chunk_bounds": [_sz, _vp, _d, _i, _vp, _vp],
+    "mhip_select_aabb_overlap_any": [_sz, _vp, _d, _i, _vp, _vp, C.POINTER(_sz), _vp],
     "mhip_aabb_bounds": [_sz, _vp, _d, C.POINTER(_d), _vp],
     "mhip_bbpgd_solve_contact_unfused": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
                                          C.POINTER(SolveResult), _vp],

@@ -98,7 +98,8 @@ struct mhip_comm {
     std::vector<size_t> send_rows, recv_first_row, recv_rows;
     DeviceBuffer send_index;        // owned indices (0-based in the owned block), peer after peer
     DeviceBuffer send_index_local;  // the same as local indices (+ n_lo): what the velocity halo gathers
-    DeviceBuffer stage;             // boxes / counts on their way through the all-gather; packed send rows
+    DeviceBuffer stage;             // counts on their way through the all-gather; packed send rows
+    DeviceBuffer regions;           // this rank's chunk boxes + everybody's, all-gathered
   } ghost;
 };
 
@@ -184,6 +185,7 @@ int mhip_comm_destroy(mhip_comm_t c) {
   c->ghost.send_index.release();
   c->ghost.send_index_local.release();
   c->ghost.stage.release();
+  c->ghost.regions.release();
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   if (c->ready) (void)hipEventDestroy(c->ready);
@@ -339,20 +341,23 @@ int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, 
   auto& gp = c->ghost;
   gp.valid = false;
   const int W = c->world, R = c->rank;
-  // rank boxes
-  double box[6];
-  if (int e = mhip_aabb_bounds(n, aabb, buffer, box, stream)) return e;
-  std::vector<double> boxes;
-  if (int e = host_all_gather(c, box, 6, boxes, s)) return e;
-  // per peer: the owned bodies whose grown box meets the peer's box
+  // rank regions: kGhostBoxes chunk boxes + their union per rank, all-gathered device to device
+  constexpr int kGhostBoxes = 64;
+  const size_t region = 6 * (size_t)(kGhostBoxes + 1);
+  if (int e = gp.regions.reserve((region + (size_t)W * region + 2) * sizeof(double))) return e;
+  double* mine = gp.regions.as<double>();
+  double* all = mine + region;
+  if (int e = mhip_aabb_chunk_bounds(n, aabb, buffer, kGhostBoxes, mine, stream)) return e;
+  if (int e = mhip_comm_all_gather(c, mine, region, all, stream)) return e;
+  // per peer: the owned bodies whose grown box meets any of the peer's boxes
   if (int e = gp.send_index.reserve(((size_t)(W > 1 ? W - 1 : 1) * n + 2) * sizeof(int32_t))) return e;
   std::vector<double> send_cnt((size_t)W, 0.0);
   size_t off = 0;
   for (int p = 0; p < W; ++p) {
     if (p == R || n == 0) continue;
     size_t cnt = 0;
-    if (int e = mhip_select_aabb_overlap(n, aabb, buffer, &boxes[6 * (size_t)p], gp.send_index.as<int32_t>() + off, &cnt,
-                                         stream))
+    if (int e = mhip_select_aabb_overlap_any(n, aabb, buffer, kGhostBoxes, all + (size_t)p * region,
+                                             gp.send_index.as<int32_t>() + off, &cnt, stream))
       return e;
     send_cnt[(size_t)p] = (double)cnt;
     off += cnt;

@@ -87,6 +87,70 @@ struct KeepBoxOverlap {  // closed interval test of geom::intersects (AABB.hpp:4
   __device__ void emit(size_t i, size_t slot) const { out[slot] = static_cast<int32_t>(i); }
 };
 
+// The same test against a rank described by several boxes: boxes [nboxes + 1][6] on the device, the last one their
+// union (a quick reject).  A rank's curve-ordered bodies are cut into nboxes consecutive chunks, each a compact blob, so
+// the union of the chunk boxes hugs the rank's true region where one bounding box of a curve range does not (a range
+// that ends a little past an octant of the Hilbert curve has a box a whole slab larger).
+struct KeepAnyBoxOverlap {
+  const double* aabb;
+  double buffer;
+  const double* boxes;
+  int nboxes;
+  int32_t* out;
+  __device__ static bool meets(const double* b, double buffer, const double* q) {
+    const bool disjoint = (b[3] + buffer) < q[0] || (b[4] + buffer) < q[1] || (b[5] + buffer) < q[2] ||
+                          q[3] < (b[0] - buffer) || q[4] < (b[1] - buffer) || q[5] < (b[2] - buffer);
+    return !disjoint;
+  }
+  __device__ bool keep(size_t i) const {
+    const double* b = aabb + 6 * i;
+    if (!meets(b, buffer, boxes + 6 * (size_t)nboxes)) return false;
+    for (int k = 0; k < nboxes; ++k)
+      if (meets(b, buffer, boxes + 6 * (size_t)k)) return true;
+    return false;
+  }
+  __device__ void emit(size_t i, size_t slot) const { out[slot] = static_cast<int32_t>(i); }
+};
+
+// workgroup k: bounds of the grown boxes of chunk k = bodies [k * per, (k + 1) * per); an empty chunk gives the inverted
+// box, which meets nothing.  Workgroup nchunks: the union, from the chunk boxes (second launch).
+__global__ void __launch_bounds__(kBlock) k_chunk_bounds(size_t n, size_t per, const double* __restrict__ aabb,
+                                                        double buffer, double* __restrict__ out) {
+  __shared__ double scratch[kBlock / 64];
+  const size_t first = blockIdx.x * per, last = (first + per < n) ? first + per : n;
+  double lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308};
+  double hi[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
+  for (size_t i = first + threadIdx.x; i < last; i += blockDim.x) {
+    const double* b = aabb + 6 * i;
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = dmin(lo[k], b[k] - buffer);
+      hi[k] = dmax(hi[k], b[3 + k] + buffer);
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    const double a = -block_max(-lo[k], scratch);
+    const double b = block_max(hi[k], scratch);
+    if (threadIdx.x == 0) {
+      out[6 * blockIdx.x + k] = a;
+      out[6 * blockIdx.x + 3 + k] = b;
+    }
+  }
+}
+__global__ void k_union_box(int nboxes, double* __restrict__ boxes) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308};
+  double hi[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
+  for (int i = 0; i < nboxes; ++i)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = dmin(lo[k], boxes[6 * i + k]);
+      hi[k] = dmax(hi[k], boxes[6 * i + 3 + k]);
+    }
+  for (int k = 0; k < 3; ++k) {
+    boxes[6 * (size_t)nboxes + k] = lo[k];
+    boxes[6 * (size_t)nboxes + 3 + k] = hi[k];
+  }
+}
+
 template <class Op>
 __global__ void __launch_bounds__(kBlock) k_compact_count(size_t n, Op op, int32_t* __restrict__ tile_count) {
   __shared__ int seg[kCompactSegs];
@@ -247,6 +311,31 @@ int mhip_select_aabb_overlap(size_t n, const double* aabb, double buffer, const 
   MHIP_REQUIRE(aabb && idx_out, MHIP_ERR_INVALID_ARGUMENT, "aabb / idx_out is null");
   MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
   const KeepBoxOverlap op{aabb, buffer, Box{{box6[0], box6[1], box6[2]}, {box6[3], box6[4], box6[5]}}, idx_out};
+  return compact(n, op, count_out, as_stream(stream));
+}
+
+int mhip_aabb_chunk_bounds(size_t n, const double* aabb, double buffer, int nchunks, double* boxes,
+                           mhip_stream_t stream) {
+  MHIP_REQUIRE(nchunks >= 1 && nchunks <= 4096, MHIP_ERR_INVALID_ARGUMENT, "nchunks must be in [1, 4096]");
+  MHIP_REQUIRE(boxes != nullptr && (n == 0 || aabb != nullptr), MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  hipStream_t s = as_stream(stream);
+  const size_t per = (n + (size_t)nchunks - 1) / (size_t)nchunks;
+  k_chunk_bounds<<<(unsigned)nchunks, kBlock, 0, s>>>(n, per ? per : 1, aabb, buffer, boxes);
+  MHIP_LAUNCH_CHECK();
+  k_union_box<<<1, 64, 0, s>>>(nchunks, boxes);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_select_aabb_overlap_any(size_t n, const double* aabb, double buffer, int nboxes, const double* boxes,
+                                 int32_t* idx_out, size_t* count_out, mhip_stream_t stream) {
+  MHIP_REQUIRE(count_out != nullptr, MHIP_ERR_INVALID_ARGUMENT, "count_out is null");
+  *count_out = 0;
+  MHIP_REQUIRE(nboxes >= 1 && boxes != nullptr, MHIP_ERR_INVALID_ARGUMENT, "boxes missing");
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(aabb && idx_out, MHIP_ERR_INVALID_ARGUMENT, "aabb / idx_out is null");
+  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
+  const KeepAnyBoxOverlap op{aabb, buffer, boxes, nboxes, idx_out};
   return compact(n, op, count_out, as_stream(stream));
 }
 

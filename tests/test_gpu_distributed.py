@@ -148,3 +148,51 @@ def test_ballot_compactions_match_numpy(n):
                                                 C.c_void_p(idx.data_ptr()), C.byref(cnt), None))
         disjoint = ((aabb[:, 3:] + buf) < box[:3]).any(axis=1) | (box[3:] < (aabb[:, :3] - buf)).any(axis=1)
         np.testing.assert_array_equal(host(idx)[: cnt.value], np.nonzero(~disjoint)[0])
+
+
+@pytest.mark.parametrize("n,nchunks", [(1, 4), (50, 64), (1000, 7), (70_000, 64)])
+def test_chunk_boxes_and_any_box_selection(n, nchunks):
+    # mhip_aabb_chunk_bounds / mhip_select_aabb_overlap_any: a rank's region as several boxes and the ghost candidates
+    # against it, versus the same written in numpy (closed interval tests, ascending order, empty chunks inverted)
+    import ctypes as C
+    import numpy as np
+    import torch
+    from gpu_util import dev, host
+    from mundy_amd import capi
+    lib = capi.load()
+    rng = np.random.default_rng(n + nchunks)
+    # a "rank" whose bodies are in a spatially coherent order (sorted along x) and a set of query boxes around it
+    lo = rng.uniform(0, 20, (n, 3))
+    lo = lo[np.argsort(lo[:, 0])]
+    aabb = np.concatenate([lo, lo + rng.uniform(0.1, 1.0, (n, 3))], axis=1)
+    buf = 0.15
+    boxes = torch.empty((nchunks + 1, 6), dtype=torch.float64, device="cuda")
+    capi.check(lib.mhip_aabb_chunk_bounds(n, C.c_void_p(dev(aabb).data_ptr()), buf, nchunks,
+                                          C.c_void_p(boxes.data_ptr()), None))
+    per = -(-n // nchunks)
+    want = np.empty((nchunks + 1, 6))
+    for k in range(nchunks):
+        ch = aabb[k * per:(k + 1) * per]
+        want[k] = ([np.finfo(float).max] * 3 + [-np.finfo(float).max] * 3) if len(ch) == 0 else \
+            np.concatenate([ch[:, :3].min(0) - buf, ch[:, 3:].max(0) + buf])
+    want[nchunks] = np.concatenate([want[:nchunks, :3].min(0), want[:nchunks, 3:].max(0)])
+    np.testing.assert_array_equal(host(boxes), want)
+    m = 5000
+    qlo = rng.uniform(-2, 22, (m, 3))
+    q = np.concatenate([qlo, qlo + rng.uniform(0.05, 0.6, (m, 3))], axis=1)
+    idx = torch.empty(m, dtype=torch.int32, device="cuda")
+    cnt = C.c_size_t(0)
+    capi.check(lib.mhip_select_aabb_overlap_any(m, C.c_void_p(dev(q).data_ptr()), buf, nchunks,
+                                                C.c_void_p(boxes.data_ptr()), C.c_void_p(idx.data_ptr()), C.byref(cnt),
+                                                None))
+    hit = np.zeros(m, bool)
+    for k in range(nchunks):
+        b = want[k]
+        hit |= ~(((q[:, 3:] + buf) < b[:3]).any(axis=1) | (b[3:] < (q[:, :3] - buf)).any(axis=1))
+    np.testing.assert_array_equal(host(idx)[: cnt.value], np.nonzero(hit)[0])
+    # conservative: whatever meets a member's grown box meets its chunk's box
+    member = np.zeros(m, bool)
+    for j in rng.integers(0, n, 50):
+        b = np.concatenate([aabb[j, :3] - buf, aabb[j, 3:] + buf])
+        member |= ~(((q[:, 3:] + buf) < b[:3]).any(axis=1) | (b[3:] < (q[:, :3] - buf)).any(axis=1))
+    assert not np.any(member & ~hit)
