@@ -119,6 +119,25 @@ def test_all_bodies_in_one_cell_and_clusters(ops, oracle):
             g.close()
 
 
+def test_crowded_cells_need_several_lds_tiles(ops, oracle):
+    # one large body sets the cell edge, thousands of small ones crowd a few cells: the LDS-staged search (k_pairs_lds)
+    # must walk a run of records in several 512-record tiles, and rows get long (the big body touches hundreds)
+    from gpu_util import dev, host
+    rng = np.random.default_rng(8)
+    c = np.concatenate([rng.uniform(0, 4, (3500, 3)), [[2.0, 2.0, 2.0]], rng.uniform(30, 34, (1200, 3))])
+    r = np.concatenate([np.full(3500, 0.06), [3.0], np.full(1200, 0.08)])
+    aabb = oracle.compute_aabb_spheres(c, r)
+    lo, hi, R = oracle.grow(aabb, r, 0.02)
+    for kind in (0, 1):
+        for symmetric in (False, True):
+            exp = oracle.search(kind, lo, hi, c, R, symmetric=symmetric, method="brute")
+            g = _links(ops, kind, 0.02, symmetric)
+            g.generate(dev(aabb), dev(c), dev(r))
+            assert len(exp) > 3000
+            np.testing.assert_array_equal(host(g.pairs), exp)
+            g.close()
+
+
 def test_rebuild_rule(ops):
     # GenNeighborLinkers.hpp:510-543, :603-615: generate() returns False until a centre moves > buffer/2
     from gpu_util import dev
