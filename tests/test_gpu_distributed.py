@@ -95,6 +95,24 @@ def test_nccl_transport_single_rank():
         assert torch.equal(st.pairs, ref.links.pairs)
         assert s["num_iters"] == r.num_iters            # one rank: identical arithmetic to the fused driver
         assert torch.equal(st.lam, ref.lam)
+        # how often the host polls for convergence changes nothing but the number of idle launches after convergence;
+        # sampled timing on: the profile reports only iterations that did work
+        for poll in (1, 5, 64):
+            st2 = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), 0,
+                                              comm=comm, cfg=cfg, poll_every=poll)
+            st2.profile = True
+            s2 = st2.step(integrate=False)
+            assert s2["num_iters"] == r.num_iters and torch.equal(st2.lam, ref.lam), poll
+            # every 8th iteration of a chunk is bracketed by events (all of them when a chunk is a single iteration)
+            most = r.num_iters + 1 if poll < 8 else r.num_iters // 8 + r.num_iters // poll + 2
+            assert 0 < st2.prof["iters"] <= most and st2.prof["body_ms"] > 0 and st2.prof["con_ms"] > 0, st2.prof
+            st2.op.close()
+        # an iteration cap below convergence: not an error, converged = False, num_iters = the cap (convex.hpp:642-675)
+        st3 = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), 0,
+                                          comm=comm, cfg=ops.PGDConfig(max_iters=7, tol=1e-6), poll_every=3)
+        s3 = st3.step(integrate=False)
+        assert not s3["converged"] and s3["num_iters"] == 7
+        st3.op.close()
         comm.close()
     finally:
         dist.destroy_process_group()
