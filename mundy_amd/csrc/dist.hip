@@ -448,6 +448,8 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
                "negative peer count");
   if (poll_every == 0) poll_every = 32;
   hipStream_t s = as_stream(stream);
+  if (c->in_flight)  // an earlier solve ended in an error between start and finish: close that exchange first
+    if (int e = mhip_comm_exchange_finish(c, stream)) return e;
   // message lists of the velocity halo (rows of 6 doubles)
   size_t send_total = 0;
   for (int k = 0; k < halo->num_send_peers; ++k) send_total += halo->send_rows[k];
