@@ -940,12 +940,17 @@ __global__ void __launch_bounds__(kBlock) k_inc_count(size_t C, size_t N, const 
     atomicAdd(&deg[ij.y], 1);
   }
 }
+// entries use 31 bits; while the lists are being ordered bit 31 marks the second priority class (priority >= 0 or NaN),
+// set here from one coalesced read of priority[c] instead of a gather per entry in the sort
 __global__ void __launch_bounds__(kBlock) k_inc_fill(size_t C, const int2* __restrict__ pairs,
-                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ inc) {
+                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ inc,
+                                                    const double* __restrict__ priority) {
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
     const int2 ij = pairs[c];
-    inc[atomicAdd(&cursor[ij.x], 1)] = static_cast<int32_t>(c << 1);
-    inc[atomicAdd(&cursor[ij.y], 1)] = static_cast<int32_t>((c << 1) | 1);
+    const unsigned cls = (priority && !(priority[c] < 0.0)) ? 0x80000000u : 0u;
+    const unsigned e = static_cast<unsigned>(c << 1) | cls;
+    inc[atomicAdd(&cursor[ij.x], 1)] = static_cast<int32_t>(e);
+    inc[atomicAdd(&cursor[ij.y], 1)] = static_cast<int32_t>(e | 1u);
   }
 }
 // Each body's list in a fixed order whatever order the atomics arrived in: ascending (constraint, side) -- or, given a
@@ -957,10 +962,7 @@ __global__ void __launch_bounds__(kBlock) k_inc_sort(size_t N, const int32_t* __
   const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (b >= N) return;
   const int32_t beg = inc_ptr[b], end = inc_ptr[b + 1];
-  unsigned* u = reinterpret_cast<unsigned*>(inc);
-  if (priority)  // entries use 31 bits: bit 31 marks the second class while sorting
-    for (int32_t i = beg; i < end; ++i)
-      if (!(priority[u[i] >> 1] < 0.0)) u[i] |= 0x80000000u;
+  unsigned* u = reinterpret_cast<unsigned*>(inc);  // bit 31 = second class, set by k_inc_fill
   for (int32_t i = beg + 1; i < end; ++i) {
     const unsigned v = u[i];
     int32_t j = i - 1;
@@ -1545,7 +1547,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   he = hipMemcpyAsync(deg, op->inc_ptr.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
   if (C > 0) {
-    k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>());
+    k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>(), priority);
     k_inc_sort<<<grid_exact(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(), priority);
   }
   he = hipGetLastError();
