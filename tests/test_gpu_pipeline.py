@@ -31,11 +31,14 @@ def test_config2_100k_spheres_lcp(mods, oracle):
     assert_bits_equal(host(st.contacts["normal"]), onrm, "normal")
     mt, _ = synth.dry_mobility(r)
     xo, go, ro = oracle.solve_cqpp_contact(pairs, onrm, None, None, mt, None, 5e-3, osep, np.zeros(len(pairs)),
-                                           max_iters=10000, tol=tol, threads=True, fast=True)
+                                           max_iters=10000, tol=tol, threads=False, fast=True)
+    # (the serial oracle: the OpenMP one sums forces with atomics and stops somewhere else in the tolerance ball every
+    # run -- 363 to 472 iterations and up to 15 tol away from the serial gradient on this very problem)
     assert res.converged and ro["converged"]
-    # BB step lengths amplify summation-order rounding (the OpenMP oracle's own count varies run to run): same ballpark
+    # BB step lengths amplify summation-order rounding: same ballpark, not the same count
     assert 0.5 * ro["num_iters"] <= res.num_iters <= 2.0 * ro["num_iters"]
     g = host(st.op.apply(st.lam) + st.contacts["sep"])
+    print("config 1: iterations gpu %d oracle %d, max |g - g_oracle| = %.3g" % (res.num_iters, ro["num_iters"], np.abs(g - go).max()))
     np.testing.assert_allclose(g, go, atol=20 * tol)                      # fp64 tolerance on the constraint gradient
     lam = host(st.lam)
     assert lam.min() >= 0 and np.abs(np.minimum(lam, g)).max() <= 10 * tol
@@ -68,7 +71,7 @@ def test_three_step_rod_trajectory(mods, oracle):
         seg = oracle.spherocylinder_segments(c, q, r, L)
         con = oracle.contact_spherocylinders(pairs, seg, c)
         x, g, ro = oracle.solve_cqpp_contact(pairs, con["normal"], con["ra"], con["rb"], mt, mr, dt, con["sep"],
-                                             np.zeros(len(pairs)), max_iters=20000, tol=tol, threads=True, fast=False)
+                                             np.zeros(len(pairs)), max_iters=20000, tol=tol, threads=False, fast=False)
         assert s.converged and ro["converged"]
         # body velocities from the multipliers, then the reference's Euler + rotate_quaternion update
         F = np.zeros((len(r), 3)); T = np.zeros((len(r), 3))
