@@ -50,7 +50,11 @@ def test_nccl_transport_single_rank():
     import ctypes as C
     from mundy_amd import capi, distributed as D, ops, pipeline, synth
     if not dist.is_initialized():
-        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1,
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
     try:
         comm = D.Comm()
