@@ -191,3 +191,42 @@ def test_reordering_leaves_the_physics_unchanged(mods, oracle):
         np.testing.assert_array_equal(p, p0)
         np.testing.assert_allclose(g, g0, atol=20 * tol)
         np.testing.assert_allclose(c, c0, atol=1e-4)
+
+
+def test_trajectory_with_neighbour_list_reuse(mods, oracle):
+    # A time loop as the reference's apps run it (NgpLcp.cpp:835-920): the neighbour list is rebuilt only when a body
+    # has moved more than half the search buffer since the last build (GenNeighborLinkers.hpp:603-615), otherwise
+    # reused.  The invariant that makes reuse safe: every pair that overlaps at the start of a step is in the list the
+    # step uses -- checked against the oracle's search on the step's starting positions -- and steps with and without
+    # a rebuild must both occur.  The overlapping random start relaxes: fewer iterations, shallower overlaps.
+    ops, pipeline, synth = mods
+    from gpu_util import dev, host
+    b = synth.spherocylinders(6000, volume_fraction=0.2, seed=21)
+    tol, dt, buf = 1e-6, 5e-3, 0.4
+    st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]),
+                                 dev(b["length"]), dt=dt, search_buffer=buf, cfg=ops.PGDConfig(max_iters=20000, tol=tol))
+    r, L = b["radius"], b["length"]
+    brad = oracle.bounding_radius_spherocylinders(r, L)
+    rebuilt, iters, deepest = [], [], []
+    for step in range(14):
+        c0, q0 = host(st.center).copy(), host(st.quat).copy()
+        s = st.step(integrate=True)
+        assert s.converged, step
+        rebuilt.append(bool(s.rebuilt))
+        iters.append(s.num_iters)
+        aabb = oracle.compute_aabb_spherocylinders(c0, q0, r, L)
+        lo, hi, R = oracle.grow(aabb, brad, 0.0)
+        pairs = oracle.search(oracle.SEARCH_AABB, lo, hi, c0, R)
+        con = oracle.contact_spherocylinders(pairs, oracle.spherocylinder_segments(c0, q0, r, L), c0)
+        touching = pairs[con["sep"] < 0.0].astype(np.int64)
+        deepest.append(float(con["sep"].min()) if len(pairs) else 0.0)
+        used = host(st.links.pairs).astype(np.int64)
+        key = lambda p: p[:, 0] * len(r) + p[:, 1]  # noqa: E731
+        missing = np.setdiff1d(key(touching), key(used))
+        assert len(missing) == 0, (step, rebuilt, len(missing))
+        c, q = host(st.center), host(st.quat)
+        assert np.isfinite(c).all() and np.isfinite(q).all()
+        np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-12)
+    print("rebuilt", rebuilt, "iterations", iters, "deepest overlap at step start", ["%.3g" % d for d in deepest])
+    assert rebuilt[0] and any(rebuilt[1:]) and not all(rebuilt[1:]), rebuilt
+    assert iters[-1] < iters[0] and deepest[-1] > 0.1 * deepest[0]
