@@ -99,6 +99,29 @@ def main():
             ok = ok and bool(v)
         print("DIST_RESULT", "PASS" if ok else "FAIL", "mixed" if mixed else "rods", "world", world, "contacts", len(rp), "iters", iters,
               "single", rs.num_iters)
+    # a short trajectory: the owned bodies of every rank, advanced by three more full steps (ghost plan, list, solve and
+    # Euler update each step), track the single-rank trajectory of the same system
+    steps = int(os.environ.get("DIST_STEPS", "0"))
+    if steps and not mixed:
+        for _ in range(steps):
+            stats = st.step(integrate=True)
+        mine = dict(c=st.center.cpu().numpy(), q=st.quat.cpu().numpy(), conv=stats["converged"])
+        allc = [None] * world if rank == 0 else None
+        dist.gather_object(mine, allc, dst=0)
+        if rank == 0:
+            for _ in range(steps):
+                rs = ref.step(integrate=True, force_rebuild=True)
+            c_ref, q_ref = ref.center.cpu().numpy(), ref.quat.cpu().numpy()
+            c_all = np.concatenate([o["c"] for o in allc])
+            q_all = np.concatenate([o["q"] for o in allc])
+            dc = np.abs(c_all - c_ref).max()
+            dq = np.abs(np.abs(np.sum(q_all * q_ref, axis=1)) - 1.0).max()
+            moved = np.abs(c_ref - g_center).max()
+            good = all(o["conv"] for o in allc) and rs.converged and dc <= 1e-4 and dq <= 1e-8
+            print(("ok   " if good else "FAIL ") + "%d-step trajectory vs single rank: max |dc| %.3g (bodies moved up to %.3g), "
+                  "quaternion defect %.3g" % (steps, dc, moved, dq))
+            ok = ok and good
+            print("DIST_TRAJECTORY", "PASS" if good else "FAIL")
     flag = torch.tensor([1 if ok else 0])
     dist.broadcast(flag, src=0)
     dist.destroy_process_group()

@@ -36,6 +36,11 @@ def test_distributed_equals_single_rank(world):
     _run(world, 29610 + world)
 
 
+def test_distributed_trajectory_tracks_single_rank():
+    # three more full steps (ghost plan, neighbour list, solve, Euler update on every rank) after the checked one
+    _run(2, None, {"DIST_STEPS": "3", "DIST_BODIES": "8000"})
+
+
 def test_distributed_mixed_shapes_equals_single_rank():
     # BASELINE configs[4] as a parity case: spheres + spherocylinders + ellipsoids, Hilbert-partitioned over 2 ranks
     _run(2, 29620, {"DIST_MIXED": "1", "DIST_BODIES": "9000"})
