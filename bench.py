@@ -93,6 +93,12 @@ def parse():
     p.add_argument("--strong", action="store_true",
                    help="N > 1: partition ONE system of --bodies rods over the N GPUs (BASELINE configs[3] read "
                         "literally: 10^6 total; strong scaling) instead of --bodies per GPU (weak scaling, the default)")
+    p.add_argument("--mixed", action="store_true",
+                   help="BASELINE configs[4] instead of the headline workload: --bodies bodies, one third each spheres "
+                        "(r 0.5), spherocylinders (r 0.5, L 2) and ellipsoids (0.8, 0.5, 0.4), random orientations, "
+                        "--mixed-phi volume fraction; shape classes binned, L-BFGS ellipsoid distances, vector-arm "
+                        "operator.  N = 1 only; never the default line.")
+    p.add_argument("--mixed-phi", type=float, default=0.30)
     p.add_argument("--friction", type=float, default=None,
                    help="BUILD EXTENSION, parity unpinned: Coulomb coefficient of the cone-complementarity solver "
                         "(the reference has no frictional solver; default = its frictionless LCP).  N = 1 only.")
@@ -132,7 +138,11 @@ def main():
     n = args.bodies
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     if world > 1:
+        if args.mixed:
+            raise SystemExit("--mixed is a single-GPU line (the mixed distributed path is covered by the tests)")
         return main_distributed(args, rank, world, dist, ops, synth, dev)
+    if args.mixed:
+        return main_mixed(args, ops, pipeline, synth, dev)
     b = synth.spherocylinders(n, seed=1234)
     center, quat = dev(b["center"]), dev(b["quat"])
     radius, length = dev(b["radius"]), dev(b["length"])
@@ -226,6 +236,74 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main_mixed(args, ops, pipeline, synth, dev):
+    """BASELINE configs[4] on one GPU: mixed spheres / spherocylinders / ellipsoids ("divergent distance kernels").  The
+    ellipsoid classes run the reference's 9-start L-BFGS shared-normal distance (compute bound, no HBM roofline); the
+    roofline object is that of the BBPGD sweeps with explicit lever arms (KIN_RIGID)."""
+    n = args.bodies
+    b = synth.mixed_bodies(n, volume_fraction=args.mixed_phi, seed=1234)
+    cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
+    st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=args.buffer, cfg=cfg,
+                                 kinds=dev(b["kind"]), shape=dev(b["shape"]))
+    pristine = st.snapshot()
+    prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
+
+    def one_step(timed_kernels, timed_stages=False):
+        st.restore(pristine)
+        if args.reorder:
+            st.reorder_bodies(cell_size=args.reorder_cell, lo=[0.0, 0.0, 0.0])
+        st.profile_next = timed_kernels
+        s = st.step(integrate=True, force_rebuild=True, timed=timed_stages)
+        if timed_kernels:
+            a, c, k = st.op.get_profile()
+            prof["body_ms"] += a
+            prof["con_ms"] += c
+            prof["iters"] += k
+        return s
+
+    for _ in range(args.warmup):
+        one_step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = [one_step(True) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stage_ms = one_step(False, timed_stages=True).timings_ms
+    contacts, iters = stats[-1].num_contacts, [s.num_iters for s in stats]
+    roof, extra = None, {}
+    if prof["iters"] > 0:
+        # explicit lever arms: k_constraint streams pair 8 + normal 24 + arms 48 + packed (x, g) 16 + q 8, writes 16;
+        # k_body per half edge entry 4 + (n, r) record 48 + iterate gather 16, per body row pointer 4 + mobilities 16 +
+        # velocity row 48
+        by = {"k_constraint": 120.0 * contacts + 48.0 * n, "k_body": 2 * 68.0 * contacts + 68.0 * n}
+        ms = {"k_constraint": prof["con_ms"] / prof["iters"], "k_body": prof["body_ms"] / prof["iters"]}
+        ent = {k: {"bound": "hbm", "kernel": k + "<X_SOLVE,KIN_RIGID>", "achieved": round(by[k] / (ms[k] * 1e-3) / 1e9, 1),
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "traffic": None, "avg_launch_ms": round(ms[k], 4), "launches": prof["iters"],
+                   "bytes_per_launch": by[k]} for k in ms}
+        dom = max(ms, key=ms.get)
+        roof = ent[dom]
+        extra = {k: v for k, v in ent.items() if k != dom}
+    out = {
+        "metric": "timesteps/sec, 10^6 mixed sphere / spherocylinder / ellipsoid bodies, frictionless LCP contact (BBPGD)",
+        "value": round(args.steps / elapsed, 4), "unit": "timesteps/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[4] on one GPU: %.3gM bodies, one third each spheres r=0.5, spherocylinders r=0.5 L=2, "
+                               "ellipsoids (0.8, 0.5, 0.4), random orientations, %.0f%% volume fraction, AABB+%.2g neighbour "
+                               "list, class-binned narrow phase (L-BFGS ellipsoid distances), frictionless LCP tol %.0e"
+                               % (n / 1e6, 100 * args.mixed_phi, args.buffer, args.tol),
+                   "bodies_per_gpu": n, "contacts_per_gpu": contacts, "bbpgd_iters_per_step": iters,
+                   "converged": [bool(s.converged) for s in stats], "parallelism": "single GPU"},
+        "contact_pairs_per_sec": round(contacts * args.steps / elapsed, 1),
+        "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
+        "roofline": roof, "cpu_baseline": None,
+        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+    }
+    out.update(extra)
+    print(json.dumps(out))
 
 
 def main_distributed(args, rank, world, dist, ops, synth, dev):
