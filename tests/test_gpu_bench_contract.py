@@ -45,3 +45,12 @@ def test_friction_extension_line_is_labelled():
     d = _run(["--friction", "0.3", "--no-cpu-baseline"])
     assert "EXTENSION" in d["config"]["workload"] and "build extension" in d["metric"]
     assert d["cpu_baseline"] is None
+
+
+def test_mixed_line_names_configs4():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mixed", "--bodies", "9000", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "configs[4]" in d["config"]["workload"] and "mixed" in d["metric"]
+    assert d["config"]["converged"] == [True] and d["stage_ms"]["narrowphase"] > 0 and d["roofline"]["bound"] == "hbm"
