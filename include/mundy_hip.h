@@ -435,9 +435,11 @@ int mhip_copy_strided(size_t n, size_t width, const double* src, size_t src_stri
  * TODO at :1057.
  *
  * A communicator is one rank's end of a group of `world` ranks, one rank per GPU.  Two transports:
- *   - RCCL (mhip_comm_create_rccl): grouped ncclSend / ncclRecv and ncclAllGather over xGMI, issued on a stream the
- *     communicator owns and ordered against the caller's stream with events, so an exchange started after one kernel
- *     overlaps the kernels launched before mhip_comm_exchange_finish.  librccl is looked up at run time (dlopen of
+ *   - RCCL (mhip_comm_create_rccl): grouped ncclSend / ncclRecv over xGMI, issued on a stream the communicator owns
+ *     and ordered against the caller's stream with events, so an exchange started after one kernel overlaps the
+ *     kernels launched before mhip_comm_exchange_finish; ncclAllGather goes straight onto the caller's stream (it sits
+ *     on the critical path of every solver iteration).  A message addressed to oneself is delivered as a local copy
+ *     (the host transport rejects it).  librccl is looked up at run time (dlopen of
  *     the already loaded librccl.so.1 or the one on the library path): no link dependency.  The 128-byte unique id
  *     is made by rank 0 (mhip_comm_unique_id) and handed to the other ranks by the launcher (MPI_Bcast in an MPI
  *     host, the torch.distributed store in bench.py).
