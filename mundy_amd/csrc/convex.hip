@@ -1466,6 +1466,7 @@ struct OpWorkspaces {
   SolverState* host_state = nullptr;
   std::vector<hipEvent_t> events;
   bool held = false;
+  int device = -1;  // the spare set is only handed to an operator on the device that allocated it
 };
 static std::mutex g_spare_mutex;
 static OpWorkspaces g_spare;
@@ -1484,7 +1485,8 @@ static void free_workspaces(OpWorkspaces& w) {
 }
 static void adopt_spare_workspaces(mhip_contact_op* op) {
   std::lock_guard<std::mutex> lock(g_spare_mutex);
-  if (!g_spare.held) return;
+  int dev = -1;
+  if (!g_spare.held || hipGetDevice(&dev) != hipSuccess || dev != g_spare.device) return;
   for (int k = 0; k < 14; ++k) {
     *op_buffers(op, k) = g_spare.buf[k];
     g_spare.buf[k] = DeviceBuffer{};
@@ -1643,9 +1645,11 @@ int mhip_contact_op_destroy(mhip_contact_op_t op) {
   delete op;
   {
     std::lock_guard<std::mutex> lock(g_spare_mutex);
-    if (!g_spare.held) {
+    int dev = -1;
+    if (!g_spare.held && hipGetDevice(&dev) == hipSuccess) {
       g_spare = std::move(w);
       g_spare.held = true;
+      g_spare.device = dev;
       return MHIP_SUCCESS;
     }
   }
