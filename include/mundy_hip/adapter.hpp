@@ -453,6 +453,12 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
     check(mhip_broadphase_get_pairs(h_, p.data(), nullptr, nullptr, stream));
     return p;
   }
+  /// the same into a caller-owned buffer that only grows (a time loop then stops allocating); returns its data()
+  int32_t* links_into(DeviceArray<int32_t>& out, mhip_stream_t stream = nullptr) const {
+    if (out.size() < 2 * num_pairs_) out = DeviceArray<int32_t>(2 * num_pairs_ + num_pairs_ / 4 + 16);
+    check(mhip_broadphase_get_pairs(h_, out.data(), nullptr, nullptr, stream));
+    return out.data();
+  }
 
  private:
   void guard(const char* what) const {

@@ -12,6 +12,14 @@
 namespace mundy_hip {
 namespace mech {
 
+/// grow-only workspace: reallocates only when the buffer is too small, so a time loop stops allocating after its
+/// first steps (hipMalloc / hipFree cost more than most kernels of a step)
+template <class T>
+inline T* workspace(DeviceArray<T>& a, size_t n) {
+  if (a.size() < n) a = DeviceArray<T>(n + n / 8 + 16);
+  return a.data();
+}
+
 struct StepStats {
   size_t num_contacts = 0;
   unsigned num_iters = 0;
@@ -49,22 +57,25 @@ class SpherocylinderStepper {
     check(mhip_compute_aabb_spherocylinders(n_, center_.data(), quat_.data(), radius_.data(), length_.data(),
                                             aabb_.data(), nullptr));
     st.rebuilt = links_.generate(n_, aabb_.data(), center_.data(), brad_.data(), nullptr, force_rebuild);
-    if (st.rebuilt) pairs_ = links_.links();
+    if (st.rebuilt) links_.links_into(pairs_);
     const size_t C = links_.num_links();
     st.num_contacts = C;
     check(mhip_spherocylinder_segments(n_, center_.data(), quat_.data(), radius_.data(), length_.data(), seg_.data(),
                                        nullptr));
-    DeviceVector sep(C), normal(3 * C), s(C), t(C);
-    check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep.data(), normal.data(), nullptr,
-                                       nullptr, nullptr, nullptr, s.data(), t.data(), nullptr));
-    ContactOperator op(C, n_, pairs_.data(), normal.data(), ContactOperator::Rods{s.data(), t.data(), seg_.data()},
-                       mob_t_.data(), mob_r_.data(), dt_, nullptr, /*priority=*/sep.data());
-    DeviceVector x(std::vector<double>(C, 0.0)), g(C), x_tmp(C), g_tmp(C);  // lambda = 0 (NgpLcp.cpp:890-891)
+    double *sep = workspace(w_sep_, C), *normal = workspace(w_normal_, 3 * C), *s = workspace(w_s_, C),
+           *t = workspace(w_t_, C);
+    check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep, normal, nullptr, nullptr, nullptr,
+                                       nullptr, s, t, nullptr));
+    ContactOperator op(C, n_, pairs_.data(), normal, ContactOperator::Rods{s, t, seg_.data()}, mob_t_.data(),
+                       mob_r_.data(), dt_, nullptr, /*priority=*/sep);
+    double *x = workspace(lambda_, C), *g = workspace(w_g_, C), *x_tmp = workspace(w_xt_, C),
+           *g_tmp = workspace(w_gt_, C);
+    check(mhip_fill(C, x, 0.0, nullptr));  // lambda = 0 (NgpLcp.cpp:890-891)
+    num_lambda_ = C;
     const mhip_space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
     const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};
     mhip_solve_result res{};
-    check(mhip_bbpgd_solve_contact(op.handle(), sep.data(), &lcp, &pc, x.data(), g.data(), x_tmp.data(), g_tmp.data(),
-                                   &res, nullptr));
+    check(mhip_bbpgd_solve_contact(op.handle(), sep, &lcp, &pc, x, g, x_tmp, g_tmp, &res, nullptr));
     st.num_iters = res.num_iters;
     st.residual = res.residual;
     st.converged = res.converged != 0;
@@ -74,14 +85,15 @@ class SpherocylinderStepper {
       check(mhip_integrate_euler(n_, dt_, vel, center_.data(), quat_.data(), nullptr));
     }
     check(mhip_stream_synchronize(nullptr));
-    lambda_ = std::move(x);
     return st;
   }
 
   size_t num_bodies() const { return n_; }
   const DeviceVector& center() const { return center_; }
   const DeviceVector& quat() const { return quat_; }
+  /// multipliers of the last step: the first num_lambda() entries (the buffer only ever grows)
   const DeviceVector& lambda() const { return lambda_; }
+  size_t num_lambda() const { return num_lambda_; }
   const DeviceArray<int32_t>& pairs() const { return pairs_; }
 
  private:
@@ -93,6 +105,8 @@ class SpherocylinderStepper {
   double dt_;
   convex::PGDConfig<double> cfg_;
   DeviceVector center_, quat_, radius_, length_, mob_t_, mob_r_, brad_, aabb_, seg_, tmp_, lambda_;
+  DeviceVector w_sep_, w_normal_, w_s_, w_t_, w_g_, w_xt_, w_gt_;  // per-step workspaces (grow-only)
+  size_t num_lambda_ = 0;
   DeviceArray<int32_t> perm_, pairs_;
   mesh::GenNeighborLinks links_;
 };
@@ -141,46 +155,50 @@ class DistributedSpherocylinderStepper {
       check(mhip_copy_strided(n_, f.w, f.v->data(), f.w, rec_.data() + col, kRecord, nullptr));
       col += f.w;
     }
-    DeviceVector local(kRecord * nl);
-    check(mhip_ghost_exchange(comm_, kRecord, rec_.data(), local.data(), nullptr));
-    DeviceVector l_gid(nl), l_center(3 * nl), l_quat(4 * nl), l_radius(nl), l_length(nl), l_mt(nl), l_mr(nl);
-    DeviceVector* out[] = {&l_gid, &l_center, &l_quat, &l_radius, &l_length, &l_mt, &l_mr};
+    double* local = workspace(w_local_, kRecord * nl);
+    check(mhip_ghost_exchange(comm_, kRecord, rec_.data(), local, nullptr));
+    double* l_field[7] = {workspace(l_gid_, nl),    workspace(l_center_, 3 * nl), workspace(l_quat_, 4 * nl),
+                          workspace(l_radius_, nl), workspace(l_length_, nl),     workspace(l_mt_, nl),
+                          workspace(l_mr_, nl)};
     col = 0;
     for (size_t k = 0; k < 7; ++k) {
-      check(mhip_copy_strided(nl, fields[k].w, local.data() + col, kRecord, out[k]->data(), fields[k].w, nullptr));
+      check(mhip_copy_strided(nl, fields[k].w, local + col, kRecord, l_field[k], fields[k].w, nullptr));
       col += fields[k].w;
     }
+    double *l_center = l_field[1], *l_quat = l_field[2], *l_radius = l_field[3], *l_length = l_field[4];
     // neighbour list over owned + ghosts; ghost-ghost pairs dropped, interior contacts first
-    DeviceVector l_aabb(6 * nl), l_brad(nl), seg(8 * nl);
-    check(mhip_compute_aabb_spherocylinders(nl, l_center.data(), l_quat.data(), l_radius.data(), l_length.data(),
-                                            l_aabb.data(), nullptr));
-    check(mhip_bounding_radius_spherocylinders(nl, l_radius.data(), l_length.data(), l_brad.data(), nullptr));
-    links_.generate(nl, l_aabb.data(), l_center.data(), l_brad.data(), nullptr, /*force=*/true);
-    const DeviceArray<int32_t> all_pairs = links_.links();
+    double *l_aabb = workspace(w_aabb_, 6 * nl), *l_brad = workspace(w_brad_, nl), *seg = workspace(w_seg_, 8 * nl);
+    check(mhip_compute_aabb_spherocylinders(nl, l_center, l_quat, l_radius, l_length, l_aabb, nullptr));
+    check(mhip_bounding_radius_spherocylinders(nl, l_radius, l_length, l_brad, nullptr));
+    links_.generate(nl, l_aabb, l_center, l_brad, nullptr, /*force=*/true);
+    const int32_t* all_pairs = links_.links_into(w_all_pairs_);
     const size_t c_all = links_.num_links();
-    DeviceArray<int32_t> pairs(2 * c_all + 2);
-    DeviceArray<unsigned char> counted(c_all + 1);
+    int32_t* pairs = workspace(w_pairs_, 2 * c_all + 2);
+    unsigned char* counted = workspace(w_counted_, c_all + 1);
     size_t n_int = 0, C = 0;
-    check(mhip_partition_pairs_owned(c_all, all_pairs.data(), n_lo, n_, pairs.data(), counted.data(), &n_int, &C, nullptr));
+    check(mhip_partition_pairs_owned(c_all, all_pairs, n_lo, n_, pairs, counted, &n_int, &C, nullptr));
     st.num_contacts = st.local_contacts = C;
     st.interior_contacts = n_int;
-    check(mhip_spherocylinder_segments(nl, l_center.data(), l_quat.data(), l_radius.data(), l_length.data(), seg.data(),
+    check(mhip_spherocylinder_segments(nl, l_center, l_quat, l_radius, l_length, seg, nullptr));
+    double *sep = workspace(w_sep_, C), *normal = workspace(w_normal_, 3 * C), *s = workspace(w_s_, C),
+           *t = workspace(w_t_, C);
+    check(mhip_contact_spherocylinders(C, pairs, seg, nullptr, sep, normal, nullptr, nullptr, nullptr, nullptr, s, t,
                                        nullptr));
-    DeviceVector sep(C), normal(3 * C), s(C), t(C);
-    check(mhip_contact_spherocylinders(C, pairs.data(), seg.data(), nullptr, sep.data(), normal.data(), nullptr, nullptr,
-                                       nullptr, nullptr, s.data(), t.data(), nullptr));
-    ContactOperator op(C, nl, pairs.data(), normal.data(), ContactOperator::Rods{s.data(), t.data(), seg.data()},
-                       l_mt.data(), l_mr.data(), dt_, nullptr, /*priority=*/sep.data());
-    DeviceVector vel(std::vector<double>(6 * nl, 0.0));
-    check(mhip_contact_op_set_partition(op.handle(), n_lo, n_, counted.data(), vel.data()));
-    lay.halo.velocity = vel.data();
-    DeviceVector x(std::vector<double>(C, 0.0)), g(C), x_tmp(C), g_tmp(C);
+    ContactOperator op(C, nl, pairs, normal, ContactOperator::Rods{s, t, seg}, l_field[5], l_field[6], dt_, nullptr,
+                       /*priority=*/sep);
+    double* vel = workspace(w_vel_, 6 * nl);
+    check(mhip_fill(6 * nl, vel, 0.0, nullptr));
+    check(mhip_contact_op_set_partition(op.handle(), n_lo, n_, counted, vel));
+    lay.halo.velocity = vel;
+    double *x = workspace(lambda_, C), *g = workspace(w_g_, C), *x_tmp = workspace(w_xt_, C),
+           *g_tmp = workspace(w_gt_, C);
+    check(mhip_fill(C, x, 0.0, nullptr));
+    num_lambda_ = C;
     const mhip_space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
     const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};
     mhip_solve_result res{};
-    check(mhip_bbpgd_solve_contact_distributed(op.handle(), comm_, &lay.halo, n_int, sep.data(), &lcp, &pc, x.data(),
-                                               g.data(), x_tmp.data(), g_tmp.data(), /*poll_every=*/32, &res, nullptr,
-                                               nullptr));
+    check(mhip_bbpgd_solve_contact_distributed(op.handle(), comm_, &lay.halo, n_int, sep, &lcp, &pc, x, g, x_tmp, g_tmp,
+                                               /*poll_every=*/32, &res, nullptr, nullptr));
     st.num_iters = res.num_iters;
     st.residual = res.residual;
     st.converged = res.converged != 0;
@@ -188,19 +206,20 @@ class DistributedSpherocylinderStepper {
     if (integrate) {
       const double* v = nullptr;
       check(mhip_contact_op_body_velocity(op.handle(), &v));
-      check(mhip_integrate_euler(n_, dt_, v + 6 * n_lo, l_center.data() + 3 * n_lo, l_quat.data() + 4 * n_lo, nullptr));
-      check(mhip_deep_copy(3 * n_, center_.data(), l_center.data() + 3 * n_lo, nullptr));
-      check(mhip_deep_copy(4 * n_, quat_.data(), l_quat.data() + 4 * n_lo, nullptr));
+      check(mhip_integrate_euler(n_, dt_, v + 6 * n_lo, l_center + 3 * n_lo, l_quat + 4 * n_lo, nullptr));
+      check(mhip_deep_copy(3 * n_, center_.data(), l_center + 3 * n_lo, nullptr));
+      check(mhip_deep_copy(4 * n_, quat_.data(), l_quat + 4 * n_lo, nullptr));
     }
     check(mhip_stream_synchronize(nullptr));
-    lambda_ = std::move(x);
     return st;
   }
 
   size_t num_bodies() const { return n_; }
   const DeviceVector& center() const { return center_; }
   const DeviceVector& quat() const { return quat_; }
+  /// multipliers of the last step: the first num_lambda() entries (the buffer only ever grows)
   const DeviceVector& lambda() const { return lambda_; }
+  size_t num_lambda() const { return num_lambda_; }
 
  private:
   mhip_comm_t comm_;
@@ -208,6 +227,12 @@ class DistributedSpherocylinderStepper {
   double dt_, buffer_;
   convex::PGDConfig<double> cfg_;
   DeviceVector center_, quat_, radius_, length_, mob_t_, mob_r_, aabb_, rec_, gid_, lambda_;
+  // per-step workspaces (grow-only): local records and fields, geometry, contacts, solver vectors
+  DeviceVector w_local_, l_gid_, l_center_, l_quat_, l_radius_, l_length_, l_mt_, l_mr_, w_aabb_, w_brad_, w_seg_,
+      w_sep_, w_normal_, w_s_, w_t_, w_vel_, w_g_, w_xt_, w_gt_;
+  DeviceArray<int32_t> w_pairs_, w_all_pairs_;
+  DeviceArray<unsigned char> w_counted_;
+  size_t num_lambda_ = 0;
   mesh::GenNeighborLinks links_;
 };
 
