@@ -240,6 +240,13 @@ int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraint
                                 const int32_t* pairs, const double* normal, const double* arc_s, const double* arc_t,
                                 const double* seg, const double* mob_trans, const double* mob_rot, double dt,
                                 const double* priority, mhip_stream_t stream);
+/* Same pairs, new geometry (a step that reuses the neighbour list): keeps the incidence index and redoes only the
+ * half-edge records / rod axes from the new arrays (which replace the ones given at create; mobilities and dt stay).
+ * A quarter of the cost of building the operator again.  The order inside a body's list is the one fixed at create. */
+int mhip_contact_op_refresh(mhip_contact_op_t handle, const double* normal, const double* ra, const double* rb,
+                            mhip_stream_t stream);
+int mhip_contact_op_refresh_rods(mhip_contact_op_t handle, const double* normal, const double* arc_s,
+                                 const double* arc_t, const double* seg, mhip_stream_t stream);
 int mhip_contact_op_destroy(mhip_contact_op_t handle);
 /* A destroyed operator leaves its device workspaces in one process-wide spare set that the next create adopts (no
  * allocation in the steady state of a time loop); this frees that set. */

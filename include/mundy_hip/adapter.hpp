@@ -496,6 +496,13 @@ class ContactOperator {
   ~ContactOperator() { mhip_contact_op_destroy(h_); }
   ContactOperator(const ContactOperator&) = delete;
   ContactOperator& operator=(const ContactOperator&) = delete;
+  /// same pairs, new geometry (a step that reuses the neighbour list): the incidence index stays
+  void refresh(const double* normal, const double* ra, const double* rb, mhip_stream_t stream = nullptr) {
+    check(mhip_contact_op_refresh(h_, normal, ra, rb, stream));
+  }
+  void refresh(const double* normal, Rods rods, mhip_stream_t stream = nullptr) {
+    check(mhip_contact_op_refresh_rods(h_, normal, rods.arc_s, rods.arc_t, rods.segments, stream));
+  }
   void apply(const DeviceVector& x, DeviceVector& y) const { check(mhip_contact_op_apply(h_, x.data(), y.data(), nullptr)); }
   mhip_contact_op_t handle() const { return h_; }
 

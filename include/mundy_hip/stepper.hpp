@@ -6,6 +6,7 @@
 // All arrays stay on the device; the only host reads are the pair count and the solver's convergence polls.
 #pragma once
 #include <chrono>
+#include <memory>
 
 #include "mundy_hip/adapter.hpp"
 
@@ -66,8 +67,13 @@ class SpherocylinderStepper {
            *t = workspace(w_t_, C);
     check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep, normal, nullptr, nullptr, nullptr,
                                        nullptr, s, t, nullptr));
-    ContactOperator op(C, n_, pairs_.data(), normal, ContactOperator::Rods{s, t, seg_.data()}, mob_t_.data(),
-                       mob_r_.data(), dt_, nullptr, /*priority=*/sep);
+    // the operator follows the contact list: rebuilt with it, otherwise only its geometry is refreshed
+    if (st.rebuilt || !op_)
+      op_.reset(new ContactOperator(C, n_, pairs_.data(), normal, ContactOperator::Rods{s, t, seg_.data()},
+                                    mob_t_.data(), mob_r_.data(), dt_, nullptr, /*priority=*/sep));
+    else
+      op_->refresh(normal, ContactOperator::Rods{s, t, seg_.data()});
+    ContactOperator& op = *op_;
     double *x = workspace(lambda_, C), *g = workspace(w_g_, C), *x_tmp = workspace(w_xt_, C),
            *g_tmp = workspace(w_gt_, C);
     check(mhip_fill(C, x, 0.0, nullptr));  // lambda = 0 (NgpLcp.cpp:890-891)
@@ -109,6 +115,7 @@ class SpherocylinderStepper {
   size_t num_lambda_ = 0;
   DeviceArray<int32_t> perm_, pairs_;
   mesh::GenNeighborLinks links_;
+  std::unique_ptr<ContactOperator> op_;
 };
 
 // One rank's share of a spherocylinder system cut along a space-filling curve: this rank owns the bodies

@@ -105,6 +105,8 @@ SIGNATURES = {
     "mhip_gemv": [_sz, _vp, _vp, _vp, _vp],
     "mhip_contact_op_create": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp],
     "mhip_contact_op_create_rods": [C.POINTER(_vp), _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp],
+    "mhip_contact_op_refresh": [_vp, _vp, _vp, _vp, _vp],
+    "mhip_contact_op_refresh_rods": [_vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_contact_op_destroy": [_vp],
     "mhip_contact_op_apply": [_vp, _vp, _vp, _vp],
     "mhip_contact_op_body_velocity": [_vp, C.POINTER(_vp)],

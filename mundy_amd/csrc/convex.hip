@@ -1633,6 +1633,59 @@ int mhip_contact_op_create_rods(mhip_contact_op_t* handle, size_t num_constraint
                            seg, mob_trans, mob_rot, dt, priority, stream);
 }
 
+// Same contact list, new geometry: the incidence index, the slot table and the list order stay (they depend on the pairs
+// only; the priority classes keep the order they had when the operator was built, which affects nothing but locality
+// and the summation order), the half-edge records, the rod axes and the views of the per-contact arrays are redone.
+static int refresh_contact_op(mhip_contact_op_t op, const double* normal, const double* ra, const double* rb,
+                              const double* arc_s, const double* arc_t, const double* seg, mhip_stream_t stream) {
+  TraceRange trace_range("ContactOperator::refresh");
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  const size_t C = op->view.C, N = op->view.N;
+  MHIP_REQUIRE(C == 0 || normal, MHIP_ERR_INVALID_ARGUMENT, "normal must not be null");
+  if (op->kin == KIN_RIGID) MHIP_REQUIRE(C == 0 || (ra && rb), MHIP_ERR_INVALID_ARGUMENT, "ra / rb must not be null");
+  if (op->kin == KIN_ROD)
+    MHIP_REQUIRE((C == 0 || (arc_s && arc_t)) && (N == 0 || seg), MHIP_ERR_INVALID_ARGUMENT,
+                 "arclength arrays / seg must not be null");
+  MHIP_REQUIRE(!op->stage.active, MHIP_ERR_RUNTIME, "a staged solve is in progress");
+  hipStream_t s = as_stream(stream);
+  op->last_stream = s;
+  if (op->kin == KIN_ROD && N > 0) {
+    MHIP_HIP(hipMemsetAsync(op->omega.ptr, 0, (3 * N + 2) * sizeof(double), s));
+    k_rod_axes<<<grid_for(N), kBlock, 0, s>>>(N, seg, op->axis.as<double>());
+  }
+  if (op->view.vel == op->vel.as<double>()) MHIP_HIP(hipMemsetAsync(op->view.vel, 0, 6 * N * sizeof(double), s));
+  if (C > 0) {
+    const size_t ne = 2 * C;
+    const int32_t* inc = op->inc.as<int32_t>();
+    double* half = op->half.as<double>();
+    if (op->kin == KIN_ROD) k_half_build<KIN_ROD><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
+    else if (op->kin == KIN_RIGID) k_half_build<KIN_RIGID><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
+    else k_half_build<KIN_TRANS><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
+  }
+  MHIP_LAUNCH_CHECK();
+  op->view.normal = normal;
+  op->view.ra = ra;
+  op->view.rb = rb;
+  op->view.arc_s = arc_s;
+  op->view.arc_t = arc_t;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_refresh(mhip_contact_op_t op, const double* normal, const double* ra, const double* rb,
+                            mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(op->kin != KIN_ROD, MHIP_ERR_INVALID_ARGUMENT, "a rod operator is refreshed with mhip_contact_op_refresh_rods");
+  return refresh_contact_op(op, normal, op->kin == KIN_RIGID ? ra : nullptr, op->kin == KIN_RIGID ? rb : nullptr, nullptr,
+                            nullptr, nullptr, stream);
+}
+
+int mhip_contact_op_refresh_rods(mhip_contact_op_t op, const double* normal, const double* arc_s, const double* arc_t,
+                                 const double* seg, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(op->kin == KIN_ROD, MHIP_ERR_INVALID_ARGUMENT, "not a rod operator");
+  return refresh_contact_op(op, normal, nullptr, nullptr, arc_s, arc_t, seg, stream);
+}
+
 int mhip_contact_op_destroy(mhip_contact_op_t op) {
   if (!op) return MHIP_SUCCESS;
   // whatever still runs on the operator's stream reads these buffers: wait before they can be handed on

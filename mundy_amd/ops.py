@@ -408,6 +408,22 @@ class ContactOperator:
         self._h = h
         self._device = normal.device
 
+    def refresh(self, normal, ra=None, rb=None, rod=None):
+        """same pairs, new geometry (a step that reuses the neighbour list): keeps the incidence index, redoes the
+        half-edge records from the new arrays (mhip_contact_op_refresh[_rods])"""
+        pairs, _, _, _, mob_trans, mob_rot, old_rod, priority = self._keep
+        if (rod is None) != (old_rod is None):
+            raise ValueError("refresh must keep the operator's kinematics")
+        if rod is not None:
+            arc_s, arc_t, seg = rod
+            capi.check(capi.load().mhip_contact_op_refresh_rods(self._h, _ptr(normal, cols=3), _ptr(arc_s), _ptr(arc_t),
+                                                                _ptr(seg, cols=8), _stream()))
+        else:
+            capi.check(capi.load().mhip_contact_op_refresh(self._h, _ptr(normal, cols=3),
+                                                           _ptr(ra, allow_none=True, name="ra"),
+                                                           _ptr(rb, allow_none=True, name="rb"), _stream()))
+        self._keep = (pairs, normal, ra, rb, mob_trans, mob_rot, rod, priority)
+
     def apply(self, x, y=None):
         y = torch.empty_like(x) if y is None else y
         capi.check(capi.load().mhip_contact_op_apply(self._h, _ptr(x), _ptr(y), _stream()))

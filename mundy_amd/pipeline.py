@@ -148,7 +148,10 @@ class ContactStepper:
 
     def resolve_collisions(self, rebuilt):
         c = self.contacts
-        if self.op is not None:
+        # a step that reuses the neighbour list keeps the operator's incidence index and only refreshes its geometry
+        reuse = (not rebuilt and self.op is not None and self.friction is None and
+                 self.op.num_constraints == self.links.num_pairs and getattr(self.op, "_h", None))
+        if self.op is not None and not reuse:
             self.op.close()
         if self.friction is not None:
             ra, rb = ops.surface_lever_arms(self.links.pairs, c["normal"], c["ra"], c["rb"], self.radius)
@@ -158,8 +161,13 @@ class ContactStepper:
             self.impulse, self.lam = p, (p * c["normal"]).sum(dim=1)
             return res
         if self.kind == "spherocylinder" and self.rod_kinematics:
-            self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, mob_rot=self.mob_rot,
-                                          rod=(c["s"], c["t"], self.seg), priority=c["sep"])
+            if reuse:
+                self.op.refresh(c["normal"], rod=(c["s"], c["t"], self.seg))
+            else:
+                self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt,
+                                              mob_rot=self.mob_rot, rod=(c["s"], c["t"], self.seg), priority=c["sep"])
+        elif reuse:
+            self.op.refresh(c["normal"], ra=c.get("ra"), rb=c.get("rb"))
         else:
             self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c.get("ra"),
                                           rb=c.get("rb"), mob_rot=self.mob_rot, priority=c["sep"])

@@ -170,6 +170,47 @@ def test_contact_operator_apply(ops, oracle, maker, n):
     op.close()
 
 
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 3000), (_rod_problem, 3000), (_rod_problem_arclength, 3000)])
+def test_contact_operator_refresh_equals_rebuild(ops, oracle, maker, n):
+    # a step that reuses the neighbour list keeps the operator and refreshes its geometry (mhip_contact_op_refresh*):
+    # same pairs, perturbed normals / arms / segments.  The refreshed operator must act like one built from scratch on
+    # the new geometry (same terms; the order inside a body's list is the one fixed at create, so rounding level) and
+    # solve the LCP to the same point.
+    from gpu_util import dev, host
+    P = maker(oracle, n, seed=5)
+    rng = np.random.default_rng(1)
+    nrm2 = P["normal"] + 0.05 * rng.normal(size=P["normal"].shape)
+    nrm2 /= np.linalg.norm(nrm2, axis=1, keepdims=True)
+    Q = dict(P, normal=nrm2, sep=P["sep"] + 0.01 * rng.normal(size=P["sep"].shape))
+    if P["ra"] is not None:
+        Q["ra"] = P["ra"] + 0.02 * rng.normal(size=P["ra"].shape)
+        Q["rb"] = P["rb"] + 0.02 * rng.normal(size=P["rb"].shape)
+    if P.get("rod"):
+        seg2 = P["seg"].copy()
+        seg2[:, :6] += 0.02 * rng.normal(size=(len(seg2), 6))
+        Q.update(seg=seg2, s=np.clip(P["s"] + 0.03 * rng.normal(size=P["s"].shape), 0, 1),
+                 t=np.clip(P["t"] + 0.03 * rng.normal(size=P["t"].shape), 0, 1))
+    op = _gpu_op(ops, P)
+    x = dev(rng.uniform(0, 1, len(P["pairs"])))
+    y_old = host(op.apply(x))
+    opt = lambda a: None if a is None else dev(a)  # noqa: E731
+    if P.get("rod"):
+        op.refresh(dev(Q["normal"]), rod=(dev(Q["s"]), dev(Q["t"]), dev(Q["seg"])))
+    else:
+        op.refresh(dev(Q["normal"]), ra=opt(Q["ra"]), rb=opt(Q["rb"]))
+    fresh = _gpu_op(ops, Q)
+    y, yf = host(op.apply(x)), host(fresh.apply(x))
+    assert np.abs(y - y_old).max() > 1e-6 * np.abs(y_old).max()       # the geometry did change
+    np.testing.assert_allclose(y, yf, rtol=1e-12, atol=1e-12 * np.abs(yf).max())
+    cfg = ops.PGDConfig(max_iters=20000, tol=1e-6)
+    xa, ga, ra_ = ops.solve_lcp(op, dev(Q["sep"]), dev(np.zeros(len(Q["sep"]))), cfg)
+    xb, gb, rb_ = ops.solve_lcp(fresh, dev(Q["sep"]), dev(np.zeros(len(Q["sep"]))), cfg)
+    assert ra_.converged and rb_.converged
+    np.testing.assert_allclose(host(ga), host(gb), atol=20 * 1e-6)
+    op.close()
+    fresh.close()
+
+
 def test_rod_operator_body_velocity_matches_vector_form(ops, oracle):
     # the rod-compressed operator keeps (U, W x u) in its velocity rows; body_velocity() hands back (U, W), equal to
     # the vector-arm operator's to rounding (arm (s - 1/2) u vs (p0 + s u) - c: one ulp of the centre coordinate)
