@@ -289,13 +289,16 @@ class DistributedContactStepper:
         return ops.compute_aabb_spherocylinders(center, quat, r, ln), ops.bounding_radius_spherocylinders(r, ln)
 
     # -- ghost halo -----------------------------------------------------------------------------------------------------
-    def _exchange_ghosts(self):
-        """ghost plan + body-record exchange, both inside the library (mhip_ghost_plan / mhip_ghost_exchange)"""
+    def _exchange_ghosts(self, replan=True):
+        """ghost plan + body-record exchange, both inside the library (mhip_ghost_plan / mhip_ghost_exchange).
+        replan=False moves the current records of the same ghosts through the plan of the last rebuild."""
         lib, comm = capi.load(), self.comm
         n, dev = self.n, self.center.device
-        aabb, _ = self._aabb(self.center, self.quat, self.shape, self.kind)
-        lay = self._layout = capi.GhostLayout()
-        capi.check(lib.mhip_ghost_plan(comm._h, n, _p(aabb), self.buffer, C.byref(lay), _stream()))
+        if replan:
+            aabb, _ = self._aabb(self.center, self.quat, self.shape, self.kind)
+            lay = self._layout = capi.GhostLayout()
+            capi.check(lib.mhip_ghost_plan(comm._h, n, _p(aabb), self.buffer, C.byref(lay), _stream()))
+        lay = self._layout
         n_lo, n_hi = int(lay.num_ghost_lo), int(lay.num_ghost_hi)
         # records of the owned bodies: gid, centre, quaternion, shape, kind, mobilities
         gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
@@ -312,7 +315,12 @@ class DistributedContactStepper:
         self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=int(lay.num_sent))
 
     # -- one step -------------------------------------------------------------------------------------------------------------
-    def step(self, integrate=True):
+    def step(self, integrate=True, force_rebuild=True):
+        """force_rebuild=False applies the reference's rebuild rule across the ranks (GenNeighborLinkers.hpp:603-615 and
+        the all-reduce of its parallel build): the ghosts' current state travels through the plan of the last rebuild,
+        every rank tests its local bodies (owned + ghosts) against half the search buffer, one all-gather of the flags
+        decides for everybody; without a rebuild the ghost layout, the pair list, its interior / boundary split and the
+        operator's incidence index are kept and only the contact geometry is refreshed."""
         lib, comm = capi.load(), self.comm
         self.phase_ms = {}
         t_last = [time.perf_counter()]
@@ -325,38 +333,58 @@ class DistributedContactStepper:
                 t_last[0] = now
 
         tick("start")
-        self._exchange_ghosts()
+        reuse = False
+        if not force_rebuild and self.op is not None and getattr(self, "_layout", None) is not None:
+            self._exchange_ghosts(replan=False)
+            moved = self.links.needs_rebuild(self.local["center"])
+            flags = comm.all_gather(torch.tensor([1.0 if moved else 0.0], dtype=torch.float64))
+            reuse = not bool(flags.max().item() > 0.0)
+        if not reuse:
+            self._exchange_ghosts()
         tick("ghost_exchange")
         L, dev = self.local, self.center.device
         nl = self.n_local
-        aabb, brad = self._aabb(L["center"], L["quat"], L["shape"], L["kind"])
-        self.links.generate(aabb, L["center"], brad, force=True)
-        tick("aabb_neighbour_list")
-        c_all = self.links.num_pairs
-        pairs = torch.empty((c_all, 2), dtype=torch.int32, device=dev)
-        counted = torch.empty(c_all, dtype=torch.uint8, device=dev)
-        cnt = C.c_size_t(0)
-        n_int = C.c_size_t(0)  # interior contacts (both bodies owned) first, boundary contacts (one ghost) after
-        capi.check(lib.mhip_partition_pairs_owned(c_all, _p(self.links.pairs), self.n_lo, self.n, _p(pairs),
-                                                  _p(counted), C.byref(n_int), C.byref(cnt), _stream()))
-        nc, nci = int(cnt.value), int(n_int.value)
-        pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
-        tick("partition_pairs")
+        self.stats["rebuilt"] = not reuse
+        if reuse:
+            pairs, counted, nci = self.pairs, self.counted, self._nci
+            nc = pairs.shape[0]
+        else:
+            aabb, brad = self._aabb(L["center"], L["quat"], L["shape"], L["kind"])
+            self.links.generate(aabb, L["center"], brad, force=True)
+            tick("aabb_neighbour_list")
+            c_all = self.links.num_pairs
+            pairs = torch.empty((c_all, 2), dtype=torch.int32, device=dev)
+            counted = torch.empty(c_all, dtype=torch.uint8, device=dev)
+            cnt = C.c_size_t(0)
+            n_int = C.c_size_t(0)  # interior contacts (both bodies owned) first, boundary contacts (one ghost) after
+            capi.check(lib.mhip_partition_pairs_owned(c_all, _p(self.links.pairs), self.n_lo, self.n, _p(pairs),
+                                                      _p(counted), C.byref(n_int), C.byref(cnt), _stream()))
+            nc, nci = int(cnt.value), int(n_int.value)
+            pairs, counted = pairs[:nc].contiguous(), counted[:nc].contiguous()
+            self._nci = nci
+            tick("partition_pairs")
         mob_t, mob_r = L["mob_t"], L["mob_r"]
-        if self.op is not None:
+        if self.op is not None and not reuse:
             self.op.close()
         if self.mixed:
             seg = None
             con = ops.contact_mixed(pairs, L["kind"], L["center"], L["quat"], L["shape"])
-            op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, ra=con["ra"], rb=con["rb"],
-                                               mob_rot=mob_r, priority=con["sep"])
+            if reuse:
+                self.op.refresh(con["normal"], ra=con["ra"], rb=con["rb"])
+            else:
+                self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, ra=con["ra"], rb=con["rb"],
+                                              mob_rot=mob_r, priority=con["sep"])
         else:
             seg = ops.spherocylinder_segments(L["center"], L["quat"], L["shape"][:, 0].contiguous(),
                                               L["shape"][:, 1].contiguous())
             con = ops.contact_spherocylinders(pairs, seg, L["center"], want_points=False, arms="arclength")
             # rod-compressed kinematics: velocity rows (and the halo) carry (U, W x u); (U, W) = body_velocity()
-            op = self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
-                                               rod=(con["s"], con["t"], seg), priority=con["sep"])
+            if reuse:
+                self.op.refresh(con["normal"], rod=(con["s"], con["t"], seg))
+            else:
+                self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
+                                              rod=(con["s"], con["t"], seg), priority=con["sep"])
+        op = self.op
         tick("narrow_phase_operator")
         self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
         self._keep = (pairs, counted, con, mob_t, mob_r, seg)

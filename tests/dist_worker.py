@@ -21,7 +21,9 @@ def main():
     from mundy_amd import distributed as D, ops, pipeline, synth
 
     mixed = os.environ.get("DIST_MIXED", "0") == "1"   # BASELINE configs[4]: spheres + rods + ellipsoids
-    b = synth.mixed_bodies(n_total, volume_fraction=0.25, seed=7) if mixed else synth.spherocylinders(n_total, seed=7)
+    phi, buf = float(os.environ.get("DIST_PHI", "0.4")), float(os.environ.get("DIST_BUFFER", "0.1"))
+    b = synth.mixed_bodies(n_total, volume_fraction=0.25, seed=7) if mixed else \
+        synth.spherocylinders(n_total, seed=7, volume_fraction=phi)
     order = D.hilbert_order(b["center"], 0.0, b["box"], level=5)
     starts = D.partition_ranges(n_total, world)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
@@ -32,12 +34,12 @@ def main():
     if mixed:
         g_kind, g_shape = b["kind"][order], b["shape"][order]
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), None, None, a, comm=D.Comm(),
-                                         search_buffer=0.1, cfg=cfg, poll_every=8, kind=dev(g_kind[a:e]),
+                                         search_buffer=buf, cfg=cfg, poll_every=8, kind=dev(g_kind[a:e]),
                                          shape=dev(g_shape[a:e]))
     else:
         g_radius, g_length = b["radius"][order], b["length"][order]
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]),
-                                         a, comm=D.Comm(), search_buffer=0.1, cfg=cfg, poll_every=8)
+                                         a, comm=D.Comm(), search_buffer=buf, cfg=cfg, poll_every=8)
     stats = st.step(integrate=False)
     gid = st.local["gid"].cpu().numpy().astype(np.int64)
     pairs = st.pairs.cpu().numpy()
@@ -49,11 +51,11 @@ def main():
     ok = True
     if rank == 0:
         if mixed:
-            ref = pipeline.ContactStepper("mixed", dev(g_center), None, dev(g_quat), search_buffer=0.1, cfg=cfg,
+            ref = pipeline.ContactStepper("mixed", dev(g_center), None, dev(g_quat), search_buffer=buf, cfg=cfg,
                                           kinds=dev(g_kind), shape=dev(g_shape))
         else:
             ref = pipeline.ContactStepper("spherocylinder", dev(g_center), dev(g_radius), dev(g_quat), dev(g_length),
-                                          search_buffer=0.1, cfg=cfg)
+                                          search_buffer=buf, cfg=cfg)
         rs = ref.step(integrate=False)
         rp = ref.links.pairs.cpu().numpy().astype(np.int64)
         rg = (ref.op.apply(ref.lam) + ref.contacts["sep"]).cpu().numpy()
@@ -102,15 +104,20 @@ def main():
     # a short trajectory: the owned bodies of every rank, advanced by three more full steps (ghost plan, list, solve and
     # Euler update each step), track the single-rank trajectory of the same system
     steps = int(os.environ.get("DIST_STEPS", "0"))
+    reuse = os.environ.get("DIST_REUSE", "0") == "1"   # the rebuild rule across ranks instead of a rebuild every step
     if steps and not mixed:
+        rebuilt = []
         for _ in range(steps):
-            stats = st.step(integrate=True)
+            stats = st.step(integrate=True, force_rebuild=not reuse)
+            rebuilt.append(bool(stats["rebuilt"]))
         mine = dict(c=st.center.cpu().numpy(), q=st.quat.cpu().numpy(), conv=stats["converged"])
         allc = [None] * world if rank == 0 else None
         dist.gather_object(mine, allc, dst=0)
         if rank == 0:
+            ref_rebuilt = []
             for _ in range(steps):
-                rs = ref.step(integrate=True, force_rebuild=True)
+                rs = ref.step(integrate=True, force_rebuild=not reuse)
+                ref_rebuilt.append(bool(rs.rebuilt))
             c_ref, q_ref = ref.center.cpu().numpy(), ref.quat.cpu().numpy()
             c_all = np.concatenate([o["c"] for o in allc])
             q_all = np.concatenate([o["q"] for o in allc])
@@ -120,6 +127,11 @@ def main():
             good = all(o["conv"] for o in allc) and rs.converged and dc <= 1e-4 and dq <= 1e-8
             print(("ok   " if good else "FAIL ") + "%d-step trajectory vs single rank: max |dc| %.3g (bodies moved up to %.3g), "
                   "quaternion defect %.3g" % (steps, dc, moved, dq))
+            if reuse:
+                # every rank takes the same decision (it is all-gathered), and it is the single-rank one
+                same = rebuilt == ref_rebuilt and (False in rebuilt) and (True in rebuilt)
+                print(("ok   " if same else "FAIL ") + "rebuild decisions %s (single rank %s)" % (rebuilt, ref_rebuilt))
+                good = good and same
             ok = ok and good
             print("DIST_TRAJECTORY", "PASS" if good else "FAIL")
     flag = torch.tensor([1 if ok else 0])

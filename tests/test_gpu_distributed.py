@@ -41,6 +41,12 @@ def test_distributed_trajectory_tracks_single_rank():
     _run(2, None, {"DIST_STEPS": "3", "DIST_BODIES": "8000"})
 
 
+def test_distributed_trajectory_with_list_reuse():
+    # the rebuild rule across ranks: ghosts refreshed through the old plan, one all-gathered decision, list / partition /
+    # incidence index reused when nobody moved more than half the buffer; decisions equal the single-rank ones
+    _run(3, None, {"DIST_STEPS": "8", "DIST_REUSE": "1", "DIST_BODIES": "6000", "DIST_PHI": "0.2", "DIST_BUFFER": "0.4"})
+
+
 def test_distributed_mixed_shapes_equals_single_rank():
     # BASELINE configs[4] as a parity case: spheres + spherocylinders + ellipsoids, Hilbert-partitioned over 2 ranks
     _run(2, 29620, {"DIST_MIXED": "1", "DIST_BODIES": "9000"})
