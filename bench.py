@@ -379,6 +379,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
             # the system size (algorithmic) from what the halo and the all-gather cost per iteration
             "constraint_updates_per_sec": round(contacts_global * sum(iters) / elapsed, 1),
             "halo_wait_ms_per_iteration": round(st.prof.get("halo_wait_ms", 0.0) / max(1, st.prof["iters"]), 4),
+            # host wall time per phase of the last step on rank 0 (each phase ends with a device sync)
+            "stage_ms": {k: round(v, 3) for k, v in st.phase_ms.items() if k != "start"},
             "roofline": roof, "cpu_baseline": None,
         }
         out.update(extra)
