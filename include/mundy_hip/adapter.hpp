@@ -446,6 +446,12 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
     generated_ = true;
     return true;
   }
+  /// the rebuild test on its own (:603-615): has any body moved more than half the search buffer since the last build?
+  bool objects_moved_too_much(size_t n, const double* center, mhip_stream_t stream = nullptr) const {
+    int flag = 1;
+    check(mhip_broadphase_needs_rebuild(h_, n, center, &flag, stream));
+    return flag != 0;
+  }
   size_t num_links() const { return num_pairs_; }
   /// (source, target) pairs, sorted by (source, target)
   DeviceArray<int32_t> links(mhip_stream_t stream = nullptr) const {

@@ -146,15 +146,13 @@ class DistributedSpherocylinderStepper {
     size_t ghosts = 0, local_contacts = 0, interior_contacts = 0, owned_contacts = 0;
   };
 
-  DistStats step(bool integrate = true) {
+  /// force_rebuild = false applies the reference's rebuild rule across the ranks: the ghosts' current state travels
+  /// through the plan of the last rebuild, every rank tests its local bodies (owned + ghosts) against half the search
+  /// buffer (GenNeighborLinkers.hpp:603-615), one all-gather of the flags decides for everybody; without a rebuild the
+  /// ghost layout, the partitioned pair list and the operator's incidence index are kept.
+  DistStats step(bool integrate = true, bool force_rebuild = true) {
     DistStats st;
-    check(mhip_compute_aabb_spherocylinders(n_, center_.data(), quat_.data(), radius_.data(), length_.data(),
-                                            aabb_.data(), nullptr));
-    mhip_ghost_layout lay{};
-    check(mhip_ghost_plan(comm_, n_, aabb_.data(), buffer_, &lay, nullptr));
-    const size_t n_lo = lay.num_ghost_lo, nl = n_lo + n_ + lay.num_ghost_hi;
-    st.ghosts = nl - n_;
-    // interleave the owned fields into records, exchange, split the local records into fields again
+    // the owned fields interleaved into records (what travels to the ranks that hold these bodies as ghosts)
     const struct { const DeviceVector* v; size_t w; } fields[] = {{&gid_, 1}, {&center_, 3}, {&quat_, 4}, {&radius_, 1},
                                                                   {&length_, 1}, {&mob_t_, 1}, {&mob_r_, 1}};
     size_t col = 0;
@@ -162,41 +160,78 @@ class DistributedSpherocylinderStepper {
       check(mhip_copy_strided(n_, f.w, f.v->data(), f.w, rec_.data() + col, kRecord, nullptr));
       col += f.w;
     }
-    double* local = workspace(w_local_, kRecord * nl);
-    check(mhip_ghost_exchange(comm_, kRecord, rec_.data(), local, nullptr));
-    double* l_field[7] = {workspace(l_gid_, nl),    workspace(l_center_, 3 * nl), workspace(l_quat_, 4 * nl),
-                          workspace(l_radius_, nl), workspace(l_length_, nl),     workspace(l_mt_, nl),
-                          workspace(l_mr_, nl)};
-    col = 0;
-    for (size_t k = 0; k < 7; ++k) {
-      check(mhip_copy_strided(nl, fields[k].w, local + col, kRecord, l_field[k], fields[k].w, nullptr));
-      col += fields[k].w;
+    auto exchange_and_split = [&]() {  // records through the current plan, then split into fields again
+      const size_t nl = lay_.num_ghost_lo + n_ + lay_.num_ghost_hi;
+      double* local = workspace(w_local_, kRecord * nl);
+      check(mhip_ghost_exchange(comm_, kRecord, rec_.data(), local, nullptr));
+      double* l_field[7] = {workspace(l_gid_, nl),    workspace(l_center_, 3 * nl), workspace(l_quat_, 4 * nl),
+                            workspace(l_radius_, nl), workspace(l_length_, nl),     workspace(l_mt_, nl),
+                            workspace(l_mr_, nl)};
+      size_t c0 = 0;
+      for (size_t k = 0; k < 7; ++k) {
+        check(mhip_copy_strided(nl, fields[k].w, local + c0, kRecord, l_field[k], fields[k].w, nullptr));
+        c0 += fields[k].w;
+      }
+      return nl;
+    };
+    bool reuse = false;
+    size_t nl = 0;
+    if (!force_rebuild && op_) {
+      nl = exchange_and_split();
+      double flag = links_.objects_moved_too_much(nl, l_center_.data()) ? 1.0 : 0.0;
+      int world = 1;
+      check(mhip_comm_info(comm_, nullptr, &world, nullptr));
+      double* d = workspace(w_flags_, 1 + static_cast<size_t>(world));
+      check(mhip_memcpy_h2d(d, &flag, sizeof flag, nullptr));
+      check(mhip_comm_all_gather(comm_, d, 1, d + 1, nullptr));
+      std::vector<double> all(static_cast<size_t>(world));
+      check(mhip_memcpy_d2h(all.data(), d + 1, all.size() * sizeof(double), nullptr));
+      reuse = true;
+      for (double f : all) reuse = reuse && f == 0.0;
     }
-    double *l_center = l_field[1], *l_quat = l_field[2], *l_radius = l_field[3], *l_length = l_field[4];
-    // neighbour list over owned + ghosts; ghost-ghost pairs dropped, interior contacts first
-    double *l_aabb = workspace(w_aabb_, 6 * nl), *l_brad = workspace(w_brad_, nl), *seg = workspace(w_seg_, 8 * nl);
-    check(mhip_compute_aabb_spherocylinders(nl, l_center, l_quat, l_radius, l_length, l_aabb, nullptr));
-    check(mhip_bounding_radius_spherocylinders(nl, l_radius, l_length, l_brad, nullptr));
-    links_.generate(nl, l_aabb, l_center, l_brad, nullptr, /*force=*/true);
-    const int32_t* all_pairs = links_.links_into(w_all_pairs_);
-    const size_t c_all = links_.num_links();
-    int32_t* pairs = workspace(w_pairs_, 2 * c_all + 2);
-    unsigned char* counted = workspace(w_counted_, c_all + 1);
-    size_t n_int = 0, C = 0;
-    check(mhip_partition_pairs_owned(c_all, all_pairs, n_lo, n_, pairs, counted, &n_int, &C, nullptr));
+    if (!reuse) {
+      check(mhip_compute_aabb_spherocylinders(n_, center_.data(), quat_.data(), radius_.data(), length_.data(),
+                                              aabb_.data(), nullptr));
+      check(mhip_ghost_plan(comm_, n_, aabb_.data(), buffer_, &lay_, nullptr));
+      nl = exchange_and_split();
+    }
+    const size_t n_lo = lay_.num_ghost_lo;
+    st.ghosts = nl - n_;
+    st.rebuilt = !reuse;
+    double *l_center = l_center_.data(), *l_quat = l_quat_.data(), *l_radius = l_radius_.data(),
+           *l_length = l_length_.data();
+    double* seg = workspace(w_seg_, 8 * nl);
+    if (!reuse) {
+      // neighbour list over owned + ghosts; ghost-ghost pairs dropped, interior contacts first
+      double *l_aabb = workspace(w_aabb_, 6 * nl), *l_brad = workspace(w_brad_, nl);
+      check(mhip_compute_aabb_spherocylinders(nl, l_center, l_quat, l_radius, l_length, l_aabb, nullptr));
+      check(mhip_bounding_radius_spherocylinders(nl, l_radius, l_length, l_brad, nullptr));
+      links_.generate(nl, l_aabb, l_center, l_brad, nullptr, /*force=*/true);
+      const int32_t* all_pairs = links_.links_into(w_all_pairs_);
+      const size_t c_all = links_.num_links();
+      int32_t* pairs = workspace(w_pairs_, 2 * c_all + 2);
+      unsigned char* counted = workspace(w_counted_, c_all + 1);
+      check(mhip_partition_pairs_owned(c_all, all_pairs, n_lo, n_, pairs, counted, &n_int_, &num_contacts_, nullptr));
+    }
+    const size_t C = num_contacts_;
+    const int32_t* pairs = w_pairs_.data();
     st.num_contacts = st.local_contacts = C;
-    st.interior_contacts = n_int;
+    st.interior_contacts = n_int_;
     check(mhip_spherocylinder_segments(nl, l_center, l_quat, l_radius, l_length, seg, nullptr));
     double *sep = workspace(w_sep_, C), *normal = workspace(w_normal_, 3 * C), *s = workspace(w_s_, C),
            *t = workspace(w_t_, C);
     check(mhip_contact_spherocylinders(C, pairs, seg, nullptr, sep, normal, nullptr, nullptr, nullptr, nullptr, s, t,
                                        nullptr));
-    ContactOperator op(C, nl, pairs, normal, ContactOperator::Rods{s, t, seg}, l_field[5], l_field[6], dt_, nullptr,
-                       /*priority=*/sep);
+    if (reuse)
+      op_->refresh(normal, ContactOperator::Rods{s, t, seg});
+    else
+      op_.reset(new ContactOperator(C, nl, pairs, normal, ContactOperator::Rods{s, t, seg}, l_mt_.data(), l_mr_.data(),
+                                    dt_, nullptr, /*priority=*/sep));
+    ContactOperator& op = *op_;
     double* vel = workspace(w_vel_, 6 * nl);
     check(mhip_fill(6 * nl, vel, 0.0, nullptr));
-    check(mhip_contact_op_set_partition(op.handle(), n_lo, n_, counted, vel));
-    lay.halo.velocity = vel;
+    check(mhip_contact_op_set_partition(op.handle(), n_lo, n_, w_counted_.data(), vel));
+    lay_.halo.velocity = vel;
     double *x = workspace(lambda_, C), *g = workspace(w_g_, C), *x_tmp = workspace(w_xt_, C),
            *g_tmp = workspace(w_gt_, C);
     check(mhip_fill(C, x, 0.0, nullptr));
@@ -204,12 +239,11 @@ class DistributedSpherocylinderStepper {
     const mhip_space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
     const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};
     mhip_solve_result res{};
-    check(mhip_bbpgd_solve_contact_distributed(op.handle(), comm_, &lay.halo, n_int, sep, &lcp, &pc, x, g, x_tmp, g_tmp,
-                                               /*poll_every=*/32, &res, nullptr, nullptr));
+    check(mhip_bbpgd_solve_contact_distributed(op.handle(), comm_, &lay_.halo, n_int_, sep, &lcp, &pc, x, g, x_tmp,
+                                               g_tmp, /*poll_every=*/32, &res, nullptr, nullptr));
     st.num_iters = res.num_iters;
     st.residual = res.residual;
     st.converged = res.converged != 0;
-    st.rebuilt = true;
     if (integrate) {
       const double* v = nullptr;
       check(mhip_contact_op_body_velocity(op.handle(), &v));
@@ -237,10 +271,13 @@ class DistributedSpherocylinderStepper {
   // per-step workspaces (grow-only): local records and fields, geometry, contacts, solver vectors
   DeviceVector w_local_, l_gid_, l_center_, l_quat_, l_radius_, l_length_, l_mt_, l_mr_, w_aabb_, w_brad_, w_seg_,
       w_sep_, w_normal_, w_s_, w_t_, w_vel_, w_g_, w_xt_, w_gt_;
+  DeviceVector w_flags_;
   DeviceArray<int32_t> w_pairs_, w_all_pairs_;
   DeviceArray<unsigned char> w_counted_;
-  size_t num_lambda_ = 0;
+  size_t num_lambda_ = 0, n_int_ = 0, num_contacts_ = 0;
+  mhip_ghost_layout lay_{};  // of the last rebuild; its lists live in the communicator until the next plan
   mesh::GenNeighborLinks links_;
+  std::unique_ptr<ContactOperator> op_;
 };
 
 }  // namespace mech

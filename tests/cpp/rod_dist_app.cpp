@@ -2,7 +2,8 @@
 // through mundy_hip/stepper.hpp (mech::DistributedSpherocylinderStepper): one process per rank, RCCL transport, no
 // Python, no torch, no MPI.  The launcher's only job -- handing the 128-byte RCCL id from rank 0 to the others -- is
 // done through a file in <rendezvous_dir> (an MPI host would MPI_Bcast it).
-// Usage: rod_dist_app <input.bin> <steps> <rank> <world> <rendezvous_dir>
+// Usage: rod_dist_app <input.bin> <steps> <rank> <world> <rendezvous_dir> [reuse]
+//   reuse: apply the rebuild rule across ranks instead of rebuilding the neighbour list every step
 //   input.bin: uint64 n, then doubles center[3n] quat[4n] radius[n] length[n] mob_trans[n] mob_rot[n], bodies already in
 //   curve order; rank r owns the r-th of `world` equal contiguous ranges and uses device r % device_count.
 // Prints one line per step and a bit-level checksum of the rank's final centres / orientations.
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
   }
   const int steps = std::atoi(argv[2]), rank = std::atoi(argv[3]), world = std::atoi(argv[4]);
   const std::string dir = argv[5];
+  const bool reuse = argc > 6 && std::string(argv[6]) == "reuse";
   std::FILE* f = std::fopen(argv[1], "rb");
   if (!f) {
     std::perror(argv[1]);
@@ -101,11 +103,11 @@ int main(int argc, char** argv) {
                                               /*search_buffer=*/0.1, cfg);
     for (int k = 0; k < steps; ++k) {
       const auto t0 = std::chrono::steady_clock::now();
-      const auto s = st.step(true);
+      const auto s = st.step(true, /*force_rebuild=*/!reuse);
       const double ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      std::printf("STEP %d rank %d contacts %zu iterations %u residual %.17g converged %d ghosts %zu interior %zu ms %.3f\n",
+      std::printf("STEP %d rank %d contacts %zu iterations %u residual %.17g converged %d ghosts %zu interior %zu rebuilt %d ms %.3f\n",
                   k, rank, s.local_contacts, s.num_iters, s.residual, s.converged ? 1 : 0, s.ghosts, s.interior_contacts,
-                  ms);
+                  s.rebuilt ? 1 : 0, ms);
     }
     std::printf("CHECKSUM rank %d center %016llx quat %016llx\n", rank, checksum(st.center().download()),
                 checksum(st.quat().download()));

@@ -102,6 +102,24 @@ def test_cpp_distributed_stepper_over_rccl(tmp_path):
     line = [ln_ for ln_ in p.stdout.splitlines() if ln_.startswith("CHECKSUM")][0].split()
     assert line[4] == checksum(st.center.cpu().numpy()) and line[6] == checksum(st.quat.cpu().numpy())
 
+    # the same with the rebuild rule (across the one rank there is): list, partition and incidence index reused when
+    # nobody moved more than half the buffer -- decisions, iteration counts and the final state equal the Python loop's
+    p = subprocess.run([exe, str(inp), "10", "0", "1", str(tmp_path), "reuse"], capture_output=True, text=True, timeout=600)
+    print(p.stdout[-3000:], p.stderr[-2000:])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    steps = [ln_.split() for ln_ in p.stdout.splitlines() if ln_.startswith("STEP")]
+    st = pipeline.ContactStepper("spherocylinder", dev(c), dev(r), dev(q), dev(ln), search_buffer=0.1,
+                                 cfg=ops.PGDConfig(max_iters=10000, tol=1e-5), mob_trans=dev(mt), mob_rot=dev(mr))
+    rebuilt = []
+    for k in range(10):
+        s = st.step()
+        rebuilt.append(int(s.rebuilt))
+        assert int(steps[k][5]) == s.num_contacts and int(steps[k][7]) == s.num_iters and int(steps[k][17]) == int(s.rebuilt)
+        assert float(steps[k][9]) == s.residual
+    assert 0 in rebuilt[1:] and rebuilt[0] == 1, rebuilt
+    line = [ln_ for ln_ in p.stdout.splitlines() if ln_.startswith("CHECKSUM")][0].split()
+    assert line[4] == checksum(st.center.cpu().numpy()) and line[6] == checksum(st.quat.cpu().numpy())
+
 
 @pytest.mark.gpu
 def test_cpp_rod_stepper_reproduces_the_python_driver(tmp_path):
