@@ -36,6 +36,12 @@ def test_distributed_equals_single_rank(world):
     _run(world, 29610 + world)
 
 
+@pytest.mark.parametrize("bodies", [2, 5])
+def test_distributed_fewer_bodies_than_ranks_or_barely_more(bodies):
+    # 3 ranks, 2 bodies: one rank owns nothing, holds no ghosts and still takes part in every exchange and reduction
+    _run(3, None, {"DIST_BODIES": str(bodies), "DIST_PHI": "0.5"})
+
+
 def test_distributed_trajectory_tracks_single_rank():
     # three more full steps (ghost plan, neighbour list, solve, Euler update on every rank) after the checked one
     _run(2, None, {"DIST_STEPS": "3", "DIST_BODIES": "8000"})
