@@ -74,7 +74,8 @@ def main():
         # iteration count is only comparable within a band; the converged state is checked below
         checks["iterations comparable to single rank (%d vs %d)" % (iters[0], rs.num_iters)] = \
             0.5 * rs.num_iters <= iters[0] <= 2.0 * rs.num_iters + 10
-        if checks["pair set == single-rank neighbour list"]:
+        dilute = len(rp) == 0   # no contact anywhere: every rank solves an empty problem and still joins the collectives
+        if checks["pair set == single-rank neighbour list"] and not dilute:
             dg = np.abs(allg[srt] - rg).max()
             checks["gradient vs single rank (max diff %.3g)" % dg] = dg <= 20 * tol
             checks["LCP conditions"] = allx.min() >= 0 and allg.min() >= -10 * tol and \
@@ -94,9 +95,10 @@ def main():
                         checks["duplicate contact %s bitwise equal" % (k,)] = False
                 elif world > 1:
                     dup[k] = (x.tobytes(), g.tobytes())
-        checks["%d duplicated cross-rank contacts found" % n_dup] = (n_dup > 0) or world == 1
+        checks["%d duplicated cross-rank contacts found" % n_dup] = (n_dup > 0) or world == 1 or dilute
         # (a rank that owns nothing -- fewer bodies than ranks -- holds no ghosts either, but takes part in every collective)
-        checks["ghosts exchanged"] = world == 1 or all(o["stats"]["ghosts"] > 0 for o in gathered if len(o["vel"]) > 0)
+        checks["ghosts exchanged"] = world == 1 or dilute or \
+            all(o["stats"]["ghosts"] > 0 for o in gathered if len(o["vel"]) > 0)
         for k, v in checks.items():
             print(("ok   " if v else "FAIL ") + k)
             ok = ok and bool(v)

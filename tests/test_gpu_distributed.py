@@ -42,6 +42,11 @@ def test_distributed_fewer_bodies_than_ranks_or_barely_more(bodies):
     _run(3, None, {"DIST_BODIES": str(bodies), "DIST_PHI": "0.5"})
 
 
+def test_distributed_without_any_contact():
+    # a dilute system: empty neighbour lists and empty LCPs on every rank, zero iterations, collectives still matched
+    _run(3, None, {"DIST_BODIES": "60", "DIST_PHI": "0.0005", "DIST_STEPS": "2"})
+
+
 def test_distributed_trajectory_tracks_single_rank():
     # three more full steps (ghost plan, neighbour list, solve, Euler update on every rank) after the checked one
     _run(2, None, {"DIST_STEPS": "3", "DIST_BODIES": "8000"})
