@@ -372,7 +372,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                        "ghost_bodies_total": ghosts_global, "bbpgd_iters_per_step": iters,
                        "converged": [bool(s["converged"]) for s in stats],
                        "parallelism": "hilbert domain decomposition dd%d: ghost-body halo per rebuild; per BBPGD "
-                                      "iteration ghost-velocity send/recv + 3-double all-gather (RCCL)" % world},
+                                      "iteration ghost-velocity send/recv + 3-double all-gather (RCCL)" % world,
+                       "transport": comm.transport},
             "contact_pairs_per_sec": round(contacts_global * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
             # contacts x iterations per second over all ranks: separates the growth of the BBPGD iteration count with

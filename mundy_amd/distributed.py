@@ -21,6 +21,7 @@ torch.distributed carries the messages; with the gloo backend (tests, several ra
 staged through the host.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -107,15 +108,38 @@ class Comm:
         self.direct = self.enabled and dist.get_backend(group) == "nccl"
         self._h = C.c_void_p()
         self._callbacks = None
+        self.transport = "host"
         if self.direct:
-            ident = C.create_string_buffer(capi.COMM_ID_BYTES)
-            if self.rank == 0:
-                capi.check(lib.mhip_comm_unique_id(ident))
-            t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).cuda()
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), capi.COMM_ID_BYTES)
-            capi.check(lib.mhip_comm_create_rccl(C.byref(self._h), ident, self.rank, self.world))
-        else:
+            # the library's own RCCL communicator.  Should creating it fail on ANY rank (decided together, so that all
+            # ranks take the same road) the step still runs, staged through host memory over a gloo group -- slow, and
+            # said so loudly; it is not a second compute path, only a second wire.
+            err = None
+            try:
+                if os.environ.get("MUNDY_TEST_FAIL_RCCL") == "1":   # the tests' way into the fallback branch
+                    raise RuntimeError("RCCL refused (forced by MUNDY_TEST_FAIL_RCCL)")
+                ident = C.create_string_buffer(capi.COMM_ID_BYTES)
+                if self.rank == 0:
+                    capi.check(lib.mhip_comm_unique_id(ident))
+                t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).cuda()
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), capi.COMM_ID_BYTES)
+                capi.check(lib.mhip_comm_create_rccl(C.byref(self._h), ident, self.rank, self.world))
+            except Exception as e:  # noqa: BLE001
+                err = e
+            bad = torch.tensor([0.0 if err is None else 1.0], device="cuda")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+            if bad.item() > 0.0:
+                import sys
+                print("mundy_amd: the RCCL communicator could not be created on every rank (%s); falling back to the "
+                      "host-callback transport over gloo -- expect a host-bound iteration" % (err,), file=sys.stderr)
+                if self._h:
+                    lib.mhip_comm_destroy(self._h)
+                    self._h = C.c_void_p()
+                self.direct = False
+                self.group = dist.new_group(backend="gloo")
+            else:
+                self.transport = "rccl"
+        if not self.direct:
             self._callbacks = (capi.EXCHANGE_FN(self._exchange_cb), capi.ALL_GATHER_FN(self._all_gather_cb))
             capi.check(lib.mhip_comm_create_host(C.byref(self._h), self.rank, self.world, self._callbacks[0],
                                                  self._callbacks[1], None))

@@ -140,6 +140,20 @@ def test_nccl_transport_single_rank():
         assert not s3["converged"] and s3["num_iters"] == 7
         st3.op.close()
         comm.close()
+        # if the library's RCCL communicator cannot be made, every rank falls back -- together -- to the host-callback
+        # transport over a gloo group: same step, same result
+        os.environ["MUNDY_TEST_FAIL_RCCL"] = "1"
+        try:
+            comm2 = D.Comm()
+        finally:
+            del os.environ["MUNDY_TEST_FAIL_RCCL"]
+        assert comm2.transport == "host" and not comm2.direct
+        st4 = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), 0,
+                                          comm=comm2, cfg=cfg)
+        s4 = st4.step(integrate=False)
+        assert s4["num_iters"] == r.num_iters and torch.equal(st4.lam, ref.lam)
+        st4.op.close()
+        comm2.close()
     finally:
         dist.destroy_process_group()
 
