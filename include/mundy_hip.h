@@ -258,6 +258,13 @@ int mhip_contact_op_apply(mhip_contact_op_t handle, const double* x, double* y, 
  * (sampled launches of each kernel) since profiling was enabled.  All out pointers [host]. */
 /* sizes the operator was created with (either pointer may be NULL) */
 int mhip_contact_op_sizes(mhip_contact_op_t handle, size_t* num_constraints, size_t* num_bodies);
+/* How the two sweeps are laid out on the chip -- time only, never results: every sum that reaches an iterate is a
+ * double-double pair rounded once, so any mapping gives the same bits (tests/test_gpu_convex.py checks exactly that).
+ *   xcd_tile        consecutive 256-item tiles handed to one XCD (8 XCDs with private L2s; 0 = identity mapping,
+ *                   default 32); -1 keeps the current value
+ *   lanes_per_body  lanes that share one body's contact list in the body sweep: 2, 4, 8 or 16 (default by mean
+ *                   degree); -1 keeps the current value */
+int mhip_contact_op_set_work_mapping(mhip_contact_op_t handle, int xcd_tile, int lanes_per_body);
 int mhip_contact_op_set_profiling(mhip_contact_op_t handle, int enable);
 int mhip_contact_op_get_profile(mhip_contact_op_t handle, double* body_ms, double* constraint_ms, size_t* iterations);
 /* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate (valid in stream order after
@@ -293,28 +300,32 @@ int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, d
                                       mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
 /* Staged form of the same fused iteration for domain-decomposed runs: the host interleaves the halo
  * exchange and the cross-rank reduction between the stages, all asynchronously on `stream`:
- *     begin;  body(init) -> [ghost velocity halo] -> constraint(init, local3) -> [all-gather local3] -> finalize(init)
- *     repeat: body -> [halo] -> constraint(local3) -> [all-gather] -> finalize;   poll every k iterations;   end
+ *     begin;  body(init) -> [ghost velocity halo] -> constraint(init, local) -> [all-gather local] -> finalize(init)
+ *     repeat: body -> [halo] -> constraint(local) -> [all-gather] -> finalize;   poll every k iterations;   end
  * mhip_contact_op_set_partition: bodies [first, first+count) of the local index space are owned (swept by the body
  * stage), the rest are ghosts whose rows of `velocity` ([num_bodies][6], caller owned so the halo can write it) are
  * filled by the exchange; counted_contacts[c] != 0 marks contacts this rank contributes to the reductions (NULL: all).
- * local3 / gathered are DEVICE arrays of (max residual term, sum dx^2, sum dx dg) triples; finalize reduces the
- * `nparts` gathered triples in order, so every rank derives bit-identical step sizes.
+ * local / gathered are DEVICE arrays of reduction records of MHIP_BBPGD_REDUCTION_WIDTH doubles:
+ *     (max residual term, sum dx^2 as a double-double pair hi, lo, sum dx dg as a double-double pair hi, lo).
+ * The two Barzilai-Borwein sums travel unrounded (~106 bits) and finalize adds the `nparts` gathered records in order
+ * and rounds once, so every rank derives bit-identical step sizes and the rank count does not reach the result (the
+ * same holds inside a rank for the workgroup mapping and, in the body sweep, for the order of a body's contact list).
  * Replaces: stk::all_reduce_max / stk::all_reduce_sum x3 per iteration (scrap/lcp_spheres/NGPSpheresLCP.cpp:371,
- * :450-452) with one 3-double all-gather, and the ghost field refresh of :1057 (left "TODO" there). */
+ * :450-452) with one 5-double all-gather, and the ghost field refresh of :1057 (left "TODO" there). */
+#define MHIP_BBPGD_REDUCTION_WIDTH 5
 int mhip_contact_op_set_partition(mhip_contact_op_t handle, size_t body_first, size_t body_count,
                                   const unsigned char* counted_contacts, double* velocity);
 int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_space* space /*[host]*/,
                            const mhip_pgd_config* config /*[host]*/, double* x, double* g, double* x_tmp,
                            double* g_tmp, mhip_stream_t stream);
 int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream);
-int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream);
+int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local, mhip_stream_t stream);
 /* the constraint stage in pieces: sweep a sub-range of the constraints (any number of disjoint ranges per iteration,
  * e.g. interior contacts before the halo has landed, boundary contacts after), then reduce every sweep's partials of
- * this iteration into local3.  stage_constraint == constraint_range(0, C) + reduce. */
+ * this iteration into local.  stage_constraint == constraint_range(0, C) + reduce. */
 int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_first, size_t c_count,
                                       mhip_stream_t stream);
-int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream);
+int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local, mhip_stream_t stream);
 int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gathered, int nparts,
                               mhip_stream_t stream);
 int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, int* done /*[host]*/,
@@ -526,8 +537,8 @@ typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that
 /* The domain-decomposed BBPGD solve, whole loop on the host side of this library (no interpreter between the stages):
  *   begin;  per iteration: body sweep of the owned bodies -> pack + start the velocity halo -> constraint sweep of the
  *   interior contacts [0, interior_contacts) while the halo is in flight -> finish halo -> sweep of the boundary
- *   contacts -> local (max, sum dx^2, sum dx dg) -> all-gather -> every rank reduces the triples in rank order (bit-
- *   identical steps) ;  convergence polled every poll_every iterations (0: 32) ;  end.
+ *   contacts -> local (max, sum dx^2, sum dx dg) record -> all-gather -> every rank reduces the records in rank order
+ *   (bit-identical steps) ;  convergence polled every poll_every iterations (0: 32) ;  end.
  * Same iterates as the mhip_bbpgd_stage_* sequence driven by hand.  op must carry mhip_contact_op_set_partition; the
  * four solver vectors are caller owned as in mhip_bbpgd_solve_contact.  profile may be NULL. */
 int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t comm, const mhip_velocity_halo* halo,

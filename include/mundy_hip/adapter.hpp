@@ -452,6 +452,9 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
     check(mhip_broadphase_needs_rebuild(h_, n, center, &flag, stream));
     return flag != 0;
   }
+  /// the body numbering changed (reordering, migration): the next generate() builds a new list whatever the rebuild
+  /// rule says (the reference re-collects its entity indices when they change, GenNeighborLinkers.hpp:745-800)
+  void invalidate() { generated_ = false; }
   size_t num_links() const { return num_pairs_; }
   /// (source, target) pairs, sorted by (source, target)
   DeviceArray<int32_t> links(mhip_stream_t stream = nullptr) const {

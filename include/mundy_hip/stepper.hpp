@@ -51,6 +51,9 @@ class SpherocylinderStepper {
     gather(brad_, 1);
     gather(mob_t_, 1);
     gather(mob_r_, 1);
+    // the neighbour list and the operator's incidence index are in the old numbering
+    links_.invalidate();
+    op_.reset();
   }
 
   StepStats step(bool integrate = true, bool force_rebuild = false) {

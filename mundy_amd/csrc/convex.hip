@@ -111,45 +111,61 @@ __device__ inline double residual_term(int kind, double x, double g, const Space
   return fabs(x - sp.project(x - kSmallStep * g));
 }
 
-// reductions: partials[block] then an ordered final pass.  OP: 0 = sum (x-y)^2, 1 = sum (x1-x2)(y1-y2), 2 = max resid
+// reductions: partials[block] then a single-workgroup final pass.  OP: 0 = sum (x-y)^2, 1 = sum (x1-x2)(y1-y2),
+// 2 = max resid.  The sums are double-double (see mhip_internal.hpp): partials are (hi, lo) planes kMaxGrid apart.
 template <int OP>
 __global__ void __launch_bounds__(kBlock)
     k_reduce_partials(size_t n, const double* __restrict__ a, const double* __restrict__ b,
                       const double* __restrict__ c, const double* __restrict__ d, int resid_kind, Space sp,
                       double* __restrict__ partials) {
-  __shared__ double scratch[kBlock / 64];
-  double acc = (OP == 2) ? kLowest : 0.0;
+  __shared__ double scratch[2 * kBlock / 64];
+  double mx = kLowest;
+  DD acc{0.0, 0.0};
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     if (OP == 0) {
       const double df = a[i] - b[i];
-      acc += df * df;
+      dd_add(acc, df * df);
     } else if (OP == 1) {
-      acc += (a[i] - b[i]) * (c[i] - d[i]);
+      dd_add(acc, (a[i] - b[i]) * (c[i] - d[i]));
     } else {
       const double v = residual_term(resid_kind, a[i], b[i], sp);
-      if (v > acc) acc = v;
+      if (v > mx) mx = v;
     }
   }
-  const double r = (OP == 2) ? block_max(acc, scratch) : block_sum(acc, scratch);
-  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  if (OP == 2) {
+    const double r = block_max(mx, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+  } else {
+    const DD r = block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+      partials[blockIdx.x] = r.hi;
+      partials[kMaxGrid + blockIdx.x] = r.lo;
+    }
+  }
 }
 template <int OP>
 __global__ void __launch_bounds__(kBlock) k_reduce_final(int nparts, const double* __restrict__ partials,
                                                         double* __restrict__ out) {
-  __shared__ double scratch[kBlock / 64];
-  double acc = (OP == 2) ? kLowest : 0.0;
+  __shared__ double scratch[2 * kBlock / 64];
+  double mx = kLowest;
+  DD acc{0.0, 0.0};
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
     if (OP == 2) {
-      if (partials[i] > acc) acc = partials[i];
+      if (partials[i] > mx) mx = partials[i];
     } else {
-      acc += partials[i];
+      dd_add(acc, DD{partials[i], partials[kMaxGrid + i]});
     }
   }
-  const double r = (OP == 2) ? block_max(acc, scratch) : block_sum(acc, scratch);
-  if (threadIdx.x == 0) *out = r;
+  if (OP == 2) {
+    const double r = block_max(mx, scratch);
+    if (threadIdx.x == 0) *out = r;
+  } else {
+    const DD r = block_sum(acc, scratch);
+    if (threadIdx.x == 0) *out = dd_value(r);
+  }
 }
 
-// y = A x, row-major n x n: one wavefront per row (KokkosBlas::gemv "N")
+// y = A x, row-major n x n: one wavefront per row (KokkosBlas::gemv "N"), double-double row sums
 __global__ void __launch_bounds__(kBlock) k_gemv(size_t n, const double* __restrict__ A, const double* __restrict__ x,
                                                 double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
@@ -157,10 +173,10 @@ __global__ void __launch_bounds__(kBlock) k_gemv(size_t n, const double* __restr
   const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
   for (size_t row = wave; row < n; row += nwaves) {
     const double* Ar = A + row * n;
-    double acc = 0.0;
-    for (size_t j = lane; j < n; j += 64) acc += Ar[j] * x[j];
+    DD acc{0.0, 0.0};
+    for (size_t j = lane; j < n; j += 64) dd_add(acc, Ar[j] * x[j]);
     acc = wave_sum(acc);
-    if (lane == 0) y[row] = acc;
+    if (lane == 0) y[row] = dd_value(acc);
   }
 }
 
@@ -244,10 +260,10 @@ __global__ void __launch_bounds__(64)
 
 // thread-local scratch for the blocking S1 reductions (the stream is synchronised before they return)
 struct ReduceScratch {
-  DeviceBuffer dev;  // kMaxGrid partials + 1 result
+  DeviceBuffer dev;  // 2 planes of kMaxGrid partials + 1 result
   double* host = nullptr;
   int ensure() {
-    if (int e = dev.reserve((kMaxGrid + 8) * sizeof(double))) return e;
+    if (int e = dev.reserve((2 * kMaxGrid + 8) * sizeof(double))) return e;
     if (!host) MHIP_HIP(hipHostMalloc(reinterpret_cast<void**>(&host), 8 * sizeof(double)));
     return MHIP_SUCCESS;
   }
@@ -263,7 +279,7 @@ int reduce_to_host(size_t n, const double* a, const double* b, const double* c, 
   ReduceScratch& rs = reduce_scratch();
   if (int e = rs.ensure()) return e;
   double* partials = rs.dev.as<double>();
-  double* out = partials + kMaxGrid;
+  double* out = partials + 2 * kMaxGrid;
   const unsigned grid = grid_for(n);
   k_reduce_partials<OP><<<grid, kBlock, 0, stream>>>(n, a, b, c, d, resid_kind, sp, partials);
   MHIP_LAUNCH_CHECK();
@@ -444,7 +460,8 @@ __global__ void __launch_bounds__(kBlock)
   if (t / G >= op.body_count) return;  // whole groups leave together (G divides the wave size)
   const size_t b = op.body_first + t / G;
   constexpr int HW = (KIN == KIN_RIGID) ? 6 : (KIN == KIN_ROD ? 4 : 3);
-  V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
+  // force and torque sums in double-double: their rounded values do not depend on the order of the list, on G or on U
+  DD3 Fdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, Tdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
@@ -484,9 +501,9 @@ __global__ void __launch_bounds__(kBlock)
       const V3 n{h0[u].x, h0[u].y, h1[u].x};
       V3 f{lam[u] * n.x, lam[u] * n.y, lam[u] * n.z};
       if (!(e[u] & 1)) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
-      F = F + f;
-      if (KIN == KIN_RIGID) T = T + cross(V3{h1[u].y, h2[u].x, h2[u].y}, f);  // torque r x (+/- lam n)
-      if (KIN == KIN_ROD) T = T + h1[u].y * f;  // S = sum coef f; the torque is u x S, formed once per body below
+      dd_add(Fdd, f);
+      if (KIN == KIN_RIGID) dd_add(Tdd, cross(V3{h1[u].y, h2[u].x, h2[u].y}, f));  // torque r x (+/- lam n)
+      if (KIN == KIN_ROD) dd_add(Tdd, h1[u].y * f);  // S = sum coef f; the torque is u x S, formed once per body below
     }
   };
   // activity masks apply when Proj(0 - step g) == 0 is guaranteed for g >= 0: LCP space, finite non-negative step
@@ -526,16 +543,17 @@ __global__ void __launch_bounds__(kBlock)
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
-    F.x += __shfl_xor(F.x, off, 64);
-    F.y += __shfl_xor(F.y, off, 64);
-    F.z += __shfl_xor(F.z, off, 64);
+    dd_add(Fdd.x, dd_shfl_xor(Fdd.x, off));
+    dd_add(Fdd.y, dd_shfl_xor(Fdd.y, off));
+    dd_add(Fdd.z, dd_shfl_xor(Fdd.z, off));
     if (KIN != KIN_TRANS) {
-      T.x += __shfl_xor(T.x, off, 64);
-      T.y += __shfl_xor(T.y, off, 64);
-      T.z += __shfl_xor(T.z, off, 64);
+      dd_add(Tdd.x, dd_shfl_xor(Tdd.x, off));
+      dd_add(Tdd.y, dd_shfl_xor(Tdd.y, off));
+      dd_add(Tdd.z, dd_shfl_xor(Tdd.z, off));
     }
   }
   if (sub != 0) return;
+  const V3 F = dd_value(Fdd), T = dd_value(Tdd);  // the one rounding of each sum
   const double mt = op.mt[b];
   double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
   V3 W{0.0, 0.0, 0.0};
@@ -556,12 +574,24 @@ __global__ void __launch_bounds__(kBlock)
   v[2] = make_double2(W.y, W.z);
 }
 
+// one reduction record = kRed doubles (max residual term; sum dx^2 and sum dx dg as double-double pairs), stored as
+// planes `stride` apart
+constexpr int kRed = MHIP_BBPGD_REDUCTION_WIDTH;
+static_assert(kRed == 5, "record layout: max, num.hi, num.lo, den.hi, den.lo");
+__device__ inline void store_partial(double* __restrict__ p, size_t stride, size_t slot, double rmax, DD num, DD den) {
+  p[slot] = rmax;
+  p[stride + slot] = num.hi;
+  p[2 * stride + slot] = num.lo;
+  p[3 * stride + slot] = den.hi;
+  p[4 * stride + slot] = den.lo;
+}
+
 template <int MODE, int KIN, bool PACKED>
 __global__ void __launch_bounds__(kBlock)
     k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
                  int resid_kind, double* __restrict__ partials) {
-  __shared__ double scratch[kBlock / 64];
+  __shared__ double scratch[2 * kBlock / 64];
   const double* xt = X0;
   const double* gt = G0;
   double* xn = X1;
@@ -580,7 +610,8 @@ __global__ void __launch_bounds__(kBlock)
     xn = X0;
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  double rmax = kLowest, num = 0.0, den = 0.0;
+  double rmax = kLowest;
+  DD num{0.0, 0.0}, den{0.0, 0.0};
   const size_t ntiles = (op.c_end - op.c_first + kBlock - 1) / kBlock;
   for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
     const size_t c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
@@ -632,39 +663,36 @@ __global__ void __launch_bounds__(kBlock)
         if (r > rmax) rmax = r;
         if (MODE == X_SOLVE) {
           const double dx = xc - x_old;
-          num += dx * dx;            // diff_dot(x, x_old)              (convex.hpp:507)
-          den += dx * (g - g_old);   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+          dd_add(num, dx * dx);            // diff_dot(x, x_old)              (convex.hpp:507)
+          dd_add(den, dx * (g - g_old));   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
         }
       }
     }
   }
   if (MODE != X_APPLY) {
     const double m = block_max(rmax, scratch);
-    const double s1 = block_sum(num, scratch);
-    const double s2 = block_sum(den, scratch);
-    if (threadIdx.x == 0) {  // three planes of values: the final pass reads them coalesced
+    const DD s1 = block_sum(num, scratch);
+    const DD s2 = block_sum(den, scratch);
+    if (threadIdx.x == 0) {  // kRed planes of values: the final pass reads them coalesced
       const size_t stride = op.part_stride ? op.part_stride : gridDim.x;
-      const size_t slot = op.part_offset + blockIdx.x;
-      partials[slot] = m;
-      partials[stride + slot] = s1;
-      partials[2 * stride + slot] = s2;
+      store_partial(partials, stride, op.part_offset + blockIdx.x, m, s1, s2);
     }
   }
 }
 
 constexpr int kFinalBlock = 1024;  // threads of the single-workgroup final passes
-// ordered reduction of nparts (max, num, den) triples; element (i, k) sits at partials[i * si + k * sk]
-// (block partials: si = 1, sk = nparts; the all-gathered per-rank triples: si = 3, sk = 1)
-__device__ inline void reduce_triples(int nparts, const double* __restrict__ partials, size_t si, size_t sk,
-                                      double* scratch, double& rmax, double& num, double& den) {
+// ordered reduction of nparts (max, num, den) records of kRed doubles; element (i, k) sits at partials[i * si + k * sk]
+// (block partials: si = 1, sk = plane distance; the all-gathered per-rank records: si = kRed, sk = 1)
+__device__ inline void reduce_records(int nparts, const double* __restrict__ partials, size_t si, size_t sk,
+                                      double* scratch, double& rmax, DD& num, DD& den) {
   rmax = kLowest;
-  num = 0.0;
-  den = 0.0;
+  num = DD{0.0, 0.0};
+  den = DD{0.0, 0.0};
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    const double m = partials[i * si];
-    if (m > rmax) rmax = m;
-    num += partials[i * si + sk];
-    den += partials[i * si + 2 * sk];
+    const double* r = partials + i * si;
+    if (r[0] > rmax) rmax = r[0];
+    dd_add(num, DD{r[sk], r[2 * sk]});
+    dd_add(den, DD{r[3 * sk], r[4 * sk]});
   }
   rmax = block_max(rmax, scratch);
   num = block_sum(num, scratch);
@@ -672,42 +700,34 @@ __device__ inline void reduce_triples(int nparts, const double* __restrict__ par
 }
 
 // first level of the final reduction when there are tens of thousands of block partials: workgroup b folds the
-// contiguous slice b of each plane into one triple (fixed slices, fixed order: deterministic)
+// contiguous slice b of each plane into one record (fixed slices, fixed order: deterministic)
 constexpr int kFoldGroups = 64;
 __global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, size_t stride,
                                                          const double* __restrict__ partials,
                                                          const SolverState* __restrict__ st, int check_done,
                                                          double* __restrict__ folded) {
-  __shared__ double scratch[kBlock / 64];
+  __shared__ double scratch[2 * kBlock / 64];
   if (check_done && st->done) return;
   const int per = (nparts + gridDim.x - 1) / gridDim.x;
   const int lo = blockIdx.x * per, hi = (lo + per < nparts) ? lo + per : nparts;
-  double rmax = kLowest, num = 0.0, den = 0.0;
-  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const double m = partials[i];
-    if (m > rmax) rmax = m;
-    num += partials[stride + i];
-    den += partials[2 * stride + i];
-  }
-  rmax = block_max(rmax, scratch);
-  num = block_sum(num, scratch);
-  den = block_sum(den, scratch);
-  if (threadIdx.x == 0) {
-    folded[blockIdx.x] = rmax;
-    folded[gridDim.x + blockIdx.x] = num;
-    folded[2 * gridDim.x + blockIdx.x] = den;
-  }
+  double rmax;
+  DD num, den;
+  reduce_records(hi > lo ? hi - lo : 0, partials + lo, 1, stride, scratch, rmax, num, den);
+  if (threadIdx.x == 0) store_partial(folded, gridDim.x, blockIdx.x, rmax, num, den);
 }
 
 template <int MODE>
 __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const double* __restrict__ partials, size_t si,
                                                          size_t sk, SolverState* __restrict__ st, int resid_kind,
                                                          double tol, unsigned max_iters) {
-  __shared__ double scratch[kFinalBlock / 64];
+  __shared__ double scratch[2 * kFinalBlock / 64];
   if (MODE == X_SOLVE && st->done) return;
-  double rmax, num, den;
-  reduce_triples(nparts, partials, si, sk, scratch, rmax, num, den);
+  double rmax;
+  DD numdd, dendd;
+  reduce_records(nparts, partials, si, sk, scratch, rmax, numdd, dendd);
   if (threadIdx.x != 0) return;
+  const double num = dd_value(numdd);  // the BB dot products, each rounded once
+  double den = dd_value(dendd);
   const double res = (resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF) ? rmax / kSmallStep : rmax;
   st->residual = res;
   if (MODE == X_INIT) {
@@ -735,19 +755,17 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
   }
 }
 
-// block partials -> one (max, num, den) triple (this rank's contribution to the all-gather of SURVEY 8e step 3)
-__global__ void __launch_bounds__(kFinalBlock) k_reduce_local3(int nparts, const double* __restrict__ partials,
-                                                              size_t stride, const SolverState* __restrict__ st,
-                                                              int check_done, double* __restrict__ out3) {
-  __shared__ double scratch[kFinalBlock / 64];
+// block partials -> one (max, num, den) record of kRed doubles (this rank's contribution to the all-gather of SURVEY
+// 8e step 3; the sums travel as double-double pairs so that the rank count does not reach the rounded result)
+__global__ void __launch_bounds__(kFinalBlock) k_reduce_local(int nparts, const double* __restrict__ partials,
+                                                             size_t stride, const SolverState* __restrict__ st,
+                                                             int check_done, double* __restrict__ out) {
+  __shared__ double scratch[2 * kFinalBlock / 64];
   if (check_done && st->done) return;
-  double rmax, num, den;
-  reduce_triples(nparts, partials, 1, stride, scratch, rmax, num, den);
-  if (threadIdx.x == 0) {
-    out3[0] = rmax;
-    out3[1] = num;
-    out3[2] = den;
-  }
+  double rmax;
+  DD num, den;
+  reduce_records(nparts, partials, 1, stride, scratch, rmax, num, den);
+  if (threadIdx.x == 0) store_partial(out, 1, 0, rmax, num, den);
 }
 
 // ---- the scrap app's BBPGD variant: resolve_collisions, scrap/lcp_spheres/NgpLcp.cpp:558-759 ----------
@@ -760,25 +778,30 @@ __global__ void __launch_bounds__(kFinalBlock) k_reduce_local3(int nparts, const
 template <int KIN, bool INIT>
 __global__ void __launch_bounds__(kBlock)
     k_scrap_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
-                       double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q,
-                       double* __restrict__ partials) {
-  __shared__ double scratch[kBlock / 64];
+                       double* __restrict__ G0, double* __restrict__ G1, double* __restrict__ D0,
+                       double* __restrict__ D1, const double* __restrict__ q, double* __restrict__ partials) {
+  __shared__ double scratch[2 * kBlock / 64];
   const double* xt = X0;
   const double* gt = G0;
   double* xn = X1;
   double* gn = INIT ? G0 : G1;
+  // dt * sep_dot of the two iterates, kept beside g = sep + dt * sep_dot: the scrap code forms gkdiff from the sep_dot
+  // values themselves (dt * (sep_dot - sep_dot_tmp), :700-712), which is not (g - g_tmp) bit for bit
+  const double* dt_old = D0;
+  double* dn = INIT ? D0 : D1;
   double step = 0.0;
   bool first = false;
   if (!INIT) {
     if (st->done) return;
     if (st->flips & 1u) {
-      xt = X1; gt = G1; xn = X0; gn = G0;
+      xt = X1; gt = G1; xn = X0; gn = G0; dt_old = D1; dn = D0;
     }
     step = st->step;
     first = (st->iter == 0);
   }
   const Space sp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
-  double rmax = kLowest, xx = 0.0, xg = 0.0, gg = 0.0;
+  double rmax = kLowest;
+  DD xx{0.0, 0.0}, xg{0.0, 0.0}, gg{0.0, 0.0};
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
     const int2 ij = op.pairs[c];
     // UpdateConGammas (:532-548): max(lam_tmp - alpha * (sep + dt * sep_dot), 0)
@@ -801,26 +824,27 @@ __global__ void __launch_bounds__(kBlock)
       vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
     const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
-    const double g = q[c] + op.dt * sdot;  // sep_new = sep_old + dt * sep_dot
+    const double gdt = op.dt * sdot;
+    const double g = q[c] + gdt;  // sep_new = sep_old + dt * sep_dot
     gn[c] = g;
+    dn[c] = gdt;
     if (!INIT) xn[c] = xc;
     const double r = (xc < 1e-12) ? fabs((g < 0.0) ? g : 0.0) : fabs(g);
     if (r > rmax) rmax = r;
     if (!INIT) {
       const double dx = xc - xt[c];
-      const double dg = g - gt[c];  // = dt * (sep_dot - sep_dot_tmp)
-      xx += dx * dx;
-      xg += dx * dg;
-      gg += dg * dg;
+      const double dg = gdt - dt_old[c];  // dt * (sep_dot - sep_dot_tmp)
+      dd_add(xx, dx * dx);
+      dd_add(xg, dx * dg);
+      dd_add(gg, dg * dg);
     }
   }
   const double m = block_max(rmax, scratch);
-  const double s0 = block_sum(xx, scratch), s1 = block_sum(xg, scratch), s2 = block_sum(gg, scratch);
-  if (threadIdx.x == 0) {
-    partials[4 * blockIdx.x] = m;
-    partials[4 * blockIdx.x + 1] = s0;
-    partials[4 * blockIdx.x + 2] = s1;
-    partials[4 * blockIdx.x + 3] = s2;
+  const DD s0 = block_sum(xx, scratch), s1 = block_sum(xg, scratch), s2 = block_sum(gg, scratch);
+  if (threadIdx.x == 0) {  // record of 7: max, then the three sums as double-double pairs
+    double* r = partials + 7 * blockIdx.x;
+    r[0] = m;
+    r[1] = s0.hi; r[2] = s0.lo; r[3] = s1.hi; r[4] = s1.lo; r[5] = s2.hi; r[6] = s2.lo;
   }
 }
 
@@ -830,20 +854,23 @@ template <bool INIT>
 __global__ void __launch_bounds__(kBlock) k_scrap_finalize(int nparts, const double* __restrict__ partials,
                                                           SolverState* __restrict__ st, double tol,
                                                           unsigned max_iters) {
-  __shared__ double scratch[kBlock / 64];
+  __shared__ double scratch[2 * kBlock / 64];
   if (!INIT && st->done) return;
-  double rmax = kLowest, xx = 0.0, xg = 0.0, gg = 0.0;
+  double rmax = kLowest;
+  DD sxx{0.0, 0.0}, sxg{0.0, 0.0}, sgg{0.0, 0.0};
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
-    if (partials[4 * i] > rmax) rmax = partials[4 * i];
-    xx += partials[4 * i + 1];
-    xg += partials[4 * i + 2];
-    gg += partials[4 * i + 3];
+    const double* r = partials + 7 * i;
+    if (r[0] > rmax) rmax = r[0];
+    dd_add(sxx, DD{r[1], r[2]});
+    dd_add(sxg, DD{r[3], r[4]});
+    dd_add(sgg, DD{r[5], r[6]});
   }
   rmax = block_max(rmax, scratch);
-  xx = block_sum(xx, scratch);
-  xg = block_sum(xg, scratch);
-  gg = block_sum(gg, scratch);
+  sxx = block_sum(sxx, scratch);
+  sxg = block_sum(sxg, scratch);
+  sgg = block_sum(sgg, scratch);
   if (threadIdx.x != 0) return;
+  const double xx = dd_value(sxx), xg = dd_value(sxg), gg = dd_value(sgg);
   st->residual = rmax;
   if (INIT) {
     st->iter = 0;
@@ -1092,7 +1119,7 @@ __global__ void __launch_bounds__(kBlock)
   const int sub = static_cast<int>(t % G);
   if (t / G >= op.body_count) return;
   const size_t b = op.body_first + t / G;
-  V3 F{0.0, 0.0, 0.0}, T{0.0, 0.0, 0.0};
+  DD3 Fdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, Tdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
   for (int32_t k0 = beg + sub; k0 < end; k0 += G * U) {
     int32_t e[U];
@@ -1116,16 +1143,17 @@ __global__ void __launch_bounds__(kBlock)
       const V3 p = friction_iterate<INIT>(static_cast<size_t>(e[u] >> 1), Pt, p_init, n, mu, step, step_is_zero,
                                           nullptr, nullptr);
       const V3 f = (e[u] & 1) ? p : V3{-p.x, -p.y, -p.z};  // source: -p, target: +p
-      F = F + f;
-      T = T + cross(r, f);
+      dd_add(Fdd, f);
+      dd_add(Tdd, cross(r, f));
     }
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
-    F.x += __shfl_xor(F.x, off, 64); F.y += __shfl_xor(F.y, off, 64); F.z += __shfl_xor(F.z, off, 64);
-    T.x += __shfl_xor(T.x, off, 64); T.y += __shfl_xor(T.y, off, 64); T.z += __shfl_xor(T.z, off, 64);
+    dd_add(Fdd.x, dd_shfl_xor(Fdd.x, off)); dd_add(Fdd.y, dd_shfl_xor(Fdd.y, off)); dd_add(Fdd.z, dd_shfl_xor(Fdd.z, off));
+    dd_add(Tdd.x, dd_shfl_xor(Tdd.x, off)); dd_add(Tdd.y, dd_shfl_xor(Tdd.y, off)); dd_add(Tdd.z, dd_shfl_xor(Tdd.z, off));
   }
   if (sub != 0) return;
+  const V3 F = dd_value(Fdd), T = dd_value(Tdd);
   const double mt = op.mt[b], mr = op.mr[b];
   double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
   v[0] = make_double2(mt * F.x, mt * F.y);
@@ -1139,7 +1167,7 @@ __global__ void __launch_bounds__(kBlock)
     k_constraint_friction(OpView op, const SolverState* __restrict__ st, double* __restrict__ P0,
                           double* __restrict__ P1, const double* __restrict__ p_init, const double* __restrict__ sep,
                           double mu, double* __restrict__ partials) {
-  __shared__ double scratch[kBlock / 64];
+  __shared__ double scratch[2 * kBlock / 64];
   const double* Pt = P0;
   double* Pn = INIT ? P0 : P1;
   double step = 0.0;
@@ -1152,7 +1180,8 @@ __global__ void __launch_bounds__(kBlock)
     step = st->step;
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  double rmax = kLowest, num = 0.0, den = 0.0;
+  double rmax = kLowest;
+  DD num{0.0, 0.0}, den{0.0, 0.0};
   const size_t ntiles = (op.C + kBlock - 1) / kBlock;
   for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
     const size_t c = lin * kBlock + threadIdx.x;
@@ -1177,19 +1206,15 @@ __global__ void __launch_bounds__(kBlock)
       if (r > rmax) rmax = r;
       if (!INIT) {
         const V3 dp = p - p_old, dg = g - g_old;
-        num += dot(dp, dp);
-        den += dot(dp, dg);
+        dd_add(num, dot(dp, dp));
+        dd_add(den, dot(dp, dg));
       }
     }
   }
   const double m = block_max(rmax, scratch);
-  const double s1 = block_sum(num, scratch);
-  const double s2 = block_sum(den, scratch);
-  if (threadIdx.x == 0) {
-    partials[blockIdx.x] = m;
-    partials[(size_t)gridDim.x + blockIdx.x] = s1;
-    partials[2 * (size_t)gridDim.x + blockIdx.x] = s2;
-  }
+  const DD s1 = block_sum(num, scratch);
+  const DD s2 = block_sum(den, scratch);
+  if (threadIdx.x == 0) store_partial(partials, gridDim.x, blockIdx.x, m, s1, s2);
 }
 
 // latest iterate -> caller's p [C][3], g [C][3]
@@ -1219,8 +1244,7 @@ struct mhip_contact_op {
   DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half, axis, omega, vel_out;
   DeviceBuffer iterate;  // packed (x, g) ping-pong pair of the fused / staged solvers: 2 x C x 16 bytes
   DeviceBuffer body_mask, pos;  // activity masks of the packed LCP solves (see OpView)
-  int lanes_per_body = 8;
-  int body_unroll = 1;  // independent half-edge chains per lane (k_body's U)
+  int lanes_per_body = 4;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
   struct Stage {
@@ -1243,7 +1267,7 @@ namespace {
 int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double* X1, const double* G0,
                    const double* G1, Space sp, hipStream_t s, bool packed = false) {
   if (op->view.N == 0) return MHIP_SUCCESS;
-  const int G = op->lanes_per_body;
+  const int G = (op->lanes_per_body == 2 || op->lanes_per_body == 8 || op->lanes_per_body == 16) ? op->lanes_per_body : 4;
   if (op->view.body_count == 0) return MHIP_SUCCESS;
   const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
   op->last_stream = s;
@@ -1257,20 +1281,10 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   } while (0)
 #define BODY(M, R)                                    \
   do {                                                \
-    const int lay = G * 10 + op->body_unroll;         \
-    if (lay == 14) BODY4(M, R, 1, 4);                 \
-    else if (lay == 18) BODY4(M, R, 1, 8);            \
-    else if (lay == 24) BODY4(M, R, 2, 4);            \
-    else if (lay == 28) BODY4(M, R, 2, 8);            \
-    else if (lay == 48) BODY4(M, R, 4, 8);            \
-    else if (lay == 41) BODY4(M, R, 4, 1);            \
-    else if (lay == 44) BODY4(M, R, 4, 4);            \
-    else if (lay == 81) BODY4(M, R, 8, 1);            \
-    else if (lay == 82) BODY4(M, R, 8, 2);            \
-    else if (lay == 84) BODY4(M, R, 8, 4);            \
-    else if (lay == 162) BODY4(M, R, 16, 2);          \
-    else if (lay == 321) BODY4(M, R, 32, 1);          \
-    else BODY4(M, R, 16, 1);                          \
+    if (G == 2) BODY4(M, R, 2, 4);                    \
+    else if (G == 8) BODY4(M, R, 8, 4);               \
+    else if (G == 16) BODY4(M, R, 16, 2);             \
+    else BODY4(M, R, 4, 4);                           \
   } while (0)
 #define BODYK(K) \
   do { if (mode == X_APPLY) BODY(X_APPLY, K); else if (mode == X_INIT) BODY(X_INIT, K); else BODY(X_SOLVE, K); } while (0)
@@ -1313,7 +1327,7 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
 inline void fold_partials(unsigned& nparts, size_t& stride, double*& parts, const SolverState* st, int check_done,
                           hipStream_t s) {
   if (nparts <= 4096) return;  // one workgroup reads a few thousand triples as fast as a second launch would
-  double* folded = parts + 3 * stride;
+  double* folded = parts + kRed * stride;
   k_fold_partials<<<kFoldGroups, kBlock, 0, s>>>((int)nparts, stride, parts, st, check_done, folded);
   parts = folded;
   nparts = kFoldGroups;
@@ -1328,13 +1342,8 @@ constexpr unsigned kStageStride = 2 * 32768;
 // per workgroup.
 constexpr int kMaxConstraintGrid = 32768;
 unsigned constraint_grid(size_t C) {
-  static const int cap = [] {
-    const char* e = getenv("MHIP_CONSTRAINT_GRID");
-    const int v = e ? atoi(e) : kMaxConstraintGrid;
-    return v < 8 ? 8 : (v > kMaxConstraintGrid ? kMaxConstraintGrid : v);
-  }();
   const size_t g = (C + kBlock - 1) / kBlock;
-  return static_cast<unsigned>(g == 0 ? 1 : (g > (size_t)cap ? cap : g));
+  return static_cast<unsigned>(g == 0 ? 1 : (g > (size_t)kMaxConstraintGrid ? kMaxConstraintGrid : g));
 }
 
 int check_config(const mhip_pgd_config* cfg) {
@@ -1522,7 +1531,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   if (int e = op->cursor.reserve((N + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->inc.reserve((2 * C + 2) * sizeof(int32_t))) return bail(e);
   if (int e = op->vel.reserve((6 * N + 2) * sizeof(double))) return bail(e);
-  if (int e = op->partials.reserve((6 * kMaxConstraintGrid + 3 * kFoldGroups + 64) * sizeof(double))) return bail(e);
+  if (int e = op->partials.reserve(((size_t)kRed * kStageStride + kRed * kFoldGroups + 64) * sizeof(double))) return bail(e);
   if (int e = op->state.reserve(sizeof(SolverState) + 64)) return bail(e);
   if (int e = op->scanws.reserve(scan_workspace_bytes(N + 1) + 64)) return bail(e);
   if (!op->host_state) {
@@ -1577,14 +1586,10 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
     // G lanes per body, each keeping U half-edge chains in flight.  Measured at 10^6 rods (mean degree 15.2, a third
     // of it active; MI355X), walking every entry: (16,1) 0.198 ms, (8,1) 0.164, (8,2) 0.154, (4,4) 0.157, (8,4) 0.150
     // per sweep; walking only the entries the activity masks flag: (8,4) 0.144, (4,4) 0.137, (2,8) 0.142, (1,8) 0.156.
+    // With double-double sums (one rounding per sum): (4,4) 0.138 ms, (2,4) 0.151, (8,4) 0.182, (8,2) 0.156, (4,8) 0.149.
+    // The layout only moves time: the sums, hence the iterates, are the same for every G (tests).
     const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
-    const char* env = getenv("MHIP_LANES_PER_BODY");
-    op->lanes_per_body = env ? atoi(env) : (mean_deg <= 24.0 ? 4 : 8);
-    op->body_unroll = 4;
-    if (op->lanes_per_body != 1 && op->lanes_per_body != 2 && op->lanes_per_body != 4 && op->lanes_per_body != 8 &&
-        op->lanes_per_body != 16 && op->lanes_per_body != 32)
-      op->lanes_per_body = 8;
-    if (const char* ue = getenv("MHIP_BODY_UNROLL")) op->body_unroll = atoi(ue);
+    op->lanes_per_body = mean_deg <= 24.0 ? 4 : (mean_deg <= 96.0 ? 8 : 16);
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
@@ -1599,16 +1604,10 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   }
   op->view.body_mask = op->body_mask.as<unsigned long long>();
   op->view.pos = op->pos.as<unsigned char>();
-  if (const char* me = getenv("MHIP_BODY_MASKS"))  // A/B runs
-    if (atoi(me) == 0) op->view.body_mask = nullptr;
   // XCD-contiguous tiles (xcd_tile): 32 consecutive tiles per XCD inside windows of 256.  Measured at 10^6 rods:
   // FETCH_SIZE per launch 740 -> 637 MB (k_constraint) and 683 -> 621 MB (k_body), k_constraint 0.1305 -> 0.128 ms,
-  // k_body unchanged.  MHIP_XCD_TILE=T overrides (0 = identity mapping); clamped so a window stays a few thousand tiles.
+  // k_body unchanged.  mhip_contact_op_set_work_mapping overrides (0 = identity mapping).
   op->view.xcd_aware = 32;
-  if (const char* xe = getenv("MHIP_XCD_TILE")) {
-    const int t = atoi(xe);
-    op->view.xcd_aware = t < 0 ? 0 : (t > 4096 ? 4096 : t);
-  }
   *handle = op;
   return MHIP_SUCCESS;
 }
@@ -1731,6 +1730,19 @@ int mhip_contact_op_sizes(mhip_contact_op_t op, size_t* num_constraints, size_t*
   MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
   if (num_constraints) *num_constraints = op->view.C;
   if (num_bodies) *num_bodies = op->view.N;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_set_work_mapping(mhip_contact_op_t op, int xcd_tile, int lanes_per_body) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(xcd_tile >= -1 && xcd_tile <= 4096, MHIP_ERR_INVALID_ARGUMENT,
+               "xcd_tile must be in [0, 4096] (or -1 to keep the current value), got %d", xcd_tile);
+  MHIP_REQUIRE(lanes_per_body == -1 || lanes_per_body == 2 || lanes_per_body == 4 || lanes_per_body == 8 ||
+                   lanes_per_body == 16,
+               MHIP_ERR_INVALID_ARGUMENT, "lanes_per_body must be 2, 4, 8 or 16 (or -1 to keep), got %d", lanes_per_body);
+  MHIP_REQUIRE(!op->stage.active, MHIP_ERR_RUNTIME, "a staged solve is in progress");
+  if (xcd_tile >= 0) op->view.xcd_aware = xcd_tile;
+  if (lanes_per_body > 0) op->lanes_per_body = lanes_per_body;
   return MHIP_SUCCESS;
 }
 
@@ -1966,8 +1978,11 @@ int mhip_scrap_bbpgd_solve_contact(mhip_contact_op_t op, const double* sep, doub
   double* parts = op->partials.as<double>();
   const unsigned cgrid = grid_for(C);
   const Space lcp{MHIP_SPACE_LOWER_BOUND, 0.0, 0.0};
+  if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
+  double* D0 = op->iterate.as<double>();  // dt * sep_dot of the two iterates (see k_scrap_constraint)
+  double* D1 = D0 + C;
   auto constraint = [&](bool init) {
-#define SCON(R, I) k_scrap_constraint<R, I><<<cgrid, kBlock, 0, s>>>(op->view, st, lam_tmp, lam, g_tmp, g, sep, parts)
+#define SCON(R, I) k_scrap_constraint<R, I><<<cgrid, kBlock, 0, s>>>(op->view, st, lam_tmp, lam, g_tmp, g, D0, D1, sep, parts)
     if (op->kin == KIN_ROD) { if (init) SCON(KIN_ROD, true); else SCON(KIN_ROD, false); }
     else if (op->kin == KIN_RIGID) { if (init) SCON(KIN_RIGID, true); else SCON(KIN_RIGID, false); }
     else { if (init) SCON(KIN_TRANS, true); else SCON(KIN_TRANS, false); }
@@ -2008,9 +2023,9 @@ int mhip_scrap_bbpgd_solve_contact(mhip_contact_op_t op, const double* sep, doub
     const unsigned g2 = grid_for(op->view.N);
     k_max_speed<<<g2, kBlock, 0, s>>>(op->view.N, op->view.vel, mp);
     MHIP_LAUNCH_CHECK();
-    k_reduce_final<2><<<1, kBlock, 0, s>>>((int)g2, mp, mp + kMaxGrid);
+    k_reduce_final<2><<<1, kBlock, 0, s>>>((int)g2, mp, mp + 2 * kMaxGrid);
     MHIP_LAUNCH_CHECK();
-    MHIP_HIP(hipMemcpyAsync(rs.host, mp + kMaxGrid, sizeof(double), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipMemcpyAsync(rs.host, mp + 2 * kMaxGrid, sizeof(double), hipMemcpyDeviceToHost, s));
     MHIP_HIP(hipStreamSynchronize(s));
     *max_speed = rs.host[0] < 0.0 ? 0.0 : rs.host[0];
   }
@@ -2093,38 +2108,38 @@ int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_f
   return MHIP_SUCCESS;
 }
 
-int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
+int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local, mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
-  MHIP_REQUIRE(local3 != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local3 is null");
+  MHIP_REQUIRE(local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local record is null");
   hipStream_t s = as_stream(stream);
   unsigned np = op->stage.part_used;
   size_t ps = kStageStride;
   double* pp = op->partials.as<double>();
   fold_partials(np, ps, pp, op->state.as<SolverState>(), init ? 0 : 1, s);
-  k_reduce_local3<<<1, final_block(np), 0, s>>>((int)np, pp, ps, op->state.as<SolverState>(), init ? 0 : 1, local3);
+  k_reduce_local<<<1, final_block(np), 0, s>>>((int)np, pp, ps, op->state.as<SolverState>(), init ? 0 : 1, local);
   MHIP_LAUNCH_CHECK();
   op->stage.part_used = 0;
   return MHIP_SUCCESS;
 }
 
-int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local3, mhip_stream_t stream) {
+int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local, mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   op->stage.part_used = 0;
   if (int e = mhip_bbpgd_stage_constraint_range(op, init, 0, op->view.C, stream)) return e;
-  return mhip_bbpgd_stage_reduce(op, init, local3, stream);
+  return mhip_bbpgd_stage_reduce(op, init, local, stream);
 }
 
 int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gathered, int nparts,
                               mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
-  MHIP_REQUIRE(gathered != nullptr && nparts >= 1, MHIP_ERR_INVALID_ARGUMENT, "gathered triples missing");
+  MHIP_REQUIRE(gathered != nullptr && nparts >= 1, MHIP_ERR_INVALID_ARGUMENT, "gathered records missing");
   const auto& cfg = op->stage.cfg;
   SolverState* st = op->state.as<SolverState>();
   if (init)
-    k_finalize<X_INIT><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, 3, 1, st, cfg.residual_kind,
+    k_finalize<X_INIT><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, kRed, 1, st, cfg.residual_kind,
                                                                          cfg.tol, cfg.max_iters);
   else
-    k_finalize<X_SOLVE><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, 3, 1, st,
+    k_finalize<X_SOLVE><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, kRed, 1, st,
                                                                           cfg.residual_kind, cfg.tol, cfg.max_iters);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;

@@ -456,9 +456,10 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
   MHIP_REQUIRE(send_total == 0 || (halo->send_index && halo->velocity), MHIP_ERR_INVALID_ARGUMENT,
                "velocity halo without send_index / velocity");
   if (int e = c->send_rows.reserve((6 * send_total + 2) * sizeof(double))) return e;
-  if (int e = c->triples.reserve((3 + 3 * (size_t)c->world) * sizeof(double))) return e;
-  double* local3 = c->triples.as<double>();
-  double* gathered = local3 + 3;
+  constexpr int kRed = MHIP_BBPGD_REDUCTION_WIDTH;
+  if (int e = c->triples.reserve((kRed + kRed * (size_t)c->world) * sizeof(double))) return e;
+  double* local3 = c->triples.as<double>();  // this rank's reduction record
+  double* gathered = local3 + kRed;
   std::vector<const double*> sbuf(halo->num_send_peers);
   std::vector<size_t> scount(halo->num_send_peers);
   {
@@ -517,7 +518,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     if (int e = mhip_bbpgd_stage_constraint_range(op, init, interior_contacts, C - interior_contacts, stream)) return e;
     if (int e = mhip_bbpgd_stage_reduce(op, init, local3, stream)) return e;
     if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
-    if (int e = mhip_comm_all_gather(c, local3, 3, gathered, stream)) return e;
+    if (int e = mhip_comm_all_gather(c, local3, kRed, gathered, stream)) return e;
     return mhip_bbpgd_stage_finalize(op, init, gathered, c->world, stream);
   };
 

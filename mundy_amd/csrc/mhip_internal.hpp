@@ -169,6 +169,63 @@ __device__ inline double block_max(double v, double* scratch) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Double-double accumulation (cascaded summation with error-free TwoSum: Ogita, Rump, Oishi 2005).  Every sum whose
+// rounding feeds the Barzilai-Borwein step -- the two BB dot products and the per-body force / torque sums -- is kept as
+// an unevaluated pair hi + lo and rounded to one double once, at the end.  The pair carries ~106 bits, so the rounded
+// result is the correctly rounded exact sum unless that sum lies within ~n 2^-106 (relative) of a rounding boundary:
+// the summation order (lanes per body, tile -> workgroup mapping, rank count) no longer reaches the iterates, and a
+// serial CPU evaluation with the same pair arithmetic lands on the same bits.
+// ------------------------------------------------------------------------------------------------------------------
+struct DD {
+  double hi, lo;
+};
+__host__ __device__ inline void dd_add(DD& a, double b) {
+  const double s = a.hi + b;
+  const double bb = s - a.hi;
+  const double e = (a.hi - (s - bb)) + (b - bb);  // a.hi + b == s + e exactly
+  a.hi = s;
+  a.lo += e;
+}
+__host__ __device__ inline void dd_add(DD& a, const DD& b) {
+  dd_add(a, b.hi);
+  a.lo += b.lo;
+}
+// one rounding of hi + lo; an overflowed / NaN sum is reported as the plain sum would (lo is NaN there)
+__host__ __device__ inline double dd_value(const DD& a) { return (a.hi - a.hi == 0.0) ? a.hi + a.lo : a.hi; }
+struct DD3 {
+  DD x, y, z;
+};
+__host__ __device__ inline void dd_add(DD3& a, V3 b) {
+  dd_add(a.x, b.x);
+  dd_add(a.y, b.y);
+  dd_add(a.z, b.z);
+}
+__host__ __device__ inline V3 dd_value(const DD3& a) { return {dd_value(a.x), dd_value(a.y), dd_value(a.z)}; }
+__device__ inline DD dd_shfl_xor(DD v, int off) { return {__shfl_xor(v.hi, off, 64), __shfl_xor(v.lo, off, 64)}; }
+__device__ inline DD dd_shfl_down(DD v, int off) { return {__shfl_down(v.hi, off, 64), __shfl_down(v.lo, off, 64)}; }
+__device__ inline DD wave_sum(DD v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dd_add(v, dd_shfl_down(v, off));
+  return v;
+}
+// `scratch` holds 2 * kBlock/64 doubles; result valid in thread 0
+__device__ inline DD block_sum(DD v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    scratch[2 * w] = v.hi;
+    scratch[2 * w + 1] = v.lo;
+  }
+  __syncthreads();
+  DD r{0.0, 0.0};
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) dd_add(r, DD{scratch[2 * i], scratch[2 * i + 1]});
+  }
+  __syncthreads();
+  return r;
+}
+
 // projection onto the separable 1-D convex spaces of convex.hpp:46-115
 struct Space {
   int kind;

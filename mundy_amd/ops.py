@@ -286,6 +286,10 @@ class GenNeighborLinks:
                                                              C.byref(flag), _stream()))
         return bool(flag.value)
 
+    def invalidate(self):
+        """the body numbering changed (reordering, migration): the next generate() rebuilds whatever the rebuild rule says"""
+        self._generated = False
+
     def generate(self, aabb, center, bounding_radius, force=False):
         if not self._concretized:
             raise RuntimeError("Cannot generate links before concretization.")  # :511
@@ -439,6 +443,10 @@ class ContactOperator:
         out = torch.empty((n, 6), dtype=torch.float64, device=self._device)
         capi.check(capi.load().mhip_deep_copy(6 * n, _ptr(out), p, _stream()))
         return out
+
+    def set_work_mapping(self, xcd_tile=-1, lanes_per_body=-1):
+        """layout of the sweeps on the chip (time only; results do not depend on it)"""
+        capi.check(capi.load().mhip_contact_op_set_work_mapping(self._h, int(xcd_tile), int(lanes_per_body)))
 
     def set_profiling(self, enable=True):
         capi.check(capi.load().mhip_contact_op_set_profiling(self._h, 1 if enable else 0))

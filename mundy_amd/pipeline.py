@@ -82,6 +82,7 @@ class ContactStepper:
         self.op = None
         self.lam = None
         self.contacts = None
+        self.work_mapping = None  # (xcd_tile, lanes_per_body) for ContactOperator.set_work_mapping: time only
 
     # -- stages -----------------------------------------------------------------------------------------------------
     _BODY_ARRAYS = ("center", "radius", "quat", "length", "bounding_radius", "mob_trans", "mob_rot", "shape", "kinds")
@@ -118,6 +119,13 @@ class ContactStepper:
             t = getattr(self, name, None)
             if t is not None:
                 t.copy_(ops.gather_rows(perm, t) if t.dtype == torch.float64 else t[perm.long()])
+        # the neighbour list, the operator's incidence index and the multipliers are in the old numbering: a reused list
+        # would pair the wrong bodies unless the displacement test happened to fire, so force the rebuild
+        self.links.invalidate()
+        if self.op is not None:
+            self.op.close()
+            self.op = None
+        self.lam = None
         return perm
 
     def compute_aabb(self):
@@ -171,6 +179,8 @@ class ContactStepper:
         else:
             self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c.get("ra"),
                                           rb=c.get("rb"), mob_rot=self.mob_rot, priority=c["sep"])
+        if self.work_mapping is not None:
+            self.op.set_work_mapping(*self.work_mapping)
         if getattr(self, "profile_next", False):
             self.op.set_profiling(True)  # per-kernel HIP-event timing of the fused iteration (bench.py roofline)
         nc = self.links.num_pairs

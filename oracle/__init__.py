@@ -332,9 +332,47 @@ def solve_cqpp_dense(A, q, space, x0, resid_kind=RESID_PROJECTED_DIFF, max_iters
     return x, g, _result(it, res, conv)
 
 
-def contact_op_apply(pairs, normal, ra, rb, mt, mr, dt, x, n_bodies):
+SUM_SERIAL, SUM_COMPENSATED = 0, 1
+
+
+def set_sum_mode(mode, fast=False):
+    """How the BB-step reductions and per-body sums are rounded (mundy_oracle.hpp, SumMode): SUM_SERIAL = plain serial
+    sums (Kokkos-Serial), SUM_COMPENSATED = double-double pairs rounded once (what the device path does)."""
+    lib(fast).o_set_sum_mode(C.c_int(int(mode)))
+
+
+class compensated_sums:
+    """`with oracle.compensated_sums():` -- order-independent sums for the enclosed oracle calls (both builds)."""
+
+    def __enter__(self):
+        for fast in (False, True):
+            set_sum_mode(SUM_COMPENSATED, fast)
+        return self
+
+    def __exit__(self, *exc):
+        for fast in (False, True):
+            set_sum_mode(SUM_SERIAL, fast)
+        return False
+
+
+def _rod_args(rod, n_bodies):
+    s, t, seg = rod
+    seg = _f(seg)
+    assert seg.shape == (n_bodies, 8), seg.shape
+    return _f(s), _f(t), seg
+
+
+def contact_op_apply(pairs, normal, ra, rb, mt, mr, dt, x, n_bodies, rod=None, body_velocity=False):
+    """y = dt D^T M D x.  rod=(s, t, seg): the spherocylinder operator in rod-axis form (ContactOpRod) instead of the
+    vector arms ra, rb; body_velocity=True also returns the (U, W) rows [N][6] (rod form only)."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     y = np.empty(len(pairs))
+    if rod is not None:
+        s, t, seg = _rod_args(rod, n_bodies)
+        vel = np.zeros((n_bodies, 6)) if body_velocity else None
+        lib().o_contact_op_apply_rod(C.c_size_t(len(pairs)), C.c_size_t(n_bodies), _p(pairs), _p(_f(normal)), _p(s),
+                                     _p(t), _p(seg), _p(_f(mt)), _p(_f(mr)), C.c_double(dt), _p(_f(x)), _p(y), _p(vel))
+        return (y, vel) if body_velocity else y
     lib().o_contact_op_apply(C.c_size_t(len(pairs)), C.c_size_t(n_bodies), _p(pairs), _p(_f(normal)),
                              _p(None if ra is None else _f(ra)), _p(None if rb is None else _f(rb)), _p(_f(mt)),
                              _p(None if mr is None else _f(mr)), C.c_double(dt), _p(_f(x)), _p(y))
@@ -342,9 +380,25 @@ def contact_op_apply(pairs, normal, ra, rb, mt, mr, dt, x, n_bodies):
 
 
 def solve_cqpp_contact(pairs, normal, ra, rb, mt, mr, dt, q, x0, space=(LOWER_BOUND, 0.0, 0.0),
-                       resid_kind=RESID_PROJECTED_DIFF, max_iters=1000, tol=1e-8, threads=False, fast=False):
-    """BBPGD (convex.hpp:614-666) on A = dt D^T M D (NgpLcp.cpp:442-548).  threads=True runs the OpenMP baseline."""
+                       resid_kind=RESID_PROJECTED_DIFF, max_iters=1000, tol=1e-8, threads=False, fast=False,
+                       rod=None):
+    """BBPGD (convex.hpp:614-666) on A = dt D^T M D (NgpLcp.cpp:442-548).  threads=True runs the OpenMP baseline.
+    rod=(s, t, seg) solves with the rod-axis form of the spherocylinder operator (ContactOpRod, serial)."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    if rod is not None:
+        assert not threads
+        mt, q = _f(mt), _f(q)
+        s, t, seg = _rod_args(rod, len(mt))
+        c = len(pairs)
+        x = _f(x0).copy()
+        g, x_tmp, g_tmp = np.zeros(c), np.zeros(c), np.zeros(c)
+        it, res, conv = C.c_uint(), C.c_double(), C.c_int()
+        lib(fast).o_solve_cqpp_contact_rod(
+            C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(_f(normal)), _p(s), _p(t), _p(seg), _p(mt), _p(_f(mr)),
+            C.c_double(dt), _p(q), C.c_int(space[0]), C.c_double(space[1]), C.c_double(space[2]), C.c_int(resid_kind),
+            C.c_uint(max_iters), C.c_double(tol), _p(x), _p(g), _p(x_tmp), _p(g_tmp), C.byref(it), C.byref(res),
+            C.byref(conv))
+        return x, g, _result(it, res, conv)
     normal, mt, q = _f(normal), _f(mt), _f(q)
     ra = None if ra is None else _f(ra)
     rb = None if rb is None else _f(rb)
@@ -472,13 +526,22 @@ def minimize_test(kind, x0):
     return L.o_minimize_test(C.c_int(kind), _p(x)), x
 
 
-def scrap_resolve_collisions(pairs, normal, ra, rb, mt, mr, dt, sep, lam0, max_allowable_overlap=1e-5, max_iters=10000):
-    """resolve_collisions of scrap/lcp_spheres/NgpLcp.cpp:558-759 (dry).  Returns (lam, g = sep + dt*sep_dot, result)."""
+def scrap_resolve_collisions(pairs, normal, ra, rb, mt, mr, dt, sep, lam0, max_allowable_overlap=1e-5, max_iters=10000,
+                             rod=None):
+    """resolve_collisions of scrap/lcp_spheres/NgpLcp.cpp:558-759 (dry).  Returns (lam, g = sep + dt*sep_dot, result).
+    rod=(s, t, seg): with the rod-axis form of the spherocylinder operator."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     c = len(pairs)
     lam, g = _f(lam0).copy(), np.zeros(c)
     res, it, spd = C.c_double(), C.c_int(), C.c_double()
     mt = _f(mt)
+    if rod is not None:
+        s, t, seg = _rod_args(rod, len(mt))
+        lib().o_scrap_resolve_collisions_rod(
+            C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(_f(normal)), _p(s), _p(t), _p(seg), _p(mt), _p(_f(mr)),
+            C.c_double(dt), _p(_f(sep)), C.c_double(max_allowable_overlap), C.c_int(max_iters), _p(lam), _p(g),
+            C.byref(res), C.byref(it), C.byref(spd))
+        return lam, g, dict(max_abs_projected_sep=res.value, ite_count=it.value, max_speed=spd.value)
     lib().o_scrap_resolve_collisions(
         C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(_f(normal)), _p(None if ra is None else _f(ra)),
         _p(None if rb is None else _f(rb)), _p(mt), _p(None if mr is None else _f(mr)), C.c_double(dt), _p(_f(sep)),

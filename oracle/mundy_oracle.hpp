@@ -891,6 +891,38 @@ struct Space {
 };
 enum ResidualKind : int { kProjectedDiff = 0, kProjectedGradient = 1 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Summation mode of every reduction whose rounding feeds the Barzilai-Borwein step (diff_dot x2, the per-body force /
+// torque sums of the contact operators, the rows of the dense operator).
+//   kSumSerial       plain left-to-right double sums: what Kokkos-Serial executes (the reference; on a parallel
+//                    backend its own order -- and, with atomics, its iteration count -- changes from run to run).
+//   kSumCompensated  the same sums carried as unevaluated pairs hi + lo (TwoSum cascade, ~106 bits) and rounded once:
+//                    the correctly rounded exact sum unless that sum lies within ~n 2^-106 of a rounding boundary, i.e.
+//                    independent of the summation order.  The device path sums this way, so in this mode the oracle's
+//                    iterates, and hence its ITERATION COUNT, are comparable bit for bit with a tree-ordered device
+//                    sum -- BB steps amplify rounding differences of plain sums into +/-15 % of the count.
+// Same algorithm either way; the mode only fixes how the rounding of a sum is defined.
+// ---------------------------------------------------------------------------------------------------------------
+enum SumMode : int { kSumSerial = 0, kSumCompensated = 1 };
+inline int& sum_mode() {
+  static int mode = kSumSerial;
+  return mode;
+}
+struct Acc {
+  double hi = 0.0, lo = 0.0;
+  void add(double b) {
+    if (sum_mode() == kSumSerial) {
+      hi += b;
+      return;
+    }
+    const double s = hi + b;
+    const double bb = s - hi;
+    lo += (hi - (s - bb)) + (b - bb);  // hi + b == s + error exactly (Knuth TwoSum)
+    hi = s;
+  }
+  double value() const { return (sum_mode() == kSumSerial || !(hi - hi == 0.0)) ? hi : hi + lo; }
+};
+
 // KokkosBackend vector kernels, serial order (convex.hpp:201-284).
 inline void axpby(double alpha, const double* x, double beta, double* y, size_t n) {
   const bool az = std::fabs(alpha) < kZeroTol, bz = std::fabs(beta) < kZeroTol;
@@ -918,21 +950,21 @@ inline void wrapped_axpbyz(double alpha, const double* x, double beta, const dou
   }
 }
 inline double diff_dot(const double* x, const double* y, size_t n) {
-  double sum = 0;
+  Acc sum;
   for (size_t i = 0; i < n; ++i) {
     const double diff = x[i] - y[i];
-    sum += diff * diff;
+    sum.add(diff * diff);
   }
-  return sum;
+  return sum.value();
 }
 inline double diff_dot(const double* x1, const double* x2, const double* y1, const double* y2, size_t n) {
-  double sum = 0;
+  Acc sum;
   for (size_t i = 0; i < n; ++i) {
     const double xd = x1[i] - x2[i];
     const double yd = y1[i] - y2[i];
-    sum += xd * yd;
+    sum.add(xd * yd);
   }
-  return sum;
+  return sum.value();
 }
 // convex.hpp:434-496.  Kokkos::Max<double> starts from the lowest finite double.
 inline double residual(int kind, const double* x, const double* g, size_t n, const Space& sp) {
@@ -1067,9 +1099,9 @@ struct DenseOp {
   size_t n;
   void operator()(const double* x, double* y) const {
     for (size_t i = 0; i < n; ++i) {
-      double acc = 0;
-      for (size_t j = 0; j < n; ++j) acc += A[i * n + j] * x[j];
-      y[i] = acc;
+      Acc acc;
+      for (size_t j = 0; j < n; ++j) acc.add(A[i * n + j] * x[j]);
+      y[i] = acc.value();
     }
   }
 };
@@ -1089,12 +1121,15 @@ struct ContactOp {
   double dt;
   size_t C, N;
   mutable std::vector<double> F, T, U, W;
+  mutable std::vector<Acc> Fa, Ta;
   void operator()(const double* x, double* y) const {
-    F.assign(3 * N, 0.0);
+    Fa.assign(3 * N, Acc{});
+    F.resize(3 * N);
     U.resize(3 * N);
     const bool rot = (ra && rb && mr);
     if (rot) {
-      T.assign(3 * N, 0.0);
+      Ta.assign(3 * N, Acc{});
+      T.resize(3 * N);
       W.resize(3 * N);
     }
     for (size_t c = 0; c < C; ++c) {
@@ -1103,22 +1138,26 @@ struct ContactOp {
       const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
       const V3 f{lam * n.x, lam * n.y, lam * n.z};
       for (int k = 0; k < 3; ++k) {
-        F[3 * i + k] += -f[k];
-        F[3 * j + k] += f[k];
+        Fa[3 * i + k].add(-f[k]);
+        Fa[3 * j + k].add(f[k]);
       }
       if (rot) {
         const V3 a{ra[3 * c], ra[3 * c + 1], ra[3 * c + 2]}, b{rb[3 * c], rb[3 * c + 1], rb[3 * c + 2]};
         const V3 ta = cross(a, f), tb = cross(b, f);
         for (int k = 0; k < 3; ++k) {
-          T[3 * i + k] += -ta[k];
-          T[3 * j + k] += tb[k];
+          Ta[3 * i + k].add(-ta[k]);
+          Ta[3 * j + k].add(tb[k]);
         }
       }
     }
     for (size_t b = 0; b < N; ++b)
       for (int k = 0; k < 3; ++k) {
+        F[3 * b + k] = Fa[3 * b + k].value();
         U[3 * b + k] = mt[b] * F[3 * b + k];
-        if (rot) W[3 * b + k] = mr[b] * T[3 * b + k];
+        if (rot) {
+          T[3 * b + k] = Ta[3 * b + k].value();
+          W[3 * b + k] = mr[b] * T[3 * b + k];
+        }
       }
     for (size_t c = 0; c < C; ++c) {
       const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
@@ -1130,6 +1169,72 @@ struct ContactOp {
         vi = vi + cross(wi, a);
         vj = vj + cross(wj, b);
       }
+      const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
+      y[c] = dt * sdot;
+    }
+  }
+};
+
+// The same operator for spherocylinders with the lever arms written through the rod axis: a rod's contact point lies
+// on its centreline, cp = c + (s - 1/2) u with u = p1 - p0 (endpoints as compute_aabb.hpp:115-117 places them), so
+//   r x f = (s - 1/2) (u x f)   ->   T_b = u_b x S_b,  S_b = sum (s - 1/2) f      (one cross product per body)
+//   W x r = (s - 1/2) (W x u)   ->   v_contact = U_b + (s - 1/2) Z_b,  Z_b = W_b x u_b
+// Algebraically ContactOp with ra = (s - 1/2) u_i, rb = (t - 1/2) u_j; the association differs, so the two agree to
+// rounding (one ulp of the arm), not bitwise.  This is the association the device path evaluates (its half-edge
+// records hold (n, s - 1/2)); with kSumCompensated the two produce the same bits.  Like the 6-DOF form of ContactOp it
+// has no counterpart in the reference (its LCP app is spheres only): parity unpinned.
+struct ContactOpRod {
+  const int32_t* pairs;   // [C][2]
+  const double* normal;   // [C][3]
+  const double* arc_s;    // [C] arclength parameter of the closest point on the first rod, in [0, 1]
+  const double* arc_t;    // [C] ... on the second rod
+  const double* seg;      // [N][8] segment records (p0, p1, radius, -)
+  const double* mt;       // [N]
+  const double* mr;       // [N]
+  double dt;
+  size_t C, N;
+  mutable std::vector<double> U, Z, Wv;
+  mutable std::vector<Acc> Fa, Sa;
+  void operator()(const double* x, double* y) const {
+    Fa.assign(3 * N, Acc{});
+    Sa.assign(3 * N, Acc{});
+    U.resize(3 * N);
+    Z.resize(3 * N);
+    Wv.resize(3 * N);
+    for (size_t c = 0; c < C; ++c) {
+      const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
+      const double lam = x[c];
+      const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
+      const V3 f{lam * n.x, lam * n.y, lam * n.z};
+      const double ci = arc_s[c] - 0.5, cj = arc_t[c] - 0.5;
+      for (int k = 0; k < 3; ++k) {
+        Fa[3 * i + k].add(-f[k]);
+        Fa[3 * j + k].add(f[k]);
+        Sa[3 * i + k].add(ci * (-f[k]));
+        Sa[3 * j + k].add(cj * f[k]);
+      }
+    }
+    for (size_t b = 0; b < N; ++b) {
+      const double* r = seg + 8 * b;
+      const V3 u{r[3] - r[0], r[4] - r[1], r[5] - r[2]};
+      const V3 Fb{Fa[3 * b].value(), Fa[3 * b + 1].value(), Fa[3 * b + 2].value()};
+      const V3 Sb{Sa[3 * b].value(), Sa[3 * b + 1].value(), Sa[3 * b + 2].value()};
+      const V3 tq = cross(u, Sb);
+      const V3 w{mr[b] * tq.x, mr[b] * tq.y, mr[b] * tq.z};
+      const V3 z = cross(w, u);
+      for (int k = 0; k < 3; ++k) {
+        U[3 * b + k] = mt[b] * Fb[k];
+        Wv[3 * b + k] = w[k];
+        Z[3 * b + k] = z[k];
+      }
+    }
+    for (size_t c = 0; c < C; ++c) {
+      const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
+      const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
+      const double ci = arc_s[c] - 0.5, cj = arc_t[c] - 0.5;
+      const V3 zi{Z[3 * i], Z[3 * i + 1], Z[3 * i + 2]}, zj{Z[3 * j], Z[3 * j + 1], Z[3 * j + 2]};
+      const V3 vi = V3{U[3 * i], U[3 * i + 1], U[3 * i + 2]} + zi * ci;
+      const V3 vj = V3{U[3 * j], U[3 * j + 1], U[3 * j + 2]} + zj * cj;
       const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
       y[c] = dt * sdot;
     }
@@ -1160,21 +1265,28 @@ struct FrictionOp {
   double dt;
   size_t C, N;
   mutable std::vector<double> F, T;
+  mutable std::vector<Acc> Fa, Ta;
   // g = A p + q, serial scatter / mobility / gather
   void gradient(const double* p, double* g) const {
-    F.assign(3 * N, 0.0);
-    T.assign(3 * N, 0.0);
+    Fa.assign(3 * N, Acc{});
+    Ta.assign(3 * N, Acc{});
+    F.resize(3 * N);
+    T.resize(3 * N);
     for (size_t c = 0; c < C; ++c) {
       const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
       const V3 f{p[3 * c], p[3 * c + 1], p[3 * c + 2]};
       const V3 a{ra[3 * c], ra[3 * c + 1], ra[3 * c + 2]}, b{rb[3 * c], rb[3 * c + 1], rb[3 * c + 2]};
       const V3 ta = cross(a, f), tb = cross(b, f);
       for (int k = 0; k < 3; ++k) {
-        F[3 * i + k] += -f[k];
-        F[3 * j + k] += f[k];
-        T[3 * i + k] += -ta[k];
-        T[3 * j + k] += tb[k];
+        Fa[3 * i + k].add(-f[k]);
+        Fa[3 * j + k].add(f[k]);
+        Ta[3 * i + k].add(-ta[k]);
+        Ta[3 * j + k].add(tb[k]);
       }
+    }
+    for (size_t k = 0; k < 3 * N; ++k) {
+      F[k] = Fa[k].value();
+      T[k] = Ta[k].value();
     }
     for (size_t c = 0; c < C; ++c) {
       const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
@@ -1230,12 +1342,15 @@ inline SolveResult solve_friction_contact(const FrictionOp& op, double mu, unsig
       finish(pn, gn);
       return out;
     }
-    double num = 0.0, den = 0.0;
-    for (size_t k = 0; k < 3 * C; ++k) {
-      const double dx = pn[k] - pt[k];
-      num += dx * dx;
-      den += dx * (gn[k] - gt[k]);
+    Acc numa, dena;  // one term per contact: the right-fold dot products of its three components
+    for (size_t c = 0; c < C; ++c) {
+      const V3 dp{pn[3 * c] - pt[3 * c], pn[3 * c + 1] - pt[3 * c + 1], pn[3 * c + 2] - pt[3 * c + 2]};
+      const V3 dg{gn[3 * c] - gt[3 * c], gn[3 * c + 1] - gt[3 * c + 1], gn[3 * c + 2] - gt[3 * c + 2]};
+      numa.add(dot(dp, dp));
+      dena.add(dot(dp, dg));
     }
+    const double num = numa.value();
+    double den = dena.value();
     den += 1e-14 * (std::fabs(den) < 1e-14 ? 1.0 : 0.0);
     step = num / den;
     pt.swap(pn);
@@ -1256,7 +1371,8 @@ struct ScrapResult {
   int ite_count;
   double max_speed;
 };
-inline ScrapResult scrap_resolve_collisions(const ContactOp& A, const double* sep, double max_allowable_overlap,
+template <class Op>  // ContactOp or ContactOpRod
+ScrapResult scrap_resolve_collisions(const Op& A, const double* sep, double max_allowable_overlap,
                                             int max_col_iterations, double* lam, double* lam_tmp, double* sep_dot_dt,
                                             double* sep_dot_dt_tmp) {
   // sep_dot_dt holds dt * signed_sep_dot (the operator returns dt * sdot); the scrap code keeps sdot and multiplies by
@@ -1285,14 +1401,15 @@ inline ScrapResult scrap_resolve_collisions(const ContactOp& A, const double* se
       A(lam, sep_dot_dt);
       res = residual(lam, sep_dot_dt);
       if (res < max_allowable_overlap) break;
-      double xx = 0, xg = 0, gg = 0;
+      Acc sxx, sxg, sgg;
       for (size_t i = 0; i < C; ++i) {
         const double xd = lam[i] - lam_tmp[i];
         const double gd = sep_dot_dt[i] - sep_dot_dt_tmp[i];
-        xx += xd * xd;
-        xg += xd * gd;
-        gg += gd * gd;
+        sxx.add(xd * xd);
+        sxg.add(xd * gd);
+        sgg.add(gd * gd);
       }
+      const double xx = sxx.value(), xg = sxg.value(), gg = sgg.value();
       double a, b;
       if (ite_count % 2 == 0) {
         a = xx; b = xg;

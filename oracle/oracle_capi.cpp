@@ -336,7 +336,7 @@ void o_solve_small_cqpp_batch(size_t batch, size_t n, const double* A, const dou
 
 void o_contact_op_apply(size_t C, size_t N, const int32_t* pairs, const double* normal, const double* ra,
                         const double* rb, const double* mt, const double* mr, double dt, const double* x, double* y) {
-  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}};
+  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}, {}, {}};
   op(x, y);
 }
 
@@ -344,11 +344,54 @@ void o_solve_cqpp_contact(size_t C, size_t N, const int32_t* pairs, const double
                           const double* rb, const double* mt, const double* mr, double dt, const double* q, int kind,
                           double lo, double hi, int resid_kind, unsigned max_iters, double tol, double* x, double* g,
                           double* x_tmp, double* g_tmp, unsigned* num_iters, double* res, int* converged) {
-  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}};
+  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}, {}, {}};
   const SolveResult r = solve_cqpp(op, q, Space{kind, lo, hi}, resid_kind, max_iters, tol, C, x, g, x_tmp, g_tmp);
   *num_iters = r.num_iters;
   *res = r.residual;
   *converged = r.converged;
+}
+
+// summation mode of the BB-step reductions and the per-body sums (mundy_oracle.hpp, SumMode)
+void o_set_sum_mode(int mode) { sum_mode() = (mode == kSumCompensated) ? kSumCompensated : kSumSerial; }
+int o_get_sum_mode() { return sum_mode(); }
+
+// the spherocylinder operator in rod-axis form (ContactOpRod)
+void o_contact_op_apply_rod(size_t C, size_t N, const int32_t* pairs, const double* normal, const double* arc_s,
+                            const double* arc_t, const double* seg, const double* mt, const double* mr, double dt,
+                            const double* x, double* y, double* body_velocity /* [N][6] = (U, W) or null */) {
+  ContactOpRod op{pairs, normal, arc_s, arc_t, seg, mt, mr, dt, C, N, {}, {}, {}, {}, {}};
+  op(x, y);
+  if (body_velocity)
+    for (size_t b = 0; b < N; ++b)
+      for (int k = 0; k < 3; ++k) {
+        body_velocity[6 * b + k] = op.U[3 * b + k];
+        body_velocity[6 * b + 3 + k] = op.Wv[3 * b + k];
+      }
+}
+void o_solve_cqpp_contact_rod(size_t C, size_t N, const int32_t* pairs, const double* normal, const double* arc_s,
+                              const double* arc_t, const double* seg, const double* mt, const double* mr, double dt,
+                              const double* q, int kind, double lo, double hi, int resid_kind, unsigned max_iters,
+                              double tol, double* x, double* g, double* x_tmp, double* g_tmp, unsigned* num_iters,
+                              double* res, int* converged) {
+  ContactOpRod op{pairs, normal, arc_s, arc_t, seg, mt, mr, dt, C, N, {}, {}, {}, {}, {}};
+  const SolveResult r = solve_cqpp(op, q, Space{kind, lo, hi}, resid_kind, max_iters, tol, C, x, g, x_tmp, g_tmp);
+  *num_iters = r.num_iters;
+  *res = r.residual;
+  *converged = r.converged;
+}
+void o_scrap_resolve_collisions_rod(size_t C, size_t N, const int32_t* pairs, const double* normal,
+                                    const double* arc_s, const double* arc_t, const double* seg, const double* mt,
+                                    const double* mr, double dt, const double* sep, double max_allowable_overlap,
+                                    int max_iters, double* lam, double* g, double* res, int* ite_count,
+                                    double* max_speed) {
+  ContactOpRod op{pairs, normal, arc_s, arc_t, seg, mt, mr, dt, C, N, {}, {}, {}, {}, {}};
+  std::vector<double> lam_tmp(C), gdt(C), gdt_tmp(C);
+  const ScrapResult r = scrap_resolve_collisions(op, sep, max_allowable_overlap, max_iters, lam, lam_tmp.data(),
+                                                 gdt.data(), gdt_tmp.data());
+  for (size_t i = 0; i < C; ++i) g[i] = sep[i] + gdt[i];
+  *res = r.max_abs_projected_sep;
+  *ite_count = r.ite_count;
+  *max_speed = r.max_speed;
 }
 
 // build extension (parity unpinned): frictional cone complementarity solve, serial
@@ -356,7 +399,7 @@ void o_solve_friction_contact(size_t C, size_t N, const int32_t* pairs, const do
                               const double* rb, const double* mt, const double* mr, double dt, const double* sep,
                               double mu, unsigned max_iters, double tol, double* p, double* g, unsigned* num_iters,
                               double* res, int* converged) {
-  FrictionOp op{pairs, normal, ra, rb, mt, mr, sep, dt, C, N, {}, {}};
+  FrictionOp op{pairs, normal, ra, rb, mt, mr, sep, dt, C, N, {}, {}, {}, {}};
   const SolveResult r = solve_friction_contact(op, mu, max_iters, tol, p, g);
   *num_iters = r.num_iters;
   *res = r.residual;
@@ -370,7 +413,7 @@ void o_scrap_resolve_collisions(size_t C, size_t N, const int32_t* pairs, const 
                                 const double* rb, const double* mt, const double* mr, double dt, const double* sep,
                                 double max_allowable_overlap, int max_iters, double* lam, double* g,
                                 double* res, int* ite_count, double* max_speed) {
-  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}};
+  ContactOp op{pairs, normal, ra, rb, mt, mr, dt, C, N, {}, {}, {}, {}, {}, {}};
   std::vector<double> lam_tmp(C), gdt(C), gdt_tmp(C);
   const ScrapResult r = scrap_resolve_collisions(op, sep, max_allowable_overlap, max_iters, lam, lam_tmp.data(),
                                                  gdt.data(), gdt_tmp.data());

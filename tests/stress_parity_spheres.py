@@ -26,14 +26,16 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     pairs = oracle.search(kind, lo, hi, c, R, box=box)
     sep, nrm = oracle.contact_spheres(pairs, c, r, box=box)
     mt, _ = synth.dry_mobility(r)
-    xo, go, ro = oracle.solve_cqpp_contact(pairs, nrm, None, None, mt, None, 5e-3, sep, np.zeros(len(pairs)),
-                                           max_iters=50000, tol=tol, threads=True)
+    with oracle.compensated_sums():
+        xo, go, ro = oracle.solve_cqpp_contact(pairs, nrm, None, None, mt, None, 5e-3, sep, np.zeros(len(pairs)),
+                                               max_iters=50000, tol=tol)
     ok_pairs = np.array_equal(st.links.pairs.cpu().numpy(), pairs)
     ok_sep = ok_pairs and np.array_equal(st.contacts["sep"].cpu().numpy(), sep) and \
         np.array_equal(st.contacts["normal"].cpu().numpy(), nrm)
     g = (st.op.apply(st.lam) + st.contacts["sep"]).cpu().numpy() if ok_pairs else None
     dg = float(np.abs(g - go).max()) if ok_pairs and len(pairs) else 0.0
-    ok = ok_pairs and ok_sep and res.converged and ro["converged"] and dg <= 20 * tol
+    ok = ok_pairs and ok_sep and res.converged and ro["converged"] and dg <= 20 * tol and \
+        abs(res.num_iters - ro["num_iters"]) <= 2
     bad += not ok
     print("%s case %2d: n=%5d phi=%.2f buf=%.2f %s %s contacts=%7d iters gpu/oracle %5d/%5d |dg|=%.2e pairs %s sep/normal %s"
           % ("ok  " if ok else "FAIL", case, n, phi, buf, "periodic" if periodic else "free    ",

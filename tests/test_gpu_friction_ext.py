@@ -46,10 +46,12 @@ def test_friction_solve_matches_oracle_and_cone_conditions(ops, oracle, mu):
     tol = 1e-6
     op = _op(ops, P)
     p, g, r = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=ops.PGDConfig(max_iters=50000, tol=tol))
-    po, go, ro = oracle.solve_friction_contact(P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"], 5e-3,
-                                               P["sep"], mu, max_iters=50000, tol=tol)
+    with oracle.compensated_sums():   # double-double sums on both sides: the same trajectory
+        po, go, ro = oracle.solve_friction_contact(P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"], 5e-3,
+                                                   P["sep"], mu, max_iters=50000, tol=tol)
     assert r.converged and ro["converged"] and r.residual <= tol
-    assert 0.5 * ro["num_iters"] <= r.num_iters <= 2.0 * ro["num_iters"] + 10
+    print("friction mu=%g: iterations gpu %d oracle %d" % (mu, r.num_iters, ro["num_iters"]))
+    assert abs(r.num_iters - ro["num_iters"]) <= 2
     p, g = host(p), host(g)
     cone_checks(p, g, P["normal"], mu, tol)
     np.testing.assert_allclose(g, go, atol=40 * tol)          # the gradient is unique, the impulses need not be
