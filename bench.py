@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""bench.py -- timesteps/s and contact-pairs/s of the contact hot path on 10^6 spherocylinders per GPU.
+"""bench.py -- timesteps/s and contact-pairs/s of the contact hot path on 10^6 spherocylinders.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
 torch.distributed.run, one rank per GPU.  W untimed warm-up steps, then exactly K timed steps bracketed by a barrier +
@@ -13,15 +13,17 @@ L = 2) at 40 % volume fraction, random positions/orientations (overlaps allowed,
 Every step starts from the same pristine input (restored by a device copy inside the timed region), so all steps do
 identical work.  Inputs are resident in HBM before the timed region starts.
 
-N > 1 (weak scaling): ONE system of N x 10^6 spherocylinders in a box grown to keep the 40 % volume fraction, cut along
-a Hilbert curve into N contiguous ranges, one per GPU: ghost-body halo at the neighbour-list build, and per BBPGD
-iteration a ghost-velocity halo (RCCL send/recv) + one 3-double all-gather.  The iteration loop and the transport are
-C++ inside libmundy_hip (csrc/dist.hip); torch.distributed only launches (RCCL id broadcast, barrier, max over ranks).
-`value` = timesteps of 10^6-spherocylinder shards completed per second over all ranks (= N x global timesteps/s).
-The BBPGD iteration count grows with the system (767 iterations at 10^6 rods, ~960 at 2*10^6, ~1430 at 8*10^6 on this
-packing), so weak-scaling efficiency is bounded by that growth before any communication cost.
-`--strong` instead cuts ONE --bodies system over the N GPUs (BASELINE configs[3] read literally) and reports its
-timesteps/s with "scaling": "strong".
+N > 1 runs BASELINE configs[3] as written: the SAME 10^6-spherocylinder system, cut along a Hilbert curve into N
+contiguous ranges, one per GPU ("scaling": "strong"; `value` = timesteps/s of that one system): ghost-body halo at the
+neighbour-list build, and per BBPGD iteration a ghost-velocity halo (RCCL send/recv) + one 5-double all-gather.  The
+iteration loop and the transport are C++ inside libmundy_hip (csrc/dist.hip); torch.distributed only launches (RCCL id
+broadcast, barrier, max over ranks).  Every sum that feeds the BB step is a double-double pair rounded once, so the
+partitioned run takes the single-GPU run's iterates and iteration count.  The line is refused (exit code 3) unless the
+halo really travels over RCCL: a run that fell back to the host-staged transport is not a measurement of xGMI
+(`--allow-host-transport` for development boxes where several ranks share one GPU).
+`--weak` instead grows the system with N (--bodies per GPU, "scaling": "weak", `value` = N x global timesteps/s); the
+BBPGD iteration count grows with the system, which that line folds into what reads as a scaling curve -- so both lines
+also carry `constraint_updates_per_sec` (contacts x iterations per second), which does not.
 """
 import argparse
 import json
@@ -41,40 +43,60 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+# one metric for every N: the N = 1 line is BASELINE configs[2], the N > 1 lines are configs[3] -- the same system
+METRIC = "timesteps/sec, 10^6 spherocylinders, frictionless LCP contact (BBPGD)"
 
 
-def kernel_bytes(contacts, bodies):
-    """Algorithmic bytes per launch of the two sweeps of one fused BBPGD iteration (rod-compressed kinematics).
+def kernel_bytes(contacts, bodies, active_contacts=None):
+    """Algorithmic bytes per launch of the two sweeps of one fused BBPGD iteration (rod-compressed kinematics): every
+    array the launch REQUIRES, counted once (a gathered table once per row, not once per reader) -- what HBM must move
+    even with perfect caches.  This is what roofline.achieved divides.
+      k_constraint  every constraint is evaluated every iteration: pair 8 + normal 24 + arclengths 16 + packed (x, g) 16
+                    + q 8 read, packed (x, g) 16 written = 88 B per constraint; the 48-byte (U, W x u) body rows once
+                    each = 48 B per body
+      k_body        walks only the half edges its activity masks flag (a contact with x = 0, g >= 0 stays at
+                    Proj(0 - step g) = 0 and adds nothing): per ACTIVE half edge incidence entry 4 + (n, s - 1/2)
+                    record 32 = 36 B; per ACTIVE contact its packed iterate 16 B (gathered by both of its half edges,
+                    counted once); per body row pointer 4 + mask 8 + mobilities 16 + axis 24 + velocity row 48 +
+                    angular velocity 24 = 124 B.  `active_contacts` is measured in the run (state at the end of the
+                    solve); None = every contact (the pre-mask count).
+    SURVEY 8(d)'s own figure, 368 C + 96 N per iteration, charges a gathered row to every contact that reads it and
+    assumes vector lever arms; this implementation streams scalar arclengths and serves the 48 MB row table from L2 /
+    Infinity Cache, so that figure divided by the measured time exceeds the HBM peak (1.39 x at 10^6 rods) -- it is
+    unusable as a denominator here and is not printed."""
+    act = contacts if active_contacts is None else active_contacts
+    return {"k_constraint": 88.0 * contacts + 48.0 * bodies,
+            "k_body": 2 * 36.0 * act + 16.0 * act + 124.0 * bodies}
 
-    "compulsory": every array touched once -- what HBM must move even with perfect caches; this is roofline.achieved.
-    "gather_counted": SURVEY 8(d)'s convention, where a gathered row is charged to every contact that reads it.  The
-    body rows (48 MB at 10^6 rods) and the iterate largely come from L2 / Infinity Cache, so the gather-counted rate
-    can exceed the HBM peak; it is reported next to the compulsory one, never instead of it.
-      k_constraint  streams per constraint: pair 8 + normal 24 + arclengths 16 + packed (x, g) 16 + q 8 read,
-                    packed (x, g) 16 written = 88 B; gathers two 48-byte body rows (U, W x u)
-      k_body        per half edge: incidence entry 4 + 32-byte record + 16-byte iterate gather; per body: row pointer
-                    4 + mobilities 16 + axis 24 + velocity row 48 + angular velocity 24 = 116 B
-    """
-    return {
-        "k_constraint": {"compulsory": 88.0 * contacts + 48.0 * bodies, "gather_counted": (88.0 + 96.0) * contacts},
-        "k_body": {"compulsory": (2 * 36.0 + 16.0) * contacts + 116.0 * bodies,
-                   "gather_counted": 2 * 52.0 * contacts + 116.0 * bodies},
-    }
 
-
-def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label=""):
-    kb = kernel_bytes(contacts, bodies)
+def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", active_contacts=None):
+    kb = kernel_bytes(contacts, bodies, active_contacts)
     ms = {"k_constraint": con_ms, "k_body": body_ms}
     ent = {}
     for k in ms:
-        a = kb[k]["compulsory"] / (ms[k] * 1e-3) / 1e9
+        a = kb[k] / (ms[k] * 1e-3) / 1e9
         ent[k] = {"bound": "hbm", "kernel": k + "<X_SOLVE,KIN_ROD>" + label, "achieved": round(a, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
-                  "avg_launch_ms": round(ms[k], 4), "launches": launches, "bytes_per_launch": kb[k]["compulsory"],
-                  "achieved_gather_counted": round(kb[k]["gather_counted"] / (ms[k] * 1e-3) / 1e9, 1)}
+                  "traffic_source": None, "avg_launch_ms": round(ms[k], 4), "launches": launches,
+                  "bytes_per_launch": kb[k]}
+    if active_contacts is not None:
+        ent["k_body"]["active_contact_fraction"] = round(active_contacts / max(1, contacts), 4)
     dominant = max(ms, key=ms.get)  # the sweep with the longer launch is the one the step waits on
     other = "k_body" if dominant == "k_constraint" else "k_constraint"
     return ent[dominant], {other: ent[other]}, dominant, other
+
+
+def attach_traffic(roof, extra, dom, oth, n, buffer):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (scripts/profile_bench.sh:
+    separate FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE + WRITE_SIZE as the gfx950 guide prescribes).  They are NOT
+    measured in this run -- the source is named next to the number."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and n == 1_000_000 and buffer == 0.1:
+        tj = json.load(open(tpath))
+        src = "profiles/traffic.json (%s)" % tj.get("_source", "rocprofv3 --pmc passes of `python bench.py`, committed")
+        for ent, k in ((roof, dom), (extra[oth], oth)):
+            ent["traffic"] = tj.get(k, {}).get("hbm_bytes_per_launch")
+            ent["traffic_source"] = src if ent["traffic"] is not None else None
 
 
 def parse():
@@ -90,9 +112,20 @@ def parse():
     p.add_argument("--no-reorder", dest="reorder", action="store_false", help="skip the per-step Z-order reordering")
     p.add_argument("--reorder-cell", type=float, default=3.0, help="lattice edge of the Morton keys")
     p.add_argument("--cpu-iters", type=int, default=12, help="BBPGD iterations timed on the host cores")
-    p.add_argument("--strong", action="store_true",
-                   help="N > 1: partition ONE system of --bodies rods over the N GPUs (BASELINE configs[3] read "
-                        "literally: 10^6 total; strong scaling) instead of --bodies per GPU (weak scaling, the default)")
+    p.add_argument("--weak", action="store_true",
+                   help="N > 1: --bodies rods PER GPU (one system of N x --bodies, weak scaling) instead of the default, "
+                        "BASELINE configs[3] as written: ONE system of --bodies rods partitioned over the N GPUs")
+    p.add_argument("--strong", action="store_true", help="(the default for N > 1; kept for older command lines)")
+    p.add_argument("--distributed", action="store_true",
+                   help="take the partitioned path even with one rank (under torch.distributed.run): one rank over RCCL")
+    p.add_argument("--allow-host-transport", action="store_true",
+                   help="print a line even when the halo is staged through host memory (gloo) instead of RCCL; "
+                        "without it such a run exits with code 3")
+    p.add_argument("--xcd-tile", type=int, default=-1, help="tile -> XCD mapping of the sweeps (time only)")
+    p.add_argument("--lanes-per-body", type=int, default=-1, help="lanes per body of the body sweep (time only)")
+    p.add_argument("--relaxed-steps", type=int, default=2,
+                   help="N = 1: after the headline steps, advance the packing by this many full steps and time --steps "
+                        "more from THAT state (labelled `relaxed_packing`; SURVEY 8d.3 allows one relaxation pre-pass)")
     p.add_argument("--mixed", action="store_true",
                    help="BASELINE configs[4] instead of the headline workload: --bodies bodies, one third each spheres "
                         "(r 0.5), spherocylinders (r 0.5, L 2) and ellipsoids (0.8, 0.5, 0.4), random orientations, "
@@ -118,7 +151,7 @@ def main():
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.distributed:
         # a transport that stalls must end the run, not sit on the node: dump the stacks and exit after the limit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("MUNDY_BENCH_WATCHDOG_S", "900")), exit=True)
@@ -137,7 +170,7 @@ def main():
 
     n = args.bodies
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    if world > 1:
+    if world > 1 or args.distributed:
         if args.mixed:
             raise SystemExit("--mixed is a single-GPU line (the mixed distributed path is covered by the tests)")
         return main_distributed(args, rank, world, dist, ops, synth, dev)
@@ -150,6 +183,8 @@ def main():
     stepper = pipeline.ContactStepper("spherocylinder", center, radius, quat, length, dt=5e-3, viscosity=1e-3,
                                       search_buffer=args.buffer, search_kind=ops.SEARCH_AABB, cfg=cfg,
                                       friction=args.friction)
+    if args.xcd_tile >= 0 or args.lanes_per_body > 0:
+        stepper.work_mapping = (args.xcd_tile, args.lanes_per_body)
     pristine = stepper.snapshot()
     prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 
@@ -185,6 +220,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # contacts the body sweep's masks flag at the end of the solve: not (x == 0 and 0 <= g < inf)
+    active = None
+    if args.friction is None and stepper.lam is not None and getattr(stepper, "grad", None) is not None:
+        lam_t, g_t = stepper.lam, stepper.grad
+        active = int((~((lam_t == 0) & (g_t >= 0) & torch.isfinite(g_t))).sum().item())
     stage_ms = one_step(False, timed_stages=True).timings_ms  # one extra, untimed step for the stage breakdown
     contacts = stats[-1].num_contacts
     iters = [s.num_iters for s in stats]
@@ -195,14 +235,36 @@ def main():
     roof, extra = None, {}
     if prof["iters"] > 0:
         roof, extra, dom, oth = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"],
-                                                 prof["body_ms"] / prof["iters"], prof["iters"])
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (scripts/profile_bench.sh:
-        # separate FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE + WRITE_SIZE as the gfx950 guide prescribes)
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and n == 1_000_000 and args.buffer == 0.1:
-            tj = json.load(open(tpath))
-            roof["traffic"] = tj.get(dom, {}).get("hbm_bytes_per_launch")
-            extra[oth]["traffic"] = tj.get(oth, {}).get("hbm_bytes_per_launch")
+                                                 prof["body_ms"] / prof["iters"], prof["iters"], active_contacts=active)
+        attach_traffic(roof, extra, dom, oth, n, args.buffer)
+
+    # ---- a second, labelled figure: the same step from a RELAXED packing (what a running simulation sees) -----------
+    relaxed = None
+    if args.relaxed_steps > 0 and args.friction is None and dist is None:
+        stepper.restore(pristine)
+        if args.reorder:
+            stepper.reorder_bodies(cell_size=args.reorder_cell, lo=[0.0, 0.0, 0.0])
+        for _ in range(args.relaxed_steps):   # the relaxation pre-pass: full steps of the same path, untimed
+            stepper.step(integrate=True, force_rebuild=True)
+        pristine_relaxed = stepper.snapshot()
+
+        def relaxed_step():
+            stepper.restore(pristine_relaxed)
+            stepper.links.invalidate()
+            stepper.profile_next = False
+            return stepper.step(integrate=True, force_rebuild=True)
+
+        relaxed_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rstats = [relaxed_step() for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        r_el = time.perf_counter() - t1
+        relaxed = {"what": "the same step (reorder excluded: bodies stay Z-ordered) from the packing reached after %d "
+                           "full steps of this path from the raw input; NOT the headline value" % args.relaxed_steps,
+                   "timesteps_per_sec": round(args.steps / r_el, 4), "ms_per_step": round(1e3 * r_el / args.steps, 3),
+                   "contacts": rstats[-1].num_contacts, "bbpgd_iters_per_step": [s.num_iters for s in rstats],
+                   "converged": [bool(s.converged) for s in rstats]}
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this box's host cores, rank 0 ---------
     cpu = None
@@ -211,21 +273,22 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",
+            "metric": METRIC,
             "value": round(value, 4), "unit": "timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: %.3gM spherocylinders r=0.5 L=2 at 40%% volume fraction, random packing, "
                                    "AABB+%.2g neighbour list, frictionless LCP tol %.0e" % (n / 1e6, args.buffer, args.tol),
-                       "bodies_per_gpu": n, "contacts_per_gpu": contacts, "bbpgd_iters_per_step": iters,
-                       "converged": [bool(s.converged) for s in stats],
-                       "parallelism": "single GPU (N > 1: hilbert domain decomposition with RCCL halo)"},
+                       "bodies_per_gpu": n, "bodies_total": n, "contacts_per_gpu": contacts, "contacts_total": contacts,
+                       "bbpgd_iters_per_step": iters, "converged": [bool(s.converged) for s in stats],
+                       "parallelism": "single GPU (N > 1: the same system, hilbert domain decomposition with RCCL halo)"},
             "contact_pairs_per_sec": round(world * contacts * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(world * sum(iters) / elapsed, 1),
             # contacts x iterations per second: the rate that stays comparable when the iteration count changes
             "constraint_updates_per_sec": round(world * contacts * sum(iters) / elapsed, 1),
             "roofline": roof, "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "relaxed_packing": relaxed,
         }
         if args.friction is not None:  # never the default line: an extension without a reference to pin it on
             out["metric"] = "timesteps/sec, 10^6 spherocylinders per GPU, FRICTIONAL cone-complementarity contact (build extension)"
@@ -309,7 +372,8 @@ def main_mixed(args, ops, pipeline, synth, dev):
 def main_distributed(args, rank, world, dist, ops, synth, dev):
     """N > 1: one Hilbert-partitioned system of world x bodies rods, RCCL halo (see module docstring)."""
     from mundy_amd import distributed as D
-    n = args.bodies // world if args.strong else args.bodies
+    strong = not args.weak
+    n = args.bodies // world if strong else args.bodies
     n_total = n * world
     # every rank derives the same global order from the counter-based generator (no set-up communication)
     centers, box = synth.spherocylinder_centers(np.arange(n_total), n_total, seed=1234)
@@ -321,6 +385,16 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     b = synth.spherocylinders(len(mine), seed=1234, n_total=n_total, indices=mine)
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
     comm = D.Comm()
+    if comm.transport != "rccl" and not args.allow_host_transport:
+        # every rank takes this branch together (the transport is negotiated): a halo staged through host memory is not
+        # a measurement of the xGMI path, so no line is printed
+        if rank == 0:
+            print("bench.py: the halo transport is %r, not RCCL -- refusing to print a scaling line "
+                  "(--allow-host-transport overrides, for development only)" % comm.transport, file=sys.stderr, flush=True)
+        comm.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(3)
     comm.self_check()  # pairwise messages + all-gather with known contents, before anything is timed
     st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
                                      comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=32)
@@ -351,6 +425,10 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                        dtype=torch.float64, device="cuda")
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     contacts_global, ghosts_global = int(tot[0].item()), int(tot[1].item())
+    per_rank = torch.zeros(world, dtype=torch.float64, device="cuda")
+    per_rank[rank] = stats[-1]["owned_contacts"]
+    dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    per_rank_contacts = [int(v) for v in per_rank.tolist()]
     iters = [s["num_iters"] for s in stats]
     roof, extra = None, {}
     if st.prof["iters"] > 0:
@@ -358,21 +436,23 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                                              st.prof["body_ms"] / st.prof["iters"], st.prof["iters"], ", rank 0")
     if rank == 0:
         out = {
-            "metric": ("timesteps/sec, one %.3g-spherocylinder system over all GPUs, frictionless LCP contact (BBPGD)" % n_total)
-            if args.strong else "timesteps/sec, 10^6 spherocylinders per GPU, frictionless LCP contact (BBPGD)",
-            # weak: world x (10^6-rod workloads per second); strong: timesteps per second of the one fixed-size system
-            "value": round((1 if args.strong else world) * args.steps / elapsed, 4), "unit": "timesteps/s",
+            "metric": METRIC if strong else
+            "timesteps/sec, 10^6 spherocylinders PER GPU (one system of N x 10^6), frictionless LCP contact (BBPGD)",
+            # strong: timesteps per second of the one fixed-size system; weak: world x (10^6-rod workloads per second)
+            "value": round((1 if strong else world) * args.steps / elapsed, 4), "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[3]: %.3gM spherocylinders r=0.5 L=2 at 40%% volume fraction, one system "
                                    "Hilbert-partitioned over %d GPUs, AABB+%.2g neighbour list, frictionless LCP tol %.0e"
                                    % (n_total / 1e6, world, args.buffer, args.tol),
                        "bodies_per_gpu": n, "bodies_total": n_total, "contacts_total": contacts_global,
                        "ghost_bodies_total": ghosts_global, "bbpgd_iters_per_step": iters,
+                       "owned_contacts_per_rank": per_rank_contacts,
+                       "contact_imbalance_max_over_mean": round(max(per_rank_contacts) * world / max(1, sum(per_rank_contacts)), 4),
                        "converged": [bool(s["converged"]) for s in stats],
                        "parallelism": "hilbert domain decomposition dd%d: ghost-body halo per rebuild; per BBPGD "
-                                      "iteration ghost-velocity send/recv + 3-double all-gather (RCCL)" % world,
+                                      "iteration ghost-velocity send/recv + 5-double all-gather (RCCL)" % world,
                        "transport": comm.transport},
             "contact_pairs_per_sec": round(contacts_global * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),

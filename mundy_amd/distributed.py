@@ -93,6 +93,43 @@ def partition_ranges(n_total, world):
 
 
 # ---- communication ------------------------------------------------------------------------------------------------------
+def negotiate_direct_transport(group, rank, make_id, create, device):
+    """Decides, identically on every rank of `group`, whether the direct (RCCL) communicator exists everywhere.
+
+    rank 0 calls make_id() -> COMM_ID_BYTES bytes; every rank then calls create(id_bytes).  Either may raise on any
+    subset of the ranks.  The sequence of collectives is the same on every rank whatever fails where: ONE broadcast of
+    (id, status byte) from rank 0 -- a failed make_id travels as status 0 instead of skipping the broadcast, which
+    would leave the other ranks inside it -- then ONE all-reduce of the per-rank outcome.  Returns (ok, error seen on
+    this rank or None).  `device`: where the two small tensors live (cuda for nccl groups, cpu for gloo)."""
+    n = capi.COMM_ID_BYTES
+    buf = torch.zeros(n + 1, dtype=torch.uint8)
+    err = None
+    if rank == 0:
+        try:
+            raw = bytes(make_id())
+            if len(raw) != n:
+                raise RuntimeError("unique id has %d bytes, expected %d" % (len(raw), n))
+            buf[:n] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            buf[n] = 1
+        except Exception as e:  # noqa: BLE001
+            err = e
+    t = buf.to(device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    t = t.cpu()
+    bad = 0.0
+    if int(t[n]) == 1:
+        try:
+            create(t[:n].numpy().tobytes())
+        except Exception as e:  # noqa: BLE001
+            err, bad = e, 1.0
+    else:
+        bad = 1.0
+        err = err or RuntimeError("rank 0 could not make the unique id")
+    flag = torch.tensor([bad], dtype=torch.float32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return flag.item() == 0.0, err
+
+
 class Comm:
     """One rank's communicator of the C library (mhip_comm_*, csrc/dist.hip).  torch.distributed is only the launcher:
     it carries the RCCL unique id from rank 0 to the others, and, when the process group is not nccl (gloo in the
@@ -112,23 +149,24 @@ class Comm:
         if self.direct:
             # the library's own RCCL communicator.  Should creating it fail on ANY rank (decided together, so that all
             # ranks take the same road) the step still runs, staged through host memory over a gloo group -- slow, and
-            # said so loudly; it is not a second compute path, only a second wire.
-            err = None
-            try:
-                if os.environ.get("MUNDY_TEST_FAIL_RCCL") == "1":   # the tests' way into the fallback branch
+            # said so loudly; it is not a second compute path, only a second wire.  bench.py refuses to time it.
+            forced = os.environ.get("MUNDY_TEST_FAIL_RCCL", "")   # the tests' way into the fallback branch
+
+            def make_id():
+                if forced in ("1", "rank0"):
                     raise RuntimeError("RCCL refused (forced by MUNDY_TEST_FAIL_RCCL)")
                 ident = C.create_string_buffer(capi.COMM_ID_BYTES)
-                if self.rank == 0:
-                    capi.check(lib.mhip_comm_unique_id(ident))
-                t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).cuda()
-                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                ident = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), capi.COMM_ID_BYTES)
+                capi.check(lib.mhip_comm_unique_id(ident))
+                return ident.raw
+
+            def create(raw):
+                if forced == "1" or forced == "rank%d" % self.rank:
+                    raise RuntimeError("RCCL refused (forced by MUNDY_TEST_FAIL_RCCL)")
+                ident = C.create_string_buffer(raw, capi.COMM_ID_BYTES)
                 capi.check(lib.mhip_comm_create_rccl(C.byref(self._h), ident, self.rank, self.world))
-            except Exception as e:  # noqa: BLE001
-                err = e
-            bad = torch.tensor([0.0 if err is None else 1.0], device="cuda")
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-            if bad.item() > 0.0:
+
+            ok, err = negotiate_direct_transport(group, self.rank, make_id, create, torch.device("cuda"))
+            if not ok:
                 import sys
                 print("mundy_amd: the RCCL communicator could not be created on every rank (%s); falling back to the "
                       "host-callback transport over gloo -- expect a host-bound iteration" % (err,), file=sys.stderr)
@@ -136,7 +174,12 @@ class Comm:
                     lib.mhip_comm_destroy(self._h)
                     self._h = C.c_void_p()
                 self.direct = False
-                self.group = dist.new_group(backend="gloo")
+                # the same ranks, in the same order, as the group the caller gave (its rank numbering is kept)
+                if group is None:
+                    self.group = dist.new_group(backend="gloo")
+                else:
+                    self.group = dist.new_group(ranks=dist.get_process_group_ranks(group), backend="gloo",
+                                                use_local_synchronization=True)
             else:
                 self.transport = "rccl"
         if not self.direct:

@@ -187,7 +187,7 @@ class ContactStepper:
         if rebuilt or self.lam is None or not self.warm_start or self.lam.shape[0] != nc:
             self.lam = torch.zeros(nc, dtype=torch.float64, device=self.center.device)  # NgpLcp.cpp:890-891
         x, g, res = ops.solve_lcp(self.op, c["sep"], self.lam, self.cfg)
-        self.lam = x
+        self.lam, self.grad = x, g
         return res
 
     def integrate(self):

@@ -77,14 +77,18 @@ for name, sub, scale in (("FETCH_SIZE", "pmc_fetch", 2.0), ("WRITE_SIZE", "pmc_w
         traffic.setdefault(k, {})[name] = b
         print("%-14s launches %5d  effective %5d  raw %.1f KiB/launch  -> %.4g bytes/launch" % (k, len(vals[k]), len(e), sum(e) / len(e), b))
 if traffic:
-    for k in traffic:
+    for k in list(traffic):
         traffic[k]["hbm_bytes_per_launch"] = sum(traffic[k].get(n, 0.0) for n in ("FETCH_SIZE", "WRITE_SIZE"))
         if k in eff:
             traffic[k]["trace_avg_effective_us"] = eff[k] / 1e3
+    traffic["_source"] = ("scripts/profile_bench.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py "
+                          "--steps 1 --warmup 0 --max-iters 200`, 2 x FETCH_SIZE + WRITE_SIZE per effective launch"
+                          % os.path.basename(out.rstrip("/")).replace("prof_", ""))
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print("\n## HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
     for k, v in traffic.items():
-        print("%-14s %.4g bytes" % (k, v["hbm_bytes_per_launch"]))
+        if isinstance(v, dict):
+            print("%-14s %.4g bytes" % (k, v["hbm_bytes_per_launch"]))
 
 # diagnostic pass: L2 hit rate and the wave-cycle split of the two sweeps
 f = find("pmc_l2", "*counter_collection.csv")

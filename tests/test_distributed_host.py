@@ -156,3 +156,54 @@ def test_comm_two_ranks_gloo(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert p.stdout.count("COMM_OK") == 2
+
+
+NEGOTIATE_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group(backend="gloo")
+from mundy_amd import capi, distributed as D
+r = dist.get_rank()
+cpu = torch.device("cpu")
+made = []
+def run(fail_id_on_rank0, fail_create_on):
+    def make_id():
+        if fail_id_on_rank0:
+            raise RuntimeError("no unique id (librccl not loadable)")
+        return bytes(range(capi.COMM_ID_BYTES %% 256)) + bytes(capi.COMM_ID_BYTES - capi.COMM_ID_BYTES %% 256)
+    def create(raw):
+        assert raw == bytes(range(capi.COMM_ID_BYTES %% 256)) + bytes(capi.COMM_ID_BYTES - capi.COMM_ID_BYTES %% 256)
+        if r in fail_create_on:
+            raise RuntimeError("create refused on rank %%d" %% r)
+        made.append(1)
+    return D.negotiate_direct_transport(None, r, make_id, create, cpu)
+# every combination ends in the same decision on both ranks and no rank is left inside a collective (the advisor's
+# case: rank 0 alone fails to make the id; before, it skipped the broadcast the other ranks were waiting in)
+ok, err = run(True, ())
+assert not ok and err is not None
+ok, err = run(False, (1,))
+assert not ok and ((err is not None) == (r == 1))
+ok, err = run(False, (0,))
+assert not ok and ((err is not None) == (r == 0))
+ok, err = run(False, ())
+assert ok and err is None and len(made) >= 1
+# a sub-group keeps its rank numbering in the fallback group
+g = dist.new_group(ranks=[1, 0])
+ok, err = D.negotiate_direct_transport(g, dist.get_rank(g), lambda: bytes(capi.COMM_ID_BYTES), lambda raw: None, cpu)
+assert ok
+dist.barrier()
+dist.destroy_process_group()
+print("NEGOTIATE_OK", r)
+'''
+
+
+def test_direct_transport_negotiation_two_ranks_gloo(tmp_path):
+    # ADVICE r1 (medium): the RCCL -> host fallback must keep the control flow identical on all ranks whichever rank
+    # fails at whichever point
+    script = tmp_path / "negotiate_worker.py"
+    script.write_text(NEGOTIATE_WORKER % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert p.stdout.count("NEGOTIATE_OK") == 2

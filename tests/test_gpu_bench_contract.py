@@ -27,12 +27,21 @@ def test_default_line_has_the_contract_keys():
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "timesteps/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["scaling"] == "strong" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
     assert all(d["config"]["converged"]) and d["config"]["contacts_per_gpu"] > 100_000
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert key in r, key
+    # the body sweep's bytes are those its activity masks require, with the active fraction measured in the run
+    kb = r if r["kernel"].startswith("k_body") else d["k_body"]
+    assert 0.0 < kb["active_contact_fraction"] < 1.0
+    assert kb["bytes_per_launch"] == pytest.approx(
+        88.0 * kb["active_contact_fraction"] * d["config"]["contacts_per_gpu"] + 124.0 * d["config"]["bodies_per_gpu"], rel=1e-3)
+    # the second, labelled figure: the same step from the relaxed packing
+    rp = d["relaxed_packing"]
+    assert "NOT the headline" in rp["what"] and all(rp["converged"]) and rp["timesteps_per_sec"] > 0
+    assert max(rp["bbpgd_iters_per_step"]) < min(d["config"]["bbpgd_iters_per_step"])
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0.0 < r["frac"] < 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3)
     c = d["cpu_baseline"]
@@ -54,3 +63,40 @@ def test_mixed_line_names_configs4():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert "configs[4]" in d["config"]["workload"] and "mixed" in d["metric"]
     assert d["config"]["converged"] == [True] and d["stage_ms"]["narrowphase"] > 0 and d["roofline"]["bound"] == "hbm"
+
+
+def _torchrun(extra, env=None):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--distributed",
+           "--bodies", "30000", "--steps", "1", "--warmup", "1"] + extra
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", **(env or {})))
+
+
+def test_partitioned_line_is_configs3_and_refuses_a_host_staged_halo():
+    # one rank over RCCL: the partitioned path prints configs[3]'s line ("strong": the one fixed-size system) ...
+    p = _torchrun([])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["scaling"] == "strong" and "configs[3]" in d["config"]["workload"] and d["config"]["transport"] == "rccl"
+    assert d["config"]["bodies_total"] == 30000 and "constraint_updates_per_sec" in d
+    assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
+    assert d["config"]["contact_imbalance_max_over_mean"] == 1.0
+    # ... a run whose RCCL communicator could not be made falls back to the host-staged transport and prints NO line
+    p = _torchrun([], env={"MUNDY_TEST_FAIL_RCCL": "1"})
+    assert p.returncode != 0 and "refusing to print a scaling line" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # ... unless told to (development boxes), and then the line says which wire ran
+    p = _torchrun(["--allow-host-transport"], env={"MUNDY_TEST_FAIL_RCCL": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["transport"] == "host"
+    # the weak line keeps its own metric name
+    p = _torchrun(["--weak"])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["scaling"] == "weak" and "PER GPU" in d["metric"]
