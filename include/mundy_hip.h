@@ -143,9 +143,14 @@ int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, cons
  * Predicate (defined here; the reference's is third party): MHIP_SEARCH_SPHERES = bounding spheres
  * (centre, bounding_radius + buffer), closed test d^2 <= (Ri + Rj)^2; MHIP_SEARCH_AABB = aabb grown by buffer on every
  * face, closed interval test of geom::intersects (AABB.hpp:420-431).  Results are canonical: sorted by (i, j);
- * symmetric = 0 gives unique i < j pairs, 1 gives both orientations, never i == j.
+ * symmetric = 0 gives unique i < j pairs, 1 gives both orientations; i == j only with include_self.
+ * Search method (GenNeighborLinks::set_search_method, :443-447; the reference's default is stk::search::MORTON_LBVH):
+ * the uniform cell grid (cell edge = twice the largest reach; fastest when bodies are of similar size), a linear BVH over
+ * 63-bit Morton keys (adapts to each body's size: size-disperse systems), or AUTO = LBVH when the largest reach exceeds
+ * twice the mean reach (free boundaries; the periodic search always runs on the grid).  Same lists either way.
  * ---------------------------------------------------------------------------------------------------------------- */
 enum { MHIP_SEARCH_SPHERES = 0, MHIP_SEARCH_AABB = 1 };
+enum { MHIP_SEARCH_METHOD_AUTO = 0, MHIP_SEARCH_METHOD_GRID = 1, MHIP_SEARCH_METHOD_MORTON_LBVH = 2 };
 
 typedef struct mhip_broadphase* mhip_broadphase_t;
 
@@ -155,6 +160,8 @@ typedef struct {
   double buffer;   /* search buffer added to every volume */
   int periodic;    /* 0 free space, 1 orthorhombic periodic box [0,box) */
   double box[3];
+  int method;       /* MHIP_SEARCH_METHOD_* (0 = AUTO) */
+  int include_self; /* 0 = ExcludeSelfInteractions (GenNeighborLinkers.hpp:185-200), 1 = (i, i) is a result */
 } mhip_broadphase_config;
 
 int mhip_broadphase_create(mhip_broadphase_t* handle);
@@ -168,6 +175,43 @@ int mhip_broadphase_build(mhip_broadphase_t handle, const mhip_broadphase_config
 /* Copies the pair list ([num_pairs][2] int32) and/or the CSR form (row_ptr[n+1], col[num_pairs]); NULL skips. */
 int mhip_broadphase_get_pairs(mhip_broadphase_t handle, int32_t* pairs, int32_t* row_ptr, int32_t* col,
                               mhip_stream_t stream);
+/* The rest of the seam: who may pair with whom, and results in the reference's vocabulary.
+ *   set_sets        acts_on(source_selector, target_selector) (GenNeighborLinkers.hpp:486-507): is_source / is_target
+ *                   [n] bytes (NULL = every body); a result (s, t) needs s in the sources and t in the targets -- with
+ *                   symmetric = 0 additionally s < t.  The reference's domain and range views are two selections of one
+ *                   entity population (specializations_, :626-629), which is what the two masks express.
+ *   set_exclusions  search_filters::ExcludeConnectedEntities (:202-236) and the existing-link set kept when duplicate
+ *                   links are not allowed (:91-113, :643-648): CSR (ex_ptr [n + 1], ex_idx) of partners a source must
+ *                   not be paired with; the ordered pair (s, t) is dropped when t is in the list of s.
+ *   set_identities  (stk::mesh::EntityId, owner rank) of every body (:575-584); NULL id = the local index, NULL owner = 0
+ * All three copy their arrays into the handle; sets / exclusions invalidate the current list (the next needs_rebuild
+ * says yes).  get_ident_pairs returns the list as IdentProcIntersection rows (domain id, domain proc, range id, range
+ * proc), any output NULL to skip.  method_used: which structure the last build ran on (MHIP_SEARCH_METHOD_*). */
+int mhip_broadphase_set_sets(mhip_broadphase_t handle, size_t n, const unsigned char* is_source,
+                             const unsigned char* is_target, mhip_stream_t stream);
+int mhip_broadphase_set_exclusions(mhip_broadphase_t handle, size_t n, const int32_t* ex_ptr, const int32_t* ex_idx,
+                                   size_t num_entries, mhip_stream_t stream);
+int mhip_broadphase_set_identities(mhip_broadphase_t handle, size_t n, const uint64_t* entity_id,
+                                   const int32_t* owner_rank, mhip_stream_t stream);
+int mhip_broadphase_get_ident_pairs(mhip_broadphase_t handle, uint64_t* source_id, int32_t* source_proc,
+                                    uint64_t* target_id, int32_t* target_proc, mhip_stream_t stream);
+int mhip_broadphase_method_used(mhip_broadphase_t handle, int* method /*[host]*/);
+/* The list in MuNDy's link layout, so that it can be handed to LinkData without the host-serial
+ * request_link loop of GenNeighborLinkers.hpp:714-738:
+ *   export_coo  one row per link, as the fields LinkCOOData keeps per link entity (LinkMetaData.hpp:102-106): the link's
+ *               own id first_link_id + k, MUNDY_LINKED_ENTITY_IDS [P][2] (source, target), MUNDY_LINKED_ENTITY_RANKS
+ *               [P][2] (bytes); any output NULL to skip
+ *   export_crs  entity -> connected links, as LinkCRSBucketConn keeps it per entity bucket (LinkCRSBucketConn.hpp:
+ *               183-191): entities in index order cut into buckets of bucket_capacity (STK's default bucket: 512);
+ *               num_connected_links [n]; sparse_connectivity_offsets [num_buckets][capacity + 1], bucket local;
+ *               sparse_connectivity [2 P] link ids (a link is connected to both its entities), ascending per entity;
+ *               bucket_begin [num_buckets + 1] = where each bucket's connectivity starts in sparse_connectivity */
+int mhip_links_export_coo(mhip_broadphase_t handle, uint64_t first_link_id, int source_rank, int target_rank,
+                          uint64_t* link_id, uint64_t* linked_entity_ids, unsigned char* linked_entity_ranks,
+                          mhip_stream_t stream);
+int mhip_links_export_crs(mhip_broadphase_t handle, uint64_t first_link_id, unsigned bucket_capacity,
+                          unsigned* num_connected_links, unsigned* sparse_connectivity_offsets,
+                          uint64_t* sparse_connectivity, uint64_t* bucket_begin, mhip_stream_t stream);
 /* Rebuild rule: *flag [host] = 1 iff any centre moved more than 0.5*buffer since the last build (synchronises). */
 int mhip_broadphase_needs_rebuild(mhip_broadphase_t handle, size_t n, const double* center, int* flag /*[host]*/,
                                   mhip_stream_t stream);

@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -412,6 +413,55 @@ inline PeriodicScaledMetric periodic_scaled_metric_from_unit_cell(const Point<do
 // ---- neighbour links ------------------------------------------------------------------------------------------------------
 namespace mesh {
 
+/// search_filters (GenNeighborLinkers.hpp:139-283).  The reference composes arbitrary predicates over the search results
+/// (SearchFilter<ExecSpace, Predicates...>); functors cannot cross the C ABI, so the two predicates it ships are values
+/// here and make_search_filter combines them.
+namespace search_filters {
+struct ExcludeSelfInteractions {};  // :185-200
+/// :202-236 -- a source is not linked to the targets it is connected to.  The connectivity is a CSR over the bodies
+/// (device arrays; it plays the part of ngp_mesh.get_connected_entities).
+struct ExcludeConnectedEntities {
+  size_t num_bodies;
+  const int32_t* conn_ptr;  // [num_bodies + 1]
+  const int32_t* conn_idx;
+  size_t num_entries;
+};
+struct SearchFilter {
+  bool exclude_self = false;
+  bool has_connected = false;
+  ExcludeConnectedEntities connected{0, nullptr, nullptr, 0};
+};
+inline void add_predicate(SearchFilter& f, const ExcludeSelfInteractions&) { f.exclude_self = true; }
+inline void add_predicate(SearchFilter& f, const ExcludeConnectedEntities& c) {
+  f.has_connected = true;
+  f.connected = c;
+}
+template <class... Predicates>
+std::shared_ptr<SearchFilter> make_search_filter(const Predicates&... predicates) {  // :269-272
+  auto f = std::make_shared<SearchFilter>();
+  (add_predicate(*f, predicates), ...);
+  return f;
+}
+}  // namespace search_filters
+
+/// one row of the result in stk::search's vocabulary: IdentProcIntersection (GenNeighborLinkers.hpp:118-121)
+struct IdentProcPairs {
+  DeviceArray<uint64_t> source_id, target_id;
+  DeviceArray<int32_t> source_proc, target_proc;
+};
+/// the list in LinkCOOData's per-link fields (LinkMetaData.hpp:102-106)
+struct LinkCOO {
+  DeviceArray<uint64_t> link_id, linked_entity_ids;  // [P], [P][2]
+  DeviceArray<unsigned char> linked_entity_ranks;    // [P][2]
+};
+/// entity -> connected links as LinkCRSBucketConn keeps it per bucket (LinkCRSBucketConn.hpp:183-191)
+struct LinkCRS {
+  unsigned bucket_capacity = 0;
+  size_t num_buckets = 0;
+  DeviceArray<unsigned> num_connected_links, sparse_connectivity_offsets;  // [n], [num_buckets][capacity + 1]
+  DeviceArray<uint64_t> sparse_connectivity, bucket_begin;                 // [2 P], [num_buckets + 1]
+};
+
 class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder + generate), device arrays instead of STK
  public:
   GenNeighborLinks() { check(mhip_broadphase_create(&h_)); }
@@ -426,6 +476,39 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
   GenNeighborLinks& set_search_kind(int kind) { guard("search kind"); cfg_.search_kind = kind; return *this; }
   GenNeighborLinks& set_periodic_box(double lx, double ly, double lz) {
     guard("periodic box"); cfg_.periodic = 1; cfg_.box[0] = lx; cfg_.box[1] = ly; cfg_.box[2] = lz; return *this;
+  }
+  /// stk::search::SearchMethod (:443-447; the reference's default is MORTON_LBVH): MHIP_SEARCH_METHOD_*
+  GenNeighborLinks& set_search_method(int method) { guard("search method"); cfg_.method = method; return *this; }
+  int get_search_method() const { return cfg_.method; }
+  /// :449-455.  Without a filter every body also meets itself, as stk's coarse_search reports it.
+  GenNeighborLinks& set_search_filter(std::shared_ptr<search_filters::SearchFilter> filter) {
+    guard("search filter");
+    filter_ = std::move(filter);
+    cfg_.include_self = (filter_ && filter_->exclude_self) ? 0 : 1;
+    if (filter_ && filter_->has_connected) {
+      const auto& c = filter_->connected;
+      check(mhip_broadphase_set_exclusions(h_, c.num_bodies, c.conn_ptr, c.conn_idx, c.num_entries, nullptr));
+    }
+    return *this;
+  }
+  /// acts_on(source_selector, target_selector, ...) (:486-507): byte masks over the bodies (device arrays, nullptr = all)
+  GenNeighborLinks& acts_on(size_t n, const unsigned char* source_mask, const unsigned char* target_mask) {
+    guard("source/targets");
+    check(mhip_broadphase_set_sets(h_, n, source_mask, target_mask, nullptr));
+    return *this;
+  }
+  /// (stk::mesh::EntityId, owner rank) of every body (:575-584); nullptr id = the local index, nullptr owner = 0
+  GenNeighborLinks& set_identities(size_t n, const uint64_t* entity_id, const int32_t* owner_rank) {
+    check(mhip_broadphase_set_identities(h_, n, entity_id, owner_rank, nullptr));
+    return *this;
+  }
+  /// the already-linked neighbours (get_linked_neighbors_set, :91-113), dropped from the results when duplicate links
+  /// are not allowed (set_allow_duplicate_links(false), :422-427): same CSR form as ExcludeConnectedEntities, and it
+  /// replaces that filter's list -- merge the two lists when both are wanted
+  GenNeighborLinks& set_existing_linked_neighbors(size_t n, const int32_t* ptr, const int32_t* idx, size_t entries) {
+    check(mhip_broadphase_set_exclusions(h_, n, ptr, idx, entries, nullptr));
+    generated_ = false;
+    return *this;
   }
   void concretize() {
     if (concretized_) throw std::runtime_error("Cannot concretize more than once.");
@@ -462,6 +545,35 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
     check(mhip_broadphase_get_pairs(h_, p.data(), nullptr, nullptr, stream));
     return p;
   }
+  /// the links as IdentProcIntersection rows
+  IdentProcPairs ident_links(mhip_stream_t stream = nullptr) const {
+    IdentProcPairs r{DeviceArray<uint64_t>(num_pairs_), DeviceArray<uint64_t>(num_pairs_),
+                     DeviceArray<int32_t>(num_pairs_), DeviceArray<int32_t>(num_pairs_)};
+    check(mhip_broadphase_get_ident_pairs(h_, r.source_id.data(), r.source_proc.data(), r.target_id.data(),
+                                          r.target_proc.data(), stream));
+    return r;
+  }
+  /// the links in MuNDy's link layout, ready for LinkData without the host-serial request_link loop (:714-738)
+  LinkCOO export_coo(uint64_t first_link_id, int source_rank, int target_rank, mhip_stream_t stream = nullptr) const {
+    LinkCOO r{DeviceArray<uint64_t>(num_pairs_), DeviceArray<uint64_t>(2 * num_pairs_),
+              DeviceArray<unsigned char>(2 * num_pairs_)};
+    check(mhip_links_export_coo(h_, first_link_id, source_rank, target_rank, r.link_id.data(),
+                                r.linked_entity_ids.data(), r.linked_entity_ranks.data(), stream));
+    return r;
+  }
+  LinkCRS export_crs(uint64_t first_link_id, unsigned bucket_capacity = 512, mhip_stream_t stream = nullptr) const {
+    LinkCRS r;
+    r.bucket_capacity = bucket_capacity;
+    r.num_buckets = (n_ + bucket_capacity - 1) / bucket_capacity;
+    r.num_connected_links = DeviceArray<unsigned>(n_);
+    r.sparse_connectivity_offsets = DeviceArray<unsigned>(r.num_buckets * (bucket_capacity + 1));
+    r.sparse_connectivity = DeviceArray<uint64_t>(2 * num_pairs_);
+    r.bucket_begin = DeviceArray<uint64_t>(r.num_buckets + 1);
+    check(mhip_links_export_crs(h_, first_link_id, bucket_capacity, r.num_connected_links.data(),
+                                r.sparse_connectivity_offsets.data(), r.sparse_connectivity.data(),
+                                r.bucket_begin.data(), stream));
+    return r;
+  }
   /// the same into a caller-owned buffer that only grows (a time loop then stops allocating); returns its data()
   int32_t* links_into(DeviceArray<int32_t>& out, mhip_stream_t stream = nullptr) const {
     if (out.size() < 2 * num_pairs_) out = DeviceArray<int32_t>(2 * num_pairs_ + num_pairs_ / 4 + 16);
@@ -474,7 +586,10 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
     if (concretized_) throw std::runtime_error(std::string("Cannot set ") + what + " after concretization.");
   }
   mhip_broadphase_t h_ = nullptr;
-  mhip_broadphase_config cfg_{MHIP_SEARCH_SPHERES, 0, 0.0, 0, {0, 0, 0}};
+  // no filter set: the historical behaviour of this adapter (self pairs excluded) is kept until set_search_filter is
+  // called, after which the filter decides as in the reference
+  mhip_broadphase_config cfg_{MHIP_SEARCH_SPHERES, 0, 0.0, 0, {0, 0, 0}, MHIP_SEARCH_METHOD_AUTO, 0};
+  std::shared_ptr<search_filters::SearchFilter> filter_;
   bool concretized_ = false, generated_ = false;
   size_t num_pairs_ = 0, n_ = 0;
 };

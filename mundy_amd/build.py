@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libmundy_hip.so")
-SOURCES = ["runtime.hip", "geometry.hip", "broadphase.hip", "convex.hip", "reorder.hip", "halo.hip", "ellipsoid.hip", "mixed.hip", "dist.hip"]
+SOURCES = ["runtime.hip", "sort.hip", "geometry.hip", "broadphase.hip", "convex.hip", "reorder.hip", "halo.hip", "ellipsoid.hip", "mixed.hip", "dist.hip"]
 HEADERS = ["mhip_internal.hpp", "geom_device.hpp", "ellipsoid_device.hpp", "ellipsoid_lockstep.hpp", os.path.join("..", "..", "include", "mundy_hip.h")]
 # -ffp-contract=off: a*b+c stays two roundings so per-element results are bit-identical to the scalar reference order
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

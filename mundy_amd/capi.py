@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmundy_hip.so")
 
 SUCCESS, ERR_INVALID_ARGUMENT, ERR_LOGIC, ERR_RUNTIME, ERR_HIP, ERR_NO_DEVICE = range(6)
 SEARCH_SPHERES, SEARCH_AABB = 0, 1
+SEARCH_METHOD_AUTO, SEARCH_METHOD_GRID, SEARCH_METHOD_MORTON_LBVH = 0, 1, 2
 SPACE_UNCONSTRAINED, SPACE_LOWER_BOUND, SPACE_UPPER_BOUND, SPACE_BOUNDED = 0, 1, 2, 3
 RESIDUAL_PROJECTED_DIFF, RESIDUAL_PROJECTED_GRADIENT = 0, 1
 
@@ -20,7 +21,7 @@ class MhipError(RuntimeError):
 
 class BroadphaseConfig(C.Structure):
     _fields_ = [("search_kind", C.c_int), ("symmetric", C.c_int), ("buffer", C.c_double), ("periodic", C.c_int),
-                ("box", C.c_double * 3)]
+                ("box", C.c_double * 3), ("method", C.c_int), ("include_self", C.c_int)]
 
 
 class Space(C.Structure):
@@ -94,6 +95,13 @@ SIGNATURES = {
     "mhip_broadphase_build": [_vp, C.POINTER(BroadphaseConfig), _sz, _vp, _vp, _vp, C.POINTER(_sz), _vp],
     "mhip_broadphase_get_pairs": [_vp, _vp, _vp, _vp, _vp],
     "mhip_broadphase_needs_rebuild": [_vp, _sz, _vp, C.POINTER(_i), _vp],
+    "mhip_broadphase_set_sets": [_vp, _sz, _vp, _vp, _vp],
+    "mhip_broadphase_set_exclusions": [_vp, _sz, _vp, _vp, _sz, _vp],
+    "mhip_broadphase_set_identities": [_vp, _sz, _vp, _vp, _vp],
+    "mhip_broadphase_get_ident_pairs": [_vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_broadphase_method_used": [_vp, C.POINTER(_i)],
+    "mhip_links_export_coo": [_vp, C.c_uint64, _i, _i, _vp, _vp, _vp, _vp],
+    "mhip_links_export_crs": [_vp, C.c_uint64, C.c_uint, _vp, _vp, _vp, _vp, _vp],
     "mhip_deep_copy": [_sz, _vp, _vp, _vp],
     "mhip_fill": [_sz, _vp, _d, _vp],
     "mhip_axpby": [_sz, _d, _vp, _d, _vp, _vp],

@@ -1,14 +1,23 @@
-// broadphase.hip -- neighbour-list construction (seam S3) on a uniform cell grid.
+// broadphase.hip -- neighbour-list construction (seam S3): a uniform cell grid for bodies of similar size and a linear
+// BVH over 63-bit Morton keys (the reference's search method, stk::search::MORTON_LBVH, GenNeighborLinkers.hpp:318,
+// :658) for size-disperse systems, where one large body would set the cell edge for everybody.
 //
-// Pipeline (all on the device; one host read of the pair total, where the reference's filter_view reads its scan
+// Grid pipeline (all on the device; one host read of the pair total, where the reference's filter_view reads its scan
 // total, GenNeighborLinkers.hpp:155-156):
-//   k_bounds / k_grid_params   bin-point bounds, max reach -> grid with cell edge >= 2*reach (27-cell stencil suffices)
+//   k_bounds / k_grid_params   bin-point bounds, max and mean reach -> grid with cell edge >= 2*reach (27-cell stencil)
 //   k_cell_count, scan, k_cell_scatter   counting sort of bodies into cells; 64-byte search records written in cell
 //                              order so a wavefront walking a cell reads contiguous lines
-//   k_pairs<COUNT>, scan, k_pairs<FILL>  per body: test the 27 neighbouring cells, count, then fill its CSR row,
-//                              sort the row -> pairs sorted by (i, j) without a global sort
+//   k_pairs<COUNT>, scan, k_pairs<FILL>  per body: test the 27 neighbouring cells, count, then fill its CSR row
+// LBVH pipeline:
+//   k_morton_keys, radix_sort_u64 (sort.hip)   63-bit keys of the bin points, records gathered in key order
+//   k_lbvh_build    one thread per internal node: Karras' binary radix tree from the longest common prefixes
+//   k_lbvh_refit    bottom-up box union, second arriver at a node proceeds (agent-scope fences around the ticket)
+//   k_lbvh_ropes    skip pointers -> stackless pre-order traversal
+//   k_lbvh_pairs<COUNT>, scan, k_lbvh_pairs<FILL>   per body: traverse, exact predicate at the leaves
+// Both: rows of <= 32 partners are sorted and emitted by their thread; longer rows (a large body among small ones) go
+// through the workgroup radix sort of sort.hip -> pairs sorted by (i, j) without a global sort.
 // The predicate is evaluated with the lower body index first, exactly as the CPU oracle does, so pair sets are
-// bit-identical.  Integer/comparison work only: HBM/L2-bound, no MFMA.
+// bit-identical whichever structure found them.  Integer/comparison work only: HBM/L2-bound, no MFMA.
 #include <cstdlib>
 #include <initializer_list>
 
@@ -34,7 +43,26 @@ struct BpArgs {
   int kind, symmetric, periodic;
   double buffer;
   Periodic pm;
+  // seam S3 result shaping (GenNeighborLinkers.hpp: acts_on(source, target) :486-507, search_filters :185-245):
+  int include_self;                  // 0 = ExcludeSelfInteractions (the default)
+  const unsigned char* is_source;    // [n] or null (every body is a source)
+  const unsigned char* is_target;    // [n] or null
+  const int32_t* ex_ptr;             // CSR of partners a source must not be paired with (ExcludeConnectedEntities;
+  const int32_t* ex_idx;             //   already-linked neighbours when duplicate links are not allowed), or null
 };
+
+// does the ordered pair (source i, target j), i != j or include_self, pass the sets and the filters?
+__device__ inline bool pair_allowed(const BpArgs& A, int i, int j) {
+  if (i == j && !A.include_self) return false;
+  if (!A.symmetric && j < i) return false;
+  if (A.is_target && !A.is_target[j]) return false;
+  if (A.ex_ptr) {
+    for (int32_t k = A.ex_ptr[i], e = A.ex_ptr[i + 1]; k < e; ++k)
+      if (A.ex_idx[k] == j) return false;
+  }
+  return true;
+}
+__device__ inline bool is_source(const BpArgs& A, int i) { return !A.is_source || A.is_source[i]; }
 
 __device__ inline void body_volume(const BpArgs& A, size_t i, const double* __restrict__ aabb,
                                    const double* __restrict__ center, const double* __restrict__ brad, SearchRec& r,
@@ -63,14 +91,14 @@ __device__ inline void body_volume(const BpArgs& A, size_t i, const double* __re
   r.pad = 0;
 }
 
-// partials[block][7] = min xyz, max xyz, reach
+// partials[block][8] = min xyz, max xyz, max reach, sum of reach
 __global__ void __launch_bounds__(kBlock)
     k_bounds(size_t n, BpArgs A, const double* __restrict__ aabb, const double* __restrict__ center,
              const double* __restrict__ brad, double* __restrict__ partials) {
   __shared__ double scratch[kBlock / 64];
   double mn[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308};
   double mx[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
-  double reach = 0.0;
+  double reach = 0.0, rsum = 0.0;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     SearchRec r;
     V3 p;
@@ -79,38 +107,51 @@ __global__ void __launch_bounds__(kBlock)
     mn[0] = dmin(mn[0], p.x); mn[1] = dmin(mn[1], p.y); mn[2] = dmin(mn[2], p.z);
     mx[0] = dmax(mx[0], p.x); mx[1] = dmax(mx[1], p.y); mx[2] = dmax(mx[2], p.z);
     reach = dmax(reach, rc);
+    rsum += rc;
   }
   for (int k = 0; k < 3; ++k) {
     const double a = -block_max(-mn[k], scratch);
     const double b = block_max(mx[k], scratch);
     if (threadIdx.x == 0) {
-      partials[7 * blockIdx.x + k] = a;
-      partials[7 * blockIdx.x + 3 + k] = b;
+      partials[8 * blockIdx.x + k] = a;
+      partials[8 * blockIdx.x + 3 + k] = b;
     }
   }
   const double rr = block_max(reach, scratch);
-  if (threadIdx.x == 0) partials[7 * blockIdx.x + 6] = rr;
+  const double rs = block_sum(rsum, scratch);  // only steers the choice of structure: its rounding is immaterial
+  if (threadIdx.x == 0) {
+    partials[8 * blockIdx.x + 6] = rr;
+    partials[8 * blockIdx.x + 7] = rs;
+  }
 }
 
 __global__ void __launch_bounds__(kBlock) k_grid_params(int nparts, const double* __restrict__ partials, BpArgs A, int cell_capacity,
-                              GridParams* __restrict__ gp) {
+                              GridParams* __restrict__ gp, double* __restrict__ summary /* 8 doubles */) {
   __shared__ double scratch[kBlock / 64];
   double mn[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308};
   double mx[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
-  double reach = 0.0;
+  double reach = 0.0, rsum = 0.0;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
     for (int k = 0; k < 3; ++k) {
-      mn[k] = dmin(mn[k], partials[7 * i + k]);
-      mx[k] = dmax(mx[k], partials[7 * i + 3 + k]);
+      mn[k] = dmin(mn[k], partials[8 * i + k]);
+      mx[k] = dmax(mx[k], partials[8 * i + 3 + k]);
     }
-    reach = dmax(reach, partials[7 * i + 6]);
+    reach = dmax(reach, partials[8 * i + 6]);
+    rsum += partials[8 * i + 7];
   }
   for (int k = 0; k < 3; ++k) {
     mn[k] = -block_max(-mn[k], scratch);
     mx[k] = block_max(mx[k], scratch);
   }
   reach = block_max(reach, scratch);
+  rsum = block_sum(rsum, scratch);
   if (threadIdx.x != 0) return;
+  for (int k = 0; k < 3; ++k) {  // scene box of the bin points, max reach, sum of reach: read by the host and the LBVH
+    summary[k] = mn[k];
+    summary[3 + k] = mx[k];
+  }
+  summary[6] = reach;
+  summary[7] = rsum;
   double h = 2.0 * reach * (1.0 + 1e-12);
   if (!(h > 0.0)) h = 1.0;
   for (int k = 0; k < 3; ++k) {
@@ -223,17 +264,59 @@ __device__ inline int axis_neighbours(int c, int nc, bool periodic, int out[3]) 
   return m;
 }
 
+// Row of body i: cnt unsorted partners at col[base ..).  Rows of up to kShortSegment partners are sorted (insertion
+// sort, rows are short) and emitted as (i, j) pairs by their own thread; longer ones are queued for the workgroup sort.
+struct RowSink {
+  int32_t* col;
+  int2* pairs;
+  int32_t* long_count;
+  int32_t* long_list;
+};
+__device__ inline void finish_row(const RowSink& out, int i, int32_t base, int cnt) {
+  if (cnt > kShortSegment) {
+    out.long_list[atomicAdd(out.long_count, 1)] = i;
+    return;
+  }
+  int32_t* col = out.col;
+  for (int a = 1; a < cnt; ++a) {
+    const int32_t v = col[base + a];
+    int b = a - 1;
+    while (b >= 0 && col[base + b] > v) {
+      col[base + b + 1] = col[base + b];
+      --b;
+    }
+    col[base + b + 1] = v;
+  }
+  for (int a = 0; a < cnt; ++a) out.pairs[base + a] = make_int2(i, col[base + a]);
+}
+// emits the pairs of the queued rows once sort_listed_segments_u32 has sorted them: one workgroup per row
+__global__ void __launch_bounds__(kBlock) k_emit_long_rows(const int32_t* __restrict__ row_ptr,
+                                                          const int32_t* __restrict__ col,
+                                                          const int32_t* __restrict__ long_count,
+                                                          const int32_t* __restrict__ long_list,
+                                                          int2* __restrict__ pairs) {
+  const int nlong = *long_count;
+  for (int q = blockIdx.x; q < nlong; q += gridDim.x) {
+    const int i = long_list[q];
+    for (int32_t k = row_ptr[i] + threadIdx.x; k < row_ptr[i + 1]; k += blockDim.x) pairs[k] = make_int2(i, col[k]);
+  }
+}
+
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
     k_pairs(size_t n, BpArgs A, const GridParams* __restrict__ gpp, const SearchRec* __restrict__ recs,
             const int32_t* __restrict__ slot_cell, const int32_t* __restrict__ cell_ptr,
-            int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ col,
-            int2* __restrict__ pairs) {
+            int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, RowSink out) {
   const GridParams gp = *gpp;
   const size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (s >= n) return;
   const SearchRec me = recs[s];
   const int i = static_cast<int>(me.id);
+  if (!is_source(A, i)) {
+    if (!FILL) counts[i] = 0;
+    return;
+  }
+  int32_t* col = out.col;
   const int cid = slot_cell[s];
   const int cx = cid % gp.nc[0], cy = (cid / gp.nc[0]) % gp.nc[1], cz = cid / (gp.nc[0] * gp.nc[1]);
   int xs[3], ys[3], zs[3];
@@ -250,8 +333,8 @@ __global__ void __launch_bounds__(kBlock)
         for (int32_t t = beg; t < end; ++t) {
           const SearchRec o = recs[t];
           const int j = static_cast<int>(o.id);
-          if (j == i || (!A.symmetric && j < i)) continue;
-          const bool hit = (i < j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
+          if (!pair_allowed(A, i, j)) continue;
+          const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
           if (hit) {
             if (FILL) col[base + cnt] = j;
             ++cnt;
@@ -262,17 +345,7 @@ __global__ void __launch_bounds__(kBlock)
     counts[i] = cnt;
     return;
   }
-  // sort the row ascending (rows are short), then emit (i, j)
-  for (int a = 1; a < cnt; ++a) {
-    const int32_t v = col[base + a];
-    int b = a - 1;
-    while (b >= 0 && col[base + b] > v) {
-      col[base + b + 1] = col[base + b];
-      --b;
-    }
-    col[base + b + 1] = v;
-  }
-  for (int a = 0; a < cnt; ++a) pairs[base + a] = make_int2(i, col[base + a]);
+  finish_row(out, i, base, cnt);
 }
 
 // The same search with the candidates staged through LDS (free boundaries; the periodic search keeps k_pairs, whose
@@ -289,9 +362,9 @@ template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
     k_pairs_lds(size_t n, BpArgs A, const GridParams* __restrict__ gpp, const SearchRec* __restrict__ recs,
                 const int32_t* __restrict__ slot_cell, const int32_t* __restrict__ cell_ptr,
-                int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, int32_t* __restrict__ col,
-                int2* __restrict__ pairs) {
+                int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, RowSink out) {
   __shared__ __attribute__((aligned(16))) SearchRec tile[kPairTile];
+  int32_t* col = out.col;
   const GridParams gp = *gpp;
   const size_t s0 = blockIdx.x * (size_t)kBlock;
   const size_t s = s0 + threadIdx.x;
@@ -308,6 +381,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   const int c_first = slot_cell[s0];
   const int c_last = slot_cell[(s0 + kBlock <= n ? s0 + kBlock : n) - 1];
+  const bool searching = live && is_source(A, i);  // a body outside the source set stages tiles but owns no row
   int cnt = 0;
   const int32_t base = (FILL && live) ? row_ptr[i] : 0;
   for (int dz = -1; dz <= 1; ++dz)
@@ -320,7 +394,7 @@ __global__ void __launch_bounds__(kBlock)
       const int32_t run_beg = cell_ptr[lo], run_end = cell_ptr[hi + 1];
       int32_t my_beg = 0, my_end = 0;  // this lane's candidates in the row: its cells x-1 .. x+1
       const int z = cz + dz, y = cy + dy;
-      if (live && z >= 0 && z < gp.nc[2] && y >= 0 && y < gp.nc[1]) {
+      if (searching && z >= 0 && z < gp.nc[2] && y >= 0 && y < gp.nc[1]) {
         const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < gp.nc[0] ? cx + 1 : gp.nc[0] - 1;
         const int row = (z * gp.nc[1] + y) * gp.nc[0];
         my_beg = cell_ptr[row + x0];
@@ -340,8 +414,8 @@ __global__ void __launch_bounds__(kBlock)
         for (int32_t t = b; t < e; ++t) {
           const SearchRec& o = tile[t - t0];
           const int j = static_cast<int>(o.id);
-          if (j == i || (!A.symmetric && j < i)) continue;
-          const bool hit = (i < j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
+          if (!pair_allowed(A, i, j)) continue;
+          const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
           if (hit) {
             if (FILL) col[base + cnt] = j;
             ++cnt;
@@ -354,16 +428,232 @@ __global__ void __launch_bounds__(kBlock)
     counts[i] = cnt;
     return;
   }
-  for (int a = 1; a < cnt; ++a) {  // sort the row ascending (rows are short), then emit (i, j)
-    const int32_t v = col[base + a];
-    int b = a - 1;
-    while (b >= 0 && col[base + b] > v) {
-      col[base + b + 1] = col[base + b];
-      --b;
-    }
-    col[base + b + 1] = v;
+  finish_row(out, i, base, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Linear BVH over 63-bit Morton keys (free boundaries).  Node numbering: internal nodes 0 .. n-2 (0 is the root), leaf k
+// (k-th body in key order) is node n-1+k.  A body's search volume is boxed (AABB kind: the grown box itself; sphere kind:
+// centre -/+ grown radius); an internal node's box is the union of its children's, so "query box meets node box" is
+// necessary for any leaf below it to pass the exact predicate -- the structure only prunes, the predicate decides, and
+// the lists are those of the grid search and of the brute-force oracle.
+// ------------------------------------------------------------------------------------------------------------------
+struct BvhNode {  // 64 bytes: one line per visited node
+  double lo[3], hi[3];
+  int32_t left;   // first child (node id); its sibling is the left child's rope
+  int32_t rope;   // next node in pre-order once this subtree is done or skipped, -1 = end
+  int32_t pad[2];
+};
+
+__device__ inline unsigned long long spread21(unsigned long long v) {  // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+// summary = (min xyz, max xyz of the bin points, ...) written by k_grid_params
+__global__ void __launch_bounds__(kBlock)
+    k_morton_keys(size_t n, BpArgs A, const double* __restrict__ aabb, const double* __restrict__ center,
+                  const double* __restrict__ brad, const double* __restrict__ summary,
+                  unsigned long long* __restrict__ keys, unsigned* __restrict__ order) {
+  const double ox = summary[0], oy = summary[1], oz = summary[2];
+  const double ex = summary[3] - ox, ey = summary[4] - oy, ez = summary[5] - oz;
+  const double scale = 2097152.0;  // 2^21 lattice points per axis
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    SearchRec r;
+    V3 p;
+    double rc;
+    body_volume(A, i, aabb, center, brad, r, p, rc);
+    auto q = [&](double v, double o, double e) -> unsigned long long {
+      if (!(e > 0.0)) return 0ull;
+      double f = floor((v - o) / e * scale);
+      if (!(f >= 0.0)) f = 0.0;
+      if (f > scale - 1.0) f = scale - 1.0;
+      return static_cast<unsigned long long>(f);
+    };
+    keys[i] = spread21(q(p.x, ox, ex)) | (spread21(q(p.y, oy, ey)) << 1) | (spread21(q(p.z, oz, ez)) << 2);
+    order[i] = static_cast<unsigned>(i);
   }
-  for (int a = 0; a < cnt; ++a) pairs[base + a] = make_int2(i, col[base + a]);
+}
+
+// leaf records in key order; leaf boxes
+__device__ inline void rec_box(const BpArgs& A, const SearchRec& r, double lo[3], double hi[3]) {
+  if (A.kind == MHIP_SEARCH_AABB) {
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = r.a[k];
+      hi[k] = r.b[k];
+    }
+  } else {
+    // the sphere predicate compares rounded squares; pad the box by a few ulps so that a pair the predicate accepts by
+    // rounding is never pruned (the box only prunes)
+    for (int k = 0; k < 3; ++k) {
+      const double pad = 8.9e-16 * (fabs(r.a[k]) + r.b[0]);
+      lo[k] = r.a[k] - r.b[0] - pad;
+      hi[k] = r.a[k] + r.b[0] + pad;
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    k_lbvh_leaves(size_t n, BpArgs A, const double* __restrict__ aabb, const double* __restrict__ center,
+                  const double* __restrict__ brad, const unsigned* __restrict__ order, SearchRec* __restrict__ recs,
+                  int32_t* __restrict__ slot_of) {
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+    SearchRec r;
+    V3 p;
+    double rc;
+    body_volume(A, order[k], aabb, center, brad, r, p, rc);
+    recs[k] = r;
+    slot_of[order[k]] = static_cast<int32_t>(k);
+  }
+}
+
+// length of the common prefix of the (key, position) strings of leaves a and b; -1 outside [0, n)
+__device__ inline int lcp(const unsigned long long* __restrict__ keys, int n, int a, int b) {
+  if (b < 0 || b >= n) return -1;
+  const unsigned long long x = keys[a] ^ keys[b];
+  if (x) return __clzll(static_cast<long long>(x));
+  return 64 + __clz(a ^ b);  // equal keys: the position breaks the tie (Karras 2012, section 4)
+}
+
+// Karras' binary radix tree: internal node i covers the leaf range it shares its longest prefix with
+__global__ void __launch_bounds__(kBlock)
+    k_lbvh_build(int n, const unsigned long long* __restrict__ keys, BvhNode* __restrict__ nodes,
+                 int32_t* __restrict__ right, int32_t* __restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (lcp(keys, n, i, i + 1) - lcp(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = lcp(keys, n, i, i - d);
+  int lmax = 2;
+  while (lcp(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (lcp(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = lcp(keys, n, i, j);
+  int sp = 0;
+  int t = l;
+  do {
+    t = (t + 1) / 2;
+    if (lcp(keys, n, i, i + (sp + t) * d) > dnode) sp += t;
+  } while (t > 1);
+  const int gamma = i + sp * d + (d < 0 ? d : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const int lc = (lo == gamma) ? (n - 1 + gamma) : gamma;
+  const int rc = (hi == gamma + 1) ? (n - 1 + gamma + 1) : (gamma + 1);
+  nodes[i].left = lc;
+  right[i] = rc;
+  parent[lc] = i;
+  parent[rc] = i;
+  if (i == 0) parent[0] = -1;
+}
+
+// Boxes bottom-up: every leaf climbs; at each internal node the first arriver stops, the second (which then knows both
+// children are done) forms the union and climbs on.  Children may have been written on another XCD: the writer releases
+// at agent scope before its ticket, the reader acquires after it.  min / max are exact, so the boxes do not depend on
+// who arrives first.
+__global__ void __launch_bounds__(kBlock)
+    k_lbvh_refit(int n, BpArgs A, const SearchRec* __restrict__ recs, BvhNode* nodes, const int32_t* __restrict__ right,
+                 const int32_t* __restrict__ parent, int32_t* __restrict__ ticket) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int cur = parent[n - 1 + k];
+  while (cur >= 0) {
+    __threadfence();
+    if (atomicAdd(&ticket[cur], 1) == 0) return;
+    __threadfence();
+    double lo[3], hi[3];
+    for (int side = 0; side < 2; ++side) {
+      const int c = side == 0 ? nodes[cur].left : right[cur];
+      double clo[3], chi[3];
+      if (c >= n - 1) {
+        rec_box(A, recs[c - (n - 1)], clo, chi);
+      } else {
+        const volatile BvhNode* cn = nodes + c;
+        for (int a = 0; a < 3; ++a) {
+          clo[a] = cn->lo[a];
+          chi[a] = cn->hi[a];
+        }
+      }
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = side == 0 ? clo[a] : dmin(lo[a], clo[a]);
+        hi[a] = side == 0 ? chi[a] : dmax(hi[a], chi[a]);
+      }
+    }
+    for (int a = 0; a < 3; ++a) {
+      nodes[cur].lo[a] = lo[a];
+      nodes[cur].hi[a] = hi[a];
+    }
+    cur = parent[cur];
+  }
+}
+
+// rope(x) = right sibling if x is a left child, else the rope of its parent
+__global__ void __launch_bounds__(kBlock)
+    k_lbvh_ropes(int n, BvhNode* __restrict__ nodes, const int32_t* __restrict__ right,
+                 const int32_t* __restrict__ parent, int32_t* __restrict__ leaf_rope) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= 2 * n - 1) return;
+  int cur = x, rope = -1;
+  for (;;) {
+    const int p = parent[cur];
+    if (p < 0) break;
+    if (nodes[p].left == cur) {
+      rope = right[p];
+      break;
+    }
+    cur = p;
+  }
+  if (x < n - 1) nodes[x].rope = rope;
+  else leaf_rope[x - (n - 1)] = rope;
+}
+
+// one thread per body (in key order: the lanes of a wave walk neighbouring paths): stackless traversal
+template <bool FILL>
+__global__ void __launch_bounds__(kBlock)
+    k_lbvh_pairs(int n, BpArgs A, const SearchRec* __restrict__ recs, const BvhNode* __restrict__ nodes,
+                 const int32_t* __restrict__ leaf_rope, int32_t* __restrict__ counts,
+                 const int32_t* __restrict__ row_ptr, RowSink out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const SearchRec me = recs[q];
+  const int i = static_cast<int>(me.id);
+  if (!is_source(A, i)) {
+    if (!FILL) counts[i] = 0;
+    return;
+  }
+  double qlo[3], qhi[3];
+  rec_box(A, me, qlo, qhi);
+  int cnt = 0;
+  const int32_t base = FILL ? row_ptr[i] : 0;
+  int node = (n == 1) ? 0 : 0;  // n == 1: node 0 is the only leaf
+  while (node >= 0) {
+    if (node < n - 1) {
+      const BvhNode nd = nodes[node];
+      const bool meet = !(qhi[0] < nd.lo[0] || qhi[1] < nd.lo[1] || qhi[2] < nd.lo[2] || nd.hi[0] < qlo[0] ||
+                          nd.hi[1] < qlo[1] || nd.hi[2] < qlo[2]);
+      node = meet ? nd.left : nd.rope;
+    } else {
+      const int k = node - (n - 1);
+      const SearchRec o = recs[k];
+      const int j = static_cast<int>(o.id);
+      if (pair_allowed(A, i, j)) {
+        const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
+        if (hit) {
+          if (FILL) out.col[base + cnt] = j;
+          ++cnt;
+        }
+      }
+      node = leaf_rope[k];
+    }
+  }
+  if (!FILL) {
+    counts[i] = cnt;
+    return;
+  }
+  finish_row(out, i, base, cnt);
 }
 
 // GenNeighborLinkers.hpp:603-615: moved iff sqrt(dx^2+dy^2+dz^2) > 0.5 * buffer (plain left-to-right sum there)
@@ -381,6 +671,78 @@ __global__ void __launch_bounds__(kBlock) k_moved(size_t n, const double* __rest
   if ((threadIdx.x & 63) == 0 && moved) atomicOr(flag, 1);
 }
 
+// ---- results in the reference's vocabulary -------------------------------------------------------------------------------
+// IdentProcIntersection pairs (GenNeighborLinkers.hpp:118-121): (entity id, owner rank) of source and target
+__global__ void __launch_bounds__(kBlock)
+    k_ident_pairs(size_t np, const int2* __restrict__ pairs, const uint64_t* __restrict__ id,
+                  const int32_t* __restrict__ owner, uint64_t* __restrict__ src_id, int32_t* __restrict__ src_proc,
+                  uint64_t* __restrict__ tgt_id, int32_t* __restrict__ tgt_proc) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < np; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    if (src_id) src_id[c] = id ? id[ij.x] : static_cast<uint64_t>(ij.x);
+    if (tgt_id) tgt_id[c] = id ? id[ij.y] : static_cast<uint64_t>(ij.y);
+    if (src_proc) src_proc[c] = owner ? owner[ij.x] : 0;
+    if (tgt_proc) tgt_proc[c] = owner ? owner[ij.y] : 0;
+  }
+}
+// LinkCOOData rows: link entity id, linked entity ids [2], linked entity ranks [2] (LinkMetaData.hpp:102-106)
+__global__ void __launch_bounds__(kBlock)
+    k_links_coo(size_t np, const int2* __restrict__ pairs, const uint64_t* __restrict__ id, uint64_t first_link_id,
+                unsigned char source_rank, unsigned char target_rank, uint64_t* __restrict__ link_id,
+                uint64_t* __restrict__ linked_ids, unsigned char* __restrict__ linked_ranks) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < np; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    if (link_id) link_id[c] = first_link_id + c;
+    if (linked_ids) {
+      linked_ids[2 * c] = id ? id[ij.x] : static_cast<uint64_t>(ij.x);
+      linked_ids[2 * c + 1] = id ? id[ij.y] : static_cast<uint64_t>(ij.y);
+    }
+    if (linked_ranks) {
+      linked_ranks[2 * c] = source_rank;
+      linked_ranks[2 * c + 1] = target_rank;
+    }
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_crs_count(size_t np, const int2* __restrict__ pairs,
+                                                     int32_t* __restrict__ deg) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < np; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    atomicAdd(&deg[ij.x], 1);
+    atomicAdd(&deg[ij.y], 1);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_crs_fill(size_t np, const int2* __restrict__ pairs,
+                                                    int32_t* __restrict__ cursor, unsigned* __restrict__ conn) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < np; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    conn[atomicAdd(&cursor[ij.x], 1)] = static_cast<unsigned>(c);
+    conn[atomicAdd(&cursor[ij.y], 1)] = static_cast<unsigned>(c);
+  }
+}
+// LinkCRSBucketConn per entity bucket (LinkCRSBucketConn.hpp:183-191): num_connected_links, bucket-local offsets
+// [capacity + 1] and the connected links; bucket b holds entities [b * capacity, min((b + 1) * capacity, n))
+__global__ void __launch_bounds__(kBlock)
+    k_crs_emit(size_t n, size_t nconn, unsigned capacity, const int32_t* __restrict__ ptr, const unsigned* __restrict__ conn,
+               uint64_t first_link_id, unsigned* __restrict__ num_connected, unsigned* __restrict__ bucket_offsets,
+               uint64_t* __restrict__ connectivity, uint64_t* __restrict__ bucket_begin) {
+  const size_t nb = (n + capacity - 1) / capacity;
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = tid; e < n; e += nth) num_connected[e] = static_cast<unsigned>(ptr[e + 1] - ptr[e]);
+  for (size_t q = tid; q < nb * (capacity + 1); q += nth) {
+    const size_t b = q / (capacity + 1), k = q % (capacity + 1);
+    const size_t first = b * capacity, e = first + k < n ? first + k : n;
+    bucket_offsets[q] = static_cast<unsigned>(ptr[e] - ptr[first]);
+  }
+  for (size_t b = tid; b <= nb; b += nth) bucket_begin[b] = static_cast<uint64_t>(ptr[b * capacity < n ? b * capacity : n]);
+  for (size_t t = tid; t < nconn; t += nth) connectivity[t] = first_link_id + conn[t];
+}
+
+__global__ void __launch_bounds__(kBlock) k_iota_u64(size_t n, uint64_t* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = i;
+}
+// AUTO picks the LBVH when the largest reach exceeds this multiple of the mean reach
+constexpr double kLbvhReachSpread = 2.0;
+
 }  // namespace mhip
 
 using namespace mhip;
@@ -389,9 +751,17 @@ struct mhip_broadphase {
   mhip_broadphase_config cfg{};
   bool built = false;
   size_t n = 0, num_pairs = 0;
+  int method_used = MHIP_SEARCH_METHOD_GRID;
   DeviceBuffer recs, cell_of, slot_cell, cell_cnt, cell_ptr, cursor, counts, row_ptr, col, pairs, old_center, params,
-      partials, scanws, flag;
-  int* host_scalar = nullptr;  // pinned
+      partials, scanws, flag, longrows, coltmp;
+  // LBVH
+  DeviceBuffer keys, keys_tmp, order, order_tmp, sortws, nodes, right, parent, ticket, leaf_rope, slot_of;
+  // seam S3: source / target sets, identities, exclusion lists (copies owned by the handle)
+  size_t sets_n = 0, ident_n = 0, excl_n = 0;
+  bool has_source = false, has_target = false, has_ident = false, has_excl = false;
+  DeviceBuffer is_source, is_target, entity_id, owner_rank, ex_ptr, ex_idx;
+  double* host_summary = nullptr;  // pinned, 8 doubles
+  int* host_scalar = nullptr;      // pinned
 };
 
 extern "C" {
@@ -404,6 +774,7 @@ int mhip_broadphase_create(mhip_broadphase_t* handle) {
 
 static int ensure_host_scalar(mhip_broadphase* h) {
   if (!h->host_scalar) MHIP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_scalar), 64));
+  if (!h->host_summary) MHIP_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->host_summary), 8 * sizeof(double)));
   return MHIP_SUCCESS;
 }
 
@@ -411,10 +782,71 @@ int mhip_broadphase_destroy(mhip_broadphase_t h) {
   if (!h) return MHIP_SUCCESS;
   for (DeviceBuffer* b : {&h->recs, &h->cell_of, &h->slot_cell, &h->cell_cnt, &h->cell_ptr, &h->cursor, &h->counts,
                           &h->row_ptr, &h->col, &h->pairs, &h->old_center, &h->params, &h->partials, &h->scanws,
-                          &h->flag})
+                          &h->flag, &h->longrows, &h->coltmp, &h->keys, &h->keys_tmp, &h->order, &h->order_tmp,
+                          &h->sortws, &h->nodes, &h->right, &h->parent, &h->ticket, &h->leaf_rope, &h->slot_of,
+                          &h->is_source, &h->is_target, &h->entity_id, &h->owner_rank, &h->ex_ptr, &h->ex_idx})
     b->release();
   if (h->host_scalar) (void)hipHostFree(h->host_scalar);
+  if (h->host_summary) (void)hipHostFree(h->host_summary);
   delete h;
+  return MHIP_SUCCESS;
+}
+
+static int copy_in(DeviceBuffer& dst, const void* src, size_t bytes, hipStream_t s) {
+  if (int e = dst.reserve(bytes + 16)) return e;
+  if (bytes) MHIP_HIP(hipMemcpyAsync(dst.ptr, src, bytes, hipMemcpyDeviceToDevice, s));
+  return MHIP_SUCCESS;
+}
+
+int mhip_broadphase_set_sets(mhip_broadphase_t h, size_t n, const unsigned char* is_source,
+                             const unsigned char* is_target, mhip_stream_t stream) {
+  MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
+  hipStream_t s = as_stream(stream);
+  h->sets_n = n;
+  h->has_source = is_source != nullptr;
+  h->has_target = is_target != nullptr;
+  if (is_source)
+    if (int e = copy_in(h->is_source, is_source, n, s)) return e;
+  if (is_target)
+    if (int e = copy_in(h->is_target, is_target, n, s)) return e;
+  h->built = false;  // the list no longer matches the sets: the next generate rebuilds
+  return MHIP_SUCCESS;
+}
+
+int mhip_broadphase_set_identities(mhip_broadphase_t h, size_t n, const uint64_t* entity_id, const int32_t* owner_rank,
+                                   mhip_stream_t stream) {
+  MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
+  hipStream_t s = as_stream(stream);
+  h->ident_n = n;
+  h->has_ident = entity_id != nullptr || owner_rank != nullptr;
+  if (int e = h->entity_id.reserve(n * sizeof(uint64_t) + 16)) return e;
+  if (int e = h->owner_rank.reserve(n * sizeof(int32_t) + 16)) return e;
+  if (entity_id) MHIP_HIP(hipMemcpyAsync(h->entity_id.ptr, entity_id, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+  else if (n) k_iota_u64<<<grid_for(n), kBlock, 0, s>>>(n, h->entity_id.as<uint64_t>());
+  if (owner_rank) MHIP_HIP(hipMemcpyAsync(h->owner_rank.ptr, owner_rank, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  else if (n) MHIP_HIP(hipMemsetAsync(h->owner_rank.ptr, 0, n * sizeof(int32_t), s));
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_broadphase_set_exclusions(mhip_broadphase_t h, size_t n, const int32_t* ex_ptr, const int32_t* ex_idx,
+                                   size_t num_entries, mhip_stream_t stream) {
+  MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
+  hipStream_t s = as_stream(stream);
+  h->has_excl = ex_ptr != nullptr;
+  h->excl_n = n;
+  if (ex_ptr) {
+    MHIP_REQUIRE(ex_idx != nullptr || num_entries == 0, MHIP_ERR_INVALID_ARGUMENT, "ex_idx is null");
+    if (int e = copy_in(h->ex_ptr, ex_ptr, (n + 1) * sizeof(int32_t), s)) return e;
+    if (int e = copy_in(h->ex_idx, ex_idx, num_entries * sizeof(int32_t), s)) return e;
+  }
+  h->built = false;
+  return MHIP_SUCCESS;
+}
+
+int mhip_broadphase_method_used(mhip_broadphase_t h, int* method) {
+  MHIP_REQUIRE(h != nullptr && method != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  *method = h->method_used;
   return MHIP_SUCCESS;
 }
 
@@ -426,17 +858,27 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   MHIP_REQUIRE(config != nullptr && num_pairs != nullptr, MHIP_ERR_INVALID_ARGUMENT, "config / num_pairs is null");
   MHIP_REQUIRE(config->search_kind == MHIP_SEARCH_SPHERES || config->search_kind == MHIP_SEARCH_AABB,
                MHIP_ERR_INVALID_ARGUMENT, "unknown search kind %d", config->search_kind);
+  MHIP_REQUIRE(config->method == MHIP_SEARCH_METHOD_AUTO || config->method == MHIP_SEARCH_METHOD_GRID ||
+                   config->method == MHIP_SEARCH_METHOD_MORTON_LBVH,
+               MHIP_ERR_INVALID_ARGUMENT, "unknown search method %d", config->method);
   MHIP_REQUIRE(config->buffer >= 0.0, MHIP_ERR_INVALID_ARGUMENT, "search buffer must be >= 0");
-  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies for 32-bit indices");
+  MHIP_REQUIRE(n < (1u << 30), MHIP_ERR_RUNTIME, "too many bodies for 32-bit indices");
   if (config->search_kind == MHIP_SEARCH_AABB)
     MHIP_REQUIRE(aabb != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT, "aabb is required for MHIP_SEARCH_AABB");
   else
     MHIP_REQUIRE(bounding_radius != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT,
                  "bounding_radius is required for MHIP_SEARCH_SPHERES");
   MHIP_REQUIRE(center != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT, "center is null");
-  if (config->periodic)
+  if (config->periodic) {
     MHIP_REQUIRE(config->box[0] > 0 && config->box[1] > 0 && config->box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
                  "periodic box must be positive");
+    MHIP_REQUIRE(config->method != MHIP_SEARCH_METHOD_MORTON_LBVH, MHIP_ERR_INVALID_ARGUMENT,
+                 "the periodic search runs on the cell grid (the LBVH covers free boundaries)");
+  }
+  MHIP_REQUIRE((!h->has_source && !h->has_target) || h->sets_n == n, MHIP_ERR_INVALID_ARGUMENT,
+               "source / target sets were given for %zu bodies, the build has %zu", h->sets_n, n);
+  MHIP_REQUIRE(!h->has_excl || h->excl_n == n, MHIP_ERR_INVALID_ARGUMENT,
+               "exclusion lists were given for %zu bodies, the build has %zu", h->excl_n, n);
   hipStream_t s = as_stream(stream);
   if (int e = ensure_host_scalar(h)) return e;
   h->cfg = *config;
@@ -457,17 +899,18 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   A.buffer = config->buffer;
   const double one[3] = {1, 1, 1};
   A.pm = make_periodic(config->periodic ? config->box : one);
+  A.include_self = config->include_self ? 1 : 0;
+  A.is_source = h->has_source ? h->is_source.as<unsigned char>() : nullptr;
+  A.is_target = h->has_target ? h->is_target.as<unsigned char>() : nullptr;
+  A.ex_ptr = h->has_excl ? h->ex_ptr.as<int32_t>() : nullptr;
+  A.ex_idx = h->has_excl ? h->ex_idx.as<int32_t>() : nullptr;
 
   if (int e = h->recs.reserve(n * sizeof(SearchRec))) return e;
-  if (int e = h->cell_of.reserve(n * sizeof(int32_t))) return e;
-  if (int e = h->slot_cell.reserve(n * sizeof(int32_t))) return e;
-  if (int e = h->cell_cnt.reserve((cell_capacity + 2) * sizeof(int32_t))) return e;
-  if (int e = h->cell_ptr.reserve((cell_capacity + 2) * sizeof(int32_t))) return e;
-  if (int e = h->cursor.reserve((cell_capacity + 2) * sizeof(int32_t))) return e;
   if (int e = h->counts.reserve((n + 2) * sizeof(int32_t))) return e;
   if (int e = h->old_center.reserve(3 * n * sizeof(double))) return e;
-  if (int e = h->params.reserve(sizeof(GridParams) + 64)) return e;
-  if (int e = h->partials.reserve((7 * kMaxGrid + 8) * sizeof(double))) return e;
+  if (int e = h->params.reserve(sizeof(GridParams) + 64 + 8 * sizeof(double))) return e;
+  if (int e = h->partials.reserve((8 * kMaxGrid + 8) * sizeof(double))) return e;
+  if (int e = h->longrows.reserve((n + 32) * sizeof(int32_t))) return e;
   {
     const size_t m = (size_t)cell_capacity > n ? (size_t)cell_capacity : n;
     if (int e = h->scanws.reserve(scan_workspace_bytes(m + 2) + 64)) return e;
@@ -475,37 +918,101 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   if (int e = h->flag.reserve(64)) return e;
 
   GridParams* gp = h->params.as<GridParams>();
+  double* summary = reinterpret_cast<double*>(h->params.as<char>() + sizeof(GridParams) + 8);
   const unsigned g = grid_for(n);
   k_bounds<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, h->partials.as<double>());
   MHIP_LAUNCH_CHECK();
-  k_grid_params<<<1, kBlock, 0, s>>>((int)g, h->partials.as<double>(), A, cell_capacity, gp);
+  k_grid_params<<<1, kBlock, 0, s>>>((int)g, h->partials.as<double>(), A, cell_capacity, gp, summary);
   MHIP_LAUNCH_CHECK();
-  MHIP_HIP(hipMemsetAsync(h->cell_cnt.ptr, 0, (cell_capacity + 1) * sizeof(int32_t), s));
-  k_cell_count<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, gp, h->cell_of.as<int32_t>(),
-                                   h->cell_cnt.as<int32_t>());
-  MHIP_LAUNCH_CHECK();
-  // scanning all cell_capacity slots (unused cells hold 0) keeps the grid size off the host
-  if (int e = exclusive_scan_i32(h->cell_cnt.as<int32_t>(), h->cell_ptr.as<int32_t>(), cell_capacity, h->scanws.ptr, s))
-    return e;
-  MHIP_HIP(hipMemcpyAsync(h->cursor.ptr, h->cell_ptr.ptr, (cell_capacity + 1) * sizeof(int32_t),
-                          hipMemcpyDeviceToDevice, s));
-  k_cell_scatter<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, h->cell_of.as<int32_t>(),
-                                     h->cursor.as<int32_t>(), h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>());
-  MHIP_LAUNCH_CHECK();
+
+  // Which structure: the grid's cell edge is twice the LARGEST reach, so its work grows with (max / mean reach)^3; the
+  // BVH adapts to every body's own size.  Measured on MI355X (profiles/r02_broadphase_methods.txt).
+  int method = config->method;
+  if (method == MHIP_SEARCH_METHOD_AUTO) {
+    method = MHIP_SEARCH_METHOD_GRID;
+    if (!config->periodic && n >= 2) {
+      MHIP_HIP(hipMemcpyAsync(h->host_summary, summary, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+      MHIP_HIP(hipStreamSynchronize(s));
+      const double mean_reach = h->host_summary[7] / static_cast<double>(n);
+      if (h->host_summary[6] > kLbvhReachSpread * mean_reach) method = MHIP_SEARCH_METHOD_MORTON_LBVH;
+    }
+  }
+  h->method_used = method;
+  int32_t* long_count = h->longrows.as<int32_t>();
+  int32_t* long_list = long_count + 16;
+  MHIP_HIP(hipMemsetAsync(long_count, 0, sizeof(int32_t), s));
   const unsigned gb = grid_exact(n);
-  static const bool use_lds = [] {
-    const char* e = getenv("MHIP_PAIRS_LDS");  // A/B switch of the LDS-staged search (default on)
-    return !(e && atoi(e) == 0);
-  }();
-  const bool lds = use_lds && !A.periodic;
-  if (lds)
-    k_pairs_lds<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                            h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, nullptr,
-                                            nullptr);
-  else
-    k_pairs<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                        h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, nullptr, nullptr);
-  MHIP_LAUNCH_CHECK();
+  RowSink none{nullptr, nullptr, nullptr, nullptr};
+  const int nn = static_cast<int>(n);
+
+  // ---- count pass -----------------------------------------------------------------------------------------------
+  const bool lds = !A.periodic;
+  if (method == MHIP_SEARCH_METHOD_GRID) {
+    if (int e = h->cell_of.reserve(n * sizeof(int32_t))) return e;
+    if (int e = h->slot_cell.reserve(n * sizeof(int32_t))) return e;
+    if (int e = h->cell_cnt.reserve((cell_capacity + 2) * sizeof(int32_t))) return e;
+    if (int e = h->cell_ptr.reserve((cell_capacity + 2) * sizeof(int32_t))) return e;
+    if (int e = h->cursor.reserve((cell_capacity + 2) * sizeof(int32_t))) return e;
+    MHIP_HIP(hipMemsetAsync(h->cell_cnt.ptr, 0, (cell_capacity + 1) * sizeof(int32_t), s));
+    k_cell_count<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, gp, h->cell_of.as<int32_t>(),
+                                     h->cell_cnt.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+    // scanning all cell_capacity slots (unused cells hold 0) keeps the grid size off the host
+    if (int e = exclusive_scan_i32(h->cell_cnt.as<int32_t>(), h->cell_ptr.as<int32_t>(), cell_capacity, h->scanws.ptr, s))
+      return e;
+    MHIP_HIP(hipMemcpyAsync(h->cursor.ptr, h->cell_ptr.ptr, (cell_capacity + 1) * sizeof(int32_t),
+                            hipMemcpyDeviceToDevice, s));
+    k_cell_scatter<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, h->cell_of.as<int32_t>(),
+                                       h->cursor.as<int32_t>(), h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+    if (lds)
+      k_pairs_lds<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                              h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, none);
+    else
+      k_pairs<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                          h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, none);
+    MHIP_LAUNCH_CHECK();
+  } else {
+    if (int e = h->keys.reserve(n * sizeof(unsigned long long))) return e;
+    if (int e = h->keys_tmp.reserve(n * sizeof(unsigned long long))) return e;
+    if (int e = h->order.reserve(n * sizeof(unsigned))) return e;
+    if (int e = h->order_tmp.reserve(n * sizeof(unsigned))) return e;
+    if (int e = h->sortws.reserve(radix_sort_workspace_bytes(n))) return e;
+    if (int e = h->nodes.reserve(n * sizeof(BvhNode))) return e;
+    if (int e = h->right.reserve(n * sizeof(int32_t))) return e;
+    if (int e = h->parent.reserve(2 * n * sizeof(int32_t))) return e;
+    if (int e = h->ticket.reserve(n * sizeof(int32_t))) return e;
+    if (int e = h->leaf_rope.reserve(n * sizeof(int32_t))) return e;
+    if (int e = h->slot_of.reserve(n * sizeof(int32_t))) return e;
+    k_morton_keys<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, summary, h->keys.as<unsigned long long>(),
+                                      h->order.as<unsigned>());
+    MHIP_LAUNCH_CHECK();
+    if (int e = radix_sort_u64(n, h->keys.as<unsigned long long>(), h->order.as<unsigned>(),
+                               h->keys_tmp.as<unsigned long long>(), h->order_tmp.as<unsigned>(), 8, h->sortws.ptr, s))
+      return e;
+    k_lbvh_leaves<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, h->order.as<unsigned>(),
+                                      h->recs.as<SearchRec>(), h->slot_of.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+    MHIP_HIP(hipMemsetAsync(h->parent.ptr, 0xFF, 2 * n * sizeof(int32_t), s));
+    MHIP_HIP(hipMemsetAsync(h->ticket.ptr, 0, n * sizeof(int32_t), s));
+    BvhNode* nodes = h->nodes.as<BvhNode>();
+    if (n >= 2) {
+      k_lbvh_build<<<grid_exact(n - 1), kBlock, 0, s>>>(nn, h->keys.as<unsigned long long>(), nodes,
+                                                       h->right.as<int32_t>(), h->parent.as<int32_t>());
+      MHIP_LAUNCH_CHECK();
+      k_lbvh_refit<<<gb, kBlock, 0, s>>>(nn, A, h->recs.as<SearchRec>(), nodes, h->right.as<int32_t>(),
+                                        h->parent.as<int32_t>(), h->ticket.as<int32_t>());
+      MHIP_LAUNCH_CHECK();
+    }
+    k_lbvh_ropes<<<grid_exact(2 * n - 1), kBlock, 0, s>>>(nn, nodes, h->right.as<int32_t>(), h->parent.as<int32_t>(),
+                                                         h->leaf_rope.as<int32_t>());
+    MHIP_LAUNCH_CHECK();
+    k_lbvh_pairs<false><<<gb, kBlock, 0, s>>>(nn, A, h->recs.as<SearchRec>(), nodes, h->leaf_rope.as<int32_t>(),
+                                             h->counts.as<int32_t>(), nullptr, none);
+    MHIP_LAUNCH_CHECK();
+  }
+
+  // ---- row offsets, the one host read of the pair total ---------------------------------------------------------
   if (int e = exclusive_scan_i32(h->counts.as<int32_t>(), h->row_ptr.as<int32_t>(), n, h->scanws.ptr, s)) return e;
   MHIP_HIP(hipMemcpyAsync(h->host_scalar, h->row_ptr.as<int32_t>() + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
@@ -513,15 +1020,31 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   MHIP_REQUIRE(total >= 0, MHIP_ERR_RUNTIME, "pair count overflowed 32 bits");
   h->num_pairs = static_cast<size_t>(total);
   if (int e = h->col.reserve((h->num_pairs + 2) * sizeof(int32_t))) return e;
+  if (int e = h->coltmp.reserve((h->num_pairs + 2) * sizeof(int32_t))) return e;
   if (int e = h->pairs.reserve((h->num_pairs + 2) * sizeof(int2))) return e;
-  if (lds)
-    k_pairs_lds<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                           h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(),
-                                           h->col.as<int32_t>(), h->pairs.as<int2>());
-  else
-    k_pairs<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                       h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(),
-                                       h->col.as<int32_t>(), h->pairs.as<int2>());
+  RowSink sink{h->col.as<int32_t>(), h->pairs.as<int2>(), long_count, long_list};
+
+  // ---- fill pass ------------------------------------------------------------------------------------------------
+  if (method == MHIP_SEARCH_METHOD_GRID) {
+    if (lds)
+      k_pairs_lds<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                             h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
+    else
+      k_pairs<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
+                                         h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
+  } else {
+    k_lbvh_pairs<true><<<gb, kBlock, 0, s>>>(nn, A, h->recs.as<SearchRec>(), h->nodes.as<BvhNode>(),
+                                            h->leaf_rope.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
+  }
+  MHIP_LAUNCH_CHECK();
+  // rows with more than kShortSegment partners: workgroup radix sort, then their pairs
+  int key_bits = 1;
+  while ((size_t(1) << key_bits) < n) ++key_bits;
+  if (int e = sort_listed_segments_u32(h->row_ptr.as<int32_t>(), h->col.as<unsigned>(), h->coltmp.as<unsigned>(),
+                                       key_bits, long_count, long_list, s))
+    return e;
+  k_emit_long_rows<<<1024, kBlock, 0, s>>>(h->row_ptr.as<int32_t>(), h->col.as<int32_t>(), long_count, long_list,
+                                          h->pairs.as<int2>());
   MHIP_LAUNCH_CHECK();
   MHIP_HIP(hipMemcpyAsync(h->old_center.ptr, center, 3 * n * sizeof(double), hipMemcpyDeviceToDevice, s));
   *num_pairs = h->num_pairs;
@@ -539,6 +1062,77 @@ int mhip_broadphase_get_pairs(mhip_broadphase_t h, int32_t* pairs, int32_t* row_
     MHIP_HIP(hipMemcpyAsync(row_ptr, h->row_ptr.ptr, (h->n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
   if (col && h->num_pairs)
     MHIP_HIP(hipMemcpyAsync(col, h->col.ptr, h->num_pairs * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  return MHIP_SUCCESS;
+}
+
+int mhip_broadphase_get_ident_pairs(mhip_broadphase_t h, uint64_t* source_id, int32_t* source_proc, uint64_t* target_id,
+                                    int32_t* target_proc, mhip_stream_t stream) {
+  MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
+  MHIP_REQUIRE(h->built, MHIP_ERR_RUNTIME, "mhip_broadphase_build must be called before get_ident_pairs");
+  MHIP_REQUIRE(!h->has_ident || h->ident_n == h->n, MHIP_ERR_INVALID_ARGUMENT,
+               "identities were given for %zu bodies, the list has %zu", h->ident_n, h->n);
+  if (h->num_pairs == 0) return MHIP_SUCCESS;
+  k_ident_pairs<<<grid_for(h->num_pairs), kBlock, 0, as_stream(stream)>>>(
+      h->num_pairs, h->pairs.as<int2>(), h->has_ident ? h->entity_id.as<uint64_t>() : nullptr,
+      h->has_ident ? h->owner_rank.as<int32_t>() : nullptr, source_id, source_proc, target_id, target_proc);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_links_export_coo(mhip_broadphase_t h, uint64_t first_link_id, int source_rank, int target_rank,
+                          uint64_t* link_id, uint64_t* linked_entity_ids, unsigned char* linked_entity_ranks,
+                          mhip_stream_t stream) {
+  MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
+  MHIP_REQUIRE(h->built, MHIP_ERR_RUNTIME, "mhip_broadphase_build must be called before the link export");
+  MHIP_REQUIRE(source_rank >= 0 && source_rank < 256 && target_rank >= 0 && target_rank < 256,
+               MHIP_ERR_INVALID_ARGUMENT, "entity ranks must fit 8 bits");
+  MHIP_REQUIRE(!h->has_ident || h->ident_n == h->n, MHIP_ERR_INVALID_ARGUMENT,
+               "identities were given for %zu bodies, the list has %zu", h->ident_n, h->n);
+  if (h->num_pairs == 0) return MHIP_SUCCESS;
+  k_links_coo<<<grid_for(h->num_pairs), kBlock, 0, as_stream(stream)>>>(
+      h->num_pairs, h->pairs.as<int2>(), h->has_ident ? h->entity_id.as<uint64_t>() : nullptr, first_link_id,
+      static_cast<unsigned char>(source_rank), static_cast<unsigned char>(target_rank), link_id, linked_entity_ids,
+      linked_entity_ranks);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_links_export_crs(mhip_broadphase_t h, uint64_t first_link_id, unsigned bucket_capacity,
+                          unsigned* num_connected_links, unsigned* sparse_connectivity_offsets,
+                          uint64_t* sparse_connectivity, uint64_t* bucket_begin, mhip_stream_t stream) {
+  MHIP_REQUIRE(h != nullptr, MHIP_ERR_INVALID_ARGUMENT, "broadphase handle is null");
+  MHIP_REQUIRE(h->built, MHIP_ERR_RUNTIME, "mhip_broadphase_build must be called before the link export");
+  MHIP_REQUIRE(bucket_capacity >= 1, MHIP_ERR_INVALID_ARGUMENT, "bucket capacity must be positive");
+  const size_t n = h->n, np = h->num_pairs;
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(num_connected_links && sparse_connectivity_offsets && bucket_begin && (sparse_connectivity || np == 0),
+               MHIP_ERR_INVALID_ARGUMENT, "null output array");
+  hipStream_t s = as_stream(stream);
+  // entity -> links that name it (either ordinal): degrees, offsets, fill, each list ascending by link
+  DeviceBuffer &deg = h->cell_cnt, &ptr = h->cell_ptr, &cur = h->cursor, &conn = h->keys, &tmp = h->keys_tmp;
+  if (int e = deg.reserve((n + 2) * sizeof(int32_t))) return e;
+  if (int e = ptr.reserve((n + 2) * sizeof(int32_t))) return e;
+  if (int e = cur.reserve((n + 2) * sizeof(int32_t))) return e;
+  if (int e = conn.reserve((2 * np + 2) * sizeof(unsigned))) return e;
+  if (int e = tmp.reserve((2 * np + 2) * sizeof(unsigned))) return e;
+  if (int e = h->scanws.reserve(scan_workspace_bytes(n + 2) + 64)) return e;
+  if (int e = h->longrows.reserve((n + 32) * sizeof(int32_t))) return e;
+  MHIP_HIP(hipMemsetAsync(deg.ptr, 0, (n + 1) * sizeof(int32_t), s));
+  if (np) k_crs_count<<<grid_for(np), kBlock, 0, s>>>(np, h->pairs.as<int2>(), deg.as<int32_t>());
+  MHIP_LAUNCH_CHECK();
+  if (int e = exclusive_scan_i32(deg.as<int32_t>(), ptr.as<int32_t>(), n, h->scanws.ptr, s)) return e;
+  MHIP_HIP(hipMemcpyAsync(cur.ptr, ptr.ptr, (n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (np) k_crs_fill<<<grid_for(np), kBlock, 0, s>>>(np, h->pairs.as<int2>(), cur.as<int32_t>(), conn.as<unsigned>());
+  MHIP_LAUNCH_CHECK();
+  int key_bits = 1;
+  while ((size_t(1) << key_bits) < np + 1) ++key_bits;
+  if (int e = sort_segments_u32(n, ptr.as<int32_t>(), conn.as<unsigned>(), tmp.as<unsigned>(), key_bits,
+                                h->longrows.as<int32_t>(), s))
+    return e;
+  k_crs_emit<<<grid_for(2 * np + n), kBlock, 0, s>>>(n, 2 * np, bucket_capacity, ptr.as<int32_t>(), conn.as<unsigned>(),
+                                                    first_link_id, num_connected_links, sparse_connectivity_offsets,
+                                                    sparse_connectivity, bucket_begin);
+  MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
 

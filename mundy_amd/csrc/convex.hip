@@ -984,23 +984,12 @@ __global__ void __launch_bounds__(kBlock) k_inc_fill(size_t C, const int2* __res
 // priority array, the contacts with priority < 0 first (ascending), then the others (ascending).  With priority = the
 // signed separation the contacts that overlap at the start of the step, i.e. nearly all that will carry an impulse,
 // sit together at the head of the list, so the entries and records the masked body sweep touches share sectors.
-__global__ void __launch_bounds__(kBlock) k_inc_sort(size_t N, const int32_t* __restrict__ inc_ptr,
-                                                    int32_t* __restrict__ inc, const double* __restrict__ priority) {
-  const size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (b >= N) return;
-  const int32_t beg = inc_ptr[b], end = inc_ptr[b + 1];
-  unsigned* u = reinterpret_cast<unsigned*>(inc);  // bit 31 = second class, set by k_inc_fill
-  for (int32_t i = beg + 1; i < end; ++i) {
-    const unsigned v = u[i];
-    int32_t j = i - 1;
-    while (j >= beg && u[j] > v) {
-      u[j + 1] = u[j];
-      --j;
-    }
-    u[j + 1] = v;
-  }
-  if (priority)
-    for (int32_t i = beg; i < end; ++i) u[i] &= 0x7fffffffu;
+// The sort is sort_segments_u32 (sort.hip: one thread per list up to 32 entries, a workgroup radix sort for the long
+// lists of a large body among small ones); the class bit is the key's top bit and is cleared afterwards.
+__global__ void __launch_bounds__(kBlock) k_clear_class_bit(size_t nent, int32_t* __restrict__ inc) {
+  unsigned* u = reinterpret_cast<unsigned*>(inc);
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < nent; k += (size_t)gridDim.x * blockDim.x)
+    u[k] &= 0x7fffffffu;
 }
 
 // half-edge records in incidence order: the body sweep then streams them instead of gathering normals / arms
@@ -1244,6 +1233,8 @@ struct mhip_contact_op {
   DeviceBuffer inc_ptr, inc, cursor, vel, partials, state, scanws, half, axis, omega, vel_out;
   DeviceBuffer iterate;  // packed (x, g) ping-pong pair of the fused / staged solvers: 2 x C x 16 bytes
   DeviceBuffer body_mask, pos;  // activity masks of the packed LCP solves (see OpView)
+  DeviceBuffer sort_tmp, sort_list;  // workspaces of the incidence-list sort
+  int device = -1;  // the device current at create: where every buffer of this operator lives
   int lanes_per_body = 4;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
@@ -1470,8 +1461,9 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
 // pinned state block, timing events -- are the same size step after step.  A destroyed operator therefore leaves them
 // in one process-wide spare set that the next create adopts: no hipMalloc / hipFree in the steady state (hipFree
 // alone cost 1.6 ms per step at 10^6 rods).  mhip_release_cached_workspaces() frees the spare set.
+constexpr int kOpBuffers = 16;
 struct OpWorkspaces {
-  DeviceBuffer buf[14];
+  DeviceBuffer buf[kOpBuffers];
   SolverState* host_state = nullptr;
   std::vector<hipEvent_t> events;
   bool held = false;
@@ -1480,8 +1472,9 @@ struct OpWorkspaces {
 static std::mutex g_spare_mutex;
 static OpWorkspaces g_spare;
 static DeviceBuffer* op_buffers(mhip_contact_op* op, int k) {
-  DeviceBuffer* all[14] = {&op->inc_ptr, &op->inc, &op->cursor, &op->vel, &op->partials, &op->state, &op->scanws,
-                           &op->half, &op->axis, &op->omega, &op->vel_out, &op->iterate, &op->body_mask, &op->pos};
+  DeviceBuffer* all[kOpBuffers] = {&op->inc_ptr, &op->inc,     &op->cursor,   &op->vel,      &op->partials, &op->state,
+                                   &op->scanws,  &op->half,    &op->axis,     &op->omega,    &op->vel_out,  &op->iterate,
+                                   &op->body_mask, &op->pos,   &op->sort_tmp, &op->sort_list};
   return all[k];
 }
 static void free_workspaces(OpWorkspaces& w) {
@@ -1496,7 +1489,7 @@ static void adopt_spare_workspaces(mhip_contact_op* op) {
   std::lock_guard<std::mutex> lock(g_spare_mutex);
   int dev = -1;
   if (!g_spare.held || hipGetDevice(&dev) != hipSuccess || dev != g_spare.device) return;
-  for (int k = 0; k < 14; ++k) {
+  for (int k = 0; k < kOpBuffers; ++k) {
     *op_buffers(op, k) = g_spare.buf[k];
     g_spare.buf[k] = DeviceBuffer{};
   }
@@ -1520,6 +1513,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   hipStream_t s = as_stream(stream);
   mhip_contact_op* op = new mhip_contact_op();
   op->last_stream = s;
+  (void)hipGetDevice(&op->device);
   adopt_spare_workspaces(op);
   auto bail = [&](int e) {
     mhip_contact_op_destroy(op);
@@ -1559,7 +1553,12 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
   if (C > 0) {
     k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>(), priority);
-    k_inc_sort<<<grid_exact(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(), priority);
+    if (int e = op->sort_tmp.reserve((2 * C + 2) * sizeof(unsigned))) return bail(e);
+    if (int e = op->sort_list.reserve((N + 32) * sizeof(int32_t))) return bail(e);
+    if (int e = sort_segments_u32(N, op->inc_ptr.as<int32_t>(), op->inc.as<unsigned>(), op->sort_tmp.as<unsigned>(), 32,
+                                  op->sort_list.as<int32_t>(), s))
+      return bail(e);
+    if (priority) k_clear_class_bit<<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>());
   }
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "incidence build failed: %s", hipGetErrorString(he)));
@@ -1691,17 +1690,17 @@ int mhip_contact_op_destroy(mhip_contact_op_t op) {
   // (hipFree, which this replaces, synchronised the whole device)
   (void)hipStreamSynchronize(op->last_stream);
   OpWorkspaces w;
-  for (int k = 0; k < 14; ++k) w.buf[k] = *op_buffers(op, k);
+  for (int k = 0; k < kOpBuffers; ++k) w.buf[k] = *op_buffers(op, k);
   w.host_state = op->host_state;
   w.events.swap(op->events);
+  const int home = op->device;  // the device the buffers were allocated on, whatever device is current now
   delete op;
   {
     std::lock_guard<std::mutex> lock(g_spare_mutex);
-    int dev = -1;
-    if (!g_spare.held && hipGetDevice(&dev) == hipSuccess) {
+    if (!g_spare.held && home >= 0) {
       g_spare = std::move(w);
       g_spare.held = true;
-      g_spare.device = dev;
+      g_spare.device = home;
       return MHIP_SUCCESS;
     }
   }

@@ -267,4 +267,15 @@ struct TraceRange {
 
 int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, void* workspace, hipStream_t stream);
 
+// sort.hip: stable LSD radix sort of (u64 key, u32 value) records over the key bits [0, 8 * passes), passes even (the
+// result is back in keys / vals); segment sorts (ascending, unsigned) -- see sort.hip
+constexpr int kShortSegment = 32;  // segments up to this length are sorted by one thread
+size_t radix_sort_workspace_bytes(size_t n);
+int radix_sort_u64(size_t n, unsigned long long* keys, unsigned* vals, unsigned long long* keys_tmp, unsigned* vals_tmp,
+                   int passes, void* workspace, hipStream_t stream);
+int sort_listed_segments_u32(const int32_t* seg_ptr, unsigned* data, unsigned* tmp, int key_bits,
+                             const int32_t* long_count, const int32_t* long_list, hipStream_t stream);
+int sort_segments_u32(size_t nseg, const int32_t* seg_ptr, unsigned* data, unsigned* tmp, int key_bits,
+                      int32_t* scratch, hipStream_t stream);
+
 }  // namespace mhip

@@ -10,8 +10,8 @@ from dataclasses import dataclass
 import torch
 
 from . import capi
-from .capi import (RESIDUAL_PROJECTED_DIFF, RESIDUAL_PROJECTED_GRADIENT, SEARCH_AABB, SEARCH_SPHERES,  # noqa: F401
-                   SPACE_BOUNDED, SPACE_LOWER_BOUND, SPACE_UNCONSTRAINED, SPACE_UPPER_BOUND)
+from .capi import (RESIDUAL_PROJECTED_DIFF, RESIDUAL_PROJECTED_GRADIENT, SEARCH_AABB, SEARCH_METHOD_AUTO,  # noqa: F401
+                   SEARCH_METHOD_GRID, SEARCH_METHOD_MORTON_LBVH, SEARCH_SPHERES, SPACE_BOUNDED, SPACE_LOWER_BOUND, SPACE_UNCONSTRAINED, SPACE_UPPER_BOUND)
 
 
 def _stream():
@@ -240,7 +240,7 @@ class GenNeighborLinks:
         h = C.c_void_p()
         capi.check(capi.load().mhip_broadphase_create(C.byref(h)))
         self._h = h
-        self._cfg = capi.BroadphaseConfig(SEARCH_SPHERES, 0, 0.0, 0, (C.c_double * 3)(0, 0, 0))
+        self._cfg = capi.BroadphaseConfig(SEARCH_SPHERES, 0, 0.0, 0, (C.c_double * 3)(0, 0, 0), 0, 0)
         self._concretized = False
         self._generated = False
         self.pairs = self.row_ptr = self.col = None
@@ -273,6 +273,93 @@ class GenNeighborLinks:
             self._cfg.periodic = 1
             self._cfg.box = (C.c_double * 3)(*[float(b) for b in box])
         return self
+
+    def set_search_method(self, method):
+        """stk::search::SearchMethod of the reference (:443-447; its default is MORTON_LBVH): SEARCH_METHOD_AUTO,
+        SEARCH_METHOD_GRID or SEARCH_METHOD_MORTON_LBVH -- same lists, different structure"""
+        self._setter_guard("search method")
+        self._cfg.method = int(method)
+        return self
+
+    def set_exclude_self_interactions(self, value=True):
+        """search_filters::ExcludeSelfInteractions (:185-200); the default.  False lets (i, i) be a result."""
+        self._setter_guard("search filter")
+        self._cfg.include_self = 0 if value else 1
+        return self
+
+    def acts_on(self, source_mask=None, target_mask=None):
+        """acts_on(source_selector, target_selector, ...) (:486-507): uint8 masks [n] over the bodies (None = all); a
+        result (s, t) needs s among the sources and t among the targets"""
+        self._setter_guard("source/targets")
+        self._sets = (source_mask, target_mask)
+        n = (source_mask if source_mask is not None else target_mask)
+        capi.check(capi.load().mhip_broadphase_set_sets(
+            self._h, 0 if n is None else n.shape[0], _ptr(source_mask, torch.uint8, allow_none=True, name="source_mask"),
+            _ptr(target_mask, torch.uint8, allow_none=True, name="target_mask"), _stream()))
+        return self
+
+    def set_excluded_partners(self, ex_ptr, ex_idx):
+        """search_filters::ExcludeConnectedEntities (:202-236) / the already-linked neighbours when duplicate links
+        are not allowed (:91-113): CSR (int32 ex_ptr [n + 1], ex_idx) of partners each source must not be paired with.
+        May be called again between generates (the connectivity of a mesh changes); it invalidates the list."""
+        if ex_ptr is None:
+            capi.check(capi.load().mhip_broadphase_set_exclusions(self._h, 0, None, None, 0, _stream()))
+        else:
+            capi.check(capi.load().mhip_broadphase_set_exclusions(
+                self._h, ex_ptr.shape[0] - 1, _ptr(ex_ptr, torch.int32, name="ex_ptr"),
+                _ptr(ex_idx, torch.int32, name="ex_idx"), ex_idx.shape[0], _stream()))
+        self._generated = False
+        return self
+
+    def set_identities(self, entity_id=None, owner_rank=None, n=None):
+        """(stk::mesh::EntityId, owner rank) of every body (:575-584): int64 ids (bit pattern of the u64), int32 ranks"""
+        n = n if n is not None else (entity_id if entity_id is not None else owner_rank).shape[0]
+        capi.check(capi.load().mhip_broadphase_set_identities(
+            self._h, n, _ptr(entity_id, torch.int64, allow_none=True, name="entity_id"),
+            _ptr(owner_rank, torch.int32, allow_none=True, name="owner_rank"), _stream()))
+        return self
+
+    def ident_pairs(self):
+        """the links as stk::search IdentProcIntersection rows: (source id, source proc, target id, target proc)"""
+        dev = self.pairs.device
+        sid, tid = (torch.empty(self.num_pairs, dtype=torch.int64, device=dev) for _ in range(2))
+        sp, tp = (torch.empty(self.num_pairs, dtype=torch.int32, device=dev) for _ in range(2))
+        capi.check(capi.load().mhip_broadphase_get_ident_pairs(self._h, _ptr(sid, torch.int64), _ptr(sp, torch.int32),
+                                                               _ptr(tid, torch.int64), _ptr(tp, torch.int32), _stream()))
+        return sid, sp, tid, tp
+
+    def method_used(self):
+        m = C.c_int(0)
+        capi.check(capi.load().mhip_broadphase_method_used(self._h, C.byref(m)))
+        return m.value
+
+    def export_coo(self, first_link_id=0, source_rank=3, target_rank=3):
+        """MuNDy's LinkCOOData rows (LinkMetaData.hpp:102-106): (link ids [P], linked entity ids [P, 2], linked entity
+        ranks [P, 2] uint8; 3 = stk::topology::ELEM_RANK)"""
+        dev = self.pairs.device
+        lid = torch.empty(self.num_pairs, dtype=torch.int64, device=dev)
+        ids = torch.empty((self.num_pairs, 2), dtype=torch.int64, device=dev)
+        ranks = torch.empty((self.num_pairs, 2), dtype=torch.uint8, device=dev)
+        capi.check(capi.load().mhip_links_export_coo(self._h, int(first_link_id), int(source_rank), int(target_rank),
+                                                     _ptr(lid, torch.int64), _ptr(ids, torch.int64),
+                                                     _ptr(ranks, torch.uint8), _stream()))
+        return lid, ids, ranks
+
+    def export_crs(self, first_link_id=0, bucket_capacity=512):
+        """entity -> connected links in LinkCRSBucketConn's layout (LinkCRSBucketConn.hpp:183-191), entities in index
+        order cut into buckets of bucket_capacity: (num_connected_links [n], sparse_connectivity_offsets [nb, cap + 1],
+        sparse_connectivity [2 P], bucket_begin [nb + 1])"""
+        dev = self.pairs.device
+        n = self.row_ptr.shape[0] - 1
+        nb = (n + bucket_capacity - 1) // bucket_capacity
+        num = torch.empty(n, dtype=torch.int32, device=dev)
+        offs = torch.empty((nb, bucket_capacity + 1), dtype=torch.int32, device=dev)
+        conn = torch.empty(2 * self.num_pairs, dtype=torch.int64, device=dev)
+        begin = torch.empty(nb + 1, dtype=torch.int64, device=dev)
+        capi.check(capi.load().mhip_links_export_crs(self._h, int(first_link_id), int(bucket_capacity),
+                                                     _ptr(num, torch.int32), _ptr(offs, torch.int32),
+                                                     _ptr(conn, torch.int64), _ptr(begin, torch.int64), _stream()))
+        return num, offs, conn, begin
 
     def concretize(self):
         if self._concretized:

@@ -233,6 +233,75 @@ static void test_two_coincident_spheres() {  // UnitTestGenNeighborLinks.cpp:73-
   EXPECT_TRUE((p[0] == 0 && p[1] == 1) || (p[0] == 1 && p[1] == 0));
 }
 
+static void test_gen_neighbor_links_reference_usage() {
+  // UnitTestGenNeighborLinks.cpp:73-152 as written: source == target == the spheres part, symmetry enforced, search
+  // buffer 0, filter = ExcludeSelfInteractions -> the two coincident spheres are linked, in either orientation.  Run on
+  // both search structures; with the symmetry flag both orientations are results, without it the unique one.
+  namespace sf = mesh::search_filters;
+  DeviceVector c(std::vector<double>(6, 0.0)), r(std::vector<double>(2, 1.0)), aabb(12);
+  check(mhip_compute_aabb_spheres(2, c.data(), r.data(), aabb.data(), nullptr));
+  DeviceArray<unsigned char> all(std::vector<unsigned char>{1, 1});
+  DeviceArray<uint64_t> ids(std::vector<uint64_t>{1, 2});  // declare_element(1, ...), declare_element(2, ...)
+  for (int method : {MHIP_SEARCH_METHOD_GRID, MHIP_SEARCH_METHOD_MORTON_LBVH}) {
+    for (bool symmetric : {true, false}) {
+      mesh::GenNeighborLinks g;
+      g.set_enforce_source_target_symmetry(symmetric)
+          .set_search_buffer(0.0)
+          .set_search_method(method)
+          .set_search_filter(sf::make_search_filter(sf::ExcludeSelfInteractions{}))
+          .acts_on(2, all.data(), all.data())
+          .set_identities(2, ids.data(), nullptr)
+          .concretize();
+      EXPECT_TRUE(g.is_concretized() && g.get_search_method() == method);
+      EXPECT_TRUE(g.generate(2, aabb.data(), c.data(), r.data()));
+      EXPECT_TRUE(g.num_links() == (symmetric ? 2u : 1u));
+      auto idp = g.ident_links();
+      const auto src = idp.source_id.download(), tgt = idp.target_id.download();
+      const auto sp = idp.source_proc.download();
+      for (size_t k = 0; k < g.num_links(); ++k) {
+        EXPECT_TRUE((src[k] == 1 && tgt[k] == 2) || (src[k] == 2 && tgt[k] == 1));  // :149-151
+        EXPECT_TRUE(sp[k] == 0);
+      }
+      if (symmetric) EXPECT_TRUE(src[0] == 1 && tgt[0] == 2 && src[1] == 2 && tgt[1] == 1);
+      // the links as LinkData would hold them
+      const auto coo = g.export_coo(100, 3, 3);
+      const auto lid = coo.link_id.download(), linked = coo.linked_entity_ids.download();
+      EXPECT_TRUE(lid[0] == 100 && linked[0] == src[0] && linked[1] == tgt[0]);
+      const auto crs = g.export_crs(100, 512);
+      const auto num = crs.num_connected_links.download();
+      EXPECT_TRUE(crs.num_buckets == 1 && num[0] == g.num_links() && num[1] == g.num_links());
+    }
+    // without the filter stk's coarse_search also reports every sphere against itself
+    mesh::GenNeighborLinks g2;
+    g2.set_enforce_source_target_symmetry(true).set_search_method(method).set_search_filter(sf::make_search_filter());
+    g2.concretize();
+    g2.generate(2, aabb.data(), c.data(), r.data());
+    EXPECT_TRUE(g2.num_links() == 4);
+    // distinct source and target sets: sphere 1 is the only source, sphere 2 the only target -> exactly (1, 2)
+    DeviceArray<unsigned char> s1(std::vector<unsigned char>{1, 0}), t2(std::vector<unsigned char>{0, 1});
+    mesh::GenNeighborLinks g3;
+    g3.set_enforce_source_target_symmetry(true).set_search_method(method);
+    g3.set_search_filter(sf::make_search_filter(sf::ExcludeSelfInteractions{})).acts_on(2, s1.data(), t2.data());
+    g3.set_identities(2, ids.data(), nullptr).concretize();
+    g3.generate(2, aabb.data(), c.data(), r.data());
+    EXPECT_TRUE(g3.num_links() == 1);
+    auto one = g3.ident_links();
+    EXPECT_TRUE(one.source_id.download()[0] == 1 && one.target_id.download()[0] == 2);
+    // ExcludeConnectedEntities: sphere 1 is connected to sphere 2 (local indices 0 -> 1): that link is filtered, the
+    // opposite orientation (2 has no connection to 1) stays
+    DeviceArray<int32_t> cptr(std::vector<int32_t>{0, 1, 1}), cidx(std::vector<int32_t>{1});
+    mesh::GenNeighborLinks g4;
+    g4.set_enforce_source_target_symmetry(true).set_search_method(method);
+    g4.set_search_filter(sf::make_search_filter(sf::ExcludeSelfInteractions{},
+                                                sf::ExcludeConnectedEntities{2, cptr.data(), cidx.data(), 1}));
+    g4.concretize();
+    g4.generate(2, aabb.data(), c.data(), r.data());
+    const auto p4 = g4.links().download();
+    EXPECT_TRUE(g4.num_links() == 1 && p4[0] == 1 && p4[1] == 0);
+    EXPECT_THROW(g4.acts_on(2, all.data(), all.data()), std::runtime_error);  // "Cannot set source/targets after concretization."
+  }
+}
+
 static void test_ellipsoid_sphere_cases() {
   // SharedNormalDistanceBetweenEllipsoids.AnalyticalSphereTestCases and ...EllipsoidAndPoint.AnalyticalSphereTestCases
   // (UnitTestEllipsoidEllipsoid.cpp:65-145): ellipsoids with three equal radii are spheres, tolerance 1e-4
@@ -318,6 +387,7 @@ int main() {
   test_compute_aabb_hard_coded();
   test_segment_kats();
   test_two_coincident_spheres();
+  test_gen_neighbor_links_reference_usage();
   test_periodic_metrics();
   test_ellipsoid_sphere_cases();
   std::printf("%s (%d failed checks)\n", g_failures ? "FAILED" : "ALL PASSED", g_failures);
