@@ -409,7 +409,16 @@ int mhip_bbpgd_solve_contact_unfused(mhip_contact_op_t op, const double* q, cons
  *                        neither input.  *count_out [host].
  *   select_aabb_overlap: indices (ascending) of the boxes aabb[i] grown by `buffer` that intersect (closed test) the
  *                        box `box6` [host: min xyz, max xyz] -- the ghost candidates for a neighbouring rank.
+ *   select_contacts    : BUILD OPTION (off by default: the reference's LCP app makes every neighbour pair a constraint,
+ *                        scrap/lcp_spheres/NgpLcp.cpp:346-373).  kept_index [<= c] = ascending indices of the candidate
+ *                        pairs whose signed separation is not above `cutoff` (NaN kept), by wavefront ballot + prefix
+ *                        sum; *count_out [host].  The caller gathers pairs / normals / arms with mhip_gather_rows and
+ *                        builds the operator on the kept contacts only: fewer constraints per sweep.  A dropped pair
+ *                        is a constraint that must stay inactive: check g = sep + dt sdot >= 0 on the dropped pairs
+ *                        afterwards (the steppers do, and fall back to the full list when it fails).
  * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_select_contacts(size_t c, const double* sep, double cutoff, int32_t* kept_index, size_t* count_out /*[host]*/,
+                         mhip_stream_t stream);
 int mhip_filter_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, size_t count, int32_t* pairs_out,
                             unsigned char* counted_out, size_t* count_out /*[host]*/, mhip_stream_t stream);
 /* Same selection, ordered for overlap: first the pairs with BOTH bodies owned (interior), then those with exactly one

@@ -261,11 +261,31 @@ __global__ void k_box_bounds_final(int nparts, const double* __restrict__ partia
   }
 }
 
+// contact compaction: the neighbour list holds every pair whose grown volumes meet; the contacts of THIS step are those
+// within `cutoff` of touching.  Keeps NaN separations (coincident centres) so that they are not silently lost.
+struct KeepCloseContact {
+  const double* sep;
+  double cutoff;
+  int32_t* kept;
+  __device__ bool keep(size_t k) const { return !(sep[k] > cutoff); }
+  __device__ void emit(size_t k, size_t out) const { kept[out] = static_cast<int32_t>(k); }
+};
+
 }  // namespace mhip
 
 using namespace mhip;
 
 extern "C" {
+
+int mhip_select_contacts(size_t c, const double* sep, double cutoff, int32_t* kept_index, size_t* count_out,
+                         mhip_stream_t stream) {
+  MHIP_REQUIRE(count_out != nullptr, MHIP_ERR_INVALID_ARGUMENT, "count_out is null");
+  *count_out = 0;
+  if (c == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(sep && kept_index, MHIP_ERR_INVALID_ARGUMENT, "sep / kept_index is null");
+  MHIP_REQUIRE(c < (1u << 31), MHIP_ERR_RUNTIME, "too many contacts");
+  return compact(c, KeepCloseContact{sep, cutoff, kept_index}, count_out, as_stream(stream));
+}
 
 int mhip_filter_pairs_owned(size_t c, const int32_t* pairs_in, size_t first, size_t count, int32_t* pairs_out,
                             unsigned char* counted_out, size_t* count_out, mhip_stream_t stream) {

@@ -671,6 +671,16 @@ def curve_order(center, lo, hi, level, key_table):
     return perm
 
 
+def select_contacts(sep, cutoff):
+    """BUILD OPTION: ascending indices (int32) of the candidate pairs whose signed separation is not above `cutoff`
+    (NaN kept) -- wavefront ballot / prefix-sum compaction (mhip_select_contacts)"""
+    kept = torch.empty(sep.shape[0], dtype=torch.int32, device=sep.device)
+    cnt = C.c_size_t(0)
+    capi.check(capi.load().mhip_select_contacts(sep.shape[0], _ptr(sep), float(cutoff), _ptr(kept, torch.int32),
+                                                C.byref(cnt), _stream()))
+    return kept[:int(cnt.value)]
+
+
 def gather_rows(perm, src):
     src2 = src if src.dim() == 2 else src.unsqueeze(1)
     dst = torch.empty((perm.shape[0], src2.shape[1]), dtype=src2.dtype, device=src2.device)

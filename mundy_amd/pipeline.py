@@ -32,7 +32,7 @@ class ContactStepper:
 
     def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
                  search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
-                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None, friction=None):
+                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None, friction=None, contact_cutoff=None):
         """kind = "sphere" | "spherocylinder" | "mixed".  Mixed systems (BASELINE configs[4]) pass kinds [n] int32
         (0 sphere, 1 spherocylinder, 2 ellipsoid) and shape [n, 3] = (r,-,-) / (r,L,-) / (r1,r2,r3) instead of
         radius / length."""
@@ -83,6 +83,12 @@ class ContactStepper:
         self.lam = None
         self.contacts = None
         self.work_mapping = None  # (xcd_tile, lanes_per_body) for ContactOperator.set_work_mapping: time only
+        # BUILD OPTION (None = off, the reference's behaviour: every neighbour pair is a constraint, NgpLcp.cpp:346-373):
+        # only pairs within contact_cutoff of touching become constraints of this step (ballot compaction of the
+        # candidate list); the dropped pairs are checked afterwards (they must satisfy g >= 0, i.e. stay inactive) and
+        # the step is redone on the full list if one does not.
+        self.contact_cutoff = None if contact_cutoff is None else float(contact_cutoff)
+        self.cutoff_fallbacks = 0
 
     # -- stages -----------------------------------------------------------------------------------------------------
     _BODY_ARRAYS = ("center", "radius", "quat", "length", "bounding_radius", "mob_trans", "mob_rot", "shape", "kinds")
@@ -154,16 +160,63 @@ class ContactStepper:
                                                         arms="arclength" if rodk else "vector")
         return self.contacts
 
+    def _compact_contacts(self):
+        """contacts within the cutoff -> (pairs, contact arrays) of this step's constraints, the rest kept aside"""
+        c = self.contacts
+        kept = ops.select_contacts(c["sep"], self.contact_cutoff)
+        keep_mask = torch.zeros(c["sep"].shape[0], dtype=torch.bool, device=kept.device)
+        keep_mask[kept.long()] = True
+        pairs64 = self.links.pairs.view(torch.float64).reshape(-1)       # one (i, j) row = 8 bytes
+        out = {k: (ops.gather_rows(kept, v) if isinstance(v, torch.Tensor) and v.shape[0] == keep_mask.shape[0] else v)
+               for k, v in c.items()}
+        pairs = ops.gather_rows(kept, pairs64).view(torch.int32).reshape(-1, 2)
+        return pairs, out, ~keep_mask
+
+    def _dropped_pairs_stay_inactive(self, dropped):
+        """g = sep + dt * sdot >= 0 on the pairs left out of the solve, from the body velocities it produced"""
+        if not bool(dropped.any()):
+            return True
+        c, p = self.full_contacts, self.links.pairs[dropped].long()
+        vel = self.op.body_velocity()
+        n = c["normal"][dropped]
+        vi, vj = vel[p[:, 0], :3].clone(), vel[p[:, 1], :3].clone()
+        if self.kind != "sphere":
+            if c.get("ra") is not None:
+                ra, rb = c["ra"][dropped], c["rb"][dropped]
+            else:  # arclength form: arm = (s - 1/2) (p1 - p0)
+                u = self.seg[:, 3:6] - self.seg[:, 0:3]
+                ra = (c["s"][dropped] - 0.5).unsqueeze(1) * u[p[:, 0]]
+                rb = (c["t"][dropped] - 0.5).unsqueeze(1) * u[p[:, 1]]
+            vi += torch.cross(vel[p[:, 0], 3:], ra, dim=1)
+            vj += torch.cross(vel[p[:, 1], 3:], rb, dim=1)
+        g = c["sep"][dropped] - self.dt * ((vi - vj) * n).sum(dim=1)
+        return bool((g >= -self.cfg.tol).all())
+
     def resolve_collisions(self, rebuilt):
+        if self.contact_cutoff is not None and self.friction is None:
+            self.full_contacts = self.contacts
+            pairs, self.contacts, dropped = self._compact_contacts()
+            res = self._resolve(True, pairs)       # the constraint set changes from step to step: new operator
+            if self._dropped_pairs_stay_inactive(dropped):
+                self.contact_pairs = pairs
+                return res
+            self.cutoff_fallbacks += 1             # a dropped pair would have carried an impulse: the full list decides
+            self.contacts = self.full_contacts
+            self.contact_pairs = self.links.pairs
+            return self._resolve(True, self.links.pairs)
+        self.contact_pairs = self.links.pairs
+        return self._resolve(rebuilt, self.links.pairs)
+
+    def _resolve(self, rebuilt, pairs):
         c = self.contacts
         # a step that reuses the neighbour list keeps the operator's incidence index and only refreshes its geometry
         reuse = (not rebuilt and self.op is not None and self.friction is None and
-                 self.op.num_constraints == self.links.num_pairs and getattr(self.op, "_h", None))
+                 self.op.num_constraints == pairs.shape[0] and getattr(self.op, "_h", None))
         if self.op is not None and not reuse:
             self.op.close()
         if self.friction is not None:
-            ra, rb = ops.surface_lever_arms(self.links.pairs, c["normal"], c["ra"], c["rb"], self.radius)
-            self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=ra, rb=rb,
+            ra, rb = ops.surface_lever_arms(pairs, c["normal"], c["ra"], c["rb"], self.radius)
+            self.op = ops.ContactOperator(pairs, c["normal"], self.mob_trans, self.dt, ra=ra, rb=rb,
                                           mob_rot=self.mob_rot)
             p, g, res = ops.solve_friction_contact(self.op, c["sep"], self.friction, cfg=self.cfg)
             self.impulse, self.lam = p, (p * c["normal"]).sum(dim=1)
@@ -172,18 +225,18 @@ class ContactStepper:
             if reuse:
                 self.op.refresh(c["normal"], rod=(c["s"], c["t"], self.seg))
             else:
-                self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt,
+                self.op = ops.ContactOperator(pairs, c["normal"], self.mob_trans, self.dt,
                                               mob_rot=self.mob_rot, rod=(c["s"], c["t"], self.seg), priority=c["sep"])
         elif reuse:
             self.op.refresh(c["normal"], ra=c.get("ra"), rb=c.get("rb"))
         else:
-            self.op = ops.ContactOperator(self.links.pairs, c["normal"], self.mob_trans, self.dt, ra=c.get("ra"),
+            self.op = ops.ContactOperator(pairs, c["normal"], self.mob_trans, self.dt, ra=c.get("ra"),
                                           rb=c.get("rb"), mob_rot=self.mob_rot, priority=c["sep"])
         if self.work_mapping is not None:
             self.op.set_work_mapping(*self.work_mapping)
         if getattr(self, "profile_next", False):
             self.op.set_profiling(True)  # per-kernel HIP-event timing of the fused iteration (bench.py roofline)
-        nc = self.links.num_pairs
+        nc = pairs.shape[0]
         if rebuilt or self.lam is None or not self.warm_start or self.lam.shape[0] != nc:
             self.lam = torch.zeros(nc, dtype=torch.float64, device=self.center.device)  # NgpLcp.cpp:890-891
         x, g, res = ops.solve_lcp(self.op, c["sep"], self.lam, self.cfg)
@@ -217,7 +270,7 @@ class ContactStepper:
         if integrate:
             self.integrate()
         mark("integrate")
-        st.num_contacts = self.links.num_pairs
+        st.num_contacts = self.contact_pairs.shape[0]
         st.num_iters, st.residual, st.converged = res.num_iters, res.residual, res.converged
         if timed:
             torch.cuda.synchronize()

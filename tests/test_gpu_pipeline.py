@@ -231,3 +231,43 @@ def test_trajectory_with_neighbour_list_reuse(mods, oracle):
     print("rebuilt", rebuilt, "iterations", iters, "deepest overlap at step start", ["%.3g" % d for d in deepest])
     assert rebuilt[0] and any(rebuilt[1:]) and not all(rebuilt[1:]), rebuilt
     assert iters[-1] < iters[0] and deepest[-1] > 0.1 * deepest[0]
+
+
+def test_contact_cutoff_option_compacts_the_constraint_set(mods, oracle):
+    # BUILD OPTION (off by default): only the candidate pairs within `contact_cutoff` of touching become constraints --
+    # wavefront ballot / prefix-sum compaction of the narrow-phase output.  The kept set equals the numpy selection, the
+    # solve reaches the full problem's solution (g is unique; the dropped pairs satisfy g >= 0, which is their LCP
+    # condition with lambda = 0), with far fewer constraints per sweep.
+    ops, pipeline, synth = mods
+    from gpu_util import dev, host
+    b = synth.spherocylinders(8000, seed=5)
+    tol = 1e-6
+    # a relaxed packing (what a running simulation sees): the raw random packing overlaps so deeply that bodies move by
+    # more than a rod radius within the one step that separates them, and no useful cutoff survives the check
+    pre = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]), dev(b["length"]),
+                                  search_buffer=0.3, cfg=ops.PGDConfig(max_iters=20000, tol=tol))
+    for _ in range(4):
+        pre.step(integrate=True, force_rebuild=True)
+    c0, q0 = pre.center.clone(), pre.quat.clone()
+    mk = lambda **kw: pipeline.ContactStepper("spherocylinder", c0.clone(), dev(b["radius"]), q0.clone(),  # noqa: E731
+                                              dev(b["length"]), search_buffer=0.3,
+                                              cfg=ops.PGDConfig(max_iters=20000, tol=tol), **kw)
+    full, cut = mk(), mk(contact_cutoff=0.02)
+    sf, sc = full.step(integrate=False), cut.step(integrate=False)
+    assert sf.converged and sc.converged and cut.cutoff_fallbacks == 0
+    sep_all = host(full.contacts["sep"])
+    want = np.flatnonzero(~(sep_all > 0.02))
+    assert sc.num_contacts == len(want) and sc.num_contacts < 0.6 * sf.num_contacts
+    np.testing.assert_array_equal(host(cut.contact_pairs), host(full.links.pairs)[want])
+    assert np.array_equal(host(cut.contacts["sep"]), sep_all[want])
+    assert np.array_equal(host(cut.contacts["normal"]), host(full.contacts["normal"])[want])
+    gf = host(full.op.apply(full.lam) + full.contacts["sep"])
+    gc = host(cut.op.apply(cut.lam) + cut.contacts["sep"])
+    np.testing.assert_allclose(gc, gf[want], atol=20 * tol)
+    dropped = np.setdiff1d(np.arange(len(sep_all)), want)
+    assert gf[dropped].min() >= -10 * tol                       # the pairs left out are inactive in the full solution
+    np.testing.assert_allclose(host(cut.op.body_velocity()), host(full.op.body_velocity()), atol=1e-3 * np.abs(host(full.op.body_velocity())).max())
+    # a cutoff so tight that overlapping pairs are dropped is caught by the check and the full list decides
+    bad = mk(contact_cutoff=-0.2)
+    sb = bad.step(integrate=False)
+    assert bad.cutoff_fallbacks == 1 and sb.num_contacts == sf.num_contacts and sb.converged
