@@ -397,7 +397,18 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
         sys.exit(3)
     comm.self_check()  # pairwise messages + all-gather with known contents, before anything is timed
     st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
-                                     comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=32)
+                                     comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=32,
+                                     domain=(0.0, float(box)), curve_level=6)
+    # set-up, untimed: one solve on the equal-COUNT cut to measure the work per body, then the curve is re-cut at equal
+    # WORK (1 + contacts per body) and the bodies move to their new owners (the reference rebalances with
+    # stk::balance, NGPSpheresLCP.cpp:956)
+    s0 = st.step(integrate=False)
+    before = torch.zeros(world, dtype=torch.float64, device="cuda")
+    before[rank] = s0["owned_contacts"]
+    dist.all_reduce(before, op=dist.ReduceOp.SUM)
+    imbalance_before = float(before.max().item() * world / max(1.0, before.sum().item()))
+    moved = st.rebalance(recut=True)
+    n = st.n
     pristine_c, pristine_q = st.center.clone(), st.quat.clone()
 
     def one_step(profile):
@@ -450,6 +461,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                        "ghost_bodies_total": ghosts_global, "bbpgd_iters_per_step": iters,
                        "owned_contacts_per_rank": per_rank_contacts,
                        "contact_imbalance_max_over_mean": round(max(per_rank_contacts) * world / max(1, sum(per_rank_contacts)), 4),
+                       "contact_imbalance_equal_count_cut": round(imbalance_before, 4),
+                       "bodies_moved_by_work_recut_rank0": moved["sent"],
                        "converged": [bool(s["converged"]) for s in stats],
                        "parallelism": "hilbert domain decomposition dd%d: ghost-body halo per rebuild; per BBPGD "
                                       "iteration ghost-velocity send/recv + 5-double all-gather (RCCL)" % world,

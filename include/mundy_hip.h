@@ -489,6 +489,12 @@ int mhip_morton_order(size_t n, const double* center, const double* lo /*[host] 
  * ties by index.  level <= 8. */
 int mhip_curve_order(size_t n, const double* center, const double* lo /*[host] 3*/, const double* hi /*[host] 3*/,
                      int level, const int32_t* key_table, int32_t* perm, mhip_stream_t stream);
+/* keys[i] = key_table entry of body i's cell (the value mhip_curve_order sorts by): the Hilbert position of the cell --
+ * what the work-weighted domain decomposition cuts and what decides a body's owner when it migrates */
+int mhip_curve_keys(size_t n, const double* center, const double* lo /*[host] 3*/, const double* hi /*[host] 3*/,
+                    int level, const int32_t* key_table, uint32_t* keys, mhip_stream_t stream);
+/* perm = the stable ascending order of n 64-bit keys (radix sort, 8 bits per pass): perm[k] = index of the k-th key */
+int mhip_sort_by_key_u64(size_t n, const uint64_t* keys, int32_t* perm, mhip_stream_t stream);
 /* dst[k][0..width) = src[perm[k]][0..width)  for rows of `width` doubles */
 int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst, mhip_stream_t stream);
 /* dst[k * dst_stride + c] = src[k * src_stride + c], c < width (strides in doubles): packs per-body fields into

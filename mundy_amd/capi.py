@@ -96,6 +96,8 @@ SIGNATURES = {
     "mhip_broadphase_get_pairs": [_vp, _vp, _vp, _vp, _vp],
     "mhip_broadphase_needs_rebuild": [_vp, _sz, _vp, C.POINTER(_i), _vp],
     "mhip_select_contacts": [_sz, _vp, _d, _vp, C.POINTER(_sz), _vp],
+    "mhip_curve_keys": [_sz, _vp, C.POINTER(_d), C.POINTER(_d), _i, _vp, _vp, _vp],
+    "mhip_sort_by_key_u64": [_sz, _vp, _vp, _vp],
     "mhip_broadphase_set_sets": [_vp, _sz, _vp, _vp, _vp],
     "mhip_broadphase_set_exclusions": [_vp, _sz, _vp, _vp, _sz, _vp],
     "mhip_broadphase_set_identities": [_vp, _sz, _vp, _vp, _vp],

@@ -222,6 +222,55 @@ int mhip_curve_order(size_t n, const double* center, const double* lo, const dou
   return MHIP_SUCCESS;
 }
 
+int mhip_curve_keys(size_t n, const double* center, const double* lo, const double* hi, int level,
+                    const int32_t* key_table, uint32_t* keys, mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (center && keys), MHIP_ERR_INVALID_ARGUMENT, "center / keys is null");
+  MHIP_REQUIRE(lo != nullptr && hi != nullptr && key_table != nullptr, MHIP_ERR_INVALID_ARGUMENT,
+               "lo / hi / key_table is null");
+  MHIP_REQUIRE(level >= 1 && level <= 8, MHIP_ERR_INVALID_ARGUMENT, "level must be in [1, 8], got %d", level);
+  MHIP_REQUIRE(hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2], MHIP_ERR_INVALID_ARGUMENT, "empty domain");
+  if (n == 0) return MHIP_SUCCESS;
+  hipStream_t s = as_stream(stream);
+  const size_t ncodes = size_t(1) << (3 * level);
+  ReorderScratch& rs = reorder_scratch();
+  if (int e = rs.hist.reserve((ncodes + 2) * sizeof(int32_t))) return e;  // the counting kernel also fills a histogram
+  MHIP_HIP(hipMemsetAsync(rs.hist.ptr, 0, (ncodes + 1) * sizeof(int32_t), s));
+  const V3 l{lo[0], lo[1], lo[2]}, span{hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+  k_table_count<<<grid_for(n), kBlock, 0, s>>>(n, center, l, span, level, key_table, keys, rs.hist.as<int32_t>());
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+struct SortScratch {
+  DeviceBuffer keys, keys_tmp, vals, vals_tmp, ws;
+};
+static SortScratch& sort_scratch() {
+  thread_local SortScratch s;
+  return s;
+}
+__global__ void __launch_bounds__(kBlock) k_iota_u32(size_t n, unsigned* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = static_cast<unsigned>(i);
+}
+
+int mhip_sort_by_key_u64(size_t n, const uint64_t* keys, int32_t* perm, mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (keys && perm), MHIP_ERR_INVALID_ARGUMENT, "keys / perm is null");
+  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many keys");
+  if (n == 0) return MHIP_SUCCESS;
+  hipStream_t s = as_stream(stream);
+  SortScratch& ss = sort_scratch();
+  if (int e = ss.keys.reserve(n * sizeof(unsigned long long))) return e;
+  if (int e = ss.keys_tmp.reserve(n * sizeof(unsigned long long))) return e;
+  if (int e = ss.vals_tmp.reserve(n * sizeof(unsigned))) return e;
+  if (int e = ss.ws.reserve(radix_sort_workspace_bytes(n))) return e;
+  MHIP_HIP(hipMemcpyAsync(ss.keys.ptr, keys, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+  unsigned* vals = reinterpret_cast<unsigned*>(perm);
+  k_iota_u32<<<grid_for(n), kBlock, 0, s>>>(n, vals);
+  MHIP_LAUNCH_CHECK();
+  return radix_sort_u64(n, ss.keys.as<unsigned long long>(), vals, ss.keys_tmp.as<unsigned long long>(),
+                        ss.vals_tmp.as<unsigned>(), 8, ss.ws.ptr, s);
+}
+
 int mhip_gather_rows(size_t n, size_t width, const int32_t* perm, const double* src, double* dst,
                      mhip_stream_t stream) {
   MHIP_REQUIRE(n == 0 || (perm && src && dst), MHIP_ERR_INVALID_ARGUMENT, "null argument");

@@ -316,10 +316,16 @@ class DistributedContactStepper:
     Rod systems use the rod-compressed operator; a mixed system (kind / shape given) bins its contacts by shape class
     (mhip_contact_mixed) and uses the vector-arm operator."""
 
-    RECORD = 14  # gid, centre 3, quat 4, shape 3 (r,L,- for rods), kind, translational and rotational mobility
+    # gid, centre 3, quat 4, shape 3 (r,L,- for rods), kind, translational and rotational mobility, persistent entity id
+    RECORD = 15
 
     def __init__(self, center, quat, radius, length, gid_first, *, comm=None, dt=5e-3, viscosity=1e-3,
-                 search_buffer=0.1, cfg=None, poll_every=16, kind=None, shape=None):
+                 search_buffer=0.1, cfg=None, poll_every=16, kind=None, shape=None, entity_id=None, domain=None,
+                 curve_level=5, recut_every=4):
+        """entity_id [n] (float64 or int64): ids that stay with a body when it changes owner (default: the initial
+        global ids).  domain = (lo, hi): the fixed box whose (2^curve_level)^3 Hilbert lattice decides ownership when
+        bodies migrate (rebalance / step(migrate=True)); recut_every: re-cut the curve by work every that many
+        rebalances, 0 = keep the cuts."""
         from . import synth
         self.comm = comm or Comm()
         self.mixed = kind is not None
@@ -338,6 +344,16 @@ class DistributedContactStepper:
         self.mob_t = torch.from_numpy(mt0).to(center.device)
         self.mob_r = torch.from_numpy(mr0).to(center.device)
         self.gid_first = int(gid_first)
+        self.entity_id = (torch.arange(self.gid_first, self.gid_first + self.n, dtype=torch.float64, device=center.device)
+                          if entity_id is None else entity_id.to(torch.float64).contiguous())
+        self.domain = None if domain is None else ([float(v) for v in np.broadcast_to(domain[0], 3)],
+                                                   [float(v) for v in np.broadcast_to(domain[1], 3)])
+        if not 1 <= int(curve_level) <= 7:
+            raise ValueError("curve_level must be in [1, 7]")
+        self.curve_level, self.recut_every = int(curve_level), int(recut_every)
+        self.splitters = None            # [world - 1] last lattice cell (Hilbert position) of every rank but the last
+        self._rebalances = 0
+        self._body_weight = None
         self.dt, self.viscosity, self.buffer = float(dt), float(viscosity), float(search_buffer)
         self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)
         self.poll_every = int(poll_every)
@@ -355,6 +371,78 @@ class DistributedContactStepper:
         r, ln = shape[:, 0].contiguous(), shape[:, 1].contiguous()
         return ops.compute_aabb_spherocylinders(center, quat, r, ln), ops.bounding_radius_spherocylinders(r, ln)
 
+    def _records(self):
+        """one RECORD-wide row per owned body: what travels as a ghost and what travels when a body changes owner"""
+        n, dev = self.n, self.center.device
+        gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
+        kcol = self.kind.to(torch.float64)[:, None] if self.mixed else torch.ones((n, 1), dtype=torch.float64, device=dev)
+        return torch.cat([gid[:, None], self.center, self.quat, self.shape, kcol, self.mob_t[:, None],
+                          self.mob_r[:, None], self.entity_id[:, None]], dim=1).contiguous()
+
+    # -- ownership: work-weighted cuts of the Hilbert curve, bodies migrate to the rank whose range their cell is in ----
+    def _cell_keys(self, center):
+        lo, hi = self.domain
+        if getattr(self, "_key_table", None) is None:
+            self._key_table = torch.from_numpy(hilbert_key_table(self.curve_level).astype(np.int32)).to(center.device)
+        return ops.curve_keys(center, lo, hi, self.curve_level, self._key_table).long()
+
+    def rebalance(self, recut=True, weights=None):
+        """Moves every owned body to the rank that owns its lattice cell (replaces the RCB repartition of
+        stk::balance::balanceStkMesh, scrap/lcp_spheres/NGPSpheresLCP.cpp:956, called every load_balance_frequency steps
+        in Bacteria.cpp:1076-1078).  recut=True first re-cuts the curve so that every rank gets the same WORK: weight per
+        body = 1 + its contacts in the last step (or `weights`), histogrammed over the lattice cells, all-gathered, cut
+        at equal cumulative weight -- every rank derives the same cuts.  One grouped send / recv of body records per
+        peer, through the communicator the ghost halo uses.  Returns a dict of counts."""
+        if self.domain is None:
+            raise RuntimeError("rebalance() needs the domain=(lo, hi) the stepper was given at construction")
+        comm, dev, world, rank = self.comm, self.center.device, self.comm.world, self.comm.rank
+        keys = self._cell_keys(self.center) if self.n else torch.zeros(0, dtype=torch.int64, device=dev)
+        ncell = 8 ** self.curve_level
+        if recut or self.splitters is None:
+            w = weights if weights is not None else self._body_weight
+            if w is None or w.shape[0] != self.n:
+                w = torch.ones(self.n, dtype=torch.float64, device=dev)
+            hist = torch.zeros(ncell, dtype=torch.float64, device=dev).index_add_(0, keys, w.to(torch.float64))
+            cum = np.cumsum(comm.all_gather(hist).sum(dim=0).cpu().numpy())   # identical on every rank
+            targets = cum[-1] * np.arange(1, world) / world
+            self.splitters = np.searchsorted(cum, targets, side="left").astype(np.int64)
+        # rank r owns the cells  splitters[r - 1] < key <= splitters[r]
+        dest = torch.bucketize(keys, torch.from_numpy(self.splitters).to(dev), right=False)
+        rec = self._records()
+        counts = torch.bincount(dest, minlength=world).to(torch.float64)
+        matrix = comm.all_gather(counts).cpu().numpy().astype(np.int64)       # [src][dst]
+        send = {p: rec[dest == p].contiguous() for p in range(world) if p != rank and matrix[rank][p] > 0}
+        recv = {p: torch.empty((int(matrix[p][rank]), self.RECORD), dtype=torch.float64, device=dev)
+                for p in range(world) if p != rank and matrix[p][rank] > 0}
+        comm.exchange(send, recv)
+        new = torch.cat([rec[dest == rank]] + [recv[p] for p in sorted(recv)], dim=0).contiguous()
+        n_new = new.shape[0]
+        if n_new:
+            # owned bodies in curve order, ties by entity id: the local order every rank and the single-rank run agree on
+            key2 = (self._cell_keys(new[:, 1:4].contiguous()) << 40) | new[:, 14].to(torch.int64)
+            new = ops.gather_rows(ops.sort_by_key(key2.contiguous()), new)
+        self.center, self.quat = new[:, 1:4].contiguous(), new[:, 4:8].contiguous()
+        self.shape = new[:, 8:11].contiguous()
+        if self.mixed:
+            self.kind = new[:, 11].to(torch.int32).contiguous()
+        self.mob_t, self.mob_r = new[:, 12].contiguous(), new[:, 13].contiguous()
+        self.entity_id = new[:, 14].contiguous()
+        self.n = n_new
+        sizes = comm.all_gather(torch.tensor([float(n_new)], dtype=torch.float64, device=dev)).cpu().numpy().ravel()
+        self.gid_first = int(sizes[:rank].sum())
+        # everything indexed by the old numbering goes
+        self.links.invalidate()
+        if self.op is not None:
+            self.op.close()
+            self.op = None
+        self._layout = None
+        self._body_weight = None
+        self._rebalances += 1
+        out = dict(sent=int(matrix[rank].sum() - matrix[rank][rank]), received=int(matrix[:, rank].sum() - matrix[rank][rank]),
+                   owned=n_new, recut=bool(recut))
+        self.stats.update(migrated_out=out["sent"], migrated_in=out["received"])
+        return out
+
     # -- ghost halo -----------------------------------------------------------------------------------------------------
     def _exchange_ghosts(self, replan=True):
         """ghost plan + body-record exchange, both inside the library (mhip_ghost_plan / mhip_ghost_exchange).
@@ -367,23 +455,21 @@ class DistributedContactStepper:
             capi.check(lib.mhip_ghost_plan(comm._h, n, _p(aabb), self.buffer, C.byref(lay), _stream()))
         lay = self._layout
         n_lo, n_hi = int(lay.num_ghost_lo), int(lay.num_ghost_hi)
-        # records of the owned bodies: gid, centre, quaternion, shape, kind, mobilities
-        gid = torch.arange(self.gid_first, self.gid_first + n, dtype=torch.float64, device=dev)
-        kcol = self.kind.to(torch.float64)[:, None] if self.mixed else torch.ones((n, 1), dtype=torch.float64, device=dev)
-        rec = torch.cat([gid[:, None], self.center, self.quat, self.shape, kcol, self.mob_t[:, None],
-                         self.mob_r[:, None]], dim=1).contiguous()
+        rec = self._records()
         local = torch.empty((n_lo + n + n_hi, self.RECORD), dtype=torch.float64, device=dev)
         capi.check(lib.mhip_ghost_exchange(comm._h, self.RECORD, _p(rec), _p(local), _stream()))
         self.n_lo, self.n_hi, self.n_local = n_lo, n_hi, local.shape[0]
         self.local = dict(gid=local[:, 0].contiguous(), center=local[:, 1:4].contiguous(),
                           quat=local[:, 4:8].contiguous(), shape=local[:, 8:11].contiguous(),
                           kind=local[:, 11].to(torch.int32).contiguous(), mob_t=local[:, 12].contiguous(),
-                          mob_r=local[:, 13].contiguous())
+                          mob_r=local[:, 13].contiguous(), entity=local[:, 14].contiguous())
         self.stats.update(ghosts=n_lo + n_hi, halo_send_bodies=int(lay.num_sent))
 
     # -- one step -------------------------------------------------------------------------------------------------------------
-    def step(self, integrate=True, force_rebuild=True):
-        """force_rebuild=False applies the reference's rebuild rule across the ranks (GenNeighborLinkers.hpp:603-615 and
+    def step(self, integrate=True, force_rebuild=True, migrate=False):
+        """migrate=True: before a rebuild, bodies whose lattice cell now belongs to another rank change owner
+        (rebalance); every recut_every-th time the curve is re-cut by work first.
+        force_rebuild=False applies the reference's rebuild rule across the ranks (GenNeighborLinkers.hpp:603-615 and
         the all-reduce of its parallel build): the ghosts' current state travels through the plan of the last rebuild,
         every rank tests its local bodies (owned + ghosts) against half the search buffer, one all-gather of the flags
         decides for everybody; without a rebuild the ghost layout, the pair list, its interior / boundary split and the
@@ -407,6 +493,10 @@ class DistributedContactStepper:
             flags = comm.all_gather(torch.tensor([1.0 if moved else 0.0], dtype=torch.float64))
             reuse = not bool(flags.max().item() > 0.0)
         if not reuse:
+            if migrate:
+                self.rebalance(recut=self.splitters is None or
+                               (self.recut_every > 0 and self._rebalances % self.recut_every == 0))
+                tick("migrate")
             self._exchange_ghosts()
         tick("ghost_exchange")
         L, dev = self.local, self.center.device
@@ -485,6 +575,10 @@ class DistributedContactStepper:
             self.quat.copy_(own_q)
         tick("integrate")
         owned_contacts = int(counted.sum().item()) if nc else 0
+        # work per owned body for the next re-cut: 1 + the contacts it takes part in (every contact of an owned body is
+        # present locally)
+        deg = torch.bincount(pairs.reshape(-1).long(), minlength=nl) if nc else torch.zeros(nl, dtype=torch.int64, device=dev)
+        self._body_weight = 1.0 + deg[self.n_lo:self.n_lo + self.n].to(torch.float64)
         self.stats.update(local_bodies=nl, local_contacts=nc, owned_contacts=owned_contacts,
                           num_iters=int(res.num_iters), residual=float(res.residual), converged=bool(res.converged))
         return dict(self.stats)

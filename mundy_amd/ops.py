@@ -671,6 +671,24 @@ def curve_order(center, lo, hi, level, key_table):
     return perm
 
 
+def curve_keys(center, lo, hi, level, key_table):
+    """key_table entry of every body's cell (int32 tensor): what curve_order sorts by"""
+    n = center.shape[0]
+    keys = torch.empty(n, dtype=torch.int32, device=center.device)
+    lop = (C.c_double * 3)(*[float(v) for v in lo])
+    hip = (C.c_double * 3)(*[float(v) for v in hi])
+    capi.check(capi.load().mhip_curve_keys(n, _ptr(center, cols=3), lop, hip, int(level),
+                                           _ptr(key_table.reshape(-1), torch.int32), _ptr(keys, torch.int32), _stream()))
+    return keys
+
+
+def sort_by_key(keys):
+    """stable ascending order of int64 keys (non-negative): int32 permutation (library radix sort)"""
+    perm = torch.empty(keys.shape[0], dtype=torch.int32, device=keys.device)
+    capi.check(capi.load().mhip_sort_by_key_u64(keys.shape[0], _ptr(keys, torch.int64), _ptr(perm, torch.int32), _stream()))
+    return perm
+
+
 def select_contacts(sep, cutoff):
     """BUILD OPTION: ascending indices (int32) of the candidate pairs whose signed separation is not above `cutoff`
     (NaN kept) -- wavefront ballot / prefix-sum compaction (mhip_select_contacts)"""

@@ -39,7 +39,8 @@ def main():
     else:
         g_radius, g_length = b["radius"][order], b["length"][order]
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]),
-                                         a, comm=D.Comm(), search_buffer=buf, cfg=cfg, poll_every=8)
+                                         a, comm=D.Comm(), search_buffer=buf, cfg=cfg, poll_every=8,
+                                         domain=(0.0, b["box"]), curve_level=4, recut_every=3)
     stats = st.step(integrate=False)
     gid = st.local["gid"].cpu().numpy().astype(np.int64)
     pairs = st.pairs.cpu().numpy()
@@ -108,12 +109,17 @@ def main():
     # Euler update each step), track the single-rank trajectory of the same system
     steps = int(os.environ.get("DIST_STEPS", "0"))
     reuse = os.environ.get("DIST_REUSE", "0") == "1"   # the rebuild rule across ranks instead of a rebuild every step
+    migrate = os.environ.get("DIST_MIGRATE", "0") == "1"  # bodies change owner; the curve is re-cut by work
     if steps and not mixed:
-        rebuilt = []
+        rebuilt, moved_out, imbalance = [], 0, []
         for _ in range(steps):
-            stats = st.step(integrate=True, force_rebuild=not reuse)
+            stats = st.step(integrate=True, force_rebuild=not reuse, migrate=migrate)
             rebuilt.append(bool(stats["rebuilt"]))
-        mine = dict(c=st.center.cpu().numpy(), q=st.quat.cpu().numpy(), conv=stats["converged"])
+            moved_out += stats.get("migrated_out", 0) if migrate else 0
+            imbalance.append(stats["owned_contacts"])
+        ent = st.entity_id.cpu().numpy().astype(np.int64)
+        mine = dict(c=st.center.cpu().numpy(), q=st.quat.cpu().numpy(), conv=stats["converged"], ent=ent,
+                    moved_out=moved_out, owned_contacts=imbalance, n=st.n)
         allc = [None] * world if rank == 0 else None
         dist.gather_object(mine, allc, dst=0)
         if rank == 0:
@@ -122,12 +128,26 @@ def main():
                 rs = ref.step(integrate=True, force_rebuild=not reuse)
                 ref_rebuilt.append(bool(rs.rebuilt))
             c_ref, q_ref = ref.center.cpu().numpy(), ref.quat.cpu().numpy()
-            c_all = np.concatenate([o["c"] for o in allc])
-            q_all = np.concatenate([o["q"] for o in allc])
+            ent_all = np.concatenate([o["ent"] for o in allc])
+            order_e = np.argsort(ent_all)
+            good_ids = np.array_equal(ent_all[order_e], np.arange(n_total))      # every body exactly once
+            c_all = np.concatenate([o["c"] for o in allc])[order_e]
+            q_all = np.concatenate([o["q"] for o in allc])[order_e]
             dc = np.abs(c_all - c_ref).max()
             dq = np.abs(np.abs(np.sum(q_all * q_ref, axis=1)) - 1.0).max()
             moved = np.abs(c_ref - g_center).max()
-            good = all(o["conv"] for o in allc) and rs.converged and dc <= 1e-4 and dq <= 1e-8
+            # every sum that reaches an iterate is rounded once (double-double), so neither the partition nor a change of
+            # owner reaches the trajectory: far below the 1e-4 this test used to allow
+            good = all(o["conv"] for o in allc) and rs.converged and good_ids and dc <= 1e-11 and dq <= 1e-12
+            if migrate:
+                total_moved = sum(o["moved_out"] for o in allc)
+                per_rank = np.array([o["owned_contacts"] for o in allc], dtype=np.float64)   # [rank][step]
+                imb = per_rank.max(axis=0) * world / np.maximum(1.0, per_rank.sum(axis=0))
+                owners_changed = total_moved > 0
+                print(("ok   " if owners_changed else "FAIL ") + "%d bodies changed owner over %d steps; owned bodies now %s; "
+                      "contact imbalance (max / mean) first step %.3f, after the re-cuts %.3f"
+                      % (total_moved, steps, [o["n"] for o in allc], imb[0], imb[-1]))
+                good = good and owners_changed and imb[-1] <= max(1.15, imb[0])
             print(("ok   " if good else "FAIL ") + "%d-step trajectory vs single rank: max |dc| %.3g (bodies moved up to %.3g), "
                   "quaternion defect %.3g" % (steps, dc, moved, dq))
             if reuse:

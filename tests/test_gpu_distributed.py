@@ -25,6 +25,7 @@ def _run(world, port=None, extra_env=None):
     print(p.stdout[-5000:], p.stderr[-3000:])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     tag = "_mixed" if (extra_env or {}).get("DIST_MIXED") == "1" else ""
+    tag += "_migrate" if (extra_env or {}).get("DIST_MIGRATE") == "1" else ""
     with open(os.path.join(ROOT, "gpurun_out", "dist_world%d%s.log" % (world, tag)), "w") as f:
         f.write(p.stdout[-20000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
@@ -56,6 +57,14 @@ def test_distributed_trajectory_with_list_reuse():
     # the rebuild rule across ranks: ghosts refreshed through the old plan, one all-gathered decision, list / partition /
     # incidence index reused when nobody moved more than half the buffer; decisions equal the single-rank ones
     _run(3, None, {"DIST_STEPS": "8", "DIST_REUSE": "1", "DIST_BODIES": "6000", "DIST_PHI": "0.2", "DIST_BUFFER": "0.4"})
+
+
+def test_three_ranks_40_steps_bodies_migrate_and_the_curve_is_recut_by_work():
+    # ownership follows the bodies (a body whose lattice cell now lies in another rank's range of
+    # the Hilbert curve is handed over at the rebuild), the curve is re-cut every third rebalance at equal WORK (weight
+    # 1 + contacts per body), and the 40-step trajectory still is the single-rank one
+    _run(3, None, {"DIST_STEPS": "40", "DIST_MIGRATE": "1", "DIST_BODIES": "6000", "DIST_PHI": "0.3",
+                   "DIST_BUFFER": "0.3"})
 
 
 def test_distributed_mixed_shapes_equals_single_rank():
