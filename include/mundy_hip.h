@@ -121,6 +121,14 @@ int mhip_contact_spheres(size_t c, const int32_t* pairs, const double* center, c
 int mhip_contact_spherocylinders(size_t c, const int32_t* pairs, const double* seg, const double* center, double* sep,
                                  double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
                                  double* t, mhip_stream_t stream);
+/* The same in an orthorhombic periodic box [host: 3 edge lengths]: rod j is taken at the lattice image whose centre is
+ * nearest to rod i's centre -- shift = (c_i + PeriodicScaledMetric::sep(c_i, c_j)) - c_j (periodicity.hpp:812-816), a
+ * rigid translation as wrap_rigid applies to a spherocylinder (:1094-1113).  Contact points are in rod i's image; rb is
+ * taken from the shifted centre of rod j.  center is required. */
+int mhip_contact_spherocylinders_periodic(size_t c, const int32_t* pairs, const double* seg, const double* center,
+                                          const double* box /*[host] 3*/, double* sep, double* normal, double* cp1,
+                                          double* cp2, double* ra, double* rb, double* s, double* t,
+                                          mhip_stream_t stream);
 
 /* Mixed shapes (BASELINE configs[4]): kind[n] = 0 sphere, 1 spherocylinder, 2 ellipsoid; shape[n][3] = (r,-,-) /
  * (r,L,-) / (r1,r2,r3); quat is ignored for spheres.  compute_aabb dispatches on kind (compute_aabb.hpp:72-127) and
@@ -134,6 +142,11 @@ int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center,
 int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
                        const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                        double* rb, size_t* class_counts /*[host]*/, mhip_stream_t stream);
+/* periodic box [host: 3 edge lengths]: body j at the nearest lattice image of its centre, c_j' = c_i + sep(c_i, c_j) */
+int mhip_contact_mixed_periodic(size_t c, const int32_t* pairs, const int32_t* kind, const double* center,
+                                const double* quat, const double* shape, const double* box /*[host] 3*/, double* sep,
+                                double* normal, double* cp1, double* cp2, double* ra, double* rb,
+                                size_t* class_counts /*[host]*/, mhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Broad phase (seam S3).

@@ -88,6 +88,8 @@ SIGNATURES = {
     "mhip_contact_ellipsoids": [_sz] + [_vp] * 11,
     "mhip_compute_aabb_mixed": [_sz] + [_vp] * 7,
     "mhip_contact_mixed": [_sz] + [_vp] * 11 + [C.POINTER(_sz), _vp],
+    "mhip_contact_mixed_periodic": [_sz] + [_vp] * 5 + [C.POINTER(_d)] + [_vp] * 6 + [C.POINTER(_sz), _vp],
+    "mhip_contact_spherocylinders_periodic": [_sz, _vp, _vp, _vp, C.POINTER(_d)] + [_vp] * 9,
     "mhip_contact_spheres": [_sz, _vp, _vp, _vp, C.POINTER(_d), _vp, _vp, _vp],
     "mhip_contact_spherocylinders": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_broadphase_create": [C.POINTER(_vp)],

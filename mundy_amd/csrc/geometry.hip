@@ -157,14 +157,27 @@ __global__ void __launch_bounds__(kBlock)
 
 // rods: algorithmic bytes per contact = pair 8 + 2 x 64 B segment records + 2 x 24 B centres gathered
 //       + sep 8 + normal 24 + lever arms 48 (+ optional cp 48, s/t 16)
+// PERIODIC: the second rod is taken at the lattice image whose centre is nearest to the first rod's centre
+// (PeriodicScaledMetric::sep of the centres, periodicity.hpp:812-816; rigid translation as wrap_rigid moves a
+// spherocylinder, :1094-1113): shift = (c_i + sep(c_i, c_j)) - c_j is added to both of its endpoints, and its lever arm
+// is taken from the shifted centre.  Contact points come out in the first rod's image.
+template <bool PERIODIC>
 __global__ void __launch_bounds__(kBlock)
     k_contact_rods(size_t nc, const int2* __restrict__ pairs, const double* __restrict__ seg,
-                   const double* __restrict__ center, double* __restrict__ sep, double* __restrict__ normal,
-                   double* __restrict__ cp1, double* __restrict__ cp2, double* __restrict__ ra,
-                   double* __restrict__ rb, double* __restrict__ s, double* __restrict__ t) {
+                   const double* __restrict__ center, Periodic pm, double* __restrict__ sep,
+                   double* __restrict__ normal, double* __restrict__ cp1, double* __restrict__ cp2,
+                   double* __restrict__ ra, double* __restrict__ rb, double* __restrict__ s, double* __restrict__ t) {
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nc; c += (size_t)gridDim.x * blockDim.x) {
     const int2 ij = pairs[c];
-    const SegRec a = load_seg(seg, ij.x), b = load_seg(seg, ij.y);
+    const SegRec a = load_seg(seg, ij.x);
+    SegRec b = load_seg(seg, ij.y);
+    V3 shift{0.0, 0.0, 0.0};
+    if (PERIODIC) {
+      const V3 ci = load3(center, ij.x), cj = load3(center, ij.y);
+      shift = (ci + periodic_sep(pm, ci, cj)) - cj;
+      b.p0 = b.p0 + shift;
+      b.p1 = b.p1 + shift;
+    }
     const SegSeg r = dist_segment_segment(a.p0, a.p1, b.p0, b.p1);
     const double radius_sum = a.r + b.r;
     const double inv = 1.0 / r.dist;
@@ -174,7 +187,7 @@ __global__ void __launch_bounds__(kBlock)
     if (cp1) store3(cp1, c, r.cp1);
     if (cp2) store3(cp2, c, r.cp2);
     if (ra) store3(ra, c, r.cp1 - load3(center, ij.x));
-    if (rb) store3(rb, c, r.cp2 - load3(center, ij.y));
+    if (rb) store3(rb, c, r.cp2 - (PERIODIC ? load3(center, ij.y) + shift : load3(center, ij.y)));
     if (s) s[c] = r.s;
     if (t) t[c] = r.t;
   }
@@ -321,20 +334,41 @@ int mhip_contact_spheres_triclinic(size_t c, const int32_t* pairs, const double*
   return MHIP_SUCCESS;
 }
 
-int mhip_contact_spherocylinders(size_t c, const int32_t* pairs, const double* seg, const double* center, double* sep,
-                                 double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
-                                 double* t, mhip_stream_t stream) {
+static int contact_rods(size_t c, const int32_t* pairs, const double* seg, const double* center, const double* box,
+                        double* sep, double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
+                        double* t, mhip_stream_t stream) {
   TraceRange trace_range("contact_spherocylinders");
   const size_t n = c;
   REQ_PTR(pairs); REQ_PTR(seg);
-  MHIP_REQUIRE(center != nullptr || (ra == nullptr && rb == nullptr), MHIP_ERR_INVALID_ARGUMENT,
-               "center is required when lever arms are requested");
+  MHIP_REQUIRE(center != nullptr || (ra == nullptr && rb == nullptr && box == nullptr), MHIP_ERR_INVALID_ARGUMENT,
+               "center is required when lever arms or a periodic box are requested");
   MHIP_REQUIRE((reinterpret_cast<uintptr_t>(seg) & 15) == 0, MHIP_ERR_INVALID_ARGUMENT, "seg must be 16-byte aligned");
+  if (box)
+    MHIP_REQUIRE(box[0] > 0 && box[1] > 0 && box[2] > 0, MHIP_ERR_INVALID_ARGUMENT, "periodic box must be positive");
   if (c == 0) return MHIP_SUCCESS;
-  k_contact_rods<<<grid_for(c), kBlock, 0, as_stream(stream)>>>(c, reinterpret_cast<const int2*>(pairs), seg, center,
-                                                                sep, normal, cp1, cp2, ra, rb, s, t);
+  const int2* p2 = reinterpret_cast<const int2*>(pairs);
+  const double one[3] = {1, 1, 1};
+  if (box)
+    k_contact_rods<true><<<grid_for(c), kBlock, 0, as_stream(stream)>>>(c, p2, seg, center, make_periodic(box), sep,
+                                                                        normal, cp1, cp2, ra, rb, s, t);
+  else
+    k_contact_rods<false><<<grid_for(c), kBlock, 0, as_stream(stream)>>>(c, p2, seg, center, make_periodic(one), sep,
+                                                                         normal, cp1, cp2, ra, rb, s, t);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
+}
+
+int mhip_contact_spherocylinders(size_t c, const int32_t* pairs, const double* seg, const double* center, double* sep,
+                                 double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
+                                 double* t, mhip_stream_t stream) {
+  return contact_rods(c, pairs, seg, center, nullptr, sep, normal, cp1, cp2, ra, rb, s, t, stream);
+}
+
+int mhip_contact_spherocylinders_periodic(size_t c, const int32_t* pairs, const double* seg, const double* center,
+                                          const double* box, double* sep, double* normal, double* cp1, double* cp2,
+                                          double* ra, double* rb, double* s, double* t, mhip_stream_t stream) {
+  MHIP_REQUIRE(box != nullptr, MHIP_ERR_INVALID_ARGUMENT, "box is null");
+  return contact_rods(c, pairs, seg, center, box, sep, normal, cp1, cp2, ra, rb, s, t, stream);
 }
 
 }  // extern "C"

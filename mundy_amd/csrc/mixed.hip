@@ -79,7 +79,14 @@ __global__ void __launch_bounds__(kBlock)
 
 struct MixedOut {
   double *sep, *normal, *cp1, *cp2, *ra, *rb;
+  // periodic box: body j is taken at the lattice image whose centre is nearest to body i's centre
+  // (c_j' = c_i + PeriodicScaledMetric::sep(c_i, c_j); rigid translation, periodicity.hpp:1088-1160)
+  int periodic;
+  Periodic pm;
 };
+__device__ inline void nearest_image(const MixedOut& o, const BodyD& bi, BodyD& bj) {
+  if (o.periodic) bj.c = bi.c + periodic_sep(o.pm, bi.c, bj.c);
+}
 __device__ inline void store_contact(const MixedOut& o, size_t k, bool swapped, double sep, V3 n, V3 cpA, V3 cpB, V3 ci,
                                      V3 cj) {
   // canonical (A, B) = (lower kind, higher kind); the list's (i, j) may be (B, A)
@@ -111,7 +118,9 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
   for (int32_t t = beg + blockIdx.x * blockDim.x + threadIdx.x; t < end; t += gridDim.x * blockDim.x) {
     const size_t k = static_cast<size_t>(order[t]);
     const int2 ij = pairs[k];
-    const BodyD bi = load_body(kind, center, quat, shape, ij.x), bj = load_body(kind, center, quat, shape, ij.y);
+    const BodyD bi = load_body(kind, center, quat, shape, ij.x);
+    BodyD bj = load_body(kind, center, quat, shape, ij.y);
+    nearest_image(out, bi, bj);
     const bool swapped = bi.kind > bj.kind;
     const BodyD& A = swapped ? bj : bi;
     const BodyD& B = swapped ? bi : bj;
@@ -214,7 +223,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
         if (active) {
           k = static_cast<size_t>(order[beg + idx]);
           const int2 ij = pairs[k];
-          const BodyD bi = load_body(kind, center, quat, shape, ij.x), bj = load_body(kind, center, quat, shape, ij.y);
+          const BodyD bi = load_body(kind, center, quat, shape, ij.x);
+          BodyD bj = load_body(kind, center, quat, shape, ij.y);
+          nearest_image(out, bi, bj);
           swapped = bi.kind > bj.kind;
           A = swapped ? bj : bi;
           B = swapped ? bi : bj;
@@ -289,9 +300,32 @@ int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center,
   return MHIP_SUCCESS;
 }
 
+static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kind, const double* center,
+                              const double* quat, const double* shape, const double* box, double* sep, double* normal,
+                              double* cp1, double* cp2, double* ra, double* rb, size_t* class_counts,
+                              mhip_stream_t stream);
+
 int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
                        const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                        double* rb, size_t* class_counts, mhip_stream_t stream) {
+  return contact_mixed_impl(c, pairs, kind, center, quat, shape, nullptr, sep, normal, cp1, cp2, ra, rb, class_counts,
+                            stream);
+}
+
+int mhip_contact_mixed_periodic(size_t c, const int32_t* pairs, const int32_t* kind, const double* center,
+                                const double* quat, const double* shape, const double* box, double* sep, double* normal,
+                                double* cp1, double* cp2, double* ra, double* rb, size_t* class_counts,
+                                mhip_stream_t stream) {
+  MHIP_REQUIRE(box != nullptr && box[0] > 0 && box[1] > 0 && box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
+               "periodic box must be positive");
+  return contact_mixed_impl(c, pairs, kind, center, quat, shape, box, sep, normal, cp1, cp2, ra, rb, class_counts,
+                            stream);
+}
+
+static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kind, const double* center,
+                              const double* quat, const double* shape, const double* box, double* sep, double* normal,
+                              double* cp1, double* cp2, double* ra, double* rb, size_t* class_counts,
+                              mhip_stream_t stream) {
   TraceRange trace_range("contact_mixed");
   if (class_counts)
     for (int k = 0; k < 6; ++k) class_counts[k] = 0;
@@ -319,7 +353,8 @@ int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, cons
                                          ms.order.as<int32_t>());
     MHIP_LAUNCH_CHECK();
   }
-  const MixedOut out{sep, normal, cp1, cp2, ra, rb};
+  const double unit_box[3] = {1, 1, 1};
+  const MixedOut out{sep, normal, cp1, cp2, ra, rb, box ? 1 : 0, make_periodic(box ? box : unit_box)};
   const int32_t* order = ms.order.as<int32_t>();
 #define CLASS(K, BLK, GRID) \
   k_contact_class<K, BLK><<<GRID, BLK, 0, s>>>(start, order, p2, kind, center, quat, shape, out)

@@ -173,15 +173,22 @@ def compute_aabb_mixed(kind, center, quat, shape):
     return aabb, brad
 
 
-def contact_mixed(pairs, kind, center, quat, shape, want_counts=False):
+def contact_mixed(pairs, kind, center, quat, shape, want_counts=False, box=None):
+    """box: 3 edge lengths of an orthorhombic periodic box (body j at the nearest image of its centre)"""
     c = pairs.shape[0]
     out = dict(sep=_new(center, c), normal=_new(center, c, 3), cp1=_new(center, c, 3), cp2=_new(center, c, 3),
                ra=_new(center, c, 3), rb=_new(center, c, 3))
     counts = (C.c_size_t * 6)() if want_counts else None
-    capi.check(capi.load().mhip_contact_mixed(
-        c, _ptr(pairs, torch.int32, 2), _ptr(kind, torch.int32), _ptr(center, cols=3), _ptr(quat, cols=4),
-        _ptr(shape, cols=3), _ptr(out["sep"]), _ptr(out["normal"]), _ptr(out["cp1"]), _ptr(out["cp2"]),
-        _ptr(out["ra"]), _ptr(out["rb"]), counts, _stream()))
+    if box is not None:
+        capi.check(capi.load().mhip_contact_mixed_periodic(
+            c, _ptr(pairs, torch.int32, 2), _ptr(kind, torch.int32), _ptr(center, cols=3), _ptr(quat, cols=4),
+            _ptr(shape, cols=3), (C.c_double * 3)(*[float(b) for b in box]), _ptr(out["sep"]), _ptr(out["normal"]),
+            _ptr(out["cp1"]), _ptr(out["cp2"]), _ptr(out["ra"]), _ptr(out["rb"]), counts, _stream()))
+    else:
+        capi.check(capi.load().mhip_contact_mixed(
+            c, _ptr(pairs, torch.int32, 2), _ptr(kind, torch.int32), _ptr(center, cols=3), _ptr(quat, cols=4),
+            _ptr(shape, cols=3), _ptr(out["sep"]), _ptr(out["normal"]), _ptr(out["cp1"]), _ptr(out["cp2"]),
+            _ptr(out["ra"]), _ptr(out["rb"]), counts, _stream()))
     if want_counts:
         out["class_counts"] = dict(zip(("SS", "SR", "SE", "RR", "RE", "EE"), [int(v) for v in counts]))
     return out
@@ -209,8 +216,9 @@ def contact_spheres(pairs, center, radius, box=None, out=None):
     return sep, normal
 
 
-def contact_spherocylinders(pairs, seg, center, want_points=True, out=None, arms="vector"):
-    """arms="vector": lever arms ra / rb [C,3]; arms="arclength": only (s, t), for ContactOperator(rod=...)."""
+def contact_spherocylinders(pairs, seg, center, want_points=True, out=None, arms="vector", box=None):
+    """arms="vector": lever arms ra / rb [C,3]; arms="arclength": only (s, t), for ContactOperator(rod=...).
+    box: 3 edge lengths of an orthorhombic periodic box (rod j at the nearest image of its centre)."""
     c = pairs.shape[0]
     if out is None:
         out = dict(sep=_new(seg, c), normal=_new(seg, c, 3))
@@ -221,6 +229,12 @@ def contact_spherocylinders(pairs, seg, center, want_points=True, out=None, arms
         if want_points:
             out.update(cp1=_new(seg, c, 3), cp2=_new(seg, c, 3))
     g = lambda k: _ptr(out.get(k), allow_none=True, name=k)  # noqa: E731
+    if box is not None:
+        capi.check(capi.load().mhip_contact_spherocylinders_periodic(
+            c, _ptr(pairs, torch.int32, 2), _ptr(seg, cols=8), _ptr(center, cols=3),
+            (C.c_double * 3)(*[float(b) for b in box]), g("sep"), g("normal"), g("cp1"), g("cp2"), g("ra"), g("rb"),
+            g("s"), g("t"), _stream()))
+        return out
     capi.check(capi.load().mhip_contact_spherocylinders(c, _ptr(pairs, torch.int32, 2), _ptr(seg, cols=8),
                                                         _ptr(center, cols=3), g("sep"), g("normal"), g("cp1"),
                                                         g("cp2"), g("ra"), g("rb"), g("s"), g("t"), _stream()))

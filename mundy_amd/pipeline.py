@@ -42,8 +42,6 @@ class ContactStepper:
             raise ValueError("spherocylinders need quat and length")
         if kind == "mixed" and (quat is None or kinds is None or shape is None):
             raise ValueError("mixed systems need quat, kinds and shape")
-        if kind != "sphere" and periodic_box is not None:
-            raise ValueError("periodic boxes are supported for spheres only")
         if friction is not None and kind != "spherocylinder":
             raise ValueError("the friction extension is wired for spherocylinders")
         self.kind = kind
@@ -152,12 +150,12 @@ class ContactStepper:
             sep, normal = ops.contact_spheres(pairs, self.center, self.radius, box=self.box)
             self.contacts = dict(sep=sep, normal=normal, ra=None, rb=None)
         elif self.kind == "mixed":  # pairs binned by shape class, one distance routine per class
-            self.contacts = ops.contact_mixed(pairs, self.kinds, self.center, self.quat, self.shape)
+            self.contacts = ops.contact_mixed(pairs, self.kinds, self.center, self.quat, self.shape, box=self.box)
         else:
             ops.spherocylinder_segments(self.center, self.quat, self.radius, self.length, out=self.seg)
             rodk = self.rod_kinematics and self.friction is None
             self.contacts = ops.contact_spherocylinders(pairs, self.seg, self.center, want_points=False,
-                                                        arms="arclength" if rodk else "vector")
+                                                        arms="arclength" if rodk else "vector", box=self.box)
         return self.contacts
 
     def _compact_contacts(self):
@@ -246,6 +244,10 @@ class ContactStepper:
     def integrate(self):
         vel = self.op.body_velocity()
         ops.integrate_euler(self.dt, vel, self.center, self.quat)
+        if self.box is not None:
+            # wrap_rigid_inplace of a Sphere / Spherocylinder / Ellipsoid: the centre goes back into the box,
+            # orientation and size are untouched (periodicity.hpp:1088-1113, :1156-1160)
+            ops.wrap_rigid(self.box, self.center)
 
     # -- one timestep -------------------------------------------------------------------------------------------------
     def step(self, integrate=True, force_rebuild=False, timed=False):

@@ -174,13 +174,15 @@ def contact_spheres(pairs, center, radius, box=None, fast=False):
     return sep, normal
 
 
-def contact_spherocylinders(pairs, seg, center, fast=False):
+def contact_spherocylinders(pairs, seg, center, fast=False, box=None):
+    """box: orthorhombic periodic box (3 edge lengths): rod j at the nearest image of its centre"""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     seg, center = _f(seg), _f(center)
+    box = None if box is None else _f(box)
     c = len(pairs)
     out = dict(sep=np.empty(c), normal=np.empty((c, 3)), cp1=np.empty((c, 3)), cp2=np.empty((c, 3)),
                ra=np.empty((c, 3)), rb=np.empty((c, 3)), s=np.empty(c), t=np.empty(c))
-    lib(fast).o_contact_spherocylinders(C.c_size_t(c), _p(pairs), _p(seg), _p(center), _p(out["sep"]),
+    lib(fast).o_contact_spherocylinders(C.c_size_t(c), _p(pairs), _p(seg), _p(center), _p(box), _p(out["sep"]),
                                         _p(out["normal"]), _p(out["cp1"]), _p(out["cp2"]), _p(out["ra"]),
                                         _p(out["rb"]), _p(out["s"]), _p(out["t"]))
     return out
@@ -575,13 +577,14 @@ def aabb_mixed(kind, center, quat, shape, fast=False):
     return aabb, brad
 
 
-def contact_mixed(pairs, kind, center, quat, shape, fast=False):
+def contact_mixed(pairs, kind, center, quat, shape, fast=False, box=None):
+    box = None if box is None else _f(box)
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     kind = np.ascontiguousarray(kind, dtype=np.int32)
     center, quat, shape = _f(center), _f(quat), _f(shape)
     c = len(pairs)
     out = dict(sep=np.empty(c), normal=np.empty((c, 3)), cp1=np.empty((c, 3)), cp2=np.empty((c, 3)),
                ra=np.empty((c, 3)), rb=np.empty((c, 3)))
-    lib(fast).o_contact_mixed(C.c_size_t(c), _p(pairs), _p(kind), _p(center), _p(quat), _p(shape), _p(out["sep"]),
+    lib(fast).o_contact_mixed(C.c_size_t(c), _p(pairs), _p(kind), _p(center), _p(quat), _p(shape), _p(box), _p(out["sep"]),
                               _p(out["normal"]), _p(out["cp1"]), _p(out["cp2"]), _p(out["ra"]), _p(out["rb"]))
     return out

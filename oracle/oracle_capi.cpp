@@ -133,23 +133,33 @@ void o_contact_spheres(size_t C, const int32_t* pairs, const double* center, con
   }
 }
 // seg = [N][8] records from o_spherocylinder_segments; ra/rb = closest point - body centre (lever arms).
-void o_contact_spherocylinders(size_t C, const int32_t* pairs, const double* seg, const double* center, double* sep,
-                               double* normal, double* cp1, double* cp2, double* ra, double* rb, double* s,
-                               double* t) {
+// box (null or [3]): rod j at the lattice image whose centre is nearest to rod i's centre -- shift = (c_i + sep(c_i,
+// c_j)) - c_j with PeriodicScaledMetric::sep (periodicity.hpp:812-816), a rigid translation as wrap_rigid moves a
+// spherocylinder (:1094-1113).
+void o_contact_spherocylinders(size_t C, const int32_t* pairs, const double* seg, const double* center,
+                               const double* box, double* sep, double* normal, double* cp1, double* cp2, double* ra,
+                               double* rb, double* s, double* t) {
+  const PeriodicScaledMetric pm(box ? V3{box[0], box[1], box[2]} : V3{1, 1, 1});
 #pragma omp parallel for
   for (size_t c = 0; c < C; ++c) {
     const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
     const double* si = seg + 8 * i;
     const double* sj = seg + 8 * j;
-    const RodContact rc =
-        contact_segments({si[0], si[1], si[2]}, {si[3], si[4], si[5]}, si[6], {sj[0], sj[1], sj[2]},
-                         {sj[3], sj[4], sj[5]}, sj[6]);
+    V3 shift{0.0, 0.0, 0.0};
+    V3 q0{sj[0], sj[1], sj[2]}, q1{sj[3], sj[4], sj[5]};
+    if (box) {
+      const V3 ci = ld3(center, i), cj = ld3(center, j);
+      shift = (ci + pm.sep(ci, cj)) - cj;
+      q0 = q0 + shift;
+      q1 = q1 + shift;
+    }
+    const RodContact rc = contact_segments({si[0], si[1], si[2]}, {si[3], si[4], si[5]}, si[6], q0, q1, sj[6]);
     sep[c] = rc.sep;
     st3(normal, c, rc.normal);
     if (cp1) st3(cp1, c, rc.cp1);
     if (cp2) st3(cp2, c, rc.cp2);
     if (ra) st3(ra, c, rc.cp1 - ld3(center, i));
-    if (rb) st3(rb, c, rc.cp2 - ld3(center, j));
+    if (rb) st3(rb, c, rc.cp2 - (box ? ld3(center, j) + shift : ld3(center, j)));
     if (s) s[c] = rc.s;
     if (t) t[c] = rc.t;
   }
@@ -220,19 +230,24 @@ void o_aabb_mixed(size_t n, const int32_t* kind, const double* c, const double* 
     brad[i] = bounding_radius_mixed(b);
   }
 }
+// box (null or [3]): body j at the nearest lattice image of its centre, c_j' = c_i + sep(c_i, c_j)
 void o_contact_mixed(size_t C, const int32_t* pairs, const int32_t* kind, const double* c, const double* q,
-                     const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
-                     double* rb) {
+                     const double* shape, const double* box, double* sep, double* normal, double* cp1, double* cp2,
+                     double* ra, double* rb) {
+  const PeriodicScaledMetric pm(box ? V3{box[0], box[1], box[2]} : V3{1, 1, 1});
 #pragma omp parallel for schedule(dynamic, 64)
   for (size_t k = 0; k < C; ++k) {
     const int32_t i = pairs[2 * k], j = pairs[2 * k + 1];
-    const MixedContact m = contact_mixed(ld_body(kind, c, q, shape, i), ld_body(kind, c, q, shape, j));
+    const MixedBody bi = ld_body(kind, c, q, shape, i);
+    MixedBody bj = ld_body(kind, c, q, shape, j);
+    if (box) bj.c = bi.c + pm.sep(bi.c, bj.c);
+    const MixedContact m = contact_mixed(bi, bj);
     sep[k] = m.sep;
     st3(normal, k, m.normal);
     st3(cp1, k, m.cp1);
     st3(cp2, k, m.cp2);
-    st3(ra, k, m.cp1 - ld3(c, i));
-    st3(rb, k, m.cp2 - ld3(c, j));
+    st3(ra, k, m.cp1 - bi.c);
+    st3(rb, k, m.cp2 - bj.c);
   }
 }
 

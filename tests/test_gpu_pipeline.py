@@ -271,3 +271,84 @@ def test_contact_cutoff_option_compacts_the_constraint_set(mods, oracle):
     bad = mk(contact_cutoff=-0.2)
     sb = bad.step(integrate=False)
     assert bad.cutoff_fallbacks == 1 and sb.num_contacts == sf.num_contacts and sb.converged
+
+
+def test_periodic_rods_10k_step_matches_oracle(mods, oracle):
+    # spherocylinders in an orthorhombic periodic box -- periodic neighbour search, contacts against the
+    # nearest image of the partner (PeriodicScaledMetric::sep of the centres, rigid translation), LCP, Euler update and
+    # wrap_rigid of the centres (periodicity.hpp:812-823, :1094-1113), each stage against the CPU oracle
+    ops, pipeline, synth = mods
+    from gpu_util import assert_bits_equal, dev, host
+    b = synth.spherocylinders(10_000, volume_fraction=0.3, seed=77)
+    box = [b["box"]] * 3
+    c0, q0, r, L = b["center"], b["quat"], b["radius"], b["length"]
+    tol, dt, buf = 1e-6, 5e-3, 0.2
+    st = pipeline.ContactStepper("spherocylinder", dev(c0), dev(r), dev(q0), dev(L), dt=dt, search_buffer=buf,
+                                 periodic_box=box, cfg=ops.PGDConfig(max_iters=20000, tol=tol))
+    s = st.step(integrate=True, force_rebuild=True)
+    aabb = oracle.compute_aabb_spherocylinders(c0, q0, r, L)
+    brad = oracle.bounding_radius_spherocylinders(r, L)
+    lo, hi, R = oracle.grow(aabb, brad, buf)
+    pairs = oracle.search(oracle.SEARCH_AABB, lo, hi, c0, R, box=box)
+    np.testing.assert_array_equal(host(st.links.pairs), pairs)
+    free = oracle.search(oracle.SEARCH_AABB, lo, hi, c0, R)
+    assert len(pairs) > len(free) + 100                  # the box faces do contribute pairs
+    seg = oracle.spherocylinder_segments(c0, q0, r, L)
+    con = oracle.contact_spherocylinders(pairs, seg, c0, box=box)
+    for k in ("sep", "normal", "s", "t"):
+        assert_bits_equal(host(st.contacts[k]), con[k], k)
+    # a pair across a face really is evaluated against the image: its separation is small, not a box length
+    far = np.abs(c0[pairs[:, 0]] - c0[pairs[:, 1]]).max(axis=1) > 0.5 * box[0]
+    assert far.sum() > 100 and con["sep"][far].max() < 3.5
+    mt, mr = synth.dry_mobility(r, bounding_radius=brad)
+    with oracle.compensated_sums():
+        x, g, ro = oracle.solve_cqpp_contact(pairs, con["normal"], None, None, mt, mr, dt, con["sep"], np.zeros(len(pairs)),
+                                             max_iters=20000, tol=tol, rod=(con["s"], con["t"], seg))
+        _, vel = oracle.contact_op_apply(pairs, con["normal"], None, None, mt, mr, dt, x, len(r),
+                                         rod=(con["s"], con["t"], seg), body_velocity=True)
+    assert s.converged and ro["converged"] and abs(s.num_iters - ro["num_iters"]) <= 2
+    c1, q1 = oracle.integrate_euler(dt, vel, c0, q0)
+    c1 = oracle.periodic_wrap(box, c1)
+    got = host(st.center)
+    assert got.min() >= 0.0 and got.max() < box[0]
+    d = got - c1
+    d -= np.round(d / box[0]) * box[0]                   # a centre within rounding of a face may wrap either way
+    assert np.abs(d).max() <= 1e-9
+    assert np.abs(np.abs(np.sum(host(st.quat) * q1, axis=1)) - 1.0).max() <= 1e-12
+    # images of the same system give the same step: shift every body by whole box vectors
+    shift = np.random.default_rng(0).integers(-2, 3, c0.shape) * box[0]
+    st2 = pipeline.ContactStepper("spherocylinder", dev(c0 + shift), dev(r), dev(q0), dev(L), dt=dt, search_buffer=buf,
+                                  periodic_box=box, cfg=ops.PGDConfig(max_iters=20000, tol=tol))
+    s2 = st2.step(integrate=False, force_rebuild=True)
+    np.testing.assert_array_equal(host(st2.links.pairs), pairs)
+    np.testing.assert_allclose(host(st2.contacts["sep"]), con["sep"], atol=1e-11)
+
+
+def test_periodic_mixed_shapes_contacts_match_oracle(mods, oracle):
+    # the same for the mixed sphere / spherocylinder / ellipsoid system: partner bodies at the nearest image of their
+    # centre; the cheap classes bit for bit, the L-BFGS classes at the reference's 1e-4 (see test_gpu_mixed.py)
+    ops, pipeline, synth = mods
+    from gpu_util import dev, host
+    b = synth.mixed_bodies(9000, volume_fraction=0.25, seed=5)
+    box = [b["box"]] * 3
+    st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=0.15, periodic_box=box,
+                                 cfg=ops.PGDConfig(max_iters=20000, tol=1e-5), kinds=dev(b["kind"]), shape=dev(b["shape"]))
+    s = st.step(integrate=True, force_rebuild=True)
+    assert s.converged
+    aabb, brad = oracle.aabb_mixed(b["kind"], b["center"], b["quat"], b["shape"])
+    lo, hi, R = oracle.grow(aabb, brad, 0.15)
+    pairs = oracle.search(oracle.SEARCH_AABB, lo, hi, b["center"], R, box=box)
+    np.testing.assert_array_equal(host(st.links.pairs), pairs)
+    con = oracle.contact_mixed(pairs, b["kind"], b["center"], b["quat"], b["shape"], box=box)
+    ka, kb = b["kind"][pairs[:, 0]], b["kind"][pairs[:, 1]]
+    cheap = (np.maximum(ka, kb) < 2)                      # S-S, S-R, R-R
+    far = np.abs(b["center"][pairs[:, 0]] - b["center"][pairs[:, 1]]).max(axis=1) > 0.5 * box[0]
+    assert (far & cheap).sum() > 30 and (far & ~cheap).sum() > 30
+    got = {k: host(st.contacts[k]) for k in ("sep", "normal", "ra", "rb")}
+    for k in got:
+        assert np.array_equal(got[k][cheap], con[k][cheap]), k
+    ok = np.abs(got["sep"][~cheap] - con["sep"][~cheap]) <= 1e-4
+    assert ok.mean() >= 0.995
+    assert got["sep"][far].max() < 3.0
+    c = host(st.center)
+    assert c.min() >= 0.0 and c.max() < box[0]
