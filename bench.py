@@ -43,6 +43,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak, FMA = 2 flops
+# fp64 operations (+ - x / sqrt, each counted once) of ONE objective evaluation of the ellipsoid shared-normal distance:
+# two sin/cos pairs (2 x 45), the normal (3), two foot-point maps (each: two quaternion rotations of 56 + the body-frame
+# map ~40 + 3), the distance (8) ~ 410, plus ~50 of minimiser logic per evaluation
+FLOPS_PER_EVALUATION = 460.0
 # one metric for every N: the N = 1 line is BASELINE configs[2], the N > 1 lines are configs[3] -- the same system
 METRIC = "timesteps/sec, 10^6 spherocylinders, frictionless LCP contact (BBPGD)"
 
@@ -335,6 +340,19 @@ def main_mixed(args, ops, pipeline, synth, dev):
     elapsed = time.perf_counter() - t0
     stage_ms = one_step(False, timed_stages=True).timings_ms
     contacts, iters = stats[-1].num_contacts, [s.num_iters for s in stats]
+    # The narrow phase of this config is its largest stage and is NOT bandwidth bound: the S-E, R-E and E-E classes run
+    # the 9-start L-BFGS shared-normal minimisation, ~10^3 objective evaluations per pair.  Its roofline is the fp64
+    # vector rate: algorithmic flops = evaluations (counted by the kernels) x FLOPS_PER_EVALUATION, over the stage time.
+    evals = ops.contact_mixed_last_evaluations()
+    narrow_s = 1e-3 * stage_ms["narrowphase"]
+    flops = FLOPS_PER_EVALUATION * float(sum(evals.values()))
+    ell_roof = {"bound": "fp64-vector", "kernel": "k_contact_class_lockstep<S-E | R-E | E-E>",
+                "achieved": round(flops / narrow_s / 1e12, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops / narrow_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                "objective_evaluations": evals, "flops_per_evaluation": FLOPS_PER_EVALUATION,
+                "stage_ms": round(stage_ms["narrowphase"], 3),
+                "note": "peak counts an FMA as two flops; this build never fuses a*b+c (bit parity with the scalar "
+                        "reference order), so 0.5 x peak is what it could reach"}
     roof, extra = None, {}
     if prof["iters"] > 0:
         # explicit lever arms: k_constraint streams pair 8 + normal 24 + arms 48 + packed (x, g) 16 + q 8, writes 16;
@@ -364,6 +382,8 @@ def main_mixed(args, ops, pipeline, synth, dev):
         "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
         "roofline": roof, "cpu_baseline": None,
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+        "narrow_phase_roofline": ell_roof,
+        "ellipsoid_aabb": "reference (centre -/+ q*radii, compute_aabb.hpp:82-103: not conservative for general orientations)",
     }
     out.update(extra)
     print(json.dumps(out))

@@ -139,9 +139,21 @@ int mhip_contact_spherocylinders_periodic(size_t c, const int32_t* pairs, const 
  * class_counts [host, 6] (optional) = pairs per class in the order SS, SR, SE, RR, RE, EE (synchronises if given). */
 int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center, const double* quat,
                             const double* shape, double* aabb, double* bounding_radius, mhip_stream_t stream);
+/* BUILD EXTENSION (SURVEY a7's flagged option): the same with the TIGHT CONSERVATIVE box for the ellipsoids (half extent
+ * along lab axis k = sqrt(sum_j (r_j (q e_j)[k])^2)).  The reference's box (centre -/+ q*radii, compute_aabb.hpp:82-103)
+ * is exact only for axis-aligned orientations: for a general rotation an extent can collapse towards zero, and a
+ * neighbour search on those boxes silently misses overlapping ellipsoid pairs.  Spheres and rods are unchanged. */
+int mhip_compute_aabb_mixed_conservative(size_t n, const int32_t* kind, const double* center, const double* quat,
+                                         const double* shape, double* aabb, double* bounding_radius,
+                                         mhip_stream_t stream);
 int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
                        const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                        double* rb, size_t* class_counts /*[host]*/, mhip_stream_t stream);
+/* objective evaluations the L-BFGS classes (S-E, R-E, E-E) needed in the last mhip_contact_mixed* call of this host
+ * thread, and in the last mhip_distance_ellipsoid_* / mhip_contact_ellipsoids call: these kernels are fp64-vector bound
+ * (about 2.3 * 10^3 fp64 instructions per evaluation), so evaluations x that / time is their roofline figure */
+int mhip_contact_mixed_last_evaluations(unsigned long long evaluations[3] /*[host]*/, mhip_stream_t stream);
+int mhip_ellipsoid_last_evaluations(unsigned long long* evaluations /*[host]*/, mhip_stream_t stream);
 /* periodic box [host: 3 edge lengths]: body j at the nearest lattice image of its centre, c_j' = c_i + sep(c_i, c_j) */
 int mhip_contact_mixed_periodic(size_t c, const int32_t* pairs, const int32_t* kind, const double* center,
                                 const double* quat, const double* shape, const double* box /*[host] 3*/, double* sep,

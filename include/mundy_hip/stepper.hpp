@@ -34,11 +34,17 @@ class SpherocylinderStepper {
   SpherocylinderStepper(const std::vector<double>& center, const std::vector<double>& quat,
                         const std::vector<double>& radius, const std::vector<double>& length,
                         const std::vector<double>& mob_trans, const std::vector<double>& mob_rot, double dt,
-                        double search_buffer, convex::PGDConfig<double> cfg)
+                        double search_buffer, convex::PGDConfig<double> cfg, const double* periodic_box = nullptr)
       : n_(radius.size()), dt_(dt), cfg_(cfg), center_(center), quat_(quat), radius_(radius), length_(length),
         mob_t_(mob_trans), mob_r_(mob_rot), brad_(n_), aabb_(6 * n_), seg_(8 * n_), tmp_(4 * n_), perm_(n_) {
     check(mhip_bounding_radius_spherocylinders(n_, radius_.data(), length_.data(), brad_.data(), nullptr));
-    links_.set_search_buffer(search_buffer).set_search_kind(MHIP_SEARCH_AABB).concretize();
+    links_.set_search_buffer(search_buffer).set_search_kind(MHIP_SEARCH_AABB);
+    if (periodic_box) {  // orthorhombic periodic box [0, L): periodic search, nearest-image contacts, wrap_rigid
+      periodic_ = true;
+      for (int k = 0; k < 3; ++k) box_[k] = periodic_box[k];
+      links_.set_periodic_box(box_[0], box_[1], box_[2]);
+    }
+    links_.concretize();
   }
 
   /// Z-order permutation of every per-body array by centre
@@ -68,8 +74,12 @@ class SpherocylinderStepper {
                                        nullptr));
     double *sep = workspace(w_sep_, C), *normal = workspace(w_normal_, 3 * C), *s = workspace(w_s_, C),
            *t = workspace(w_t_, C);
-    check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep, normal, nullptr, nullptr, nullptr,
-                                       nullptr, s, t, nullptr));
+    if (periodic_)
+      check(mhip_contact_spherocylinders_periodic(C, pairs_.data(), seg_.data(), center_.data(), box_, sep, normal,
+                                                  nullptr, nullptr, nullptr, nullptr, s, t, nullptr));
+    else
+      check(mhip_contact_spherocylinders(C, pairs_.data(), seg_.data(), nullptr, sep, normal, nullptr, nullptr,
+                                         nullptr, nullptr, s, t, nullptr));
     // the operator follows the contact list: rebuilt with it, otherwise only its geometry is refreshed
     if (st.rebuilt || !op_)
       op_.reset(new ContactOperator(C, n_, pairs_.data(), normal, ContactOperator::Rods{s, t, seg_.data()},
@@ -92,6 +102,8 @@ class SpherocylinderStepper {
       const double* vel = nullptr;
       check(mhip_contact_op_body_velocity(op.handle(), &vel));
       check(mhip_integrate_euler(n_, dt_, vel, center_.data(), quat_.data(), nullptr));
+      // wrap_rigid_inplace(Spherocylinder): the centre goes back into the box (periodicity.hpp:1094-1113)
+      if (periodic_) check(mhip_wrap_rigid(n_, box_, center_.data(), nullptr));
     }
     check(mhip_stream_synchronize(nullptr));
     return st;
@@ -112,6 +124,8 @@ class SpherocylinderStepper {
   }
   size_t n_;
   double dt_;
+  bool periodic_ = false;
+  double box_[3] = {0.0, 0.0, 0.0};
   convex::PGDConfig<double> cfg_;
   DeviceVector center_, quat_, radius_, length_, mob_t_, mob_r_, brad_, aabb_, seg_, tmp_, lambda_;
   DeviceVector w_sep_, w_normal_, w_s_, w_t_, w_g_, w_xt_, w_gt_;  // per-step workspaces (grow-only)

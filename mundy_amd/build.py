@@ -17,8 +17,18 @@ def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+STAMP = LIB + ".flags"
+
+
+def _flag_string():
+    return " ".join(FLAGS + os.environ.get("MHIP_EXTRA_HIPCC_FLAGS", "").split())
+
+
 def is_stale():
     if not os.path.exists(LIB):
+        return True
+    # a library built with other flags (an A/B build with -D tuning macros) is stale whatever its age
+    if not os.path.exists(STAMP) or open(STAMP).read() != _flag_string():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -53,6 +63,8 @@ def build(force=False, verbose=False):
         raise RuntimeError("libmundy_hip.so build failed")
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_flag_string())
     return LIB
 
 

@@ -2,72 +2,19 @@
 // One lane per pair; the multistart L-BFGS runs as a per-lane state machine so that the objective evaluations of a
 // wavefront stay converged and lanes refill from a global counter (ellipsoid_lockstep.hpp).  Compute bound (fp64
 // vector + transcendental), priced against the fp64 vector peak, not HBM.
-#include <cstdlib>
-
 #include "ellipsoid_lockstep.hpp"
 
 namespace mhip {
 
 constexpr int kEllBlock = 64;
-// Resources of the lockstep kernel (10^6 pairs, MI355X): ~200 VGPRs, no scratch, 30 KB of LDS per wave for the L-BFGS
-// history ring (five waves per CU): 1.2 * 10^7 pairs/s.  With the history in registers under compile-time indices:
-// 9.9 * 10^6 at one wave per SIMD, 8.9 at two (236 B of spills), 3.3 at three.  (The nested-loop kernels below, kept as
-// the bit-for-bit cross-check, ran 4.6 / 5.6 / 5.3 / 4.5 * 10^6 pairs/s at 1 / 2 / 3 / 4 waves.)
-#ifndef ELL_WAVES
-#define ELL_WAVES 1
-#endif
-#define ELL_OCC __attribute__((amdgpu_waves_per_eu(ELL_WAVES)))
+// Resources of the lockstep kernel: ~220 VGPRs, no scratch, 20 KB of LDS per wave for the L-BFGS history ring -> two
+// waves per SIMD (eight per CU).  History of the form (10^6 pairs, MI355X): one wave per SIMD with a 30 KB ring 1.2 * 10^7
+// pairs/s; the history in registers under compile-time indices 9.9 * 10^6 at one wave per SIMD, 8.9 at two (236 B of
+// spills), 3.3 at three; the plain nested-loop form (now the tests' checker) 4.6 / 5.6 / 5.3 / 4.5 * 10^6 at 1 - 4 waves.
+#define ELL_OCC __attribute__((amdgpu_waves_per_eu(2)))
 
 __device__ inline EllipsoidD load_ellipsoid(const double* c, const double* q, const double* r, size_t i) {
   return {load3(c, i), load4q(q, i), load3(r, i)};
-}
-
-__global__ void __launch_bounds__(kEllBlock) ELL_OCC
-    k_dist_ellipsoids(size_t n, const double* __restrict__ c1, const double* __restrict__ q1,
-                      const double* __restrict__ r1, const double* __restrict__ c2, const double* __restrict__ q2,
-                      const double* __restrict__ r2, double* __restrict__ dist, double* __restrict__ cp1,
-                      double* __restrict__ cp2, double* __restrict__ n1, double* __restrict__ n2) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const EllipsoidPair r = dist_ellipsoid_ellipsoid(load_ellipsoid(c1, q1, r1, i), load_ellipsoid(c2, q2, r2, i));
-  if (dist) dist[i] = r.dist;
-  if (cp1) store3(cp1, i, r.cp1);
-  if (cp2) store3(cp2, i, r.cp2);
-  if (n1) store3(n1, i, r.n1);
-  if (n2) store3(n2, i, V3{-r.n1.x, -r.n1.y, -r.n1.z});
-}
-
-__global__ void __launch_bounds__(kEllBlock) ELL_OCC
-    k_dist_point_ellipsoid(size_t n, const double* __restrict__ p, const double* __restrict__ c,
-                           const double* __restrict__ q, const double* __restrict__ r, double* __restrict__ dist,
-                           double* __restrict__ cp, double* __restrict__ nrm) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  V3 closest, normal;
-  const double d = dist_point_ellipsoid(load3(p, i), load_ellipsoid(c, q, r, i), closest, normal);
-  if (dist) dist[i] = d;
-  if (cp) store3(cp, i, closest);
-  if (nrm) store3(nrm, i, normal);
-}
-
-// contact generation over a neighbour list: sep = shared-normal signed distance, normal = n1 (outward normal of the
-// source ellipsoid), contact points = the two foot points, lever arms about the body centres.
-__global__ void __launch_bounds__(kEllBlock) ELL_OCC
-    k_contact_ellipsoids(size_t nc, const int2* __restrict__ pairs, const double* __restrict__ center,
-                         const double* __restrict__ quat, const double* __restrict__ radii, double* __restrict__ sep,
-                         double* __restrict__ normal, double* __restrict__ cp1, double* __restrict__ cp2,
-                         double* __restrict__ ra, double* __restrict__ rb) {
-  const size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (c >= nc) return;
-  const int2 ij = pairs[c];
-  const EllipsoidD e1 = load_ellipsoid(center, quat, radii, ij.x), e2 = load_ellipsoid(center, quat, radii, ij.y);
-  const EllipsoidPair r = dist_ellipsoid_ellipsoid(e1, e2);
-  if (sep) sep[c] = r.dist;
-  if (normal) store3(normal, c, r.n1);
-  if (cp1) store3(cp1, c, r.cp1);
-  if (cp2) store3(cp2, c, r.cp2);
-  if (ra) store3(ra, c, r.cp1 - e1.c);
-  if (rb) store3(rb, c, r.cp2 - e2.c);
 }
 
 // ---- lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one lane per pair, objective evaluations converged
@@ -126,8 +73,8 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
     if (active) {
       const lbfgs::V2 tp = lockstep::query_point(m);
       double st, ct, sp, cp;
-      sincos(tp.a, &st, &ct);
-      sincos(tp.b, &sp, &cp);
+      det_sincos(tp.a, st, ct);
+      det_sincos(tp.b, sp, cp);
       n1 = V3{st * cp, st * sp, ct};
       f1 = normal_to_foot_point(n1, e1);
       f2 = POINT ? e2.c : normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, e2);
@@ -143,6 +90,7 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
       if (out.cp2) store3(out.cp2, k, f2);
       if (out.ra) store3(out.ra, k, f1 - e1.c);
       if (out.rb) store3(out.rb, k, f2 - e2.c);
+      atomicAdd(counter + 1, static_cast<unsigned long long>(m.evals));  // objective evaluations, for the fp64 roofline
       active = false;
       need = true;
     }
@@ -160,9 +108,9 @@ EllipsoidScratch& ellipsoid_scratch() {
 int launch_ellipsoid_lockstep(size_t n, const EEInput& in, const EEOutput& out, hipStream_t s) {
   EllipsoidScratch& es = ellipsoid_scratch();
   if (int e = es.counter.reserve(64)) return e;
-  MHIP_HIP(hipMemsetAsync(es.counter.ptr, 0, sizeof(unsigned long long), s));
+  MHIP_HIP(hipMemsetAsync(es.counter.ptr, 0, 2 * sizeof(unsigned long long), s));
   const size_t waves = (n + 63) / 64;
-  const unsigned grid = static_cast<unsigned>(waves < 4096 ? waves : 4096);  // 256 CUs x 4 SIMDs x up to 4 waves
+  const unsigned grid = static_cast<unsigned>(waves < 2048 ? waves : 2048);  // 256 CUs x 4 SIMDs x 2 waves: all resident
   if (in.point)
     k_ellipsoid_pairs_lockstep<true><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
   else
@@ -182,12 +130,6 @@ int mhip_distance_ellipsoid_ellipsoid(size_t n, const double* c1, const double* 
                                       double* cp2, double* n1, double* n2, mhip_stream_t stream) {
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(c1 && q1 && r1 && c2 && q2 && r2, MHIP_ERR_INVALID_ARGUMENT, "ellipsoid arrays must not be null");
-  if (getenv("MHIP_ELLIPSOID_NESTED")) {  // the nested-loop form, kept for A/B and as the bit-for-bit cross-check
-    k_dist_ellipsoids<<<grid_exact(n, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(n, c1, q1, r1, c2, q2, r2, dist,
-                                                                                     cp1, cp2, n1, n2);
-    MHIP_LAUNCH_CHECK();
-    return MHIP_SUCCESS;
-  }
   return launch_ellipsoid_lockstep(n, EEInput{nullptr, c1, q1, r1, c2, q2, r2, nullptr},
                                    EEOutput{dist, cp1, cp2, n1, n2, nullptr, nullptr}, as_stream(stream));
 }
@@ -196,12 +138,6 @@ int mhip_distance_point_ellipsoid(size_t n, const double* p, const double* c, co
                                   double* dist, double* cp, double* normal, mhip_stream_t stream) {
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(p && c && q && r, MHIP_ERR_INVALID_ARGUMENT, "point / ellipsoid arrays must not be null");
-  if (getenv("MHIP_ELLIPSOID_NESTED")) {
-    k_dist_point_ellipsoid<<<grid_exact(n, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(n, p, c, q, r, dist, cp,
-                                                                                          normal);
-    MHIP_LAUNCH_CHECK();
-    return MHIP_SUCCESS;
-  }
   // closest point = the ellipsoid's foot point (cp1 slot), normal = its outward normal there (n1 slot)
   return launch_ellipsoid_lockstep(n, EEInput{nullptr, c, q, r, nullptr, nullptr, nullptr, p},
                                    EEOutput{dist, cp, nullptr, normal, nullptr, nullptr, nullptr}, as_stream(stream));
@@ -213,15 +149,23 @@ int mhip_contact_ellipsoids(size_t c, const int32_t* pairs, const double* center
   TraceRange trace_range("distance(Ellipsoid, Ellipsoid)");
   if (c == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(pairs && center && quat && radii, MHIP_ERR_INVALID_ARGUMENT, "pairs / ellipsoid arrays must not be null");
-  if (getenv("MHIP_ELLIPSOID_NESTED")) {
-    k_contact_ellipsoids<<<grid_exact(c, kEllBlock), kEllBlock, 0, as_stream(stream)>>>(
-        c, reinterpret_cast<const int2*>(pairs), center, quat, radii, sep, normal, cp1, cp2, ra, rb);
-    MHIP_LAUNCH_CHECK();
-    return MHIP_SUCCESS;
-  }
   return launch_ellipsoid_lockstep(c, EEInput{reinterpret_cast<const int2*>(pairs), center, quat, radii, nullptr,
                                               nullptr, nullptr},
                                    EEOutput{sep, cp1, cp2, normal, nullptr, ra, rb}, as_stream(stream));
+}
+
+/* objective evaluations of the last ellipsoid distance call on this host thread (synchronises the stream): with ~2.3 *
+ * 10^3 fp64 instructions per evaluation this prices the kernel against the fp64 vector peak */
+int mhip_ellipsoid_last_evaluations(unsigned long long* evaluations, mhip_stream_t stream) {
+  MHIP_REQUIRE(evaluations != nullptr, MHIP_ERR_INVALID_ARGUMENT, "evaluations is null");
+  EllipsoidScratch& es = ellipsoid_scratch();
+  *evaluations = 0;
+  if (!es.counter.ptr) return MHIP_SUCCESS;
+  unsigned long long host[2] = {0, 0};
+  MHIP_HIP(hipMemcpyAsync(host, es.counter.ptr, sizeof(host), hipMemcpyDeviceToHost, as_stream(stream)));
+  MHIP_HIP(hipStreamSynchronize(as_stream(stream)));
+  *evaluations = host[1];
+  return MHIP_SUCCESS;
 }
 
 }  // extern "C"

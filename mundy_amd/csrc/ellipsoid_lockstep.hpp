@@ -1,7 +1,8 @@
-// ellipsoid_lockstep.hpp -- the multistart L-BFGS of ellipsoid_device.hpp run in lockstep across a wavefront.
+// ellipsoid_lockstep.hpp -- the multistart L-BFGS of the ellipsoid distances (mundy_math/impl/minimize_impl.hpp:151-605
+// as called by mundy_geom/distance/EllipsoidEllipsoid.hpp:106-151) run in lockstep across a wavefront.
 //
-// One lane still owns one pair, and performs exactly the arithmetic of lbfgs::find_min / line_search in exactly their
-// order -- but the control flow is turned inside out.  Each lane carries the minimiser as an explicit state machine
+// One lane still owns one pair, and performs exactly the arithmetic of the reference's find_min / line_search in exactly
+// their order -- but the control flow is turned inside out.  Each lane carries the minimiser as an explicit state machine
 // whose only externally visible act is "evaluate the objective at this point".  The wave's loop is then
 //     evaluate the objective for all lanes at once  ->  every lane feeds the value to its own machine
 // so the expensive part (two sincos, four quaternion rotations, two foot-point maps: ~95 % of the instructions) runs
@@ -12,7 +13,7 @@
 // evaluations, and lanes are in different loops at any moment.)
 //
 // Results are bit-identical to the nested-loop form: the same evaluations at the same points in the same order per
-// lane (checked in the tests).
+// lane (the tests build that form as their own checker, tests/cpp/ellipsoid_nested_ref.hip).
 #pragma once
 #include "ellipsoid_device.hpp"
 
@@ -39,6 +40,7 @@ struct Machine {
   double cost, prev_val;
   bool been_used, stop_used, after_ls;
   int current_size, ring_head;  // the L-BFGS history itself lives in LDS (History below), as a ring buffer
+  unsigned evals;               // objective evaluations of this pair (profiling: the fp64 roofline of the class)
   // line_search (minimize_impl.hpp:233-405)
   double f0, d0, mu, alpha, last_alpha, last_val, last_val_der, a, b, a_val, b_val, a_val_der, b_val_der, thresh;
   double ls_first, ls_last, val, fp;
@@ -50,19 +52,20 @@ struct Machine {
   int phase;
 };
 
-// The lane's column of the workgroup's history tile: M entries of (s.a, s.b, y.a, y.b, rho) plus the alpha_i scratch
-// of the two-loop recursion, laid out [slot][lane] so a wave's access to one slot is conflict-free.  Kept in LDS
-// rather than registers because it is indexed at run time (a ring buffer): with compile-time indices under predicates
-// the bookkeeping cost ~1000 instructions per round, executed by the wave whenever ANY lane was in that phase.
-constexpr int kHistorySlots = 6 * M;
+// The lane's column of the workgroup's history tile: M entries of (s.a, s.b, y.a, y.b), laid out [slot][lane] so a
+// wave's access to one slot is conflict-free.  Kept in LDS rather than registers because it is indexed at run time (a
+// ring buffer): with compile-time indices under predicates the bookkeeping cost ~1000 instructions per round, executed
+// by the wave whenever ANY lane was in that phase.  20 KB per wave: EIGHT waves share a CU's 160 KB, two per SIMD.
+// What the reference also stores per entry is derived instead: rho_i = 1 / (s_i . y_i) is recomputed from the stored
+// s_i, y_i (the same division of the same operands: the same bits), and the alpha_i of the two-loop recursion live in
+// registers under compile-time indices (only ten scalars, written in one unrolled loop and read in the next).
+constexpr int kHistorySlots = 4 * M;
 struct History {
   double* col;  // &tile[0][lane]
   __device__ double& sa(int i) const { return col[(0 * M + i) * 64]; }
   __device__ double& sb(int i) const { return col[(1 * M + i) * 64]; }
   __device__ double& ya(int i) const { return col[(2 * M + i) * 64]; }
   __device__ double& yb(int i) const { return col[(3 * M + i) * 64]; }
-  __device__ double& rho(int i) const { return col[(4 * M + i) * 64]; }
-  __device__ double& alpha(int i) const { return col[(5 * M + i) * 64]; }
 };
 
 // Per-pair constants of the objective, hoisted out of the ~900 evaluations a pair needs.  qrot(q, v) computes
@@ -114,6 +117,7 @@ __device__ inline void begin_start(Machine& m) {
   m.phase = PH_COST_INIT;
 }
 __device__ inline void begin_pair(Machine& m) {
+  m.evals = 0;
   m.start = 0;
   m.best = __builtin_huge_val();
   m.best_tp = V2{0.0, 0.0};
@@ -195,31 +199,43 @@ __device__ inline void iteration_head(Machine& m, const History& h) {
         slot = m.ring_head;
         m.ring_head = (m.ring_head + 1 == M) ? 0 : m.ring_head + 1;
       }
-      h.sa(slot) = s.a; h.sb(slot) = s.b; h.ya(slot) = y.a; h.yb(slot) = y.b; h.rho(slot) = 1.0 / temp;
+      h.sa(slot) = s.a; h.sb(slot) = s.b; h.ya(slot) = y.a; h.yb(slot) = y.b;  // rho = 1 / temp: see History
     } else {
       m.current_size = 0;
       m.ring_head = 0;
     }
     if (m.current_size > 0) {
-      for (int i = m.current_size - 1; i >= 0; --i) {
-        int p = m.ring_head + i;
-        if (p >= M) p -= M;
-        const double al = h.rho(p) * lbfgs::dot2(V2{h.sa(p), h.sb(p)}, dir);
-        h.alpha(i) = al;
-        dir = V2{dir.a - al * h.ya(p), dir.b - al * h.yb(p)};
+      double alpha_i[M];  // compile-time indices only (both loops are fully unrolled): registers, no scratch
+#pragma unroll
+      for (int i = M - 1; i >= 0; --i) {
+        if (i < m.current_size) {
+          int p = m.ring_head + i;
+          if (p >= M) p -= M;
+          const V2 sp{h.sa(p), h.sb(p)}, yp{h.ya(p), h.yb(p)};
+          const double rho = 1.0 / lbfgs::dot2(sp, yp);
+          const double al = rho * lbfgs::dot2(sp, dir);
+          alpha_i[i] = al;
+          dir = V2{dir.a - al * yp.a, dir.b - al * yp.b};
+        }
       }
       int pl = m.ring_head + m.current_size - 1;
       if (pl >= M) pl -= M;
-      const V2 y_last{h.ya(pl), h.yb(pl)};
-      double H0 = 1.0 / h.rho(pl) / lbfgs::dot2(y_last, y_last);
+      const V2 s_last{h.sa(pl), h.sb(pl)}, y_last{h.ya(pl), h.yb(pl)};
+      const double rho_last = 1.0 / lbfgs::dot2(s_last, y_last);
+      double H0 = 1.0 / rho_last / lbfgs::dot2(y_last, y_last);
       H0 = lbfgs::clampd(0.001, 1000.0, H0);
       dir = V2{H0 * dir.a, H0 * dir.b};
-      for (int i = 0; i < m.current_size; ++i) {
-        int p = m.ring_head + i;
-        if (p >= M) p -= M;
-        const double beta = h.rho(p) * lbfgs::dot2(V2{h.ya(p), h.yb(p)}, dir);
-        const double al = h.alpha(i);
-        dir = V2{dir.a + (al - beta) * h.sa(p), dir.b + (al - beta) * h.sb(p)};
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        if (i < m.current_size) {
+          int p = m.ring_head + i;
+          if (p >= M) p -= M;
+          const V2 sp{h.sa(p), h.sb(p)}, yp{h.ya(p), h.yb(p)};
+          const double rho = 1.0 / lbfgs::dot2(sp, yp);
+          const double beta = rho * lbfgs::dot2(yp, dir);
+          const double al = alpha_i[i];
+          dir = V2{dir.a + (al - beta) * sp.a, dir.b + (al - beta) * sp.b};
+        }
       }
     }
   }
@@ -246,6 +262,7 @@ __device__ inline void iteration_head(Machine& m, const History& h) {
 // feeds the objective value at query_point(m) to the machine; returns true when the pair is complete (PH_FINAL done)
 __device__ inline bool advance(Machine& m, const History& h, double fv) {
   const double eps = kDerivEps;
+  ++m.evals;
   switch (m.phase) {
     case PH_COST_INIT:
       m.cost = fv;

@@ -13,6 +13,43 @@ struct Box {
 __device__ inline double dmin(double a, double b) { return (b < a) ? b : a; }
 __device__ inline double dmax(double a, double b) { return (a < b) ? b : a; }
 
+// sin and cos as ONE fixed sequence of IEEE double operations (the build never contracts a*b+c): x 2/pi to the nearest
+// integer, Cody-Waite subtraction of that multiple of pi/2 in two-part pieces, then the usual minimax polynomials on
+// [-pi/4, pi/4] with the reduction's tail carried through (the construction of fdlibm's kernels; < 1 ulp for the
+// |x| < 10^5 that occur here).  The device math library's sincos and a host libm differ in the last ulp here and there,
+// which the L-BFGS line search of the ellipsoid distances turns into another branch; a CPU evaluation of THIS sequence
+// lands on the same bits (the oracle's kTrigShared mode), and it is shorter than the library routine, which also
+// handles huge arguments.
+__device__ inline void det_sincos(double x, double& s, double& c) {
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const int n = static_cast<int>(fn);
+  double r = x - fn * 1.57079632673412561417e+00;
+  double w = fn * 6.07710050650619224932e-11;
+  {
+    const double t = r;
+    w = fn * 6.07710050630396597660e-11;
+    r = t - w;
+    w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+  }
+  const double y0 = r - w;
+  const double y1 = (r - y0) - w;
+  const double z = y0 * y0;
+  const double ps = -1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10));
+  const double rs = 8.33333333332248946124e-03 + z * ps;
+  const double v = z * y0;
+  const double sv = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+  const double pc = 2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * pc));
+  const double hz = 0.5 * z;
+  const double wc = 1.0 - hz;
+  const double cv = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+  const int q = n & 3;
+  s = (q == 0) ? sv : (q == 1) ? cv : (q == 2) ? -sv : -cv;
+  c = (q == 0) ? cv : (q == 1) ? -sv : (q == 2) ? -cv : sv;
+}
+
 // compute_aabb(Sphere): centre -/+ ones*radius  (mundy_geom/compute_aabb.hpp:72-80)
 __device__ inline Box aabb_sphere(V3 c, double r) {
   const double e = 1.0 * r;

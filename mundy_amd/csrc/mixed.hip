@@ -8,8 +8,6 @@
 // S-E and R-E have no reference implementation (empty stubs SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp): build
 // extensions, parity unpinned (see the oracle).  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
 // (r,-,-) / (r,L,-) / (r1,r2,r3).
-#include <cstdlib>
-
 #include "ellipsoid_lockstep.hpp"
 
 namespace mhip {
@@ -25,6 +23,7 @@ __device__ inline BodyD load_body(const int32_t* kind, const double* c, const do
   return {kind[i], load3(c, i), load4q(q, i), load3(shape, i)};
 }
 
+template <bool CONSERVATIVE>
 __global__ void __launch_bounds__(kBlock)
     k_aabb_mixed(size_t n, const int32_t* __restrict__ kind, const double* __restrict__ center,
                  const double* __restrict__ quat, const double* __restrict__ shape, double* __restrict__ aabb,
@@ -41,7 +40,7 @@ __global__ void __launch_bounds__(kBlock)
       bx = aabb_segment(b.c - d, b.c + d, b.s.x);
       R = 0.5 * b.s.y + b.s.x;
     } else {
-      bx = aabb_ellipsoid(b.c, b.q, b.s);
+      bx = CONSERVATIVE ? aabb_ellipsoid_conservative(b.c, b.q, b.s) : aabb_ellipsoid(b.c, b.q, b.s);
       R = dmax(b.s.x, dmax(b.s.y, b.s.z));
     }
     double* o = aabb + 6 * i;
@@ -108,9 +107,9 @@ __device__ inline V3 rod_support(const BodyD& b, V3 n) {
   return (b.c + (sg * h) * a) + b.s.x * n;
 }
 
-// at least two waves per SIMD: the ellipsoid classes would otherwise take every register (see ellipsoid.hip)
+// the closed-form classes: sphere - sphere, sphere - rod, rod - rod
 template <int CLS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(BLOCK)
     k_contact_class(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
                     const int2* __restrict__ pairs, const int32_t* __restrict__ kind, const double* __restrict__ center,
                     const double* __restrict__ quat, const double* __restrict__ shape, MixedOut out) {
@@ -137,60 +136,22 @@ __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
       const double radius_sum = A.s.x + B.s.x;
       const double inv = 1.0 / dist;
       store_contact(out, k, swapped, dist - radius_sum, (closest - A.c) * inv, A.c, closest, bi.c, bj.c);
-    } else if (CLS == 2) {  // sphere - ellipsoid: distance(Point, Ellipsoid) - r
-      V3 closest, ne;
-      const double d = dist_point_ellipsoid(A.c, EllipsoidD{B.c, B.q, B.s}, closest, ne);
-      store_contact(out, k, swapped, d - A.s.x, V3{-ne.x, -ne.y, -ne.z}, A.c, closest, bi.c, bj.c);
     } else if (CLS == 3) {  // rod - rod
       const V3 da = rod_half_axis(A.q, A.s.y), db = rod_half_axis(B.q, B.s.y);
       const SegSeg r = dist_segment_segment(A.c - da, A.c + da, B.c - db, B.c + db);
       const double radius_sum = A.s.x + B.s.x;
       const double inv = 1.0 / r.dist;
       store_contact(out, k, swapped, r.dist - radius_sum, (r.cp2 - r.cp1) * inv, r.cp1, r.cp2, bi.c, bj.c);
-    } else if (CLS == 4) {  // rod - ellipsoid (extension: shared-normal minimisation with the rod's support map)
-      const EllipsoidD el{B.c, B.q, B.s};
-      auto eval = [&](lbfgs::V2 tp, V3& n1, V3& f1, V3& f2) {
-        double st, ct, sp, cp;
-        sincos(tp.a, &st, &ct);
-        sincos(tp.b, &sp, &cp);
-        n1 = V3{st * cp, st * sp, ct};
-        f1 = rod_support(A, n1);
-        f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, el);
-        V3 sv;
-        return dist_point_point(f1, f2, sv);
-      };
-      auto objective = [&](lbfgs::V2 tp) {
-        V3 n1, f1, f2;
-        return eval(tp, n1, f1, f2);
-      };
-      const double pi = 3.141592653589793;
-      const double tg[3] = {0.0, 0.5 * pi, pi}, pg[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
-      double best = __builtin_huge_val();
-      lbfgs::V2 btp{0.0, 0.0};
-      for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b) {
-          lbfgs::V2 tp{tg[a], pg[b]};
-          const double d = lbfgs::find_min(objective, tp, 1e-8);
-          if (d < best) {
-            best = d;
-            btp = tp;
-          }
-        }
-      V3 n1, f1, f2;
-      eval(btp, n1, f1, f2);
-      store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, bi.c, bj.c);
-    } else {  // ellipsoid - ellipsoid
-      const EllipsoidPair r = dist_ellipsoid_ellipsoid(EllipsoidD{A.c, A.q, A.s}, EllipsoidD{B.c, B.q, B.s});
-      store_contact(out, k, swapped, r.dist, r.n1, r.cp1, r.cp2, bi.c, bj.c);
     }
   }
 }
 
 // The three minimisation classes (S-E, R-E, E-E) in lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one
 // lane per pair of the class, objective evaluations converged, lanes refilled from a per-class counter.  Same
-// arithmetic per lane as the nested-loop branches of k_contact_class above, which stay as the cross-check.
+// arithmetic per lane as the nested-loop form the tests build as their checker (tests/cpp/ellipsoid_nested_ref.hip).
+// Two waves per SIMD: 20 KB of LDS history per wave (ellipsoid_lockstep.hpp).
 template <int CLS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
     k_contact_class_lockstep(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
                              const int2* __restrict__ pairs, const int32_t* __restrict__ kind,
                              const double* __restrict__ center, const double* __restrict__ quat,
@@ -242,8 +203,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
     if (active) {
       const lbfgs::V2 tp = lockstep::query_point(m);
       double st, ct, sp, cp;
-      sincos(tp.a, &st, &ct);
-      sincos(tp.b, &sp, &cp);
+      det_sincos(tp.a, st, ct);
+      det_sincos(tp.b, sp, cp);
       n1 = V3{st * cp, st * sp, ct};
       const EllipsoidD elB{B.c, B.q, B.s};
       V3 sv;
@@ -270,6 +231,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1)))
       } else {
         store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, ci, cj);
       }
+      atomicAdd(counter + 4, static_cast<unsigned long long>(m.evals));  // objective evaluations of the class
       active = false;
       need = true;
     }
@@ -295,7 +257,19 @@ int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center,
                             const double* shape, double* aabb, double* bounding_radius, mhip_stream_t stream) {
   if (n == 0) return MHIP_SUCCESS;
   MHIP_REQUIRE(kind && center && quat && shape && aabb, MHIP_ERR_INVALID_ARGUMENT, "null argument");
-  k_aabb_mixed<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, kind, center, quat, shape, aabb, bounding_radius);
+  k_aabb_mixed<false><<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, kind, center, quat, shape, aabb,
+                                                                      bounding_radius);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_compute_aabb_mixed_conservative(size_t n, const int32_t* kind, const double* center, const double* quat,
+                                         const double* shape, double* aabb, double* bounding_radius,
+                                         mhip_stream_t stream) {
+  if (n == 0) return MHIP_SUCCESS;
+  MHIP_REQUIRE(kind && center && quat && shape && aabb, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  k_aabb_mixed<true><<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, kind, center, quat, shape, aabb,
+                                                                     bounding_radius);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -358,18 +332,13 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
   const int32_t* order = ms.order.as<int32_t>();
 #define CLASS(K, BLK, GRID) \
   k_contact_class<K, BLK><<<GRID, BLK, 0, s>>>(start, order, p2, kind, center, quat, shape, out)
-  const unsigned gs = g;                                                     // cheap classes: grid-stride over <= c
-  const unsigned ge = static_cast<unsigned>(c / 64 + 1 > 65535 * 8 ? 65535 * 8 : c / 64 + 1);  // L-BFGS classes
+  const unsigned gs = g;  // closed-form classes: grid-stride over <= c
   CLASS(0, kBlock, gs);
   CLASS(1, kBlock, gs);
   CLASS(3, kBlock, gs);
-  if (getenv("MHIP_ELLIPSOID_NESTED")) {  // nested-loop minimisers: A/B and bit-for-bit cross-check
-    CLASS(2, 64, ge);
-    CLASS(4, 64, ge);
-    CLASS(5, 64, ge);
-  } else {
+  {
     if (int e = ms.counters.reserve(64)) return e;
-    unsigned long long* cnt = ms.counters.as<unsigned long long>();
+    unsigned long long* cnt = ms.counters.as<unsigned long long>();  // [k]: next pair of class k; [4 + k]: its evaluations
     MHIP_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), s));
     const unsigned gl = static_cast<unsigned>(c / 64 + 1 > 2048 ? 2048 : c / 64 + 1);  // persistent waves
     k_contact_class_lockstep<2><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 0);
@@ -383,6 +352,20 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
     MHIP_HIP(hipStreamSynchronize(s));
     for (int k = 0; k < 6; ++k) class_counts[k] = static_cast<size_t>(ms.host[k + 1] - ms.host[k]);
   }
+  return MHIP_SUCCESS;
+}
+
+/* objective evaluations of the S-E, R-E and E-E classes in the last mhip_contact_mixed* call on this host thread
+ * (synchronises the stream) */
+int mhip_contact_mixed_last_evaluations(unsigned long long evaluations[3], mhip_stream_t stream) {
+  MHIP_REQUIRE(evaluations != nullptr, MHIP_ERR_INVALID_ARGUMENT, "evaluations is null");
+  MixedScratch& ms = mixed_scratch();
+  evaluations[0] = evaluations[1] = evaluations[2] = 0;
+  if (!ms.counters.ptr) return MHIP_SUCCESS;
+  unsigned long long host[8];
+  MHIP_HIP(hipMemcpyAsync(host, ms.counters.ptr, sizeof(host), hipMemcpyDeviceToHost, as_stream(stream)));
+  MHIP_HIP(hipStreamSynchronize(as_stream(stream)));
+  for (int k = 0; k < 3; ++k) evaluations[k] = host[4 + k];
   return MHIP_SUCCESS;
 }
 

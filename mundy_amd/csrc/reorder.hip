@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(kBlock)
       const double w = norm(om);
       if (w < kZeroTol) continue;
       const double winv = 1.0 / w;
-      const double sw = sin(0.5 * w * dt), cw = cos(0.5 * w * dt);
+      double sw, cw;
+      det_sincos(0.5 * w * dt, sw, cw);
       const Quat q = load4q(quat, i);
       const double s = q.w;
       const V3 p{q.x, q.y, q.z};

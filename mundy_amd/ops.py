@@ -164,12 +164,14 @@ def contact_ellipsoids(pairs, center, quat, radii):
 KIND_SPHERE, KIND_ROD, KIND_ELLIPSOID = 0, 1, 2
 
 
-def compute_aabb_mixed(kind, center, quat, shape):
+def compute_aabb_mixed(kind, center, quat, shape, conservative_ellipsoids=False):
+    """conservative_ellipsoids=True: BUILD EXTENSION, the tight conservative ellipsoid box instead of the reference's
+    (compute_aabb.hpp:82-103, which is not conservative for general orientations)"""
     n = kind.shape[0]
     aabb, brad = _new(center, n, 6), _new(center, n)
-    capi.check(capi.load().mhip_compute_aabb_mixed(n, _ptr(kind, torch.int32), _ptr(center, cols=3),
-                                                   _ptr(quat, cols=4), _ptr(shape, cols=3), _ptr(aabb), _ptr(brad),
-                                                   _stream()))
+    fn = capi.load().mhip_compute_aabb_mixed_conservative if conservative_ellipsoids else capi.load().mhip_compute_aabb_mixed
+    capi.check(fn(n, _ptr(kind, torch.int32), _ptr(center, cols=3), _ptr(quat, cols=4), _ptr(shape, cols=3),
+                  _ptr(aabb), _ptr(brad), _stream()))
     return aabb, brad
 
 
@@ -192,6 +194,19 @@ def contact_mixed(pairs, kind, center, quat, shape, want_counts=False, box=None)
     if want_counts:
         out["class_counts"] = dict(zip(("SS", "SR", "SE", "RR", "RE", "EE"), [int(v) for v in counts]))
     return out
+
+
+def contact_mixed_last_evaluations():
+    """objective evaluations of the (S-E, R-E, E-E) classes in the last contact_mixed call"""
+    ev = (C.c_ulonglong * 3)()
+    capi.check(capi.load().mhip_contact_mixed_last_evaluations(ev, _stream()))
+    return dict(SE=int(ev[0]), RE=int(ev[1]), EE=int(ev[2]))
+
+
+def ellipsoid_last_evaluations():
+    ev = C.c_ulonglong(0)
+    capi.check(capi.load().mhip_ellipsoid_last_evaluations(C.byref(ev), _stream()))
+    return int(ev.value)
 
 
 def _cell(box):

@@ -32,7 +32,8 @@ class ContactStepper:
 
     def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
                  search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
-                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None, friction=None, contact_cutoff=None):
+                 mob_rot=None, rod_kinematics=True, kinds=None, shape=None, friction=None, contact_cutoff=None,
+                 conservative_ellipsoid_box=False):
         """kind = "sphere" | "spherocylinder" | "mixed".  Mixed systems (BASELINE configs[4]) pass kinds [n] int32
         (0 sphere, 1 spherocylinder, 2 ellipsoid) and shape [n, 3] = (r,-,-) / (r,L,-) / (r1,r2,r3) instead of
         radius / length."""
@@ -45,6 +46,9 @@ class ContactStepper:
         if friction is not None and kind != "spherocylinder":
             raise ValueError("the friction extension is wired for spherocylinders")
         self.kind = kind
+        # BUILD EXTENSION, mixed systems: the tight conservative ellipsoid box in the neighbour search instead of the
+        # reference's (compute_aabb.hpp:82-103), which can miss overlapping ellipsoids of general orientation
+        self.conservative_ellipsoid_box = bool(conservative_ellipsoid_box)
         # BUILD EXTENSION (parity unpinned: the reference has no frictional solver): Coulomb coefficient, None = the
         # reference's frictionless LCP
         self.friction = None if friction is None else float(friction)
@@ -136,7 +140,8 @@ class ContactStepper:
         if self.kind == "sphere":
             self.aabb = ops.compute_aabb_spheres(self.center, self.radius)
         elif self.kind == "mixed":
-            self.aabb = ops.compute_aabb_mixed(self.kinds, self.center, self.quat, self.shape)[0]
+            self.aabb = ops.compute_aabb_mixed(self.kinds, self.center, self.quat, self.shape,
+                                               conservative_ellipsoids=self.conservative_ellipsoid_box)[0]
         else:
             self.aabb = ops.compute_aabb_spherocylinders(self.center, self.quat, self.radius, self.length)
         return self.aabb

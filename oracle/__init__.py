@@ -343,6 +343,31 @@ def set_sum_mode(mode, fast=False):
     lib(fast).o_set_sum_mode(C.c_int(int(mode)))
 
 
+TRIG_LIBM, TRIG_SHARED = 0, 1
+
+
+class shared_trig:
+    """`with oracle.shared_trig():` -- sin / cos as the fixed operation sequence the device path evaluates
+    (mundy_oracle.hpp, TrigMode) instead of libm, for the enclosed oracle calls (both builds)"""
+
+    def __enter__(self):
+        for fast in (False, True):
+            lib(fast).o_set_trig_mode(C.c_int(TRIG_SHARED))
+        return self
+
+    def __exit__(self, *exc):
+        for fast in (False, True):
+            lib(fast).o_set_trig_mode(C.c_int(TRIG_LIBM))
+        return False
+
+
+def shared_sincos(x):
+    x = _f(x)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().o_shared_sincos(C.c_size_t(x.size), _p(x), _p(s), _p(c))
+    return s, c
+
+
 class compensated_sums:
     """`with oracle.compensated_sums():` -- order-independent sums for the enclosed oracle calls (both builds)."""
 

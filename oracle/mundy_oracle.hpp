@@ -172,13 +172,76 @@ inline double bounding_radius_ellipsoid(const V3& radii) { return std::max(radii
 inline double bounding_radius_spherocylinder(double r, double length) { return 0.5 * length + r; }
 inline double bounding_radius_segment(const V3& p0, const V3& p1, double r) { return 0.5 * norm(p1 - p0) + r; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// sin / cos.  The reference calls Kokkos::sin / Kokkos::cos, i.e. the platform's libm (glibc on its CPU builds, the
+// device math library on GPU builds): values that differ between platforms in the last ulp, which the L-BFGS line
+// search of the ellipsoid distances turns into a different branch -- and occasionally another local minimum -- for a
+// fraction of a percent of the pairs.
+//   kTrigLibm    std::sin / std::cos: what the reference's host build executes (default; the reference KATs run here)
+//   kTrigShared  one fixed sequence of IEEE double operations (no FMA contraction): round x 2/pi to the nearest integer,
+//                subtract that multiple of pi/2 in two-part pieces (Cody & Waite), then the usual degree-13 / degree-14
+//                minimax polynomials on [-pi/4, pi/4] with the reduction's tail carried through (the construction of
+//                fdlibm's kernels; error < 1 ulp for the |x| < 10^5 that occur here).  The device path evaluates exactly
+//                this sequence, so in this mode the oracle and the device agree bit for bit wherever only + - x / sqrt
+//                are involved -- the mode the GPU parity tests run in.
+// ---------------------------------------------------------------------------------------------------------------
+enum TrigMode : int { kTrigLibm = 0, kTrigShared = 1 };
+inline int& trig_mode() {
+  static int mode = kTrigLibm;
+  return mode;
+}
+inline void shared_sincos(double x, double& s, double& c) {
+  const double fn = std::rint(x * 6.36619772367581382433e-01);  // x * 2/pi to the nearest integer (ties to even)
+  const int n = static_cast<int>(fn);
+  // pi/2 = p1 + p1t (p1: 33 bits, so fn * p1 is exact), then p1t = p2 + p2t for the second pass
+  double r = x - fn * 1.57079632673412561417e+00;
+  double w = fn * 6.07710050650619224932e-11;
+  {
+    const double t = r;
+    w = fn * 6.07710050630396597660e-11;
+    r = t - w;
+    w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+  }
+  const double y0 = r - w;
+  const double y1 = (r - y0) - w;  // tail of the reduced argument
+  const double z = y0 * y0;
+  // sin on [-pi/4, pi/4]
+  const double ps = -1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10));
+  const double rs = 8.33333333332248946124e-03 + z * ps;
+  const double v = z * y0;
+  const double sv = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * -1.66666666666666324348e-01);
+  // cos on [-pi/4, pi/4]
+  const double pc = 2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * pc));
+  const double hz = 0.5 * z;
+  const double wc = 1.0 - hz;
+  const double cv = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+  switch (n & 3) {
+    case 0: s = sv; c = cv; break;
+    case 1: s = cv; c = -sv; break;
+    case 2: s = -sv; c = -cv; break;
+    default: s = -cv; c = sv; break;
+  }
+}
+inline void sincos_mode(double x, double& s, double& c) {
+  if (trig_mode() == kTrigShared) {
+    shared_sincos(x, s, c);
+  } else {
+    s = std::sin(x);
+    c = std::cos(x);
+  }
+}
+
 // mundy/math/src/mundy_math/Quaternion.hpp:1366-1383 (rotate_quaternion: Delong 2015 App. A eq. 1, then normalize()
 // :409-417 with norm :1233-1235, a left-to-right sum of squares).
 inline Quat rotate_quaternion(const Quat& q, const V3& omega, double dt) {
   const double w = norm(omega);
   if (w < kZeroTol) return q;
   const double winv = 1.0 / w;
-  const double sw = std::sin(0.5 * w * dt), cw = std::cos(0.5 * w * dt);
+  double sw, cw;
+  sincos_mode(0.5 * w * dt, sw, cw);
   const double s = q.w;
   const V3 p{q.x, q.y, q.z};
   const V3 cr = cross(omega, p);
@@ -709,7 +772,9 @@ struct EllipsoidPairResult {
 inline EllipsoidPairResult distance_ellipsoid_ellipsoid(const Ellipsoid& e1, const Ellipsoid& e2) {
   EllipsoidPairResult r;
   auto objective = [&](const minimize::Vec<2>& tp) {
-    const double st = std::sin(tp[0]), ct = std::cos(tp[0]), sp = std::sin(tp[1]), cp = std::cos(tp[1]);
+    double st, ct, sp, cp;
+    sincos_mode(tp[0], st, ct);
+    sincos_mode(tp[1], sp, cp);
     r.n1 = {st * cp, st * sp, ct};
     r.n2 = {-r.n1.x, -r.n1.y, -r.n1.z};
     r.cp1 = map_surface_normal_to_foot_point(r.n1, e1);
@@ -738,7 +803,9 @@ inline EllipsoidPairResult distance_ellipsoid_ellipsoid(const Ellipsoid& e1, con
 // PointEllipsoid.hpp:94-135
 inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3& closest, V3& normal) {
   auto objective = [&](const minimize::Vec<2>& tp) {
-    const double st = std::sin(tp[0]), ct = std::cos(tp[0]), sp = std::sin(tp[1]), cp = std::cos(tp[1]);
+    double st, ct, sp, cp;
+    sincos_mode(tp[0], st, ct);
+    sincos_mode(tp[1], sp, cp);
     normal = {st * cp, st * sp, ct};
     closest = map_surface_normal_to_foot_point(normal, el);
     return distance_point_point(closest, point);
@@ -829,7 +896,9 @@ inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody&
     const Ellipsoid el{B.c, B.q, B.shape};
     V3 n1, f1, f2;
     auto objective = [&](const minimize::Vec<2>& tp) {
-      const double st = std::sin(tp[0]), ct = std::cos(tp[0]), sp = std::sin(tp[1]), cp = std::cos(tp[1]);
+      double st, ct, sp, cp;
+    sincos_mode(tp[0], st, ct);
+    sincos_mode(tp[1], sp, cp);
       n1 = {st * cp, st * sp, ct};
       f1 = rod_support_point(A, n1);
       f2 = map_surface_normal_to_foot_point({-n1.x, -n1.y, -n1.z}, el);

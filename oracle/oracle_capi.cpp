@@ -366,6 +366,11 @@ void o_solve_cqpp_contact(size_t C, size_t N, const int32_t* pairs, const double
   *converged = r.converged;
 }
 
+// sin / cos used by the ellipsoid objective and rotate_quaternion (mundy_oracle.hpp, TrigMode)
+void o_set_trig_mode(int mode) { trig_mode() = (mode == kTrigShared) ? kTrigShared : kTrigLibm; }
+void o_shared_sincos(size_t n, const double* x, double* s, double* c) {
+  for (size_t i = 0; i < n; ++i) shared_sincos(x[i], s[i], c[i]);
+}
 // summation mode of the BB-step reductions and the per-body sums (mundy_oracle.hpp, SumMode)
 void o_set_sum_mode(int mode) { sum_mode() = (mode == kSumCompensated) ? kSumCompensated : kSumSerial; }
 int o_get_sum_mode() { return sum_mode(); }

@@ -10,4 +10,5 @@ def ell():
 a, b = ell(), ell()
 ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize()
 t = time.perf_counter(); ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize(); dt = time.perf_counter() - t
-print("ellipsoid pairs %d: %.3f s  -> %.3f us/pair, %.3g pairs/s" % (n, dt, 1e6 * dt / n, n / dt))
+ev = ops.ellipsoid_last_evaluations()
+print("ellipsoid pairs %d: %.3f s  -> %.3f us/pair, %.3g pairs/s; %.0f objective evaluations per pair" % (n, dt, 1e6 * dt / n, n / dt, ev / n))

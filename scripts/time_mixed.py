@@ -1,4 +1,4 @@
-"""Narrow phase of a mixed sphere / rod / ellipsoid system (BASELINE configs[4] shapes): lockstep vs nested kernels."""
+"""Narrow phase of a mixed sphere / rod / ellipsoid system (BASELINE configs[4] shapes)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,11 +10,7 @@ dk, dc, dq, ds = dev(b["kind"]), dev(b["center"]), dev(b["quat"]), dev(b["shape"
 aabb, brad = ops.compute_aabb_mixed(dk, dc, dq, ds)
 links = ops.GenNeighborLinks().set_search_kind(ops.SEARCH_AABB).set_search_buffer(0.1).concretize()
 links.generate(aabb, dc, brad)
-for mode in ("nested", "lockstep"):
-    if mode == "nested":
-        os.environ["MHIP_ELLIPSOID_NESTED"] = "1"
-    else:
-        os.environ.pop("MHIP_ELLIPSOID_NESTED", None)
-    out = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True); torch.cuda.synchronize()
-    t = time.perf_counter(); ops.contact_mixed(links.pairs, dk, dc, dq, ds); torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print("%-8s %d bodies, %d pairs %s: narrow phase %.1f ms" % (mode, n, links.num_pairs, out["class_counts"], 1e3 * dt), flush=True)
+out = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True); torch.cuda.synchronize()
+t = time.perf_counter(); ops.contact_mixed(links.pairs, dk, dc, dq, ds); torch.cuda.synchronize(); dt = time.perf_counter() - t
+ev = ops.contact_mixed_last_evaluations()
+print("%d bodies, %d pairs %s: narrow phase %.1f ms; objective evaluations %s" % (n, links.num_pairs, out["class_counts"], 1e3 * dt, ev), flush=True)

@@ -1,6 +1,6 @@
 // rod_step_app.cpp -- the headline workload (BASELINE configs[2]: spherocylinders, frictionless LCP) driven from a C++
 // host program through mundy_hip/stepper.hpp, with no Python and no torch in the process.
-// Usage: rod_step_app <input.bin> <steps> [reorder_cell]
+// Usage: rod_step_app <input.bin> <steps> [reorder_cell] [periodic_box_edge]
 //   input.bin: uint64 n, then doubles center[3n] quat[4n] radius[n] length[n] mob_trans[n] mob_rot[n]
 // Prints one line per step and a bit-level checksum of the final centres / orientations, so the test can compare the
 // whole trajectory with the Python driver's.
@@ -34,7 +34,7 @@ static unsigned long long checksum(const std::vector<double>& v) {  // order-sen
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::fprintf(stderr, "Usage: %s <input.bin> <steps> [reorder_cell]\n", argv[0]);
+    std::fprintf(stderr, "Usage: %s <input.bin> <steps> [reorder_cell] [periodic_box_edge]\n", argv[0]);
     return 1;
   }
   std::FILE* f = std::fopen(argv[1], "rb");
@@ -53,7 +53,10 @@ int main(int argc, char** argv) {
   convex::PGDConfig<double> cfg;
   cfg.max_iters = 10000;  // NgpLcp.cpp:851-852
   cfg.tol = 1e-5;
-  mech::SpherocylinderStepper st(center, quat, radius, length, mob_t, mob_r, /*dt=*/5e-3, /*search_buffer=*/0.1, cfg);
+  const double edge = argc > 4 ? std::atof(argv[4]) : 0.0;  // > 0: cubic periodic box [0, edge)^3
+  const double box[3] = {edge, edge, edge};
+  mech::SpherocylinderStepper st(center, quat, radius, length, mob_t, mob_r, /*dt=*/5e-3, /*search_buffer=*/0.1, cfg,
+                                 edge > 0.0 ? box : nullptr);
   if (cell > 0.0) {
     const double lo[3] = {0.0, 0.0, 0.0};
     st.reorder_bodies(cell, lo);

@@ -122,7 +122,8 @@ def test_cpp_distributed_stepper_over_rccl(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_rod_stepper_reproduces_the_python_driver(tmp_path):
+@pytest.mark.parametrize("periodic", [False, True])
+def test_cpp_rod_stepper_reproduces_the_python_driver(tmp_path, periodic):
     # the headline hot path (spherocylinders, Z-order reorder, neighbour list, narrow phase, fused BBPGD, integration)
     # driven from a C++ host program (include/mundy_hip/stepper.hpp) with no Python in the process: same kernels in the
     # same order as mundy_amd/pipeline.py, so contacts, iteration counts and the final state agree bit for bit
@@ -139,7 +140,9 @@ def test_cpp_rod_stepper_reproduces_the_python_driver(tmp_path):
         for a in (b["center"], b["quat"], b["radius"], b["length"], mt, mr):
             f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
     exe = _build_rod_app()
-    p = subprocess.run([exe, str(inp), "3", "3.0"], capture_output=True, text=True, timeout=600)
+    box = [float(b["box"])] * 3 if periodic else None   # periodic search, nearest-image contacts, wrap_rigid
+    p = subprocess.run([exe, str(inp), "3", "3.0"] + (["%.17g" % b["box"]] if periodic else []), capture_output=True,
+                       text=True, timeout=600)
     print(p.stdout[-3000:], p.stderr[-2000:])
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     steps = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("STEP")]
@@ -148,7 +151,7 @@ def test_cpp_rod_stepper_reproduces_the_python_driver(tmp_path):
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]), dev(b["length"]),
                                  search_buffer=0.1, cfg=ops.PGDConfig(max_iters=10000, tol=1e-5), mob_trans=dev(mt),
-                                 mob_rot=dev(mr))
+                                 mob_rot=dev(mr), periodic_box=box)
     st.reorder_bodies(cell_size=3.0, lo=[0.0, 0.0, 0.0])
     for k in range(3):
         s = st.step()

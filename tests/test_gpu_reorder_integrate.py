@@ -66,8 +66,8 @@ def test_gather_rows(ops):
 
 
 def test_integrate_euler_vs_oracle(ops, oracle):
-    # x += dt U (NgpLcp.cpp:898) is bit-exact; rotate_quaternion (Quaternion.hpp:1366-1383) differs only through the
-    # device's sin / cos: 4 ulp of a unit quaternion component
+    # x += dt U (NgpLcp.cpp:898) is bit-exact; rotate_quaternion (Quaternion.hpp:1366-1383) goes through sin / cos: 4 ulp
+    # of a unit quaternion component against libm, bit-exact against the oracle evaluating the device's sin / cos
     from gpu_util import assert_bits_equal, dev, host
     rng = np.random.default_rng(5)
     n = 50_000
@@ -83,7 +83,9 @@ def test_integrate_euler_vs_oracle(ops, oracle):
         co, qo = oracle.integrate_euler(dt, v, c, q)
         assert_bits_equal(host(dc), co, "Euler update of the centres")
         assert_bits_equal(host(dq)[:200], q[:200], "omega ~ 0 leaves the orientation untouched")
-        np.testing.assert_allclose(host(dq), qo, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(host(dq), qo, rtol=0, atol=1e-15)    # oracle with libm sin / cos
+        with oracle.shared_trig():                                      # oracle with the device's sin / cos: exact
+            assert_bits_equal(host(dq), oracle.integrate_euler(dt, v, c, q)[1], "rotate_quaternion")
         np.testing.assert_allclose(np.linalg.norm(host(dq), axis=1), 1.0, atol=4e-16)
     ds = dev(c)
     ops.integrate_euler(5e-3, dev(v), ds)   # spheres: no orientation
