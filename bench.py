@@ -60,18 +60,19 @@ def kernel_bytes(contacts, bodies, active_contacts=None):
                     + q 8 read, packed (x, g) 16 written = 88 B per constraint; the 48-byte (U, W x u) body rows once
                     each = 48 B per body
       k_body        walks only the half edges its activity masks flag (a contact with x = 0, g >= 0 stays at
-                    Proj(0 - step g) = 0 and adds nothing): per ACTIVE half edge incidence entry 4 + (n, s - 1/2)
-                    record 32 = 36 B; per ACTIVE contact its packed iterate 16 B (gathered by both of its half edges,
-                    counted once); per body row pointer 4 + mask 8 + mobilities 16 + axis 24 + velocity row 48 +
-                    angular velocity 24 = 124 B.  `active_contacts` is measured in the run (state at the end of the
-                    solve); None = every contact (the pre-mask count).
+                    Proj(0 - step g) = 0 and adds nothing), streamed from the compact active lists: per ACTIVE half
+                    edge incidence entry 4 + (n, s - 1/2) record 32 = 36 B; per ACTIVE contact its packed iterate 16 B
+                    (gathered by both of its half edges, counted once); per body row pointer 4 + active-list pointer 4
+                    + mask 8 + snapshot mask 8 + mobilities 16 + axis 24 + velocity row 48 + angular velocity 24 =
+                    136 B.  `active_contacts` is measured in the run (state at the end of the solve); None = every
+                    contact (the pre-mask count).
     SURVEY 8(d)'s own figure, 368 C + 96 N per iteration, charges a gathered row to every contact that reads it and
     assumes vector lever arms; this implementation streams scalar arclengths and serves the 48 MB row table from L2 /
     Infinity Cache, so that figure divided by the measured time exceeds the HBM peak (1.39 x at 10^6 rods) -- it is
     unusable as a denominator here and is not printed."""
     act = contacts if active_contacts is None else active_contacts
     return {"k_constraint": 88.0 * contacts + 48.0 * bodies,
-            "k_body": 2 * 36.0 * act + 16.0 * act + 124.0 * bodies}
+            "k_body": 2 * 36.0 * act + 16.0 * act + 136.0 * bodies}
 
 
 def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", active_contacts=None):

@@ -399,6 +399,11 @@ int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gath
                               mhip_stream_t stream);
 int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, int* done /*[host]*/,
                           mhip_stream_t stream); /* synchronises */
+/* between two iterations (e.g. right after a poll): copies the entries the body sweep's activity masks flag, and their
+ * records, into compact per-body lists which the next sweeps stream instead of picking them out of the full lists
+ * (time only: the same terms are summed, and every sum is rounded once).  Optional; the fused and distributed drivers
+ * call it at their polls. */
+int mhip_bbpgd_stage_snapshot_active(mhip_contact_op_t op, mhip_stream_t stream);
 int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
 /* In-kernel small problems: convex::MundyMathBackend<Scalar, N> (convex.hpp:288-350) runs the same solver
  * on fixed-size Vector/Matrix inside a kernel; here one thread solves one dense n x n problem (1 <= n <= 16) of a

@@ -385,6 +385,18 @@ struct OpView {
   // stale because every contact is re-evaluated every iteration.  Entries beyond the 64th of a body are always walked.
   unsigned long long* body_mask;  // [N]
   const unsigned char* pos;       // [2C]: slot of (c, side) in its body's incidence list, 255 if >= 64
+  // Active lists.  The masks say which third of a body's entries matters, but those entries are strewn over its list
+  // (overlap at the start of the step predicts only ~60 % of them), so the masked sweep touches sectors of which it
+  // uses a fraction (PMC: 689 MB per launch against 346 MB it needs).  Every time the host polls for convergence the
+  // flagged entries and their records are copied, body by body, into compact arrays (k_active_*): the sweep then
+  // streams exactly what it uses.  Between two snapshots the masks keep changing a little: a contact that became active
+  // since (mask & ~snap_mask) is walked through the full list as before, one that became inactive still sits in the
+  // compact list and evaluates to lambda = 0 -- it adds nothing.  Same terms, and every sum is a double-double pair
+  // rounded once: the iterates do not notice.  null = no snapshot yet (the first iterations walk the masks).
+  const int32_t* aptr;                  // [N + 1] body -> its compact range
+  const int32_t* aent;                  // entries (c << 1 | side), snapshot order
+  const double* arec;                   // their records, same layout as `half`
+  const unsigned long long* snap_mask;  // [N] the masks the snapshot was taken from
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
@@ -466,34 +478,43 @@ __global__ void __launch_bounds__(kBlock)
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
   // issued back to back before the first use.  kk[u] = incidence slot or -1.
-  auto process = [&](const int32_t* kk) {
+  // ent / rec: the arrays kk indexes (the full lists, or the compact active lists).  EAGER: the records are fetched
+  // together with the entries instead of after the iterate is known -- one dependent level less; used where nearly
+  // every entry walked carries an impulse (flagged entries), not where two thirds do not (unmasked walks).
+  auto process = [&](const int32_t* __restrict__ ent, const double* __restrict__ rec, const int32_t* kk,
+                     const bool eager) {
     int32_t e[U];
     double lam[U];
     double2 h0[U], h1[U], h2[U];
+    auto fetch = [&](int u) {
+      const size_t k = static_cast<size_t>(kk[u]);
+      if (KIN == KIN_TRANS) {
+        const double* H = rec + k * HW;
+        h0[u] = make_double2(H[0], H[1]);
+        h1[u] = make_double2(H[2], 0.0);
+      } else {  // 48-byte (n, r) / 32-byte (n, s - 1/2) records, 16-byte aligned
+        const double2* H2 = reinterpret_cast<const double2*>(rec + k * HW);
+        h0[u] = H2[0];
+        h1[u] = H2[1];
+        if (KIN == KIN_RIGID) h2[u] = H2[2];
+      }
+    };
 #pragma unroll
-    for (int u = 0; u < U; ++u) e[u] = (kk[u] >= 0) ? op.inc[kk[u]] : -1;
+    for (int u = 0; u < U; ++u) {
+      e[u] = (kk[u] >= 0) ? ent[kk[u]] : -1;
+      h0[u] = h1[u] = h2[u] = make_double2(0.0, 0.0);
+      if (eager && kk[u] >= 0) fetch(u);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
       lam[u] = (e[u] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(e[u] >> 1), xt, gt, step, step_is_zero, sp)
                            : 0.0;
-    // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so its record
-    // is never fetched
+    // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so (when the
+    // records are not fetched eagerly) its record is never fetched
+    if (!eager) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      h0[u] = h1[u] = h2[u] = make_double2(0.0, 0.0);
-      if (lam[u] != 0.0) {
-        const size_t k = static_cast<size_t>(kk[u]);
-        if (KIN == KIN_TRANS) {
-          const double* H = op.half + k * HW;
-          h0[u] = make_double2(H[0], H[1]);
-          h1[u] = make_double2(H[2], 0.0);
-        } else {  // 48-byte (n, r) / 32-byte (n, s - 1/2) records, 16-byte aligned
-          const double2* H2 = reinterpret_cast<const double2*>(op.half + k * HW);
-          h0[u] = H2[0];
-          h1[u] = H2[1];
-          if (KIN == KIN_RIGID) h2[u] = H2[2];
-        }
-      }
+      for (int u = 0; u < U; ++u)
+        if (lam[u] != 0.0) fetch(u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -514,6 +535,16 @@ __global__ void __launch_bounds__(kBlock)
     const int32_t head = (end - beg < 64) ? end - beg : 64;
     unsigned long long mm = op.body_mask[b];
     if (head < 64) mm &= (1ull << head) - 1ull;
+    if (op.aptr != nullptr) {  // the snapshot's active entries, streamed; what became active since stays in mm
+      const int32_t ab = op.aptr[b], ae = op.aptr[b + 1];
+      for (int32_t k0 = ab + sub; k0 < ae; k0 += G * U) {
+        int32_t kc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) kc[u] = (k0 + u * G < ae) ? k0 + u * G : -1;
+        process(op.aent, op.arec, kc, true);
+      }
+      mm &= ~op.snap_mask[b];
+    }
     int32_t kk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) kk[u] = -1;
@@ -526,20 +557,20 @@ __global__ void __launch_bounds__(kBlock)
       for (int u = 0; u < U; ++u)
         if (nm == u) kk[u] = beg + bit;
       if (++nm == U) {
-        process(kk);
+        process(op.inc, op.half, kk, true);
         nm = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) kk[u] = -1;
       }
     }
-    if (nm) process(kk);
+    if (nm) process(op.inc, op.half, kk, true);
     full_from = beg + head;
   }
   for (int32_t k0 = full_from + sub; k0 < end; k0 += G * U) {
     int32_t kk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) kk[u] = (k0 + u * G < end) ? k0 + u * G : -1;
-    process(kk);
+    process(op.inc, op.half, kk, false);
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
@@ -1025,6 +1056,49 @@ __global__ void __launch_bounds__(kBlock) k_pos_build(size_t N, const int32_t* _
     }
   }
 }
+// ---- active lists: snapshot of the flagged entries (see OpView) -----------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    k_active_count(size_t first, size_t count, const int32_t* __restrict__ inc_ptr,
+                   const unsigned long long* __restrict__ body_mask, int32_t* __restrict__ cnt) {
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < count; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = first + t;
+    const int32_t deg = inc_ptr[b + 1] - inc_ptr[b];
+    unsigned long long m = body_mask[b];
+    if (deg < 64) m &= (1ull << deg) - 1ull;
+    cnt[t] = __popcll(m);
+  }
+}
+// G lanes per body copy its flagged entries and records (HW doubles each) in slot order
+template <int HW>
+__global__ void __launch_bounds__(kBlock)
+    k_active_fill(size_t first, size_t count, const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc,
+                  const double* __restrict__ half, const unsigned long long* __restrict__ body_mask,
+                  const int32_t* __restrict__ aptr_local, int32_t* __restrict__ aptr, int32_t* __restrict__ aent,
+                  double* __restrict__ arec, unsigned long long* __restrict__ snap_mask, size_t n_all) {
+  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < count; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = first + t;
+    const int32_t beg = inc_ptr[b], deg = inc_ptr[b + 1] - beg;
+    unsigned long long m = body_mask[b];
+    if (deg < 64) m &= (1ull << deg) - 1ull;
+    snap_mask[b] = m;
+    int32_t out = aptr_local[t];
+    aptr[b] = out;
+    if (t + 1 == count) aptr[b + 1] = aptr_local[count];
+    while (m) {
+      const int bit = __ffsll(static_cast<long long>(m)) - 1;
+      m &= m - 1ull;
+      const size_t k = static_cast<size_t>(beg + bit);
+      aent[out] = inc[k];
+      const double* src = half + k * HW;
+      double* dst = arec + static_cast<size_t>(out) * HW;
+#pragma unroll
+      for (int w = 0; w < HW; ++w) dst[w] = src[w];
+      ++out;
+    }
+  }
+  (void)n_all;
+}
+
 // rod axes u = p1 - p0 from the 64-byte segment records
 __global__ void __launch_bounds__(kBlock) k_rod_axes(size_t n, const double* __restrict__ seg, double* __restrict__ axis) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1234,6 +1308,7 @@ struct mhip_contact_op {
   DeviceBuffer iterate;  // packed (x, g) ping-pong pair of the fused / staged solvers: 2 x C x 16 bytes
   DeviceBuffer body_mask, pos;  // activity masks of the packed LCP solves (see OpView)
   DeviceBuffer sort_tmp, sort_list;  // workspaces of the incidence-list sort
+  DeviceBuffer aptr, aent, arec, snap_mask, acnt;  // active lists (see OpView)
   int device = -1;  // the device current at create: where every buffer of this operator lives
   int lanes_per_body = 4;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
@@ -1336,6 +1411,38 @@ unsigned constraint_grid(size_t C) {
   const size_t g = (C + kBlock - 1) / kBlock;
   return static_cast<unsigned>(g == 0 ? 1 : (g > (size_t)kMaxConstraintGrid ? kMaxConstraintGrid : g));
 }
+
+// snapshot of the flagged entries into the compact active lists (OpView::aptr ...); called where the host has just
+// polled the solver, i.e. between two iterations
+int op_snapshot_active(mhip_contact_op* op, hipStream_t s) {
+  OpView& v = op->view;
+  if (v.body_mask == nullptr || v.C == 0 || v.body_count == 0) return MHIP_SUCCESS;
+  const size_t N = v.N, C = v.C, cnt = v.body_count;
+  const int hw = (op->kin == KIN_RIGID) ? 6 : (op->kin == KIN_ROD ? 4 : 3);
+  if (int e = op->aptr.reserve((N + 2) * sizeof(int32_t))) return e;
+  if (int e = op->acnt.reserve((N + 2) * sizeof(int32_t))) return e;
+  if (int e = op->aent.reserve((2 * C + 2) * sizeof(int32_t))) return e;
+  if (int e = op->arec.reserve((2 * C + 2) * hw * sizeof(double))) return e;
+  if (int e = op->snap_mask.reserve((N + 2) * sizeof(unsigned long long))) return e;
+  int32_t* local = op->cursor.as<int32_t>();  // free since the incidence build
+  k_active_count<<<grid_for(cnt), kBlock, 0, s>>>(v.body_first, cnt, v.inc_ptr, v.body_mask, op->acnt.as<int32_t>());
+  MHIP_LAUNCH_CHECK();
+  if (int e = exclusive_scan_i32(op->acnt.as<int32_t>(), local, cnt, op->scanws.ptr, s)) return e;
+#define FILL(H)                                                                                                   \
+  k_active_fill<H><<<grid_for(cnt), kBlock, 0, s>>>(v.body_first, cnt, v.inc_ptr, v.inc, v.half, v.body_mask, local, \
+                                                    op->aptr.as<int32_t>(), op->aent.as<int32_t>(),               \
+                                                    op->arec.as<double>(), op->snap_mask.as<unsigned long long>(), N)
+  if (hw == 6) FILL(6); else if (hw == 4) FILL(4); else FILL(3);
+#undef FILL
+  MHIP_LAUNCH_CHECK();
+  v.aptr = op->aptr.as<int32_t>();
+  v.aent = op->aent.as<int32_t>();
+  v.arec = op->arec.as<double>();
+  v.snap_mask = op->snap_mask.as<unsigned long long>();
+  return MHIP_SUCCESS;
+}
+// from this many completed iterations on the masks have settled enough for a snapshot to pay
+constexpr unsigned kSnapshotAfter = 8;
 
 int check_config(const mhip_pgd_config* cfg) {
   MHIP_REQUIRE(cfg != nullptr, MHIP_ERR_INVALID_ARGUMENT, "config must not be null");
@@ -1461,7 +1568,7 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
 // pinned state block, timing events -- are the same size step after step.  A destroyed operator therefore leaves them
 // in one process-wide spare set that the next create adopts: no hipMalloc / hipFree in the steady state (hipFree
 // alone cost 1.6 ms per step at 10^6 rods).  mhip_release_cached_workspaces() frees the spare set.
-constexpr int kOpBuffers = 16;
+constexpr int kOpBuffers = 21;
 struct OpWorkspaces {
   DeviceBuffer buf[kOpBuffers];
   SolverState* host_state = nullptr;
@@ -1474,7 +1581,8 @@ static OpWorkspaces g_spare;
 static DeviceBuffer* op_buffers(mhip_contact_op* op, int k) {
   DeviceBuffer* all[kOpBuffers] = {&op->inc_ptr, &op->inc,     &op->cursor,   &op->vel,      &op->partials, &op->state,
                                    &op->scanws,  &op->half,    &op->axis,     &op->omega,    &op->vel_out,  &op->iterate,
-                                   &op->body_mask, &op->pos,   &op->sort_tmp, &op->sort_list};
+                                   &op->body_mask, &op->pos,   &op->sort_tmp, &op->sort_list, &op->aptr,    &op->aent,
+                                   &op->arec,    &op->snap_mask, &op->acnt};
   return all[k];
 }
 static void free_workspaces(OpWorkspaces& w) {
@@ -1592,7 +1700,8 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
-                    op->axis.as<double>(), op->omega.as<double>(), 0, 0, C, 0, 0, nullptr, nullptr};
+                    op->axis.as<double>(), op->omega.as<double>(), 0, 0, C, 0, 0, nullptr, nullptr,
+                    nullptr, nullptr, nullptr, nullptr};
   if (int e = op->body_mask.reserve((N + 2) * sizeof(unsigned long long))) return bail(e);
   if (int e = op->pos.reserve(2 * C + 16)) return bail(e);
   if (N > 0 && C > 0) {
@@ -1661,6 +1770,7 @@ static int refresh_contact_op(mhip_contact_op_t op, const double* normal, const 
     else k_half_build<KIN_TRANS><<<grid_for(ne), kBlock, 0, s>>>(ne, inc, normal, ra, rb, arc_s, arc_t, half);
   }
   MHIP_LAUNCH_CHECK();
+  op->view.aptr = nullptr;
   op->view.normal = normal;
   op->view.ra = ra;
   op->view.rb = rb;
@@ -1805,6 +1915,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   double* P0 = op->iterate.as<double>();
   double* P1 = P0 + 2 * C;
   if (op->view.body_mask) MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), s));
+  op->view.aptr = nullptr;  // no snapshot of the active entries yet: the masks start all-ones
   // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res   (the pair lands packed in P0)
   if (int e = op_launch_body(op, X_INIT, x, x, nullptr, nullptr, sp, s)) return e;
   if (int e = op_launch_constraint(op, X_INIT, P0, P1, x, nullptr, q, sp, rk, cgrid, s, true)) return e;
@@ -1839,6 +1950,8 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       }
     }
     if (op->host_state->done || enqueued >= config->max_iters) break;
+    if (enqueued >= kSnapshotAfter)
+      if (int e = op_snapshot_active(op, s)) return e;
     iter_before = op->host_state->iter;
     const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
     for (unsigned k = 0; k < todo; ++k) {
@@ -2041,6 +2154,7 @@ int mhip_contact_op_set_partition(mhip_contact_op_t op, size_t body_first, size_
   MHIP_REQUIRE(body_first + body_count <= op->view.N, MHIP_ERR_INVALID_ARGUMENT,
                "owned body range [%zu, %zu) exceeds the %zu local bodies", body_first, body_first + body_count,
                op->view.N);
+  op->view.aptr = nullptr;
   op->view.body_first = body_first;
   op->view.body_count = body_count;
   op->view.counted = counted_contacts;
@@ -2065,6 +2179,7 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.cfg = *config;
   op->stage.active = true;
   op->stage.part_used = 0;
+  op->view.aptr = nullptr;
   if (op->view.body_mask)
     MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), as_stream(stream)));
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
@@ -2154,6 +2269,11 @@ int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result, int* 
   result->converged = op->host_state->converged;
   *done = op->host_state->done;
   return MHIP_SUCCESS;
+}
+
+int mhip_bbpgd_stage_snapshot_active(mhip_contact_op_t op, mhip_stream_t stream) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  return op_snapshot_active(op, as_stream(stream));
 }
 
 int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result, mhip_stream_t stream) {

@@ -544,6 +544,8 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
       }
     }
     if (done || enqueued >= config->max_iters) break;
+    if (enqueued >= 8)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
+      if (int e = mhip_bbpgd_stage_snapshot_active(op, stream)) return e;
     iter_before = result->num_iters;
     const unsigned todo = (config->max_iters - enqueued < poll_every) ? config->max_iters - enqueued : poll_every;
     for (unsigned k = 0; k < todo; ++k) {

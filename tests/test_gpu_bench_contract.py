@@ -37,7 +37,7 @@ def test_default_line_has_the_contract_keys():
     kb = r if r["kernel"].startswith("k_body") else d["k_body"]
     assert 0.0 < kb["active_contact_fraction"] < 1.0
     assert kb["bytes_per_launch"] == pytest.approx(
-        88.0 * kb["active_contact_fraction"] * d["config"]["contacts_per_gpu"] + 124.0 * d["config"]["bodies_per_gpu"], rel=1e-3)
+        88.0 * kb["active_contact_fraction"] * d["config"]["contacts_per_gpu"] + 136.0 * d["config"]["bodies_per_gpu"], rel=1e-3)
     # the second, labelled figure: the same step from the relaxed packing
     rp = d["relaxed_packing"]
     assert "NOT the headline" in rp["what"] and all(rp["converged"]) and rp["timesteps_per_sec"] > 0
