@@ -36,9 +36,10 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
   lockstep::Machine m;
   m.phase = lockstep::PH_IDLE;
   EllipsoidD e1{}, e2{};
+  lockstep::Frame fr1{}, fr2{};  // per-pair constants of the foot-point maps
   size_t k = 0;
   bool active = false, need = true;
-  for (;;) {
+  for (unsigned round = 0;; ++round) {
     // lanes without a pair take the next ones from the global counter (one atomic per wave)
     const unsigned long long want = __ballot(need);
     if (want) {
@@ -62,6 +63,8 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
             e1 = load_ellipsoid(in.c1, in.q1, in.r1, k);
             e2 = load_ellipsoid(in.c2, in.q2, in.r2, k);
           }
+          fr1 = lockstep::make_frame(e1.q);
+          if (!POINT) fr2 = lockstep::make_frame(e2.q);
           lockstep::begin_pair(m);
         }
       }
@@ -70,19 +73,20 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
     // the objective for all lanes at once (EllipsoidEllipsoid.hpp:118-129): the converged part of the loop
     V3 n1{0, 0, 0}, f1{0, 0, 0}, f2{0, 0, 0};
     double fv = 0.0;
-    if (active) {
+    const bool evaluate = active && lockstep::wants_evaluation(m);  // parked lanes sit the round out
+    if (evaluate) {
       const lbfgs::V2 tp = lockstep::query_point(m);
       double st, ct, sp, cp;
       det_sincos(tp.a, st, ct);
       det_sincos(tp.b, sp, cp);
       n1 = V3{st * cp, st * sp, ct};
-      f1 = normal_to_foot_point(n1, e1);
-      f2 = POINT ? e2.c : normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, e2);
+      f1 = lockstep::normal_to_foot_point_framed(n1, e1, fr1);
+      f2 = POINT ? e2.c : lockstep::normal_to_foot_point_framed(V3{-n1.x, -n1.y, -n1.z}, e2, fr2);
       V3 sep;
       fv = dist_point_point(f1, f2, sep);
     }
-    // each lane's minimiser consumes its value (the diverging part: a few dozen flops)
-    if (active && lockstep::advance(m, hist, fv)) {  // that was the evaluation at the best of the nine starts
+    // each lane's minimiser takes its value (bookkeeping); the diverging logic runs on the wave's schedule below
+    if (evaluate && lockstep::take_value(m, fv)) {  // that was the evaluation at the best of the nine starts
       if (out.dist) out.dist[k] = dot(f2 - f1, n1);  // POINT: dot(point - closest, normal)
       if (out.n1) store3(out.n1, k, n1);
       if (out.n2) store3(out.n2, k, V3{-n1.x, -n1.y, -n1.z});
@@ -94,6 +98,7 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
       active = false;
       need = true;
     }
+    lockstep::scheduled_transitions(m, hist, active, round);
   }
 }
 

@@ -5,10 +5,11 @@
 // their order -- but the control flow is turned inside out.  Each lane carries the minimiser as an explicit state machine
 // whose only externally visible act is "evaluate the objective at this point".  The wave's loop is then
 //     evaluate the objective for all lanes at once  ->  every lane feeds the value to its own machine
-// so the expensive part (two sincos, four quaternion rotations, two foot-point maps: ~95 % of the instructions) runs
-// with all lanes converged whatever line-search branch, L-BFGS iteration, start point or pair each lane is in; only
-// the few dozen flops of minimiser logic diverge.  A lane that finishes a pair takes the next one from a global
-// counter, so no lane waits for the slowest pair of its wave either.  (One thread per pair with the minimiser called
+// so the expensive part (two sincos, four quaternion rotations, two foot-point maps: ~850 instructions) runs with all
+// lanes converged whatever line-search branch, L-BFGS iteration, start point or pair each lane is in; only the
+// minimiser logic diverges, and the wave runs its heavy pieces on a schedule rather than whenever a lane gets there
+// ("Scheduling" below).  A lane that finishes a pair takes the next one from a global counter, so no lane waits for
+// the slowest pair of its wave either.  (One thread per pair with the minimiser called
 // as ordinary nested loops spends most of its time with lanes masked off: pairs need 577...1640 objective
 // evaluations, and lanes are in different loops at any moment.)
 //
@@ -31,8 +32,35 @@ enum Phase : int {
   PH_LS1_VAL, PH_LS1_DP, PH_LS1_DM,  // bracketing loop of the line search: phi(a), phi(a + eps), phi(a - eps)
   PH_LS2_VAL, PH_LS2_DP, PH_LS2_DM,  // sectioning loop
   PH_FINAL,          // re-evaluation at the best point of the nine starts (outputs)
+  // phases without an evaluation: the lane has the values its next decision needs and waits for the wave's next pass
+  // over that piece of minimiser logic (see "Scheduling" below)
+  PH_WAIT_LS1, PH_WAIT_LS2,  // the tests at the bottom of the bracketing / sectioning loop
+  PH_WAIT_HEAD,              // head of find_min's loop: stop tests, L-BFGS direction, line-search set-up
   PH_IDLE
 };
+
+// Scheduling.  The minimiser logic between two evaluations is cheap per lane but expensive per wave: a wave executes a
+// piece of it whenever ANY of its lanes is there, and with 64 lanes in 64 different places every piece is needed every
+// round -- the L-BFGS two-loop recursion (~600 instructions) and the line-search tests (~300) against ~850 for the
+// objective itself.  So the two heavy pieces are not run every round: a lane that reaches one parks in a PH_WAIT phase
+// (it takes no evaluation meanwhile) and the wave runs the line-search tests every kLsEvery-th round and the loop head
+// every kHeadEvery-th, for all lanes parked there at once -- or at once when no lane of the wave could evaluate
+// otherwise.  A parked lane costs 1/64 of an evaluation round per round it waits; the piece it waits for costs the
+// whole wave.  Nothing a lane computes changes: same evaluations, same points, same order.
+// kLsEvery = 3 is the length of a line-search trial (phi(a), phi(a + eps), phi(a - eps)): lanes fall into step with
+// the schedule, a lane that needs another trial is back at the tests exactly when they run next, and a lane that
+// leaves the line search takes its five gradient / cost evaluations and parks for ONE round before a head pass.
+// Measured (MI355X, 4 * 10^5 E-E pairs; mixed 3 * 10^5-body narrow phase): every round 1.57 * 10^7 pairs/s, 56.6 ms;
+// (2, 4) 1.66, 50.3; (3, 3) 1.94, 43.5; (3, 6) 1.90, 42.7; (4, 4) 1.64, 51.2; (6, 6) 1.60, 50.7; (8, 8) 1.56, 51.2
+// (scripts/ab_lockstep_schedule.sh).  Holding the head pass back until 6 ... 28 lanes wait for it only loses
+// (1.84 ... 1.53): a parked lane also falls out of step.
+#ifndef MHIP_LOCKSTEP_LS_EVERY
+#define MHIP_LOCKSTEP_LS_EVERY 3
+#endif
+#ifndef MHIP_LOCKSTEP_HEAD_EVERY
+#define MHIP_LOCKSTEP_HEAD_EVERY 3
+#endif
+constexpr unsigned kLsEvery = MHIP_LOCKSTEP_LS_EVERY, kHeadEvery = MHIP_LOCKSTEP_HEAD_EVERY;
 
 struct Machine {
   // find_min (minimize_impl.hpp:407-605 with the defaults of minimize.hpp:42-51)
@@ -43,7 +71,7 @@ struct Machine {
   unsigned evals;               // objective evaluations of this pair (profiling: the fp64 roofline of the class)
   // line_search (minimize_impl.hpp:233-405)
   double f0, d0, mu, alpha, last_alpha, last_val, last_val_der, a, b, a_val, b_val, a_val_der, b_val_der, thresh;
-  double ls_first, ls_last, val, fp;
+  double ls_first, ls_last, val, fp, fm;
   int itr;
   // multistart (EllipsoidEllipsoid.hpp:106-151)
   int start;
@@ -145,17 +173,6 @@ __device__ inline V2 query_point(const Machine& m) {
   }
 }
 
-// top of the sectioning loop (minimize_impl.hpp line_search, second while): next trial alpha
-__device__ inline void sectioning_top(Machine& m) {
-  const double tau2 = 1.0 / 10.0, tau3 = 1.0 / 2.0;
-  ++m.itr;
-  m.ls_first = m.a + tau2 * (m.b - m.a);
-  m.ls_last = m.b - tau3 * (m.b - m.a);
-  m.alpha = m.a + (m.b - m.a) * lbfgs::poly_min_extrap(m.a_val, m.a_val_der, m.b_val, m.b_val_der, 1.0);
-  m.alpha = lbfgs::clampd(m.ls_first, m.ls_last, m.alpha);
-  m.phase = PH_LS2_VAL;
-}
-
 // the line search returned `alpha`: take the step, then gradient and cost at the new point
 __device__ inline void line_search_done(Machine& m, double alpha) {
   m.x = V2{alpha * m.dir.a + m.x.a, alpha * m.dir.b + m.x.b};
@@ -176,8 +193,11 @@ __device__ inline void finish_start(Machine& m) {
     m.phase = PH_FINAL;
 }
 
-// head of find_min's loop: stop tests, L-BFGS direction, line-search set-up (no objective evaluation in here)
+// head of find_min's loop: stop tests, L-BFGS direction, line-search set-up (no objective evaluation in here).
+// m.g arrives as the two central-difference numerators f(x + eps e_i) - f(x - eps e_i); the divisions happen here.
 __device__ inline void iteration_head(Machine& m, const History& h) {
+  const double eps = kDerivEps;
+  m.g = V2{m.g.a / ((m.x.a + eps) - (m.x.a - eps)), m.g.b / ((m.x.b + eps) - (m.x.b - eps))};
   if (m.stop_used && fabs(m.cost - m.prev_val) < kMinDelta) return finish_start(m);
   m.stop_used = true;
   m.prev_val = m.cost;
@@ -205,7 +225,9 @@ __device__ inline void iteration_head(Machine& m, const History& h) {
       m.ring_head = 0;
     }
     if (m.current_size > 0) {
-      double alpha_i[M];  // compile-time indices only (both loops are fully unrolled): registers, no scratch
+      double alpha_i[M], rho_i[M];  // compile-time indices only (both loops are fully unrolled): registers, no scratch
+      double rho_last = 0.0;
+      V2 y_last{0.0, 0.0};
 #pragma unroll
       for (int i = M - 1; i >= 0; --i) {
         if (i < m.current_size) {
@@ -213,15 +235,16 @@ __device__ inline void iteration_head(Machine& m, const History& h) {
           if (p >= M) p -= M;
           const V2 sp{h.sa(p), h.sb(p)}, yp{h.ya(p), h.yb(p)};
           const double rho = 1.0 / lbfgs::dot2(sp, yp);
+          if (i == m.current_size - 1) {
+            rho_last = rho;
+            y_last = yp;
+          }
           const double al = rho * lbfgs::dot2(sp, dir);
           alpha_i[i] = al;
+          rho_i[i] = rho;
           dir = V2{dir.a - al * yp.a, dir.b - al * yp.b};
         }
       }
-      int pl = m.ring_head + m.current_size - 1;
-      if (pl >= M) pl -= M;
-      const V2 s_last{h.sa(pl), h.sb(pl)}, y_last{h.ya(pl), h.yb(pl)};
-      const double rho_last = 1.0 / lbfgs::dot2(s_last, y_last);
       double H0 = 1.0 / rho_last / lbfgs::dot2(y_last, y_last);
       H0 = lbfgs::clampd(0.001, 1000.0, H0);
       dir = V2{H0 * dir.a, H0 * dir.b};
@@ -231,8 +254,7 @@ __device__ inline void iteration_head(Machine& m, const History& h) {
           int p = m.ring_head + i;
           if (p >= M) p -= M;
           const V2 sp{h.sa(p), h.sb(p)}, yp{h.ya(p), h.yb(p)};
-          const double rho = 1.0 / lbfgs::dot2(sp, yp);
-          const double beta = rho * lbfgs::dot2(yp, dir);
+          const double beta = rho_i[i] * lbfgs::dot2(yp, dir);
           const double al = alpha_i[i];
           dir = V2{dir.a + (al - beta) * sp.a, dir.b + (al - beta) * sp.b};
         }
@@ -259,9 +281,11 @@ __device__ inline void iteration_head(Machine& m, const History& h) {
   m.phase = PH_LS1_VAL;
 }
 
-// feeds the objective value at query_point(m) to the machine; returns true when the pair is complete (PH_FINAL done)
-__device__ inline bool advance(Machine& m, const History& h, double fv) {
-  const double eps = kDerivEps;
+__device__ inline bool wants_evaluation(const Machine& m) { return m.phase <= PH_FINAL; }
+
+// the lane's objective value at query_point(m) goes into the machine: bookkeeping only (a store and the next phase);
+// returns true when the pair is complete (that was the evaluation at the best of the nine starts)
+__device__ inline bool take_value(Machine& m, double fv) {
   ++m.evals;
   switch (m.phase) {
     case PH_COST_INIT:
@@ -269,125 +293,142 @@ __device__ inline bool advance(Machine& m, const History& h, double fv) {
       m.phase = PH_G0P;
       return false;
     case PH_G0P:
+    case PH_G1P:
+    case PH_LS1_DP:
+    case PH_LS2_DP:
       m.fp = fv;
-      m.phase = PH_G0M;
+      m.phase += 1;
       return false;
     case PH_G0M:
-      m.g.a = (m.fp - fv) / ((m.x.a + eps) - (m.x.a - eps));
+      m.g.a = m.fp - fv;  // numerator of the central difference (divided in iteration_head)
       m.phase = PH_G1P;
       return false;
-    case PH_G1P:
-      m.fp = fv;
-      m.phase = PH_G1M;
-      return false;
     case PH_G1M:
-      m.g.b = (m.fp - fv) / ((m.x.b + eps) - (m.x.b - eps));
-      if (m.after_ls) {
-        m.phase = PH_COST_AFTER;
-      } else {
-        iteration_head(m, h);
-      }
+      m.g.b = m.fp - fv;
+      m.phase = m.after_ls ? PH_COST_AFTER : PH_WAIT_HEAD;
       return false;
     case PH_COST_AFTER:
       m.cost = fv;
-      iteration_head(m, h);
+      m.phase = PH_WAIT_HEAD;
       return false;
     case PH_LS1_VAL:
     case PH_LS2_VAL:
       m.val = fv;
       m.phase += 1;
       return false;
-    case PH_LS1_DP:
-    case PH_LS2_DP:
-      m.fp = fv;
-      m.phase += 1;
+    case PH_LS1_DM:
+      m.fm = fv;
+      m.phase = PH_WAIT_LS1;
       return false;
-    case PH_LS1_DM: {
-      const double val = m.val, alpha = m.alpha;
-      const double val_der = (m.fp - fv) / ((alpha + eps) - (alpha - eps));
-      const double tau1a = 1.4, tau1b = 9;
-      if (val <= kMinCost) {
-        line_search_done(m, alpha);
-        return false;
-      }
-      if (val > m.f0 + kRho * alpha * m.d0 || val >= m.last_val) {
-        m.a_val = m.last_val; m.a_val_der = m.last_val_der; m.b_val = val; m.b_val_der = val_der;
-        m.a = m.last_alpha; m.b = alpha;
-        sectioning_top(m);
-        return false;
-      }
-      if (fabs(val_der) <= m.thresh) {
-        line_search_done(m, alpha);
-        return false;
-      }
-      if (m.last_alpha == alpha || m.itr >= kLsMaxIter) {
-        line_search_done(m, alpha);
-        return false;
-      }
-      if (val_der >= 0) {
-        m.a_val = val; m.a_val_der = val_der; m.b_val = m.last_val; m.b_val_der = m.last_val_der;
-        m.a = alpha; m.b = m.last_alpha;
-        sectioning_top(m);
-        return false;
-      }
-      const double temp = alpha;
-      double first, last;
-      if (m.mu > 0) {
-        first = dmin(m.mu, alpha + tau1a * (alpha - m.last_alpha));
-        last = dmin(m.mu, alpha + tau1b * (alpha - m.last_alpha));
-      } else {
-        first = dmax(m.mu, alpha + tau1a * (alpha - m.last_alpha));
-        last = dmax(m.mu, alpha + tau1b * (alpha - m.last_alpha));
-      }
-      double na;
-      if (m.last_alpha < alpha)
-        na = m.last_alpha + (alpha - m.last_alpha) * lbfgs::poly_min_extrap(m.last_val, m.last_val_der, val, val_der, 1e10);
-      else
-        na = alpha + (m.last_alpha - alpha) * lbfgs::poly_min_extrap(val, val_der, m.last_val, m.last_val_der, 1e10);
-      m.alpha = lbfgs::clampd(first, last, na);
-      m.last_alpha = temp;
-      m.last_val = val;
-      m.last_val_der = val_der;
-      ++m.itr;
-      m.phase = PH_LS1_VAL;
+    case PH_LS2_DM:
+      m.fm = fv;
+      m.phase = PH_WAIT_LS2;
       return false;
-    }
-    case PH_LS2_DM: {
-      const double val = m.val, alpha = m.alpha;
-      const double val_der = (m.fp - fv) / ((alpha + eps) - (alpha - eps));
-      if (val <= kMinCost || m.itr >= kLsMaxIter) {
-        line_search_done(m, alpha);
-        return false;
-      }
-      if (m.a == m.ls_first || m.b == m.ls_last) {
-        line_search_done(m, m.b);
-        return false;
-      }
-      const double max_possible_alpha = dmax(fabs(m.a), fabs(m.b));
-      if (fabs(max_possible_alpha * m.d0) <= fabs(m.f0) * kEps) {
-        line_search_done(m, alpha);
-        return false;
-      }
-      if (val > m.f0 + kRho * alpha * m.d0 || val >= m.a_val) {
-        m.b = alpha; m.b_val = val; m.b_val_der = val_der;
-      } else {
-        if (fabs(val_der) <= m.thresh) {
-          line_search_done(m, alpha);
-          return false;
-        }
-        if ((m.b - m.a) * val_der >= 0) {
-          m.b = m.a; m.b_val = m.a_val; m.b_val_der = m.a_val_der;
-        }
-        m.a = alpha; m.a_val = val; m.a_val_der = val_der;
-      }
-      sectioning_top(m);
-      return false;
-    }
     case PH_FINAL:
       m.phase = PH_IDLE;
       return true;
     default:
       return false;
+  }
+}
+
+// bottom of the line search's two loops (minimize_impl.hpp:300-405) for the lanes parked in PH_WAIT_LS1 / PH_WAIT_LS2.
+// The three ways on -- return alpha / go (on) sectioning / extrapolate the bracket -- are decided first and carried out
+// once below, so the cubic fit (poly_min_extrap: a square root and two divisions) exists once in the code.
+__device__ inline void line_search_tests(Machine& m) {
+  const bool l1 = m.phase == PH_WAIT_LS1, l2 = m.phase == PH_WAIT_LS2;
+  if (!(l1 || l2)) return;
+  const double eps = kDerivEps;
+  // (members a lane may return are read once, up here: a load per branch would end up as a load through a selected
+  // pointer, which keeps the members in scratch memory)
+  const double val = m.val, alpha = m.alpha, a_in = m.a, b_in = m.b;
+  const double val_der = (m.fp - m.fm) / ((alpha + eps) - (alpha - eps));
+  enum { DONE, SECTION, EXTRAPOLATE } way;
+  double done_alpha = alpha;
+  if (l1) {
+    if (val <= kMinCost) {
+      way = DONE;
+    } else if (val > m.f0 + kRho * alpha * m.d0 || val >= m.last_val) {
+      m.a_val = m.last_val; m.a_val_der = m.last_val_der; m.b_val = val; m.b_val_der = val_der;
+      m.a = m.last_alpha; m.b = alpha;
+      way = SECTION;
+    } else if (fabs(val_der) <= m.thresh) {
+      way = DONE;
+    } else if (m.last_alpha == alpha || m.itr >= kLsMaxIter) {
+      way = DONE;
+    } else if (val_der >= 0) {
+      m.a_val = val; m.a_val_der = val_der; m.b_val = m.last_val; m.b_val_der = m.last_val_der;
+      m.a = alpha; m.b = m.last_alpha;
+      way = SECTION;
+    } else {
+      way = EXTRAPOLATE;
+    }
+  } else {
+    if (val <= kMinCost || m.itr >= kLsMaxIter) {
+      way = DONE;
+    } else if (a_in == m.ls_first || b_in == m.ls_last) {
+      way = DONE;
+      done_alpha = b_in;
+    } else if (fabs(dmax(fabs(a_in), fabs(b_in)) * m.d0) <= fabs(m.f0) * kEps) {
+      way = DONE;
+    } else if (val > m.f0 + kRho * alpha * m.d0 || val >= m.a_val) {
+      m.b = alpha; m.b_val = val; m.b_val_der = val_der;
+      way = SECTION;
+    } else if (fabs(val_der) <= m.thresh) {
+      way = DONE;
+    } else {
+      if ((b_in - a_in) * val_der >= 0) {
+        m.b = a_in; m.b_val = m.a_val; m.b_val_der = m.a_val_der;
+      }
+      m.a = alpha; m.a_val = val; m.a_val_der = val_der;
+      way = SECTION;
+    }
+  }
+  if (way == DONE) return line_search_done(m, done_alpha);
+  // SECTION: top of the sectioning loop, next trial alpha inside [a, b]; EXTRAPOLATE: next trial of the bracketing loop
+  const bool fwd = m.last_alpha < alpha;
+  const bool sec = way == SECTION;
+  double pf0, pd0, pf1, pd1;
+  if (sec) {
+    pf0 = m.a_val; pd0 = m.a_val_der; pf1 = m.b_val; pd1 = m.b_val_der;
+  } else if (fwd) {
+    pf0 = m.last_val; pd0 = m.last_val_der; pf1 = val; pd1 = val_der;
+  } else {
+    pf0 = val; pd0 = val_der; pf1 = m.last_val; pd1 = m.last_val_der;
+  }
+  const double pm = lbfgs::poly_min_extrap(pf0, pd0, pf1, pd1, sec ? 1.0 : 1e10);
+  ++m.itr;
+  if (sec) {
+    const double tau2 = 1.0 / 10.0, tau3 = 1.0 / 2.0;
+    m.ls_first = m.a + tau2 * (m.b - m.a);
+    m.ls_last = m.b - tau3 * (m.b - m.a);
+    m.alpha = lbfgs::clampd(m.ls_first, m.ls_last, m.a + (m.b - m.a) * pm);
+    m.phase = PH_LS2_VAL;
+  } else {
+    const double tau1a = 1.4, tau1b = 9;
+    double first, last;
+    if (m.mu > 0) {
+      first = dmin(m.mu, alpha + tau1a * (alpha - m.last_alpha));
+      last = dmin(m.mu, alpha + tau1b * (alpha - m.last_alpha));
+    } else {
+      first = dmax(m.mu, alpha + tau1a * (alpha - m.last_alpha));
+      last = dmax(m.mu, alpha + tau1b * (alpha - m.last_alpha));
+    }
+    const double na = fwd ? m.last_alpha + (alpha - m.last_alpha) * pm : alpha + (m.last_alpha - alpha) * pm;
+    m.alpha = lbfgs::clampd(first, last, na);
+    m.last_alpha = alpha;
+    m.last_val = val;
+    m.last_val_der = val_der;
+    m.phase = PH_LS1_VAL;
+  }
+}
+
+// One round of the wave after its evaluation: the minimiser logic that is due (see "Scheduling").  `live` = the lane
+// holds a pair.  All branch conditions are wave-uniform.
+__device__ inline void scheduled_transitions(Machine& m, const History& h, bool live, unsigned round) {
+  if (round % kLsEvery == 0 || !__any(live && wants_evaluation(m))) line_search_tests(m);
+  if (round % kHeadEvery == 0 || !__any(live && wants_evaluation(m))) {
+    if (m.phase == PH_WAIT_HEAD) iteration_head(m, h);
   }
 }
 

@@ -6,7 +6,8 @@
 //   2. 6 x (flag, scan, scatter)   stable counting sort of pair indices by class (device-resident class offsets)
 //   3. one kernel per class over its index range, results scattered back to the pairs' own slots
 // S-E and R-E have no reference implementation (empty stubs SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp): build
-// extensions, parity unpinned (see the oracle).  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
+// extensions, parity unpinned (see the oracle): the point - ellipsoid minimisation with the sphere's centre, resp. the
+// closest point of the rod's centreline, as the point, minus the radius.  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
 // (r,-,-) / (r,L,-) / (r1,r2,r3).
 #include "ellipsoid_lockstep.hpp"
 
@@ -99,14 +100,6 @@ __device__ inline void store_contact(const MixedOut& o, size_t k, bool swapped, 
   if (o.rb) store3(o.rb, k, c2 - cj);
 }
 
-// rod support point for outward normal n: c + sign(n.a) (L/2) a + r n
-__device__ inline V3 rod_support(const BodyD& b, V3 n) {
-  const V3 a = qrot(b.q, V3{0.0, 0.0, 1.0});
-  const double h = 0.5 * b.s.y;
-  const double sg = copysign(1.0, dot(n, a));
-  return (b.c + (sg * h) * a) + b.s.x * n;
-}
-
 // the closed-form classes: sphere - sphere, sphere - rod, rod - rod
 template <int CLS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -166,11 +159,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
   m.phase = lockstep::PH_IDLE;
   BodyD A{}, B{};
   lockstep::Frame frA{}, frB{};  // per-pair constants of the objective (see ellipsoid_lockstep.hpp)
-  V3 rod_axis{0, 0, 0};
+  V3 rod_p0{0, 0, 0}, rod_p1{0, 0, 0};  // the rod's centreline segment (R-E)
   bool swapped = false;
   size_t k = 0;
   bool active = false, need = true;
-  for (;;) {
+  for (unsigned round = 0;; ++round) {
     const unsigned long long want = __ballot(need);
     if (want) {
       const int leader = __ffsll(static_cast<long long>(want)) - 1;
@@ -192,7 +185,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
           B = swapped ? bi : bj;
           frB = lockstep::make_frame(B.q);
           if (CLS == 5) frA = lockstep::make_frame(A.q);
-          if (CLS == 4) rod_axis = qrot(A.q, V3{0.0, 0.0, 1.0});  // what rod_support recomputes on every call
+          if (CLS == 4) {
+            const V3 hd = rod_half_axis(A.q, A.s.y);
+            rod_p0 = A.c - hd;
+            rod_p1 = A.c + hd;
+          }
           lockstep::begin_pair(m);
         }
       }
@@ -200,7 +197,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
     if (!__any(active)) break;
     V3 n1{0, 0, 0}, f1{0, 0, 0}, f2{0, 0, 0};
     double fv = 0.0;
-    if (active) {
+    const bool evaluate = active && lockstep::wants_evaluation(m);  // parked lanes sit the round out
+    if (evaluate) {
       const lbfgs::V2 tp = lockstep::query_point(m);
       double st, ct, sp, cp;
       det_sincos(tp.a, st, ct);
@@ -211,23 +209,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
       if (CLS == 2) {         // point - ellipsoid: n1 is the ellipsoid's outward normal, f1 its foot point
         f1 = lockstep::normal_to_foot_point_framed(n1, elB, frB);
         fv = dist_point_point(f1, A.c, sv);
-      } else if (CLS == 4) {  // rod support point against the ellipsoid's foot point for the opposite normal
-        const double h = 0.5 * A.s.y;  // rod_support(A, n1) with the axis hoisted
-        const double sg = copysign(1.0, dot(n1, rod_axis));
-        f1 = (A.c + (sg * h) * rod_axis) + A.s.x * n1;
-        f2 = lockstep::normal_to_foot_point_framed(V3{-n1.x, -n1.y, -n1.z}, elB, frB);
-        fv = dist_point_point(f1, f2, sv);
+      } else if (CLS == 4) {  // segment - ellipsoid: the foot point against the closest point f2 of the rod's centreline
+        double tt;
+        f1 = lockstep::normal_to_foot_point_framed(n1, elB, frB);
+        fv = dist_point_segment(f1, rod_p0, rod_p1, f2, tt, sv);
       } else {                // ellipsoid - ellipsoid
         f1 = lockstep::normal_to_foot_point_framed(n1, EllipsoidD{A.c, A.q, A.s}, frA);
         f2 = lockstep::normal_to_foot_point_framed(V3{-n1.x, -n1.y, -n1.z}, elB, frB);
         fv = dist_point_point(f1, f2, sv);
       }
     }
-    if (active && lockstep::advance(m, hist, fv)) {
+    if (evaluate && lockstep::take_value(m, fv)) {  // that was the evaluation at the best of the nine starts
       const V3 ci = swapped ? B.c : A.c, cj = swapped ? A.c : B.c;  // centres in the list's (i, j) order
       if (CLS == 2) {
         const double d = dot(A.c - f1, n1);
         store_contact(out, k, swapped, d - A.s.x, V3{-n1.x, -n1.y, -n1.z}, A.c, f1, ci, cj);
+      } else if (CLS == 4) {
+        const double d = dot(f2 - f1, n1);
+        store_contact(out, k, swapped, d - A.s.x, V3{-n1.x, -n1.y, -n1.z}, f2, f1, ci, cj);
       } else {
         store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, ci, cj);
       }
@@ -235,6 +234,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
       active = false;
       need = true;
     }
+    lockstep::scheduled_transitions(m, hist, active, round);
   }
 }
 

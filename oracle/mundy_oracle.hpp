@@ -840,8 +840,13 @@ inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3&
 //   S-E  distance(Point, Ellipsoid) - r_s (the reference's SphereEllipsoid.hpp:21-33 is an empty stub, so
 //        this routing is a build-side definition: PARITY UNPINNED), normal = -ellipsoid normal
 //   R-E  NO reference function exists (LineSegmentEllipsoid.hpp:21-33 is an empty stub).  Build extension, PARITY
-//        UNPINNED: the same shared-normal minimisation as E-E with the spherocylinder's support map
-//        foot(n) = c + sign(n.a) (L/2) a + r n  in place of the ellipsoid foot point.
+//        UNPINNED: distance(Point, Ellipsoid)'s minimisation with the point replaced by the rod's centreline segment --
+//        minimise, over the ellipsoid's outward normal n, the distance from its foot point f(n) to the closest point
+//        p of the segment (LineSegmentPoint's point-segment distance, a C^1 objective) -- then subtract the rod radius,
+//        as the sphere classes do.  A rod of zero length gives S-E.  (A spherocylinder's own support map
+//        c + sign(n.a)(L/2)a + r n jumps between the end caps where n is normal to the axis -- the very orientation
+//        of a side-on contact -- so a shared-normal minimisation over it can neither reach a contact point on the
+//        cylinder nor converge there; that was this class's first definition.)
 // The pair is evaluated in canonical class order (lower kind first) and flipped back if the list order is the reverse.
 // ---------------------------------------------------------------------------------------------------------------
 enum BodyKind : int { kSphere = 0, kRod = 1, kEllipsoid = 2 };
@@ -855,12 +860,6 @@ struct MixedContact {
   double sep;
   V3 normal, cp1, cp2;
 };
-inline V3 rod_support_point(const MixedBody& b, const V3& n) {
-  const V3 a = qrot(b.q, V3{0.0, 0.0, 1.0});
-  const double h = 0.5 * b.shape.y;
-  const double sgn = std::copysign(1.0, dot(n, a));
-  return (b.c + (sgn * h) * a) + b.shape.x * n;
-}
 inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody& B) {
   MixedContact o;
   if (A.kind == kSphere && B.kind == kSphere) {
@@ -894,23 +893,25 @@ inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody&
     o.cp2 = closest;
   } else {  // rod - ellipsoid (extension)
     const Ellipsoid el{B.c, B.q, B.shape};
-    V3 n1, f1, f2;
+    const V3 hd = spherocylinder_half_axis(A.q, A.shape.y);
+    const V3 p0 = A.c - hd, p1 = A.c + hd;
+    V3 ne, foot, closest, sepv;
+    double t;
     auto objective = [&](const minimize::Vec<2>& tp) {
       double st, ct, sp, cp;
-    sincos_mode(tp[0], st, ct);
-    sincos_mode(tp[1], sp, cp);
-      n1 = {st * cp, st * sp, ct};
-      f1 = rod_support_point(A, n1);
-      f2 = map_surface_normal_to_foot_point({-n1.x, -n1.y, -n1.z}, el);
-      return distance_point_point(f1, f2);
+      sincos_mode(tp[0], st, ct);
+      sincos_mode(tp[1], sp, cp);
+      ne = {st * cp, st * sp, ct};
+      foot = map_surface_normal_to_foot_point(ne, el);
+      return distance_point_segment(foot, p0, p1, closest, t, sepv);
     };
     constexpr double pi = 3.141592653589793;
     const double tg[3] = {0.0, 0.5 * pi, pi}, pg[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
     double best = std::numeric_limits<double>::infinity();
     minimize::Vec<2> btp{{0.0, 0.0}};
-    for (int t = 0; t < 3; ++t)
-      for (int p = 0; p < 3; ++p) {
-        minimize::Vec<2> tp{{tg[t], pg[p]}};
+    for (int t3 = 0; t3 < 3; ++t3)
+      for (int p3 = 0; p3 < 3; ++p3) {
+        minimize::Vec<2> tp{{tg[t3], pg[p3]}};
         const double d = minimize::find_min<10, 2>(objective, tp, kRelaxedZeroTol);
         if (d < best) {
           best = d;
@@ -918,8 +919,10 @@ inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody&
         }
       }
     objective(btp);
-    o.sep = dot(f2 - f1, n1);
-    o.normal = n1; o.cp1 = f1; o.cp2 = f2;
+    o.sep = dot(closest - foot, ne) - A.shape.x;
+    o.normal = {-ne.x, -ne.y, -ne.z};
+    o.cp1 = closest;
+    o.cp2 = foot;
   }
   return o;
 }

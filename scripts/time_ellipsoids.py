@@ -9,6 +9,9 @@ def ell():
     return dev(c), dev(q), dev(rng.uniform(0.4, 1.0, (n, 3)))
 a, b = ell(), ell()
 ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize()
-t = time.perf_counter(); ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize(); dt = time.perf_counter() - t
+ts = []
+for _ in range(5):
+    t = time.perf_counter(); ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+dt = float(np.median(ts))
 ev = ops.ellipsoid_last_evaluations()
 print("ellipsoid pairs %d: %.3f s  -> %.3f us/pair, %.3g pairs/s; %.0f objective evaluations per pair" % (n, dt, 1e6 * dt / n, n / dt, ev / n))

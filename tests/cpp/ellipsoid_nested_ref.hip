@@ -259,14 +259,6 @@ struct BodyD {
   Quat q;
   V3 s;
 };
-// rod support point for outward normal n: c + sign(n.a) (L/2) a + r n
-__device__ inline V3 rod_support(const BodyD& b, V3 n) {
-  const V3 a = qrot(b.q, V3{0.0, 0.0, 1.0});
-  const double h = 0.5 * b.s.y;
-  const double sg = copysign(1.0, dot(n, a));
-  return (b.c + (sg * h) * a) + b.s.x * n;
-}
-
 __device__ inline EllipsoidD load_ellipsoid(const double* c, const double* q, const double* r, size_t i) {
   return {load3(c, i), load4q(q, i), load3(r, i)};
 }
@@ -294,8 +286,8 @@ __global__ void __launch_bounds__(64)
   store3(cp, i, closest);
   store3(nrm, i, normal);
 }
-// rod (centre, quaternion, radius, length) against ellipsoid: the shared-normal minimisation with the rod's support
-// map in place of the first foot point (the R-E class of mundy_amd/csrc/mixed.hip)
+// rod (centre, quaternion, radius, length) against ellipsoid: the point - ellipsoid minimisation with the closest point
+// of the rod's centreline as the point (the R-E class of mundy_amd/csrc/mixed.hip): normal = rod -> ellipsoid
 __global__ void __launch_bounds__(64)
     k_ref_rod_ellipsoid(size_t n, const double* rc, const double* rq, const double* rshape, const double* ec,
                         const double* eq, const double* er, double* sep, double* normal, double* cp1, double* cp2) {
@@ -303,19 +295,21 @@ __global__ void __launch_bounds__(64)
   if (i >= n) return;
   const BodyD A{1, load3(rc, i), load4q(rq, i), load3(rshape, i)};
   const EllipsoidD el = load_ellipsoid(ec, eq, er, i);
-  auto eval = [&](lbfgs::V2 tp, V3& n1, V3& f1, V3& f2) {
+  const V3 hd = rod_half_axis(A.q, A.s.y);
+  const V3 p0 = A.c - hd, p1 = A.c + hd;
+  auto eval = [&](lbfgs::V2 tp, V3& ne, V3& foot, V3& closest) {
     double st, ct, sp, cp;
     det_sincos(tp.a, st, ct);
     det_sincos(tp.b, sp, cp);
-    n1 = V3{st * cp, st * sp, ct};
-    f1 = rod_support(A, n1);
-    f2 = normal_to_foot_point(V3{-n1.x, -n1.y, -n1.z}, el);
+    ne = V3{st * cp, st * sp, ct};
+    foot = normal_to_foot_point(ne, el);
     V3 sv;
-    return dist_point_point(f1, f2, sv);
+    double tt;
+    return dist_point_segment(foot, p0, p1, closest, tt, sv);
   };
   auto objective = [&](lbfgs::V2 tp) {
-    V3 n1, f1, f2;
-    return eval(tp, n1, f1, f2);
+    V3 ne, foot, closest;
+    return eval(tp, ne, foot, closest);
   };
   const double pi = 3.141592653589793;
   const double tg[3] = {0.0, 0.5 * pi, pi}, pg[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
@@ -330,12 +324,12 @@ __global__ void __launch_bounds__(64)
         btp = tp;
       }
     }
-  V3 n1, f1, f2;
-  eval(btp, n1, f1, f2);
-  sep[i] = dot(f2 - f1, n1);
-  store3(normal, i, n1);
-  store3(cp1, i, f1);
-  store3(cp2, i, f2);
+  V3 ne, foot, closest;
+  eval(btp, ne, foot, closest);
+  sep[i] = dot(closest - foot, ne) - A.s.x;
+  store3(normal, i, V3{-ne.x, -ne.y, -ne.z});
+  store3(cp1, i, closest);
+  store3(cp2, i, foot);
 }
 
 }  // namespace mhip

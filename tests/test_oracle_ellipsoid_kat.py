@@ -81,3 +81,51 @@ def test_analytical_ellipsoid_cases(oracle):
     np.testing.assert_allclose(np.linalg.norm(out["n1"], axis=1), 1.0, atol=1e-12)
     np.testing.assert_allclose(out["n2"], -out["n1"], atol=0)
     np.testing.assert_allclose(np.sum((out["cp2"] - out["cp1"]) * out["n1"], axis=1), out["dist"], atol=1e-14)
+
+
+def test_rod_ellipsoid_extension_against_a_scan_of_the_centreline(oracle):
+    # R-E has no reference implementation (LineSegmentEllipsoid.hpp is an empty stub): the build-side definition is
+    # "point - ellipsoid distance of the rod's closest centreline point, minus the rod radius".  Independent check: the
+    # point - ellipsoid distance (pinned above on the reference's own cases) scanned along the centreline -- it is a
+    # convex function of the arclength for an exterior segment, so a scan plus a ternary refinement brackets its minimum.
+    rng = np.random.default_rng(17)
+    n = 40
+    ec = rng.uniform(-0.5, 0.5, (n, 3))
+    eq = rng.normal(size=(n, 4)); eq /= np.linalg.norm(eq, axis=1, keepdims=True)
+    er = rng.uniform(0.4, 1.2, (n, 3))
+    rq = rng.normal(size=(n, 4)); rq /= np.linalg.norm(rq, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rc = ec + d * rng.uniform(1.6, 3.0, (n, 1))      # centreline stays outside the ellipsoid (largest radius 1.2 ...
+    L, r = rng.uniform(0.0, 3.0, n), rng.uniform(0.1, 0.4, n)
+    kind = np.concatenate([np.full(n, 1), np.full(n, 2)]).astype(np.int32)
+    center, quat = np.concatenate([rc, ec]), np.concatenate([rq, eq])
+    shape = np.concatenate([np.stack([r, L, np.zeros(n)], axis=1), er])
+    pairs = np.stack([np.arange(n), np.arange(n) + n], axis=1).astype(np.int32)
+    out = oracle.contact_mixed(pairs, kind, center, quat, shape)
+    seg = oracle.spherocylinder_segments(rc, rq, r, L)   # rows (p0, p1, r, L)
+    p0, p1 = seg[:, 0:3], seg[:, 3:6]
+    checked = 0
+    for i in range(n):
+        f = lambda t: oracle.distance_point_ellipsoid((p0[i] + np.asarray(t)[:, None] * (p1[i] - p0[i])),  # noqa: E731
+                                                      np.repeat(ec[i:i + 1], len(t), 0), np.repeat(eq[i:i + 1], len(t), 0),
+                                                      np.repeat(er[i:i + 1], len(t), 0))[0]
+        ts = np.linspace(0.0, 1.0, 33)
+        v = f(ts)
+        if v.min() <= 0.05:
+            continue  # ... but a long rod may still reach it: exterior cases only)
+        k = int(np.argmin(v))
+        lo, hi = ts[max(k - 1, 0)], ts[min(k + 1, 32)]
+        for _ in range(30):
+            a, b = lo + (hi - lo) / 3.0, hi - (hi - lo) / 3.0
+            fa, fb = f([a, b])
+            lo, hi = (lo, b) if fa < fb else (a, hi)
+        best = float(f([0.5 * (lo + hi)])[0])
+        assert abs(out["sep"][i] - (best - r[i])) < 2e-4, (i, out["sep"][i], best - r[i])
+        # contact points: on the centreline, resp. on the ellipsoid surface, joined by the (unit) normal
+        t_cp = np.dot(out["cp1"][i] - p0[i], p1[i] - p0[i]) / max(np.dot(p1[i] - p0[i], p1[i] - p0[i]), 1e-300)
+        assert -1e-9 <= t_cp <= 1 + 1e-9
+        gap = out["cp2"][i] - out["cp1"][i]
+        np.testing.assert_allclose(gap / np.linalg.norm(gap), out["normal"][i], atol=5e-3)
+        np.testing.assert_allclose(np.linalg.norm(gap) - r[i], out["sep"][i], atol=2e-4)
+        checked += 1
+    assert checked >= 25
