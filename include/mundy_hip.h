@@ -619,6 +619,44 @@ int mhip_ghost_plan(mhip_comm_t comm, size_t n, const double* aabb, double buffe
                     mhip_ghost_layout* layout /*[host] out*/, mhip_stream_t stream);
 int mhip_ghost_exchange(mhip_comm_t comm, size_t width, const double* records /*[n][width]*/,
                         double* local /*[num_ghost_lo + n + num_ghost_hi][width]*/, mhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Ownership follows the bodies (replaces the RCB repartition of stk::balance::balanceStkMesh,
+ * scrap/lcp_spheres/NGPSpheresLCP.cpp:956, which the bacteria app calls every load_balance_frequency steps,
+ * scrap/parameter_interface/alens/tests/performance_tests/Bacteria.cpp:1076-1078).  Ranks own contiguous ranges of
+ * the Hilbert curve over a fixed lattice: rank r owns the cells  splitters[r - 1] < key <= splitters[r].
+ *   mhip_hilbert_key_table  [host] table[ix][iy][iz] = position of the cell along mundy::math::hilbert_3d
+ *                           (mundy/math/src/mundy_math/Hilbert.hpp:48-83); (2^level)^3 entries, level <= 8; feed it to
+ *                           mhip_curve_keys / mhip_curve_order
+ *   mhip_curve_cut          cuts the curve at equal cumulative WORK: weight per body (null = 1; the steppers use
+ *                           1 + contacts of the last step) histogrammed over the cells, all-gathered, summed in rank
+ *                           order, cut where the running sum reaches r / world of the total.  Every rank computes the
+ *                           same world - 1 splitters [host].  Collective.
+ *   mhip_migrate_plan       destination rank of every owned body from its cell key; counts all-gathered.  n_new =
+ *                           bodies this rank owns afterwards.  Collective.
+ *   mhip_migrate_exchange   records [n][width] -> out [n_new][width]: the rows that stay (in their present order),
+ *                           then the arrivals, peers in increasing rank; one grouped send / recv per peer.  Any number
+ *                           of exchanges may follow one plan.  The caller then orders its rows as it likes (the
+ *                           steppers: by cell key, ties by entity id -- the order a single rank would have).
+ * Small helpers of that bookkeeping:
+ *   mhip_body_work_weights  weights[k] = 1 + number of pairs that contain local body first + k, k < count
+ *   mhip_compose_keys_u64   out[i] = major[i] << shift | (uint64) minor[i]  (cell key, then entity id: minor is an
+ *                           integer-valued double below 2^shift)
+ *   mhip_fill_sequence      dst[i] = first + i
+ * ---------------------------------------------------------------------------------------------------------------- */
+int mhip_hilbert_key_table(int level, int32_t* table /*[host] (2^level)^3*/);
+int mhip_body_work_weights(size_t c, const int32_t* pairs, size_t first, size_t count, double* weights /*[count]*/,
+                           mhip_stream_t stream);
+int mhip_compose_keys_u64(size_t n, const uint32_t* major, const double* minor, int shift, uint64_t* out,
+                          mhip_stream_t stream);
+int mhip_fill_sequence(size_t n, double first, double* dst, mhip_stream_t stream);
+int mhip_curve_cut(mhip_comm_t comm, size_t n, const uint32_t* keys, const double* weights /*[n] or null*/, size_t ncell,
+                   int64_t* splitters /*[host] world - 1*/, mhip_stream_t stream);
+int mhip_migrate_plan(mhip_comm_t comm, size_t n, const uint32_t* keys, const int64_t* splitters /*[host] world - 1*/,
+                      size_t* n_new, size_t* num_sent /*or null*/, size_t* num_received /*or null*/,
+                      mhip_stream_t stream);
+int mhip_migrate_exchange(mhip_comm_t comm, size_t width, const double* records /*[n][width]*/,
+                          double* out /*[n_new][width]*/, mhip_stream_t stream);
 typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that did work, summed */
   double body_ms, constraint_ms, halo_wait_ms;
   size_t timed_iterations;

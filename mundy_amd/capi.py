@@ -184,6 +184,13 @@ SIGNATURES = {
                                       C.POINTER(_sz)],
     "mhip_ghost_plan": [_vp, _sz, _vp, _d, C.POINTER(GhostLayout), _vp],
     "mhip_ghost_exchange": [_vp, _sz, _vp, _vp, _vp],
+    "mhip_hilbert_key_table": [_i, _vp],
+    "mhip_body_work_weights": [_sz, _vp, _sz, _sz, _vp, _vp],
+    "mhip_compose_keys_u64": [_sz, _vp, _vp, _i, _vp, _vp],
+    "mhip_fill_sequence": [_sz, _d, _vp, _vp],
+    "mhip_curve_cut": [_vp, _sz, _vp, _vp, _sz, _vp, _vp],
+    "mhip_migrate_plan": [_vp, _sz, _vp, _vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), _vp],
+    "mhip_migrate_exchange": [_vp, _sz, _vp, _vp, _vp],
     "mhip_bbpgd_solve_contact_distributed": [_vp, _vp, C.POINTER(VelocityHalo), _sz, _vp, C.POINTER(Space),
                                              C.POINTER(PgdConfig), _vp, _vp, _vp, _vp, C.c_uint,
                                              C.POINTER(SolveResult), C.POINTER(DistProfile), _vp],

@@ -475,6 +475,15 @@ __global__ void __launch_bounds__(kBlock)
   // force and torque sums in double-double: their rounded values do not depend on the order of the list, on G or on U
   DD3 Fdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, Tdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
   const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
+  // the body's own constants, needed only after the sums: fetched now, by the lane that will use them, so that they are
+  // not one more dependent memory level at the end of the chain
+  double mt = 0.0, mr = 0.0;
+  V3 axis{0.0, 0.0, 0.0};
+  if (sub == 0) {
+    mt = op.mt[b];
+    if (KIN != KIN_TRANS) mr = op.mr[b];
+    if (KIN == KIN_ROD) axis = load3(op.axis, b);
+  }
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
   // issued back to back before the first use.  kk[u] = incidence slot or -1.
@@ -585,20 +594,14 @@ __global__ void __launch_bounds__(kBlock)
   }
   if (sub != 0) return;
   const V3 F = dd_value(Fdd), T = dd_value(Tdd);  // the one rounding of each sum
-  const double mt = op.mt[b];
   double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
   V3 W{0.0, 0.0, 0.0};
-  if (KIN == KIN_RIGID) {
-    const double mr = op.mr[b];
-    W = V3{mr * T.x, mr * T.y, mr * T.z};
-  }
+  if (KIN == KIN_RIGID) W = V3{mr * T.x, mr * T.y, mr * T.z};
   if (KIN == KIN_ROD) {
-    const double mr = op.mr[b];
-    const V3 u = load3(op.axis, b);
-    const V3 tq = cross(u, T);  // T holds S = sum coef f
+    const V3 tq = cross(axis, T);  // T holds S = sum coef f
     const V3 w{mr * tq.x, mr * tq.y, mr * tq.z};
     store3(op.omega, b, w);
-    W = cross(w, u);  // the row carries Z = W x u: the contact-point velocity is U + coef Z
+    W = cross(w, axis);  // the row carries Z = W x u: the contact-point velocity is U + coef Z
   }
   v[0] = make_double2(mt * F.x, mt * F.y);  // U = F / (6 pi r mu)  (NgpLcp.cpp:484-486)
   v[1] = make_double2(mt * F.z, W.x);
@@ -1310,7 +1313,7 @@ struct mhip_contact_op {
   DeviceBuffer sort_tmp, sort_list;  // workspaces of the incidence-list sort
   DeviceBuffer aptr, aent, arec, snap_mask, acnt;  // active lists (see OpView)
   int device = -1;  // the device current at create: where every buffer of this operator lives
-  int lanes_per_body = 4;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
+  int lanes_per_body = 2;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
   struct Stage {
@@ -1694,9 +1697,11 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
     // of it active; MI355X), walking every entry: (16,1) 0.198 ms, (8,1) 0.164, (8,2) 0.154, (4,4) 0.157, (8,4) 0.150
     // per sweep; walking only the entries the activity masks flag: (8,4) 0.144, (4,4) 0.137, (2,8) 0.142, (1,8) 0.156.
     // With double-double sums (one rounding per sum): (4,4) 0.138 ms, (2,4) 0.151, (8,4) 0.182, (8,2) 0.156, (4,8) 0.149.
+    // With the compact active lists (a sweep streams the active third of a list): (2,4) 0.103 ms, (4,4) 0.108, (8,4)
+    // 0.162, (16,2) 0.255; whole step from the relaxed packing 26.6 ms with two lanes against 28.8 with four.
     // The layout only moves time: the sums, hence the iterates, are the same for every G (tests).
     const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
-    op->lanes_per_body = mean_deg <= 24.0 ? 4 : (mean_deg <= 96.0 ? 8 : 16);
+    op->lanes_per_body = mean_deg <= 24.0 ? 2 : (mean_deg <= 48.0 ? 4 : (mean_deg <= 96.0 ? 8 : 16));
   }
   op->view = OpView{C, N, p2, normal, ra, rb, mob_trans, mob_rot, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,

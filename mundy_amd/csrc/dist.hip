@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time
 
+#include <initializer_list>
 #include <vector>
 
 #include "mhip_internal.hpp"
@@ -101,12 +102,47 @@ struct mhip_comm {
     DeviceBuffer stage;             // counts on their way through the all-gather; packed send rows
     DeviceBuffer regions;           // this rank's chunk boxes + everybody's, all-gathered
   } ghost;
+  // migration plan of the last mhip_migrate_plan: which owned rows leave for which rank, how many arrive from whom
+  struct MigratePlan {
+    bool valid = false;
+    size_t n = 0, n_new = 0, keep = 0, keep_first = 0;
+    std::vector<int> send_peer, recv_peer;
+    std::vector<size_t> send_first_row, send_rows, recv_rows;
+    DeviceBuffer dest, sortkey, order, hist, stage;
+  } migrate;
 };
 
 namespace mhip {
 __global__ void __launch_bounds__(kBlock) k_offset_i32(size_t n, const int32_t* __restrict__ in, int32_t off,
                                                       int32_t* __restrict__ out) {
   for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) out[i] = in[i] + off;
+}
+// hist[key[i]] += weight[i] (1 if weights is null).  Weights are body counts / contact counts: integer-valued, so the
+// sums are exact whatever order the atomics land in.
+__global__ void __launch_bounds__(kBlock) k_weighted_hist(size_t n, const uint32_t* __restrict__ keys,
+                                                         const double* __restrict__ weights, size_t nbins,
+                                                         double* __restrict__ hist) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const size_t k = keys[i] < nbins ? keys[i] : nbins - 1;
+    atomicAdd(&hist[k], weights ? weights[i] : 1.0);
+  }
+}
+// dest[i] = number of splitters below key[i] (rank r owns the cells  splitters[r - 1] < key <= splitters[r]);
+// sortkey = dest << 32 | i, so a stable sort groups the rows by destination in their present order
+__global__ void __launch_bounds__(kBlock) k_migrate_dest(size_t n, const uint32_t* __restrict__ keys, int nsplit,
+                                                        const long long* __restrict__ splitters,
+                                                        unsigned long long* __restrict__ sortkey,
+                                                        double* __restrict__ count /*[nsplit + 1]*/) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const long long key = keys[i];
+    int lo = 0, hi = nsplit;  // first index with splitters[idx] >= key
+    while (lo < hi) {
+      const int mid = (lo + hi) / 2;
+      if (splitters[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    sortkey[i] = (static_cast<unsigned long long>(lo) << 32) | static_cast<unsigned long long>(i);
+    atomicAdd(&count[lo], 1.0);
+  }
 }
 // all-gather of a few host doubles through the communicator: out [world][count]
 static int host_all_gather(mhip_comm* c, const double* in, size_t count, std::vector<double>& out, hipStream_t s) {
@@ -186,6 +222,8 @@ int mhip_comm_destroy(mhip_comm_t c) {
   c->ghost.send_index_local.release();
   c->ghost.stage.release();
   c->ghost.regions.release();
+  for (DeviceBuffer* b : {&c->migrate.dest, &c->migrate.sortkey, &c->migrate.order, &c->migrate.hist, &c->migrate.stage})
+    b->release();
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   if (c->ready) (void)hipEventDestroy(c->ready);
@@ -432,6 +470,209 @@ int mhip_ghost_exchange(mhip_comm_t c, size_t width, const double* records, doub
   }
   if (int e = mhip_comm_exchange_start(c, (int)sbuf.size(), gp.send_peer.data(), sbuf.data(), scount.data(),
                                        (int)rbuf.size(), gp.recv_peer.data(), rbuf.data(), rcount.data(), stream))
+    return e;
+  return mhip_comm_exchange_finish(c, stream);
+}
+
+/* Lattice points of a (2^level)^3 cube in the visiting order of mundy::math::hilbert_3d (mundy/math/src/mundy_math/
+ * Hilbert.hpp:48-83) started at the origin with axes (x, y, z): each state (corner, three signed axes) expands into its
+ * eight children in curve order.  table[ix][iy][iz] = position of the cell along the curve.  Host only. */
+int mhip_hilbert_key_table(int level, int32_t* table) {
+  MHIP_REQUIRE(table != nullptr, MHIP_ERR_INVALID_ARGUMENT, "table is null");
+  MHIP_REQUIRE(level >= 0 && level <= 8, MHIP_ERR_INVALID_ARGUMENT, "level %d is not in 0..8", level);
+  struct State {
+    int c[3];
+    int d[3][3];  // dr1, dr2, dr3
+  };
+  std::vector<State> cur(1), next;
+  cur[0] = State{{0, 0, 0}, {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+  for (int s = 1 << level; s > 1; s /= 2) {
+    const int h = s / 2;
+    next.clear();
+    next.reserve(cur.size() * 8);
+    for (const State& st : cur) {
+      int cn[3];  // the corner moved to the low end of every axis that points backwards
+      for (int a = 0; a < 3; ++a) {
+        cn[a] = st.c[a];
+        for (int k = 0; k < 3; ++k)
+          if (st.d[k][a] < 0) cn[a] -= h * st.d[k][a];
+      }
+      const int (&d1)[3] = st.d[0];
+      const int (&d2)[3] = st.d[1];
+      const int (&d3)[3] = st.d[2];
+      auto child = [&](int k1, int k2, int k3, const int* a1, int s1, const int* a2, int s2, const int* a3, int s3) {
+        State ch;
+        for (int a = 0; a < 3; ++a) {
+          ch.c[a] = cn[a] + h * (k1 * d1[a] + k2 * d2[a] + k3 * d3[a]);
+          ch.d[0][a] = s1 * a1[a];
+          ch.d[1][a] = s2 * a2[a];
+          ch.d[2][a] = s3 * a3[a];
+        }
+        next.push_back(ch);
+      };
+      child(0, 0, 0, d2, 1, d3, 1, d1, 1);
+      child(1, 0, 0, d3, 1, d1, 1, d2, 1);
+      child(1, 1, 0, d3, 1, d1, 1, d2, 1);
+      child(0, 1, 0, d1, -1, d2, -1, d3, 1);
+      child(0, 1, 1, d1, -1, d2, -1, d3, 1);
+      child(1, 1, 1, d3, -1, d1, 1, d2, -1);
+      child(1, 0, 1, d3, -1, d1, 1, d2, -1);
+      child(0, 0, 1, d2, 1, d3, -1, d1, -1);
+    }
+    cur.swap(next);
+  }
+  const size_t n = static_cast<size_t>(1) << level;
+  for (size_t k = 0; k < cur.size(); ++k) {
+    const State& st = cur[k];
+    MHIP_REQUIRE(st.c[0] >= 0 && st.c[1] >= 0 && st.c[2] >= 0 && (size_t)st.c[0] < n && (size_t)st.c[1] < n &&
+                     (size_t)st.c[2] < n,
+                 MHIP_ERR_RUNTIME, "curve left the lattice");
+    table[((size_t)st.c[0] * n + (size_t)st.c[1]) * n + (size_t)st.c[2]] = static_cast<int32_t>(k);
+  }
+  return MHIP_SUCCESS;
+}
+
+int mhip_curve_cut(mhip_comm_t c, size_t n, const uint32_t* keys, const double* weights, size_t ncell,
+                   int64_t* splitters, mhip_stream_t stream) {
+  TraceRange trace_range("curve cut by work (stk::balance)");
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  MHIP_REQUIRE(n == 0 || keys != nullptr, MHIP_ERR_INVALID_ARGUMENT, "keys is null");
+  MHIP_REQUIRE(ncell >= 1 && ncell <= (1u << 24), MHIP_ERR_INVALID_ARGUMENT, "ncell out of range");
+  MHIP_REQUIRE(c->world == 1 || splitters != nullptr, MHIP_ERR_INVALID_ARGUMENT, "splitters is null");
+  hipStream_t s = as_stream(stream);
+  const size_t W = (size_t)c->world;
+  auto& mp = c->migrate;
+  if (int e = mp.hist.reserve((ncell + W * ncell + 2) * sizeof(double))) return e;
+  double* mine = mp.hist.as<double>();
+  double* all = mine + ncell;
+  MHIP_HIP(hipMemsetAsync(mine, 0, ncell * sizeof(double), s));
+  if (n) {
+    k_weighted_hist<<<grid_for(n), kBlock, 0, s>>>(n, keys, weights, ncell, mine);
+    MHIP_LAUNCH_CHECK();
+  }
+  if (int e = mhip_comm_all_gather(c, mine, ncell, all, stream)) return e;
+  std::vector<double> host(W * ncell);
+  MHIP_HIP(hipMemcpyAsync(host.data(), all, host.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  // the same sums in the same order on every rank: the same cuts
+  std::vector<double> cum(ncell);
+  double run = 0.0;
+  for (size_t k = 0; k < ncell; ++k) {
+    double t = 0.0;
+    for (size_t r = 0; r < W; ++r) t += host[r * ncell + k];
+    run += t;
+    cum[k] = run;
+  }
+  for (size_t r = 1; r < W; ++r) {  // first cell at which the cumulative weight reaches r / W of the total
+    const double target = cum[ncell - 1] * (double)r / (double)W;
+    size_t lo = 0, hi = ncell;
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (cum[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    splitters[r - 1] = static_cast<int64_t>(lo);
+  }
+  return MHIP_SUCCESS;
+}
+
+int mhip_migrate_plan(mhip_comm_t c, size_t n, const uint32_t* keys, const int64_t* splitters, size_t* n_new,
+                      size_t* num_sent, size_t* num_received, mhip_stream_t stream) {
+  TraceRange trace_range("migration plan");
+  MHIP_REQUIRE(c != nullptr && n_new != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(n == 0 || keys != nullptr, MHIP_ERR_INVALID_ARGUMENT, "keys is null");
+  MHIP_REQUIRE(c->world == 1 || splitters != nullptr, MHIP_ERR_INVALID_ARGUMENT, "splitters is null");
+  MHIP_REQUIRE(n < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies");
+  hipStream_t s = as_stream(stream);
+  const int W = c->world, R = c->rank;
+  auto& mp = c->migrate;
+  mp.valid = false;
+  for (int r = 1; r + 1 < W; ++r)
+    MHIP_REQUIRE(splitters[r - 1] <= splitters[r], MHIP_ERR_INVALID_ARGUMENT, "splitters must not decrease");
+  if (int e = mp.dest.reserve(((size_t)W + 2) * sizeof(long long))) return e;
+  if (int e = mp.sortkey.reserve((n + 2) * sizeof(unsigned long long))) return e;
+  if (int e = mp.order.reserve((n + 2) * sizeof(int32_t))) return e;
+  if (int e = mp.hist.reserve(((size_t)W + 2) * sizeof(double))) return e;
+  long long* d_split = mp.dest.as<long long>();
+  double* d_count = mp.hist.as<double>();
+  if (W > 1) MHIP_HIP(hipMemcpyAsync(d_split, splitters, (size_t)(W - 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+  MHIP_HIP(hipMemsetAsync(d_count, 0, (size_t)W * sizeof(double), s));
+  if (n) {
+    k_migrate_dest<<<grid_for(n), kBlock, 0, s>>>(n, keys, W - 1, d_split, mp.sortkey.as<unsigned long long>(), d_count);
+    MHIP_LAUNCH_CHECK();
+    if (int e = mhip_sort_by_key_u64(n, reinterpret_cast<const uint64_t*>(mp.sortkey.ptr), mp.order.as<int32_t>(), stream))
+      return e;
+  }
+  std::vector<double> mine((size_t)W), matrix;  // matrix[src][dst]
+  MHIP_HIP(hipMemcpyAsync(mine.data(), d_count, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  if (int e = host_all_gather(c, mine.data(), (size_t)W, matrix, s)) return e;
+  mp.send_peer.clear(); mp.send_first_row.clear(); mp.send_rows.clear(); mp.recv_peer.clear(); mp.recv_rows.clear();
+  size_t row = 0, arriving = 0, leaving = 0;
+  for (int p = 0; p < W; ++p) {
+    const size_t to_p = (size_t)matrix[(size_t)R * W + p], from_p = (size_t)matrix[(size_t)p * W + R];
+    if (p == R) {
+      mp.keep = to_p;
+      mp.keep_first = row;
+    } else {
+      if (to_p) {
+        mp.send_peer.push_back(p);
+        mp.send_first_row.push_back(row);
+        mp.send_rows.push_back(to_p);
+        leaving += to_p;
+      }
+      if (from_p) {
+        mp.recv_peer.push_back(p);
+        mp.recv_rows.push_back(from_p);
+        arriving += from_p;
+      }
+    }
+    row += to_p;
+  }
+  MHIP_REQUIRE(row == n, MHIP_ERR_RUNTIME, "destination counts (%zu) do not add up to the owned bodies (%zu)", row, n);
+  mp.n = n;
+  mp.n_new = mp.keep + arriving;
+  MHIP_REQUIRE(mp.n_new < (1u << 31), MHIP_ERR_RUNTIME, "too many bodies after the migration");
+  mp.valid = true;
+  *n_new = mp.n_new;
+  if (num_sent) *num_sent = leaving;
+  if (num_received) *num_received = arriving;
+  return MHIP_SUCCESS;
+}
+
+int mhip_migrate_exchange(mhip_comm_t c, size_t width, const double* records, double* out, mhip_stream_t stream) {
+  TraceRange trace_range("migration exchange");
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  auto& mp = c->migrate;
+  MHIP_REQUIRE(mp.valid, MHIP_ERR_RUNTIME, "mhip_migrate_plan has not been called");
+  MHIP_REQUIRE(width >= 1, MHIP_ERR_INVALID_ARGUMENT, "width must be at least 1");
+  MHIP_REQUIRE(mp.n == 0 || records != nullptr, MHIP_ERR_INVALID_ARGUMENT, "records is null");
+  MHIP_REQUIRE(mp.n_new == 0 || out != nullptr, MHIP_ERR_INVALID_ARGUMENT, "out is null");
+  MHIP_REQUIRE(out != records, MHIP_ERR_INVALID_ARGUMENT, "the exchange cannot run in place");
+  hipStream_t s = as_stream(stream);
+  if (int e = mp.stage.reserve((mp.n * width + 2) * sizeof(double))) return e;
+  double* packed = mp.stage.as<double>();  // the owned rows grouped by destination, each group in its present order
+  if (mp.n)
+    if (int e = mhip_gather_rows(mp.n, width, mp.order.as<int32_t>(), records, packed, stream)) return e;
+  if (mp.keep)
+    MHIP_HIP(hipMemcpyAsync(out, packed + mp.keep_first * width, mp.keep * width * sizeof(double),
+                            hipMemcpyDeviceToDevice, s));
+  if (mp.send_peer.empty() && mp.recv_peer.empty()) return MHIP_SUCCESS;
+  std::vector<const double*> sbuf(mp.send_peer.size());
+  std::vector<size_t> scount(mp.send_peer.size());
+  for (size_t k = 0; k < mp.send_peer.size(); ++k) {
+    sbuf[k] = packed + mp.send_first_row[k] * width;
+    scount[k] = mp.send_rows[k] * width;
+  }
+  std::vector<double*> rbuf(mp.recv_peer.size());
+  std::vector<size_t> rcount(mp.recv_peer.size());
+  size_t row = mp.keep;  // arrivals follow the rows that stay, peers in increasing rank
+  for (size_t k = 0; k < mp.recv_peer.size(); ++k) {
+    rbuf[k] = out + row * width;
+    rcount[k] = mp.recv_rows[k] * width;
+    row += mp.recv_rows[k];
+  }
+  if (int e = mhip_comm_exchange_start(c, (int)sbuf.size(), mp.send_peer.data(), sbuf.data(), scount.data(),
+                                       (int)rbuf.size(), mp.recv_peer.data(), rbuf.data(), rcount.data(), stream))
     return e;
   return mhip_comm_exchange_finish(c, stream);
 }

@@ -362,3 +362,61 @@ int mhip_integrate_euler(size_t n, double dt, const double* velocity, double* ce
 }
 
 }  // extern "C"
+
+namespace mhip {
+__global__ void __launch_bounds__(kBlock) k_compose_keys(size_t n, const uint32_t* __restrict__ major,
+                                                        const double* __restrict__ minor, int shift,
+                                                        unsigned long long* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    out[i] = (static_cast<unsigned long long>(major[i]) << shift) | static_cast<unsigned long long>(minor[i]);
+}
+__global__ void __launch_bounds__(kBlock) k_sequence(size_t n, double first, double* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    out[i] = first + static_cast<double>(i);
+}
+__global__ void __launch_bounds__(kBlock) k_pair_degree(size_t c, const int2* __restrict__ pairs, size_t first,
+                                                       size_t count, double* __restrict__ weights) {
+  for (size_t k = blockIdx.x * (size_t)kBlock + threadIdx.x; k < c; k += (size_t)gridDim.x * kBlock) {
+    const int2 ij = pairs[k];
+    const size_t i = static_cast<size_t>(ij.x) - first, j = static_cast<size_t>(ij.y) - first;  // wraps below `first`
+    if (i < count) atomicAdd(&weights[i], 1.0);
+    if (j < count) atomicAdd(&weights[j], 1.0);
+  }
+}
+}  // namespace mhip
+
+extern "C" {
+
+int mhip_compose_keys_u64(size_t n, const uint32_t* major, const double* minor, int shift, uint64_t* out,
+                          mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || (major && minor && out), MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  MHIP_REQUIRE(shift >= 0 && shift <= 40, MHIP_ERR_INVALID_ARGUMENT, "shift %d is not in 0..40", shift);
+  if (n == 0) return MHIP_SUCCESS;
+  mhip::k_compose_keys<<<mhip::grid_for(n), mhip::kBlock, 0, mhip::as_stream(stream)>>>(
+      n, major, minor, shift, reinterpret_cast<unsigned long long*>(out));
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_fill_sequence(size_t n, double first, double* dst, mhip_stream_t stream) {
+  MHIP_REQUIRE(n == 0 || dst, MHIP_ERR_INVALID_ARGUMENT, "dst is null");
+  if (n == 0) return MHIP_SUCCESS;
+  mhip::k_sequence<<<mhip::grid_for(n), mhip::kBlock, 0, mhip::as_stream(stream)>>>(n, first, dst);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_body_work_weights(size_t c, const int32_t* pairs, size_t first, size_t count, double* weights,
+                           mhip_stream_t stream) {
+  MHIP_REQUIRE(count == 0 || weights, MHIP_ERR_INVALID_ARGUMENT, "weights is null");
+  MHIP_REQUIRE(c == 0 || pairs, MHIP_ERR_INVALID_ARGUMENT, "pairs is null");
+  if (count == 0) return MHIP_SUCCESS;
+  if (int e = mhip_fill(count, weights, 1.0, stream)) return e;
+  if (c == 0) return MHIP_SUCCESS;
+  mhip::k_pair_degree<<<mhip::grid_for(c), mhip::kBlock, 0, mhip::as_stream(stream)>>>(
+      c, reinterpret_cast<const int2*>(pairs), first, count, weights);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+}  // extern "C"

@@ -386,6 +386,10 @@ class DistributedContactStepper:
             self._key_table = torch.from_numpy(hilbert_key_table(self.curve_level).astype(np.int32)).to(center.device)
         return ops.curve_keys(center, lo, hi, self.curve_level, self._key_table).long()
 
+    def _cell_keys32(self, center):
+        """the same keys as the library takes them (uint32 bit patterns in an int32 tensor)"""
+        return self._cell_keys(center).to(torch.int32).contiguous()
+
     def rebalance(self, recut=True, weights=None):
         """Moves every owned body to the rank that owns its lattice cell (replaces the RCB repartition of
         stk::balance::balanceStkMesh, scrap/lcp_spheres/NGPSpheresLCP.cpp:956, called every load_balance_frequency steps
@@ -395,27 +399,26 @@ class DistributedContactStepper:
         peer, through the communicator the ghost halo uses.  Returns a dict of counts."""
         if self.domain is None:
             raise RuntimeError("rebalance() needs the domain=(lo, hi) the stepper was given at construction")
-        comm, dev, world, rank = self.comm, self.center.device, self.comm.world, self.comm.rank
-        keys = self._cell_keys(self.center) if self.n else torch.zeros(0, dtype=torch.int64, device=dev)
-        ncell = 8 ** self.curve_level
+        lib, comm, dev, world, rank = capi.load(), self.comm, self.center.device, self.comm.world, self.comm.rank
+        keys = self._cell_keys32(self.center) if self.n else torch.zeros(0, dtype=torch.int32, device=dev)
         if recut or self.splitters is None:
             w = weights if weights is not None else self._body_weight
-            if w is None or w.shape[0] != self.n:
-                w = torch.ones(self.n, dtype=torch.float64, device=dev)
-            hist = torch.zeros(ncell, dtype=torch.float64, device=dev).index_add_(0, keys, w.to(torch.float64))
-            cum = np.cumsum(comm.all_gather(hist).sum(dim=0).cpu().numpy())   # identical on every rank
-            targets = cum[-1] * np.arange(1, world) / world
-            self.splitters = np.searchsorted(cum, targets, side="left").astype(np.int64)
+            if w is not None and w.shape[0] != self.n:
+                w = None
+            if w is not None:
+                w = w.to(torch.float64).contiguous()
+            splitters = np.zeros(max(world - 1, 1), dtype=np.int64)
+            capi.check(lib.mhip_curve_cut(comm._h, self.n, _p(keys), _p(w) if w is not None else None,
+                                          8 ** self.curve_level, splitters.ctypes.data, _stream()))
+            self.splitters = splitters[:world - 1].copy()
         # rank r owns the cells  splitters[r - 1] < key <= splitters[r]
-        dest = torch.bucketize(keys, torch.from_numpy(self.splitters).to(dev), right=False)
         rec = self._records()
-        counts = torch.bincount(dest, minlength=world).to(torch.float64)
-        matrix = comm.all_gather(counts).cpu().numpy().astype(np.int64)       # [src][dst]
-        send = {p: rec[dest == p].contiguous() for p in range(world) if p != rank and matrix[rank][p] > 0}
-        recv = {p: torch.empty((int(matrix[p][rank]), self.RECORD), dtype=torch.float64, device=dev)
-                for p in range(world) if p != rank and matrix[p][rank] > 0}
-        comm.exchange(send, recv)
-        new = torch.cat([rec[dest == rank]] + [recv[p] for p in sorted(recv)], dim=0).contiguous()
+        n_new, sent, received = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        spl = np.ascontiguousarray(self.splitters if world > 1 else np.zeros(1, dtype=np.int64), dtype=np.int64)
+        capi.check(lib.mhip_migrate_plan(comm._h, self.n, _p(keys), spl.ctypes.data, C.byref(n_new), C.byref(sent),
+                                         C.byref(received), _stream()))
+        new = torch.empty((n_new.value, self.RECORD), dtype=torch.float64, device=dev)
+        capi.check(lib.mhip_migrate_exchange(comm._h, self.RECORD, _p(rec), _p(new), _stream()))
         n_new = new.shape[0]
         if n_new:
             # owned bodies in curve order, ties by entity id: the local order every rank and the single-rank run agree on
@@ -438,8 +441,7 @@ class DistributedContactStepper:
         self._layout = None
         self._body_weight = None
         self._rebalances += 1
-        out = dict(sent=int(matrix[rank].sum() - matrix[rank][rank]), received=int(matrix[:, rank].sum() - matrix[rank][rank]),
-                   owned=n_new, recut=bool(recut))
+        out = dict(sent=int(sent.value), received=int(received.value), owned=n_new, recut=bool(recut))
         self.stats.update(migrated_out=out["sent"], migrated_in=out["received"])
         return out
 

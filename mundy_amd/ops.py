@@ -711,6 +711,16 @@ def curve_keys(center, lo, hi, level, key_table):
     return keys
 
 
+def hilbert_key_table(level):
+    """table[ix, iy, iz] = position of the lattice cell along mundy::math::hilbert_3d (Hilbert.hpp:48-83): the library's
+    own generator (host code, needs no GPU); numpy int32 array of shape (2^level,) * 3"""
+    import numpy as np
+    n = 1 << int(level)
+    table = np.empty((n, n, n), dtype=np.int32)
+    capi.check(capi.load().mhip_hilbert_key_table(int(level), C.c_void_p(table.ctypes.data)))
+    return table
+
+
 def sort_by_key(keys):
     """stable ascending order of int64 keys (non-negative): int32 permutation (library radix sort)"""
     perm = torch.empty(keys.shape[0], dtype=torch.int32, device=keys.device)

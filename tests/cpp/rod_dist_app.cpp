@@ -2,8 +2,10 @@
 // through mundy_hip/stepper.hpp (mech::DistributedSpherocylinderStepper): one process per rank, RCCL transport, no
 // Python, no torch, no MPI.  The launcher's only job -- handing the 128-byte RCCL id from rank 0 to the others -- is
 // done through a file in <rendezvous_dir> (an MPI host would MPI_Bcast it).
-// Usage: rod_dist_app <input.bin> <steps> <rank> <world> <rendezvous_dir> [reuse]
+// Usage: rod_dist_app <input.bin> <steps> <rank> <world> <rendezvous_dir> [reuse | migrate <box_edge>]
 //   reuse: apply the rebuild rule across ranks instead of rebuilding the neighbour list every step
+//   migrate: ownership follows the bodies over a 16^3 Hilbert lattice on [0, box_edge]^3, the curve re-cut by work
+//            every third rebalance (DistributedSpherocylinderStepper::rebalance)
 //   input.bin: uint64 n, then doubles center[3n] quat[4n] radius[n] length[n] mob_trans[n] mob_rot[n], bodies already in
 //   curve order; rank r owns the r-th of `world` equal contiguous ranges and uses device r % device_count.
 // Prints one line per step and a bit-level checksum of the rank's final centres / orientations.
@@ -50,6 +52,8 @@ int main(int argc, char** argv) {
   const int steps = std::atoi(argv[2]), rank = std::atoi(argv[3]), world = std::atoi(argv[4]);
   const std::string dir = argv[5];
   const bool reuse = argc > 6 && std::string(argv[6]) == "reuse";
+  const bool migrate = argc > 7 && std::string(argv[6]) == "migrate";
+  const double box_edge = migrate ? std::atof(argv[7]) : 0.0;
   std::FILE* f = std::fopen(argv[1], "rb");
   if (!f) {
     std::perror(argv[1]);
@@ -101,16 +105,27 @@ int main(int argc, char** argv) {
                                               rows(radius, 1, first, mine), rows(length, 1, first, mine),
                                               rows(mob_t, 1, first, mine), rows(mob_r, 1, first, mine), /*dt=*/5e-3,
                                               /*search_buffer=*/0.1, cfg);
+    if (migrate) {
+      const double lo[3] = {0.0, 0.0, 0.0}, hi[3] = {box_edge, box_edge, box_edge};
+      st.set_domain(lo, hi, /*curve_level=*/4, /*recut_every=*/3);
+    }
     for (int k = 0; k < steps; ++k) {
       const auto t0 = std::chrono::steady_clock::now();
-      const auto s = st.step(true, /*force_rebuild=*/!reuse);
+      const auto s = st.step(true, /*force_rebuild=*/!reuse, migrate);
       const double ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       std::printf("STEP %d rank %d contacts %zu iterations %u residual %.17g converged %d ghosts %zu interior %zu rebuilt %d ms %.3f\n",
                   k, rank, s.local_contacts, s.num_iters, s.residual, s.converged ? 1 : 0, s.ghosts, s.interior_contacts,
                   s.rebuilt ? 1 : 0, ms);
     }
-    std::printf("CHECKSUM rank %d center %016llx quat %016llx\n", rank, checksum(st.center().download()),
-                checksum(st.quat().download()));
+    // (the vectors are sized to the owned bodies, at least one element)
+    auto owned = [&](const DeviceVector& v, size_t w) {
+      std::vector<double> h = v.download();
+      h.resize(w * st.num_bodies());
+      return h;
+    };
+    std::printf("CHECKSUM rank %d center %016llx quat %016llx entity %016llx owned %zu\n", rank,
+                checksum(owned(st.center(), 3)), checksum(owned(st.quat(), 4)), checksum(owned(st.entity_ids(), 1)),
+                st.num_bodies());
   }
   check(mhip_comm_destroy(comm));
   return 0;

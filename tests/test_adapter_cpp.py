@@ -120,6 +120,28 @@ def test_cpp_distributed_stepper_over_rccl(tmp_path):
     line = [ln_ for ln_ in p.stdout.splitlines() if ln_.startswith("CHECKSUM")][0].split()
     assert line[4] == checksum(st.center.cpu().numpy()) and line[6] == checksum(st.quat.cpu().numpy())
 
+    # ownership follows the bodies (DistributedSpherocylinderStepper::rebalance: curve cut by work, migration plan and
+    # exchange, re-sort by (cell, entity id)) -- on the one rank there is it re-orders the owned set at every rebuild;
+    # the Python stepper drives the same library entry points, and its 3-rank trajectory is checked against a single
+    # rank in test_gpu_distributed.py
+    steps_n = 5
+    p = subprocess.run([exe, str(inp), str(steps_n), "0", "1", str(tmp_path), "migrate", repr(float(b["box"]))],
+                       capture_output=True, text=True, timeout=600)
+    print(p.stdout[-3000:], p.stderr[-2000:])
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    steps = [ln_.split() for ln_ in p.stdout.splitlines() if ln_.startswith("STEP")]
+    dst = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(ln), 0, cfg=ops.PGDConfig(max_iters=10000, tol=1e-5),
+                                      domain=(0.0, float(b["box"])), curve_level=4, recut_every=3)
+    for k in range(steps_n):
+        s = dst.step(force_rebuild=True, migrate=True)
+        assert int(steps[k][5]) == s["local_contacts"] and int(steps[k][7]) == s["num_iters"], (k, steps[k], s)
+    line = [ln_ for ln_ in p.stdout.splitlines() if ln_.startswith("CHECKSUM")][0].split()
+    assert int(line[10]) == n
+    assert line[8] == checksum(dst.entity_id.cpu().numpy())       # the same bodies in the same (cell, id) order
+    assert not np.array_equal(dst.entity_id.cpu().numpy(), np.arange(n, dtype=np.float64))   # ... and it is a new one
+    assert line[4] == checksum(dst.center.cpu().numpy()) and line[6] == checksum(dst.quat.cpu().numpy())
+    dst.op.close()
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("periodic", [False, True])

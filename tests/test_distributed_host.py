@@ -27,6 +27,21 @@ def test_hilbert_positions_match_reference_kats(oracle):
     assert np.all(np.abs(np.diff(D.hilbert_positions(5), axis=0)).sum(axis=1) == 1)
 
 
+def test_library_hilbert_table_is_the_reference_curve(oracle):
+    # mhip_hilbert_key_table (host code of the library, what the C++ stepper feeds to mhip_curve_keys): the same table
+    # as the numpy generator pinned above, and the inverse of the oracle's restatement of Hilbert.hpp:48-83
+    import pytest
+    from mundy_amd import distributed as D, ops
+    for level in range(0, 6):
+        table = ops.hilbert_key_table(level)
+        np.testing.assert_array_equal(table, D.hilbert_key_table(level).astype(np.int32))
+        if level >= 1:
+            pos = oracle.hilbert_3d(1 << level).astype(np.int64)
+            np.testing.assert_array_equal(table[pos[:, 0], pos[:, 1], pos[:, 2]], np.arange(len(pos)))
+    with pytest.raises(ValueError, match="level"):   # MHIP_ERR_INVALID_ARGUMENT -> std::invalid_argument / ValueError
+        ops.hilbert_key_table(9)
+
+
 def test_hilbert_order_and_partition():
     from mundy_amd import distributed as D
     rng = np.random.default_rng(0)
