@@ -52,7 +52,7 @@ FLOPS_PER_EVALUATION = 460.0
 METRIC = "timesteps/sec, 10^6 spherocylinders, frictionless LCP contact (BBPGD)"
 
 
-def kernel_bytes(contacts, bodies, active_contacts=None):
+def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=None):
     """Algorithmic bytes per launch of the two sweeps of one fused BBPGD iteration (rod-compressed kinematics): every
     array the launch REQUIRES, counted once (a gathered table once per row, not once per reader) -- what HBM must move
     even with perfect caches.  This is what roofline.achieved divides.
@@ -71,12 +71,22 @@ def kernel_bytes(contacts, bodies, active_contacts=None):
     Infinity Cache, so that figure divided by the measured time exceeds the HBM peak (1.39 x at 10^6 rods) -- it is
     unusable as a denominator here and is not printed."""
     act = contacts if active_contacts is None else active_contacts
-    return {"k_constraint": 88.0 * contacts + 48.0 * bodies,
-            "k_body": 2 * 36.0 * act + 16.0 * act + 136.0 * bodies}
+    con = 88.0 * contacts + 48.0 * bodies
+    body = 2 * 36.0 * act + 16.0 * act + 136.0 * bodies
+    if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
+        # cold tier (DESIGN 4): over the tiered iterations only the hot share h of the contacts is swept in full; a
+        # contact of the cold tail costs its pair 8 + wake level 8; the drift table (8 B per body) is read by the tail
+        # scan; the body sweep additionally reads each body's previous row (48) and updates its drift (8 + 8)
+        w = min(1.0, tier["tiered_iterations"] / float(iterations))
+        h = tier["mean_hot_fraction"]
+        con = (1.0 - w) * con + w * ((88.0 * h + 16.0 * (1.0 - h)) * contacts + 56.0 * bodies)
+        body += w * 64.0 * bodies
+    return {"k_constraint": con, "k_body": body}
 
 
-def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", active_contacts=None):
-    kb = kernel_bytes(contacts, bodies, active_contacts)
+def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", active_contacts=None, tier=None,
+                     iterations=None):
+    kb = kernel_bytes(contacts, bodies, active_contacts, tier, iterations)
     ms = {"k_constraint": con_ms, "k_body": body_ms}
     ent = {}
     for k in ms:
@@ -206,6 +216,8 @@ def main():
             prof["body_ms"] += a
             prof["con_ms"] += c
             prof["iters"] += k
+            prof["tier"] = stepper.op.tier_stats()
+            prof["solve_iters"] = st.num_iters
         return st
 
     def sync():
@@ -241,7 +253,8 @@ def main():
     roof, extra = None, {}
     if prof["iters"] > 0:
         roof, extra, dom, oth = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"],
-                                                 prof["body_ms"] / prof["iters"], prof["iters"], active_contacts=active)
+                                                 prof["body_ms"] / prof["iters"], prof["iters"], active_contacts=active,
+                                                 tier=prof.get("tier"), iterations=prof.get("solve_iters"))
         attach_traffic(roof, extra, dom, oth, n, args.buffer)
 
     # ---- a second, labelled figure: the same step from a RELAXED packing (what a running simulation sees) -----------
@@ -295,6 +308,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             "relaxed_packing": relaxed,
+            # cold tier of the solve (time only, same iterates): share of contacts swept in full over the tiered iterations
+            "cold_tier": prof.get("tier"),
         }
         if args.friction is not None:  # never the default line: an extension without a reference to pin it on
             out["metric"] = "timesteps/sec, 10^6 spherocylinders per GPU, FRICTIONAL cone-complementarity contact (build extension)"

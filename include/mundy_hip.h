@@ -334,6 +334,19 @@ int mhip_contact_op_sizes(mhip_contact_op_t handle, size_t* num_constraints, siz
  *   lanes_per_body  lanes that share one body's contact list in the body sweep: 2, 4, 8 or 16 (default by mean
  *                   degree); -1 keeps the current value */
 int mhip_contact_op_set_work_mapping(mhip_contact_op_t handle, int xcd_tile, int lanes_per_body);
+/* Cold tier of mhip_bbpgd_solve_contact (time only, never results).  Two thirds of the contacts of a packing are inactive
+ * (x = 0, g > 0) for most of a solve; such a contact adds exact zeros to every sum of an iteration, and how far its
+ * gradient can have moved is bounded by its two bodies' accumulated velocity changes.  From the first convergence poll on
+ * the solve therefore renumbers the contacts hot-first and sweeps the cold tail only through those bounds (16 streamed
+ * bytes per sleeping contact instead of 88); a contact that reaches its bound is evaluated like any other again.  Same
+ * iterates, bit for bit, and the same iteration count as with tiering off (every sum is a double-double pair rounded
+ * once, so the partition of the contacts does not reach the sums).  LCP solves of spheres and rods with at least 65 536
+ * contacts; mode 0 = off, 1 = on (default), 2 = test hook: leave the tiers after the first tiered iteration, as the
+ * solve does before a BB step outside [0, finite].
+ * tier_stats: iterations that ran tiered, mean share of hot contacts over them, renumberings, contacts woken. */
+int mhip_contact_op_set_tiering(mhip_contact_op_t handle, int mode);
+int mhip_contact_op_tier_stats(mhip_contact_op_t handle, size_t* tiered_iterations, double* mean_hot_fraction,
+                               size_t* renumberings, size_t* wakeups);
 int mhip_contact_op_set_profiling(mhip_contact_op_t handle, int enable);
 int mhip_contact_op_get_profile(mhip_contact_op_t handle, double* body_ms, double* constraint_ms, size_t* iterations);
 /* body velocities [num_bodies][6] = (U xyz, W xyz) from the last apply / solve iterate (valid in stream order after

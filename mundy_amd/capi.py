@@ -127,6 +127,8 @@ SIGNATURES = {
     "mhip_contact_op_apply": [_vp, _vp, _vp, _vp],
     "mhip_contact_op_body_velocity": [_vp, C.POINTER(_vp)],
     "mhip_contact_op_set_profiling": [_vp, _i],
+    "mhip_contact_op_set_tiering": [_vp, _i],
+    "mhip_contact_op_tier_stats": [_vp, C.POINTER(_sz), C.POINTER(_d), C.POINTER(_sz), C.POINTER(_sz)],
     "mhip_contact_op_set_work_mapping": [_vp, _i, _i],
     "mhip_bbpgd_stage_snapshot_active": [_vp, _vp],
     "mhip_contact_op_get_profile": [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_sz)],

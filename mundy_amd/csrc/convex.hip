@@ -397,6 +397,11 @@ struct OpView {
   const int32_t* aent;                  // entries (c << 1 | side), snapshot order
   const double* arec;                   // their records, same layout as `half`
   const unsigned long long* snap_mask;  // [N] the masks the snapshot was taken from
+  // Tiered solves (see "Cold tier" below): the body rows ping-pong between vel (even parity) and vel_alt like the
+  // iterate does, so that the rows of the last TWO iterates exist; drift [N] accumulates, per body, an upper bound of
+  // how far any of its contact-point velocities has moved (times dt) since the solve began.  null = off.
+  double* vel_alt;
+  double* drift;
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
@@ -456,11 +461,18 @@ __global__ void __launch_bounds__(kBlock)
   const double* xt = X0;
   const double* gt = G0;
   double step = 0.0;
+  double* vel_new = op.vel;         // rows this sweep writes
+  const double* vel_old = op.vel;   // rows of the previous iterate (tiered solves only)
   if (MODE == X_SOLVE) {
     if (st->done) return;
-    if (st->flips & 1u) {
+    const bool odd = st->flips & 1u;
+    if (odd) {
       xt = X1;
       gt = G1;
+    }
+    if (op.vel_alt) {
+      vel_new = odd ? op.vel : op.vel_alt;
+      vel_old = odd ? op.vel_alt : op.vel;
     }
     step = st->step;
   }
@@ -479,10 +491,16 @@ __global__ void __launch_bounds__(kBlock)
   // not one more dependent memory level at the end of the chain
   double mt = 0.0, mr = 0.0;
   V3 axis{0.0, 0.0, 0.0};
+  const bool track = MODE == X_SOLVE && op.drift != nullptr;
+  double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0;  // the body's previous row (drift bookkeeping)
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
     if (KIN == KIN_ROD) axis = load3(op.axis, b);
+    if (track) {
+      const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
+      o0 = vo[0]; o1 = vo[1]; o2 = vo[2];
+    }
   }
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
@@ -594,7 +612,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   if (sub != 0) return;
   const V3 F = dd_value(Fdd), T = dd_value(Tdd);  // the one rounding of each sum
-  double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
+  double2* v = reinterpret_cast<double2*>(vel_new + 6 * b);
   V3 W{0.0, 0.0, 0.0};
   if (KIN == KIN_RIGID) W = V3{mr * T.x, mr * T.y, mr * T.z};
   if (KIN == KIN_ROD) {
@@ -603,9 +621,17 @@ __global__ void __launch_bounds__(kBlock)
     store3(op.omega, b, w);
     W = cross(w, axis);  // the row carries Z = W x u: the contact-point velocity is U + coef Z
   }
-  v[0] = make_double2(mt * F.x, mt * F.y);  // U = F / (6 pi r mu)  (NgpLcp.cpp:484-486)
-  v[1] = make_double2(mt * F.z, W.x);
+  const V3 Ub{mt * F.x, mt * F.y, mt * F.z};  // U = F / (6 pi r mu)  (NgpLcp.cpp:484-486)
+  v[0] = make_double2(Ub.x, Ub.y);
+  v[1] = make_double2(Ub.z, W.x);
   v[2] = make_double2(W.y, W.z);
+  if (track) {
+    // |change of n . (U + coef Z)| <= |dU|_1 + |coef| |dZ|_1 with |coef| <= 1/2 (rods; spheres carry no Z): what any
+    // contact of this body can have moved by, times dt as the gradient sees it
+    double d = fabs(Ub.x - o0.x) + fabs(Ub.y - o0.y) + fabs(Ub.z - o1.x);
+    if (KIN != KIN_TRANS) d += 0.5 * (fabs(W.x - o1.y) + fabs(W.y - o2.x) + fabs(W.z - o2.y));
+    op.drift[b] += op.dt * d;
+  }
 }
 
 // one reduction record = kRed doubles (max residual term; sum dx^2 and sum dx dg as double-double pairs), stored as
@@ -620,12 +646,81 @@ __device__ inline void store_partial(double* __restrict__ p, size_t stride, size
   p[4 * stride + slot] = den.lo;
 }
 
-template <int MODE, int KIN, bool PACKED>
+// dt * sdot of contact c from the body rows `vel`: sdot = -n . (v_src - v_tgt) at the contact points (NgpLcp.cpp:526-528)
+template <int KIN>
+__device__ inline double contact_dt_sdot(const OpView& op, const double* __restrict__ vel, size_t c, int2 ij) {
+  const V3 n = load3(op.normal, c);
+  const double2* vi2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.x);
+  const double2* vj2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.y);
+  const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
+  V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
+  if (KIN == KIN_RIGID) {
+    const double2 a2 = vi2[2], b2 = vj2[2];
+    vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
+    vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+  }
+  if (KIN == KIN_ROD) {
+    const double2 a2 = vi2[2], b2 = vj2[2];
+    const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+    vi = vi + ci * V3{a1.y, a2.x, a2.y};
+    vj = vj + cj * V3{b1.y, b2.x, b2.y};
+  }
+  const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
+  return op.dt * sdot;
+}
+
+// Cold tail of a tiered solve ("Cold tier" below): the scan of [H, C) by workgroups `block` of `nblocks`.  Contacts
+// whose bodies have drifted up to their wake level are listed (one atomic per wavefront) and marked awake (level =
+// -inf); k_constraint<LISTED> evaluates the list, this iteration and after.
+struct TierCheck {
+  size_t H, C;
+  double* wake;        // [C - H]
+  int32_t* list;       // awake contacts of the tail
+  unsigned long long* counters;  // [0] = length of list
+  unsigned blocks;     // workgroups at the end of the grid that scan instead of sweeping
+};
+__device__ inline void tier_check_range(const TierCheck& tc, const int2* __restrict__ pairs,
+                                        const double* __restrict__ drift, unsigned block, unsigned nblocks) {
+  const int lane = threadIdx.x & 63;
+  for (size_t base = tc.H + block * (size_t)blockDim.x; base < tc.C; base += (size_t)nblocks * blockDim.x) {
+    const size_t c = base + threadIdx.x;
+    bool woke = false;
+    if (c < tc.C) {
+      const double level = tc.wake[c - tc.H];
+      if (level > -1.7976931348623157e308) {
+        const int2 ij = pairs[c];
+        woke = !(drift[ij.x] + drift[ij.y] < level);
+      }
+    }
+    const unsigned long long m = __ballot(woke);
+    if (m) {
+      const int leader = __ffsll(static_cast<long long>(m)) - 1;
+      unsigned long long at = 0;
+      if (lane == leader) at = atomicAdd(&tc.counters[0], static_cast<unsigned long long>(__popcll(m)));
+      at = __shfl(at, leader, 64);
+      if (woke) {
+        tc.list[at + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int32_t>(c);
+        tc.wake[c - tc.H] = -__builtin_huge_val();
+      }
+    }
+  }
+}
+
+// LISTED: the contacts swept are those of `list` (tier_counters[0] of them): the woken contacts of a tiered solve's cold
+// tail ("Cold tier" below), evaluated like any other; sleeping ones add exact zeros, among them 0 to the max.
+template <int MODE, int KIN, bool PACKED, bool LISTED = false>
 __global__ void __launch_bounds__(kBlock)
     k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
-                 int resid_kind, double* __restrict__ partials) {
+                 int resid_kind, double* __restrict__ partials, const int32_t* __restrict__ list = nullptr,
+                 const unsigned long long* __restrict__ tier_counters = nullptr, TierCheck check = TierCheck{}) {
   __shared__ double scratch[2 * kBlock / 64];
+  // (tiered solves) the last check.blocks workgroups of the grid scan the cold tail while the others sweep
+  const unsigned nblk = gridDim.x - check.blocks;
+  if (blockIdx.x >= nblk) {
+    if (MODE == X_SOLVE && !st->done) tier_check_range(check, op.pairs, op.drift, blockIdx.x - nblk, check.blocks);
+    return;
+  }
   const double* xt = X0;
   const double* gt = G0;
   double* xn = X1;
@@ -643,35 +738,27 @@ __global__ void __launch_bounds__(kBlock)
     xt = G0;
     xn = X0;
   }
+  const double* vel = op.vel;  // the rows the body sweep of this iteration wrote
+  if (MODE == X_SOLVE && op.vel_alt && !(st->flips & 1u)) vel = op.vel_alt;
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  double rmax = kLowest;
+  double rmax = LISTED ? 0.0 : kLowest;
   DD num{0.0, 0.0}, den{0.0, 0.0};
-  const size_t ntiles = (op.c_end - op.c_first + kBlock - 1) / kBlock;
-  for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
-    const size_t c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
-    if (c >= op.c_end) continue;
+  const size_t nwork = LISTED ? static_cast<size_t>(tier_counters[0]) : op.c_end - op.c_first;
+  const size_t ntiles = (nwork + kBlock - 1) / kBlock;
+  for (size_t lin = blockIdx.x; lin < ntiles; lin += nblk) {
+    size_t c;
+    if (LISTED) {
+      const size_t k = lin * kBlock + threadIdx.x;
+      if (k >= nwork) continue;
+      c = static_cast<size_t>(list[k]);
+    } else {
+      c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
+      if (c >= op.c_end) continue;
+    }
     const int2 ij = op.pairs[c];
     double x_old = 0.0, g_old = 0.0;
     const double xc = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
-    const V3 n = load3(op.normal, c);
-    const double2* vi2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.x);
-    const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
-    const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
-    V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
-    if (KIN == KIN_RIGID) {
-      const double2 a2 = vi2[2], b2 = vj2[2];
-      vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
-      vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
-    }
-    if (KIN == KIN_ROD) {
-      const double2 a2 = vi2[2], b2 = vj2[2];
-      const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
-      vi = vi + ci * V3{a1.y, a2.x, a2.y};
-      vj = vj + cj * V3{b1.y, b2.x, b2.y};
-    }
-    // sdot = -n . (v_src - v_tgt)  (NgpLcp.cpp:526-528)
-    const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
-    const double y = op.dt * sdot;
+    const double y = contact_dt_sdot<KIN>(op, vel, c, ij);
     if (MODE == X_APPLY) {
       gn[c] = y;
     } else {
@@ -708,7 +795,7 @@ __global__ void __launch_bounds__(kBlock)
     const DD s1 = block_sum(num, scratch);
     const DD s2 = block_sum(den, scratch);
     if (threadIdx.x == 0) {  // kRed planes of values: the final pass reads them coalesced
-      const size_t stride = op.part_stride ? op.part_stride : gridDim.x;
+      const size_t stride = op.part_stride ? op.part_stride : nblk;
       store_partial(partials, stride, op.part_offset + blockIdx.x, m, s1, s2);
     }
   }
@@ -750,10 +837,12 @@ __global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, size_t str
   if (threadIdx.x == 0) store_partial(folded, gridDim.x, blockIdx.x, rmax, num, den);
 }
 
+// tiered: the solve keeps contacts in a cold tier whose iterates are only known to be "x = 0, g > 0"; a step outside
+// [0, finite] would need their exact gradients, so the solve is paused (done = 2) for the host to leave the tiers first.
 template <int MODE>
 __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const double* __restrict__ partials, size_t si,
                                                          size_t sk, SolverState* __restrict__ st, int resid_kind,
-                                                         double tol, unsigned max_iters) {
+                                                         double tol, unsigned max_iters, int tiered = 0) {
   __shared__ double scratch[2 * kFinalBlock / 64];
   if (MODE == X_SOLVE && st->done) return;
   double rmax;
@@ -786,6 +875,7 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
     st->iter += 1;
     st->flips += 1;
     if (st->iter >= max_iters) st->done = 1;
+    else if (tiered == 2 || (tiered && !(st->step >= 0.0 && st->step <= 1.7976931348623157e308))) st->done = 2;
   }
 }
 
@@ -1313,6 +1403,7 @@ struct mhip_contact_op {
   DeviceBuffer sort_tmp, sort_list;  // workspaces of the incidence-list sort
   DeviceBuffer aptr, aent, arec, snap_mask, acnt;  // active lists (see OpView)
   int device = -1;  // the device current at create: where every buffer of this operator lives
+  int tiering = 1;         // the fused solve may use the cold tier (mhip_contact_op_set_tiering); 2: test hook
   int lanes_per_body = 2;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
@@ -1324,6 +1415,21 @@ struct mhip_contact_op {
     bool active = false;
     unsigned part_used = 0;  // partial slots written by this iteration's constraint sweeps
   } stage;
+  // cold tier of the fused solve (see "Cold tier")
+  struct Tier {
+    bool active = false;    // the view points at the renumbered copies and inc is remapped
+    bool tracking = false;  // the body rows ping-pong and the drifts accumulate
+    bool disabled = false;  // this solve no longer tiers
+    unsigned polled_at = 0; // iterations run at the last poll
+    double* saved_vel = nullptr;
+    int set = 0;            // geometry / iterate set in use
+    size_t H = 0;           // hot contacts [0, H), cold tail [H, C)
+    DeviceBuffer geo[2], iter[2], misc, vel2, drift;
+    OpView saved{};         // the operator's own view, restored when the tiers are left
+    // statistics of the last solve
+    size_t tiered_iterations = 0, retiers = 0, wakeups = 0;
+    double hot_sum = 0.0;   // sum over tiered iterations of H / C
+  } tier;
   // optional per-kernel timing (mhip_contact_op_set_profiling)
   bool profile = false;
   std::vector<hipEvent_t> events;  // 3 per enqueued iteration: before body, between, after constraint
@@ -1446,6 +1552,405 @@ int op_snapshot_active(mhip_contact_op* op, hipStream_t s) {
 }
 // from this many completed iterations on the masks have settled enough for a snapshot to pay
 constexpr unsigned kSnapshotAfter = 8;
+
+
+// ---- Cold tier ---------------------------------------------------------------------------------------------------------
+// Two thirds of the contacts of a packing are inactive (x = 0, g > 0) and most of them stay so for the whole solve, yet
+// the constraint sweep reads all 88 bytes of every contact every iteration just to find that out.  A contact adds
+// nothing to an iteration while it is inactive: its force is zero, its residual term is zero, dx = 0 kills its terms
+// of both BB sums.  What must never be missed is the iteration in which its gradient turns non-positive -- and that
+// can be bounded: the gradient is sep + dt * sdot, sdot is a contraction of the two bodies' contact-point velocities
+// with the unit normal, so between two iterates it moves by at most the bodies' drifts (k_body accumulates
+// drift[b] += dt (|dU|_1 + |dZ|_1 / 2) every sweep).  A contact that goes cold at gradient g0 > 0 with the drifts at
+// D0 has g > g0 / 2 > 0 for as long as  drift[i] + drift[j] < D0 + g0 / 2  =: its wake level.
+//   At a convergence poll the contacts are RENUMBERED hot-first (stable partition): geometry, q, the slot table and
+//   both packed iterates are copied into that order, the incidence entries are remapped, the compact active lists
+//   rebuilt.  A contact goes to the cold tail when x == 0 in the last two iterates and half its gradient exceeds what
+//   its two bodies are expected to drift until the next poll (their drift over the last period, scaled to the length
+//   of the next one).  The ordinary sweep then runs over [0, H) only.  The tail [H, C) is scanned by k_tier_check -- 16
+//   streamed bytes and two L2-resident gathers per sleeping contact -- which lists the contacts that have reached
+//   their level; k_constraint<LISTED> evaluates the listed ones, from then on every iteration, exactly as the ordinary
+//   sweep would (a sleeper's stale pair says x = 0, g > 0, which is all an evaluation uses of an inactive contact:
+//   Proj(0 - step g) = 0 and dx = 0).  Every sum is a double-double pair rounded once, so the partition does not reach
+//   the iterates: same bits, same iteration count as the untiered solve (tests).
+//   Leaving the tiers (end of the solve, or a BB step outside [0, finite], which would need the sleepers' exact
+//   gradients -- k_finalize pauses the solve for that): the sleepers' gradients are evaluated for the last two iterates
+//   from the two body-row buffers, everything is scattered back to the caller's numbering, inc is restored.
+constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g above this (far above rounding noise)
+constexpr size_t kTierMinContacts = 65536;  // smaller problems are launch-bound: not worth the bookkeeping
+
+struct TierGeo {
+  int2* pairs;
+  double *normal, *arc_s, *arc_t, *q;
+  int32_t* orig;
+  unsigned char* pos;
+};
+inline size_t tier_align(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
+inline size_t tier_geo_bytes(size_t C) {
+  return tier_align(C * 8) + tier_align(3 * C * 8) + 3 * tier_align(C * 8) + tier_align(C * 4) + tier_align(2 * C) + 256;
+}
+inline TierGeo tier_geo_at(void* base, size_t C) {
+  char* p = static_cast<char*>(base);
+  TierGeo g;
+  g.pairs = reinterpret_cast<int2*>(p); p += tier_align(C * 8);
+  g.normal = reinterpret_cast<double*>(p); p += tier_align(3 * C * 8);
+  g.arc_s = reinterpret_cast<double*>(p); p += tier_align(C * 8);
+  g.arc_t = reinterpret_cast<double*>(p); p += tier_align(C * 8);
+  g.q = reinterpret_cast<double*>(p); p += tier_align(C * 8);
+  g.orig = reinterpret_cast<int32_t*>(p); p += tier_align(C * 4);
+  g.pos = reinterpret_cast<unsigned char*>(p);
+  return g;
+}
+struct TierMisc {
+  int32_t *flags, *rank, *new_of, *list;
+  double* wake[2];
+  double *budget, *drift_prev;
+  unsigned long long* counters;  // [0]: contacts of the tail that are awake (= length of list)
+};
+inline size_t tier_misc_bytes(size_t C, size_t N) {
+  return 4 * tier_align((C + 2) * 4) + 2 * tier_align((C + 2) * 8) + 2 * tier_align((N + 2) * 8) + 256;
+}
+inline TierMisc tier_misc_at(void* base, size_t C, size_t N) {
+  char* p = static_cast<char*>(base);
+  TierMisc m;
+  m.flags = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
+  m.rank = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
+  m.new_of = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
+  m.list = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
+  m.wake[0] = reinterpret_cast<double*>(p); p += tier_align((C + 2) * 8);
+  m.wake[1] = reinterpret_cast<double*>(p); p += tier_align((C + 2) * 8);
+  m.budget = reinterpret_cast<double*>(p); p += tier_align((N + 2) * 8);
+  m.drift_prev = reinterpret_cast<double*>(p); p += tier_align((N + 2) * 8);
+  m.counters = reinterpret_cast<unsigned long long*>(p);
+  return m;
+}
+
+// budget[b] = what body b is expected to drift until the next poll; drift_prev <- drift
+__global__ void __launch_bounds__(kBlock) k_tier_budget(size_t N, const double* __restrict__ drift,
+                                                       double* __restrict__ drift_prev, double scale,
+                                                       double* __restrict__ budget) {
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x) {
+    const double d = drift[b];
+    budget[b] = scale * (d - drift_prev[b]);
+    drift_prev[b] = d;
+  }
+}
+// flags[c] = 1: hot.  H_old = C when the solve is not tiered yet (nobody is asleep).
+__global__ void __launch_bounds__(kBlock)
+    k_tier_classify(size_t C, const int2* __restrict__ pairs, const double2* __restrict__ Pcur,
+                    const double2* __restrict__ Pprev, const double* __restrict__ budget,
+                    const double* __restrict__ drift, const double* __restrict__ wake_old, size_t H_old,
+                    int32_t* __restrict__ flags) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    const double need = budget[ij.x] + budget[ij.y];
+    bool cold;
+    if (c >= H_old && wake_old[c - H_old] > -1.7976931348623157e308) {
+      // asleep (its pair is stale): stays cold while what is left of its level covers the coming period
+      cold = wake_old[c - H_old] - (drift[ij.x] + drift[ij.y]) > need;
+    } else {
+      const double2 a = Pcur[c], b = Pprev[c];
+      cold = a.x == 0.0 && b.x == 0.0 && a.y > kTierMinGap && a.y <= 1.7976931348623157e308 && 0.5 * a.y > need;
+    }
+    flags[c] = cold ? 0 : 1;
+  }
+}
+// src numbering -> hot-first numbering (stable): geometry, q, slot table, both packed iterates, wake levels
+template <int KIN>
+__global__ void __launch_bounds__(kBlock)
+    k_tier_permute(size_t C, size_t H, int cur_is_p1, const int2* __restrict__ pairs, const double* __restrict__ normal,
+                   const double* __restrict__ arc_s, const double* __restrict__ arc_t, const double* __restrict__ q,
+                   const int32_t* __restrict__ orig, const unsigned char* __restrict__ pos, TierGeo dst,
+                   const double2* __restrict__ P0s, const double2* __restrict__ P1s, double2* __restrict__ P0d,
+                   double2* __restrict__ P1d, const int32_t* __restrict__ flags, const int32_t* __restrict__ rank,
+                   int32_t* __restrict__ new_of, const double* __restrict__ wake_old, size_t H_old,
+                   double* __restrict__ wake_new, const double* __restrict__ drift) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const bool hot = flags[c] != 0;
+    const size_t r = static_cast<size_t>(rank[c]);
+    const size_t nc = hot ? r : H + (c - r);
+    new_of[c] = static_cast<int32_t>(nc);
+    const int2 ij = pairs[c];
+    dst.pairs[nc] = ij;
+    store3(dst.normal, nc, load3(normal, c));
+    if (KIN == KIN_ROD) {
+      dst.arc_s[nc] = arc_s[c];
+      dst.arc_t[nc] = arc_t[c];
+    }
+    dst.q[nc] = q[c];
+    dst.orig[nc] = orig ? orig[c] : static_cast<int32_t>(c);
+    dst.pos[2 * nc] = pos[2 * c];
+    dst.pos[2 * nc + 1] = pos[2 * c + 1];
+    double2 a0 = P0s[c], a1 = P1s[c];
+    if (!hot) {
+      const bool asleep = c >= H_old && wake_old[c - H_old] > -1.7976931348623157e308;
+      if (asleep) {
+        wake_new[nc - H] = wake_old[c - H_old];  // its level stands; the pair keeps saying x = 0, g > 0
+      } else {
+        const double g = cur_is_p1 ? a1.y : a0.y;
+        wake_new[nc - H] = drift[ij.x] + drift[ij.y] + 0.5 * g;
+        a0 = a1 = make_double2(0.0, g);
+      }
+    }
+    P0d[nc] = a0;
+    P1d[nc] = a1;
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_tier_remap_inc(size_t n, int32_t* __restrict__ inc,
+                                                          const int32_t* __restrict__ map) {
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x) {
+    const int32_t e = inc[k];
+    inc[k] = (map[e >> 1] << 1) | (e & 1);
+  }
+}
+// leaving the tiers: the gradient of every sleeping contact at the last two iterates, from the two row buffers
+template <int KIN>
+__global__ void __launch_bounds__(kBlock)
+    k_tier_refresh_sleepers(OpView op /*tier view*/, size_t H, const SolverState* __restrict__ st,
+                            const double* __restrict__ q, const double* __restrict__ wake, double2* __restrict__ P0,
+                            double2* __restrict__ P1) {
+  const unsigned f = st->flips;
+  const unsigned cur = (st->converged && !st->converged_at_init) ? ((f + 1u) & 1u) : (f & 1u);
+  const double* vcur = cur ? op.vel_alt : op.vel;
+  const double* vprev = cur ? op.vel : op.vel_alt;
+  double2* Pcur = cur ? P1 : P0;
+  double2* Pprev = cur ? P0 : P1;
+  for (size_t c = H + blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
+    if (!(wake[c - H] > -1.7976931348623157e308)) continue;  // awake: its pairs are exact already
+    const int2 ij = op.pairs[c];
+    Pcur[c] = make_double2(0.0, 1.0 * q[c] + 1.0 * contact_dt_sdot<KIN>(op, vcur, c, ij));
+    Pprev[c] = make_double2(0.0, 1.0 * q[c] + 1.0 * contact_dt_sdot<KIN>(op, vprev, c, ij));
+  }
+}
+// tier numbering -> the caller's: the solver's four vectors (final) ...
+__global__ void __launch_bounds__(kBlock)
+    k_tier_finish(size_t n, const SolverState* __restrict__ st, const double2* __restrict__ P0,
+                  const double2* __restrict__ P1, const int32_t* __restrict__ orig, double* __restrict__ x,
+                  double* __restrict__ g, double* __restrict__ x_tmp, double* __restrict__ g_tmp) {
+  const bool p = st->flips & 1u;
+  const double2 *cur, *old;  // as k_finish_packed
+  if (st->converged_at_init) { cur = P0; old = P0; }
+  else if (st->converged) { cur = p ? P0 : P1; old = p ? P1 : P0; }
+  else { cur = p ? P1 : P0; old = cur; }
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double2 a = cur[i], b = old[i];
+    const size_t o = static_cast<size_t>(orig[i]);
+    x[o] = a.x; g[o] = a.y; x_tmp[o] = b.x; g_tmp[o] = b.y;
+  }
+}
+// ... or the packed pairs (the solve goes on untiered)
+__global__ void __launch_bounds__(kBlock)
+    k_tier_scatter_pairs(size_t n, const double2* __restrict__ P0, const double2* __restrict__ P1,
+                         const int32_t* __restrict__ orig, double2* __restrict__ Q0, double2* __restrict__ Q1) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = static_cast<size_t>(orig[i]);
+    Q0[o] = P0[i];
+    Q1[o] = P1[i];
+  }
+}
+
+bool tier_eligible(const mhip_contact_op* op, const Space& sp, int resid_kind) {
+  const OpView& v = op->view;
+  return (op->kin == KIN_ROD || op->kin == KIN_TRANS) && v.C >= kTierMinContacts && v.body_mask != nullptr &&
+         v.counted == nullptr && v.body_first == 0 && v.body_count == v.N && sp.kind == MHIP_SPACE_LOWER_BOUND &&
+         sp.lo == 0.0 && resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF;
+}
+
+// the packed pair a tiered (or not yet tiered) solve is iterating on
+struct TierPairs {
+  double *P0, *P1;
+  const double* q;
+};
+
+// At a poll (the stream is idle, host_state is current).  First call of a solve: the drift bookkeeping starts (body
+// rows ping-pong, drift accumulates).  Later calls: classify against the drift of the period just run, and renumber
+// hot-first when that pays.  iters_done = iterations run so far, next_period = iterations until the next poll.
+// `cur` = the pairs / q in use; on return the ones to use from now on.
+int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsigned next_period, hipStream_t s) {
+  mhip_contact_op::Tier& t = op->tier;
+  OpView& v = op->view;
+  const size_t C = v.C, N = v.N;
+  if (int e = t.misc.reserve(tier_misc_bytes(C, N))) return e;
+  if (int e = op->scanws.reserve(scan_workspace_bytes(C + 2) + 64)) return e;
+  const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
+  const bool cur_is_p1 = op->host_state->flips & 1u;
+  if (!t.tracking) {
+    if (int e = t.vel2.reserve((6 * N + 8) * sizeof(double))) return e;
+    if (int e = t.drift.reserve((N + 8) * sizeof(double))) return e;
+    MHIP_HIP(hipMemsetAsync(t.drift.ptr, 0, N * sizeof(double), s));
+    MHIP_HIP(hipMemsetAsync(m.drift_prev, 0, N * sizeof(double), s));
+    // the body rows start to ping-pong: the current rows must sit in the buffer of the current parity
+    if (cur_is_p1) MHIP_HIP(hipMemcpyAsync(t.vel2.ptr, v.vel, 6 * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    t.saved_vel = v.vel;
+    v.vel_alt = t.vel2.as<double>();
+    v.drift = t.drift.as<double>();
+    t.tracking = true;
+    t.polled_at = iters_done;
+    return MHIP_SUCCESS;
+  }
+  const unsigned last_period = iters_done - t.polled_at;
+  t.polled_at = iters_done;
+  if (last_period == 0) return MHIP_SUCCESS;
+  const double scale = static_cast<double>(next_period) / static_cast<double>(last_period);
+  k_tier_budget<<<grid_for(N), kBlock, 0, s>>>(N, t.drift.as<double>(), m.drift_prev, scale, m.budget);
+  MHIP_LAUNCH_CHECK();
+  const double2* Pc = reinterpret_cast<const double2*>(cur_is_p1 ? cur.P1 : cur.P0);
+  const double2* Pp = reinterpret_cast<const double2*>(cur_is_p1 ? cur.P0 : cur.P1);
+  const double* wake_old = t.active ? m.wake[t.set] : m.wake[0];
+  const size_t H_old = t.active ? t.H : C;
+  k_tier_classify<<<grid_for(C), kBlock, 0, s>>>(C, v.pairs, Pc, Pp, m.budget, t.drift.as<double>(), wake_old, H_old,
+                                                 m.flags);
+  MHIP_LAUNCH_CHECK();
+  if (int e = exclusive_scan_i32(m.flags, m.rank, C, op->scanws.ptr, s)) return e;
+  int32_t H32 = 0;
+  unsigned long long awake = 0;
+  MHIP_HIP(hipMemcpyAsync(&H32, m.rank + C, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (t.active) MHIP_HIP(hipMemcpyAsync(&awake, m.counters, sizeof(awake), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  const size_t H = static_cast<size_t>(H32);
+  if (t.active) {
+    // renumbering costs about four constraint sweeps: only when what is swept in full (the hot range and the awake
+    // part of the tail, the latter through scattered accesses) can shrink by a tenth
+    if (10 * H >= 9 * (t.H + static_cast<size_t>(awake))) return MHIP_SUCCESS;
+  } else if (10 * H > 9 * C) {
+    return MHIP_SUCCESS;  // (almost) everything is hot: nothing to gain yet
+  }
+  const int dst_set = t.active ? (t.set ^ 1) : 0;
+  if (int e = t.geo[dst_set].reserve(tier_geo_bytes(C))) return e;
+  if (int e = t.iter[dst_set].reserve(2 * (C + 1) * sizeof(double2))) return e;
+  const TierGeo dst = tier_geo_at(t.geo[dst_set].ptr, C);
+  double2* P0d = t.iter[dst_set].as<double2>();
+  double2* P1d = P0d + C;
+  const int32_t* orig_src = nullptr;
+  if (t.active)
+    orig_src = tier_geo_at(t.geo[t.set].ptr, C).orig;
+  else
+    t.saved = v;
+#define PERMUTE(K)                                                                                                    \
+  k_tier_permute<K><<<grid_for(C), kBlock, 0, s>>>(C, H, cur_is_p1 ? 1 : 0, v.pairs, v.normal, v.arc_s, v.arc_t, cur.q, \
+                                                   orig_src, v.pos, dst, reinterpret_cast<const double2*>(cur.P0),   \
+                                                   reinterpret_cast<const double2*>(cur.P1), P0d, P1d, m.flags,      \
+                                                   m.rank, m.new_of, wake_old, H_old, m.wake[dst_set],               \
+                                                   t.drift.as<double>())
+  if (op->kin == KIN_ROD) PERMUTE(KIN_ROD); else PERMUTE(KIN_TRANS);
+#undef PERMUTE
+  MHIP_LAUNCH_CHECK();
+  k_tier_remap_inc<<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), m.new_of);
+  MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipMemsetAsync(m.counters, 0, 4 * sizeof(unsigned long long), s));  // nobody of the new tail is awake
+  v.pairs = dst.pairs;
+  v.normal = dst.normal;
+  v.arc_s = dst.arc_s;
+  v.arc_t = dst.arc_t;
+  v.pos = dst.pos;
+  cur.P0 = reinterpret_cast<double*>(P0d);
+  cur.P1 = reinterpret_cast<double*>(P1d);
+  cur.q = dst.q;
+  t.wakeups += static_cast<size_t>(awake);
+  t.active = true;
+  t.set = dst_set;
+  t.H = H;
+  t.retiers += 1;
+  return MHIP_SUCCESS;
+}
+
+// the rows of the latest iterate go back into the operator's own buffer and the row ping-pong / drift bookkeeping ends
+int tier_stop_tracking(mhip_contact_op* op, hipStream_t s) {
+  mhip_contact_op::Tier& t = op->tier;
+  if (!t.tracking) return MHIP_SUCCESS;
+  const SolverState& hs = *op->host_state;
+  const unsigned curv = (hs.converged && !hs.converged_at_init) ? ((hs.flips + 1u) & 1u) : (hs.flips & 1u);
+  if (curv == 1u)
+    MHIP_HIP(hipMemcpyAsync(t.saved_vel, t.vel2.ptr, 6 * op->view.N * sizeof(double), hipMemcpyDeviceToDevice, s));
+  op->view.vel_alt = nullptr;
+  op->view.drift = nullptr;
+  t.tracking = false;
+  return MHIP_SUCCESS;
+}
+
+// Leaves the tiers.  final: the four solver vectors are written in the caller's numbering; otherwise the packed pairs
+// go back into (P0, P1) and the solve continues untiered.  host_state must be current.
+int tier_release(mhip_contact_op* op, TierPairs& cur, bool final, double* P0, double* P1, const double* q_caller,
+                 double* x, double* g, double* x_tmp, double* g_tmp, hipStream_t s) {
+  mhip_contact_op::Tier& t = op->tier;
+  if (!t.active) return tier_stop_tracking(op, s);
+  OpView& v = op->view;
+  const size_t C = v.C, N = v.N;
+  const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
+  const TierGeo geo = tier_geo_at(t.geo[t.set].ptr, C);
+  const SolverState* st = op->state.as<SolverState>();
+  double2* T0 = reinterpret_cast<double2*>(cur.P0);
+  double2* T1 = reinterpret_cast<double2*>(cur.P1);
+  if (t.H < C) {
+    const unsigned grid = grid_for(C - t.H);
+    if (op->kin == KIN_ROD)
+      k_tier_refresh_sleepers<KIN_ROD><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
+    else
+      k_tier_refresh_sleepers<KIN_TRANS><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
+    MHIP_LAUNCH_CHECK();
+  }
+  if (final)
+    k_tier_finish<<<grid_for(C), kBlock, 0, s>>>(C, st, T0, T1, geo.orig, x, g, x_tmp, g_tmp);
+  else
+    k_tier_scatter_pairs<<<grid_for(C), kBlock, 0, s>>>(C, T0, T1, geo.orig, reinterpret_cast<double2*>(P0),
+                                                        reinterpret_cast<double2*>(P1));
+  MHIP_LAUNCH_CHECK();
+  k_tier_remap_inc<<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), geo.orig);
+  MHIP_LAUNCH_CHECK();
+  unsigned long long awake = 0;
+  MHIP_HIP(hipMemcpyAsync(&awake, m.counters, sizeof(awake), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  t.wakeups += static_cast<size_t>(awake);
+  // the active lists refer to the tier numbering: gone with it
+  const OpView keep = v;
+  v = t.saved;
+  v.xcd_aware = keep.xcd_aware;
+  v.vel_alt = keep.vel_alt;
+  v.drift = keep.drift;
+  v.aptr = nullptr;
+  t.active = false;
+  cur.P0 = P0;
+  cur.P1 = P1;
+  cur.q = q_caller;
+  return tier_stop_tracking(op, s);
+}
+
+// the constraint sweeps of a tiered iteration: [0, H) as ever; the tail [H, C) is scanned for contacts that have
+// reached their wake level, and the awake ones are evaluated from their list.  Block partials of the two evaluating
+// sweeps share the planes (hot slots first).  *nparts = partial records written.
+int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space sp, int resid_kind, unsigned* nparts,
+                                hipStream_t s) {
+  mhip_contact_op::Tier& t = op->tier;
+  const size_t C = op->view.C, N = op->view.N;
+  const SolverState* st = op->state.as<SolverState>();
+  double* parts = op->partials.as<double>();
+  const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
+  const unsigned ghot = t.H ? constraint_grid(t.H) : 0u;
+  // the tail: scanned by extra workgroups of the hot launch (a latency-bound scan under a bandwidth-bound sweep), its
+  // awake contacts then evaluated by a small grid-stride launch
+  const unsigned gcheck = t.H < C ? grid_for(C - t.H) : 0u;
+  const unsigned glist = t.H < C ? (grid_for(C - t.H) < 256u ? grid_for(C - t.H) : 256u) : 0u;
+  OpView hot = op->view, listed = op->view;
+  hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
+  listed.part_offset = ghot; listed.part_stride = kStageStride;
+  const TierCheck tc{t.H, C, m.wake[t.set], m.list, m.counters, gcheck};
+#define TIERED(K)                                                                                                   \
+  do {                                                                                                              \
+    if (ghot + gcheck)                                                                                              \
+      k_constraint<X_SOLVE, K, true><<<ghot + gcheck, kBlock, 0, s>>>(hot, st, cur.P0, cur.P1, nullptr, nullptr,   \
+                                                                     cur.q, sp, resid_kind, parts, nullptr,        \
+                                                                     nullptr, tc);                                 \
+    if (glist)                                                                                                      \
+      k_constraint<X_SOLVE, K, true, true><<<glist, kBlock, 0, s>>>(listed, st, cur.P0, cur.P1, nullptr, nullptr,  \
+                                                                   cur.q, sp, resid_kind, parts, m.list,           \
+                                                                   m.counters);                                    \
+  } while (0)
+  if (op->kin == KIN_ROD) TIERED(KIN_ROD); else TIERED(KIN_TRANS);
+#undef TIERED
+  MHIP_LAUNCH_CHECK();
+  *nparts = ghot + glist;
+  return MHIP_SUCCESS;
+}
 
 int check_config(const mhip_pgd_config* cfg) {
   MHIP_REQUIRE(cfg != nullptr, MHIP_ERR_INVALID_ARGUMENT, "config must not be null");
@@ -1571,7 +2076,7 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
 // pinned state block, timing events -- are the same size step after step.  A destroyed operator therefore leaves them
 // in one process-wide spare set that the next create adopts: no hipMalloc / hipFree in the steady state (hipFree
 // alone cost 1.6 ms per step at 10^6 rods).  mhip_release_cached_workspaces() frees the spare set.
-constexpr int kOpBuffers = 21;
+constexpr int kOpBuffers = 28;
 struct OpWorkspaces {
   DeviceBuffer buf[kOpBuffers];
   SolverState* host_state = nullptr;
@@ -1585,7 +2090,9 @@ static DeviceBuffer* op_buffers(mhip_contact_op* op, int k) {
   DeviceBuffer* all[kOpBuffers] = {&op->inc_ptr, &op->inc,     &op->cursor,   &op->vel,      &op->partials, &op->state,
                                    &op->scanws,  &op->half,    &op->axis,     &op->omega,    &op->vel_out,  &op->iterate,
                                    &op->body_mask, &op->pos,   &op->sort_tmp, &op->sort_list, &op->aptr,    &op->aent,
-                                   &op->arec,    &op->snap_mask, &op->acnt};
+                                   &op->arec,    &op->snap_mask, &op->acnt,
+                                   &op->tier.geo[0], &op->tier.geo[1], &op->tier.iter[0], &op->tier.iter[1],
+                                   &op->tier.misc, &op->tier.vel2, &op->tier.drift};
   return all[k];
 }
 static void free_workspaces(OpWorkspaces& w) {
@@ -1938,6 +2445,34 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
     op->events.resize(3 * 64);
     for (auto& ev : op->events) MHIP_HIP(hipEventCreate(&ev));
   }
+  // cold tier (see "Cold tier"): from the first snapshot on, where the problem is of the kind it covers
+  mhip_contact_op::Tier& tier = op->tier;
+  tier.disabled = !tier_eligible(op, sp, rk) || op->tiering == 0;
+  tier.tiered_iterations = tier.retiers = tier.wakeups = 0;
+  tier.hot_sum = 0.0;
+  TierPairs cur{P0, P1, q};
+  // whatever ends the solve early, the operator must not be left in the tier numbering
+  struct TierGuard {
+    mhip_contact_op* op;
+    ~TierGuard() {
+      if (!op->tier.active) {
+        op->view.vel_alt = nullptr;
+        op->view.drift = nullptr;
+        op->tier.tracking = false;
+        return;
+      }
+      op->tier.tracking = false;
+      const size_t C2 = op->view.C;
+      const TierGeo geo = tier_geo_at(op->tier.geo[op->tier.set].ptr, C2);
+      k_tier_remap_inc<<<grid_for(2 * C2), kBlock, 0, op->last_stream>>>(2 * C2, op->inc.as<int32_t>(), geo.orig);
+      (void)hipStreamSynchronize(op->last_stream);
+      const int xa = op->view.xcd_aware;
+      op->view = op->tier.saved;
+      op->view.xcd_aware = xa;
+      op->view.aptr = nullptr;
+      op->tier.active = false;
+    }
+  } tier_guard{op};
   for (;;) {
     MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
     MHIP_HIP(hipStreamSynchronize(s));
@@ -1954,36 +2489,89 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
         op->timed_iterations += 1;
       }
     }
+    if (tier.active && last_todo) {  // the iterations of the last chunk that ran (the launches after `done` were idle)
+      unsigned ran = op->host_state->iter - iter_before + ((op->host_state->converged && op->host_state->iter < config->max_iters) ? 1u : 0u);
+      if (ran > last_todo) ran = last_todo;
+      tier.tiered_iterations += ran;
+      tier.hot_sum += ran * (static_cast<double>(tier.H) / static_cast<double>(C));
+    }
+    if (op->host_state->done == 2) {
+      // paused before a step outside [0, finite]: the sleepers' exact gradients are needed -- leave the tiers for good
+      if (int e = tier_release(op, cur, false, P0, P1, q, nullptr, nullptr, nullptr, nullptr, s)) return e;
+      tier.disabled = true;
+      op->host_state->done = 0;
+      MHIP_HIP(hipMemcpyAsync(&st->done, &op->host_state->done, sizeof(int), hipMemcpyHostToDevice, s));
+      // the launches that were enqueued behind the pause did nothing: they do not count
+      enqueued = op->host_state->iter;
+    }
     if (op->host_state->done || enqueued >= config->max_iters) break;
-    if (enqueued >= kSnapshotAfter)
+    if (enqueued >= kSnapshotAfter) {
+      if (!tier.disabled) {
+        const unsigned left = config->max_iters - enqueued;
+        if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, s)) return e;
+      }
       if (int e = op_snapshot_active(op, s)) return e;
+    }
     iter_before = op->host_state->iter;
     const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
     for (unsigned k = 0; k < todo; ++k) {
       const bool pk = prof && (k % kProfileStride == 0);
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k], s));
-      if (int e = op_launch_body(op, X_SOLVE, P0, P1, nullptr, nullptr, sp, s, true)) return e;
+      if (int e = op_launch_body(op, X_SOLVE, cur.P0, cur.P1, nullptr, nullptr, sp, s, true)) return e;
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 1], s));
-      if (int e = op_launch_constraint(op, X_SOLVE, P0, P1, nullptr, nullptr, q, sp, rk, cgrid, s, true)) return e;
-      if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       unsigned np = cgrid;
       size_t ps = cgrid;
+      if (tier.active) {
+        if (int e = op_launch_constraint_tiered(op, cur, sp, rk, &np, s)) return e;
+        ps = kStageStride;
+      } else {
+        if (int e = op_launch_constraint(op, X_SOLVE, cur.P0, cur.P1, nullptr, nullptr, q, sp, rk, cgrid, s, true)) return e;
+      }
+      if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       double* pp = parts;
       fold_partials(np, ps, pp, st, 1, s);
-      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters);
+      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters,
+                                                        tier.active ? op->tiering : 0);
       MHIP_LAUNCH_CHECK();
     }
     enqueued += todo;
     last_todo = todo;
     if (chunk < 64) chunk *= 2;
   }
-  k_finish_packed<<<grid_for(C), kBlock, 0, s>>>(C, st, reinterpret_cast<const double2*>(P0),
-                                                 reinterpret_cast<const double2*>(P1), x, g, x_tmp, g_tmp);
-  MHIP_LAUNCH_CHECK();
+  if (tier.active) {
+    if (int e = tier_release(op, cur, true, P0, P1, q, x, g, x_tmp, g_tmp, s)) return e;
+  } else {
+    if (int e = tier_stop_tracking(op, s)) return e;
+    k_finish_packed<<<grid_for(C), kBlock, 0, s>>>(C, st, reinterpret_cast<const double2*>(P0),
+                                                   reinterpret_cast<const double2*>(P1), x, g, x_tmp, g_tmp);
+    MHIP_LAUNCH_CHECK();
+  }
   MHIP_HIP(hipStreamSynchronize(s));
   result->num_iters = op->host_state->iter;
   result->residual = op->host_state->residual;
   result->converged = op->host_state->converged;
+  return MHIP_SUCCESS;
+}
+
+/* cold-tier statistics of the last mhip_bbpgd_solve_contact on this operator (all zero when the solve did not tier) */
+int mhip_contact_op_tier_stats(mhip_contact_op_t op, size_t* tiered_iterations, double* mean_hot_fraction,
+                               size_t* renumberings, size_t* wakeups) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  const mhip_contact_op::Tier& t = op->tier;
+  if (tiered_iterations) *tiered_iterations = t.tiered_iterations;
+  if (mean_hot_fraction) *mean_hot_fraction = t.tiered_iterations ? t.hot_sum / static_cast<double>(t.tiered_iterations) : 0.0;
+  if (renumberings) *renumberings = t.retiers;
+  if (wakeups) *wakeups = t.wakeups;
+  return MHIP_SUCCESS;
+}
+
+/* 1 (default): mhip_bbpgd_solve_contact may keep inactive contacts in a cold tier; 0: every contact is swept every
+ * iteration; 2 (for tests): as 1, and the solve is paused after its first tiered iteration as it would be before a BB
+ * step outside [0, finite], i.e. it leaves the tiers and goes on untiered.  Time only: the iterates are the same bits. */
+int mhip_contact_op_set_tiering(mhip_contact_op_t op, int mode) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(mode >= 0 && mode <= 2, MHIP_ERR_INVALID_ARGUMENT, "tiering mode must be 0, 1 or 2, got %d", mode);
+  op->tiering = mode;
   return MHIP_SUCCESS;
 }
 

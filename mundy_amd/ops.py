@@ -564,6 +564,16 @@ class ContactOperator:
         """layout of the sweeps on the chip (time only; results do not depend on it)"""
         capi.check(capi.load().mhip_contact_op_set_work_mapping(self._h, int(xcd_tile), int(lanes_per_body)))
 
+    def set_tiering(self, mode=1):
+        """cold tier of the fused solve: 0 off, 1 on (default), 2 test hook (time only; results do not depend on it)"""
+        capi.check(capi.load().mhip_contact_op_set_tiering(self._h, int(mode)))
+
+    def tier_stats(self):
+        """(tiered iterations, mean hot share, renumberings, wake-ups) of the last solve_lcp on this operator"""
+        it, rn, wk, hot = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_double(0.0)
+        capi.check(capi.load().mhip_contact_op_tier_stats(self._h, C.byref(it), C.byref(hot), C.byref(rn), C.byref(wk)))
+        return dict(tiered_iterations=it.value, mean_hot_fraction=hot.value, renumberings=rn.value, wakeups=wk.value)
+
     def set_profiling(self, enable=True):
         capi.check(capi.load().mhip_contact_op_set_profiling(self._h, 1 if enable else 0))
 

@@ -536,3 +536,49 @@ def test_fill_and_deep_copy(ops):
         u = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
         capi.check(lib.mhip_deep_copy(n, C.c_void_p(u.data_ptr() + 8), C.c_void_p(t.data_ptr() + 8), None))
         assert torch.equal(u[1:n + 1], t[1:n + 1]) and float(u[0]) == 0.0 and float(u[-1]) == 0.0
+
+
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 60000), (_rod_problem_arclength, 12000)])
+def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
+    # the fused solve keeps inactive contacts in a cold tier from the first convergence poll on (renumbered hot-first,
+    # the tail swept only through drift bounds): x, g and the previous iterate, the iteration count and the body
+    # velocities equal the untiered solve bit for bit -- for a run to convergence, for iteration caps (61, 62) that end
+    # the solve inside the tiers at either parity, and when the solve is made to leave the tiers mid-way (what it does
+    # before a BB step outside [0, finite]); afterwards the operator is back in the caller's numbering
+    import torch
+    from gpu_util import dev
+    P = maker(oracle, n, seed=41)
+    C = len(P["pairs"])
+    assert C >= 65536, C
+    q = dev(P["sep"])
+    results = {}
+    for mode in (0, 1, 2):
+        op = _gpu_op(ops, P)
+        op.set_tiering(mode)
+        out = []
+        for max_iters in (10000, 61, 62):
+            st = tuple(dev(np.zeros(C)) for _ in range(4))
+            x, g, res = ops.solve_lcp(op, q, None, ops.PGDConfig(max_iters=max_iters, tol=1e-6), state=st)
+            stats = op.tier_stats()
+            out.append((st, res, op.body_velocity().clone(), stats))
+            if mode == 0:
+                assert stats["tiered_iterations"] == 0
+            elif mode == 1:
+                # (drift bookkeeping from the poll at 8 iterations, tiers from the poll at 24 or 56)
+                assert stats["tiered_iterations"] >= min(res.num_iters, max_iters) - 56 > 0, stats
+                assert stats["renumberings"] >= 1, stats
+                if max_iters == 10000:
+                    assert res.converged and stats["mean_hot_fraction"] < 0.85, stats
+            else:
+                assert stats["tiered_iterations"] == 1, stats
+            # back in the caller's numbering: the operator applied to the solution reproduces the gradient
+            y = op.apply(st[0])
+            np.testing.assert_allclose((y + q).cpu().numpy(), st[1].cpu().numpy(), atol=1e-9)
+        results[mode] = out
+        op.close()
+    for mode in (1, 2):
+        for (st0, r0, v0, _), (st1, r1, v1, _) in zip(results[0], results[mode]):
+            assert (r0.num_iters, r0.converged, r0.residual) == (r1.num_iters, r1.converged, r1.residual)
+            for a, b in zip(st0, st1):
+                assert torch.equal(a, b)
+            assert torch.equal(v0, v1)
