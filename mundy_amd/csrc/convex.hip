@@ -706,14 +706,17 @@ __device__ inline void tier_check_range(const TierCheck& tc, const int2* __restr
   }
 }
 
-// LISTED: the contacts swept are those of `list` (tier_counters[0] of them): the woken contacts of a tiered solve's cold
-// tail ("Cold tier" below), evaluated like any other; sleeping ones add exact zeros, among them 0 to the max.
-template <int MODE, int KIN, bool PACKED, bool LISTED = false>
-__global__ void __launch_bounds__(kBlock)
-    k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
-                 double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
-                 int resid_kind, double* __restrict__ partials, const int32_t* __restrict__ list = nullptr,
-                 const unsigned long long* __restrict__ tier_counters = nullptr, TierCheck check = TierCheck{}) {
+// The constraint sweep (k_constraint, k_constraint_listed).  LISTED: the contacts swept are those of `list`
+// (tier_counters[0] of them): the woken contacts of a tiered solve's cold tail ("Cold tier" below), evaluated like any
+// other; sleeping ones add exact zeros, among them 0 to the max.
+template <int MODE, int KIN, bool PACKED, bool LISTED>
+__device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverState* __restrict__ st,
+                                                 double* __restrict__ X0, double* __restrict__ X1,
+                                                 double* __restrict__ G0, double* __restrict__ G1,
+                                                 const double* __restrict__ q, const Space& sp, int resid_kind,
+                                                 double* __restrict__ partials, const int32_t* __restrict__ list,
+                                                 const unsigned long long* __restrict__ tier_counters,
+                                                 const TierCheck& check) {
   __shared__ double scratch[2 * kBlock / 64];
   // (tiered solves) the last check.blocks workgroups of the grid scan the cold tail while the others sweep
   const unsigned nblk = gridDim.x - check.blocks;
@@ -799,6 +802,23 @@ __global__ void __launch_bounds__(kBlock)
       store_partial(partials, stride, op.part_offset + blockIdx.x, m, s1, s2);
     }
   }
+}
+
+template <int MODE, int KIN, bool PACKED>
+__global__ void __launch_bounds__(kBlock)
+    k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
+                 double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
+                 int resid_kind, double* __restrict__ partials, TierCheck check = TierCheck{}) {
+  constraint_sweep<MODE, KIN, PACKED, false>(op, st, X0, X1, G0, G1, q, sp, resid_kind, partials, nullptr, nullptr, check);
+}
+// the woken contacts of a tiered solve's cold tail, from their list (its own name: the profiles tell the sweeps apart)
+template <int KIN>
+__global__ void __launch_bounds__(kBlock)
+    k_constraint_listed(OpView op, const SolverState* __restrict__ st, double* __restrict__ P0, double* __restrict__ P1,
+                        const double* __restrict__ q, Space sp, int resid_kind, double* __restrict__ partials,
+                        const int32_t* __restrict__ list, const unsigned long long* __restrict__ tier_counters) {
+  constraint_sweep<X_SOLVE, KIN, true, true>(op, st, P0, P1, nullptr, nullptr, q, sp, resid_kind, partials, list,
+                                             tier_counters, TierCheck{});
 }
 
 constexpr int kFinalBlock = 1024;  // threads of the single-workgroup final passes
@@ -1938,12 +1958,10 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   do {                                                                                                              \
     if (ghot + gcheck)                                                                                              \
       k_constraint<X_SOLVE, K, true><<<ghot + gcheck, kBlock, 0, s>>>(hot, st, cur.P0, cur.P1, nullptr, nullptr,   \
-                                                                     cur.q, sp, resid_kind, parts, nullptr,        \
-                                                                     nullptr, tc);                                 \
+                                                                     cur.q, sp, resid_kind, parts, tc);            \
     if (glist)                                                                                                      \
-      k_constraint<X_SOLVE, K, true, true><<<glist, kBlock, 0, s>>>(listed, st, cur.P0, cur.P1, nullptr, nullptr,  \
-                                                                   cur.q, sp, resid_kind, parts, m.list,           \
-                                                                   m.counters);                                    \
+      k_constraint_listed<K><<<glist, kBlock, 0, s>>>(listed, st, cur.P0, cur.P1, cur.q, sp, resid_kind, parts,    \
+                                                     m.list, m.counters);                                          \
   } while (0)
   if (op->kin == KIN_ROD) TIERED(KIN_ROD); else TIERED(KIN_TRANS);
 #undef TIERED

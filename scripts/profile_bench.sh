@@ -11,9 +11,9 @@ BENCH="$PWD/bench.py"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -T -d "$OUT/trace" -- python3 "$BENCH" --steps 2 --warmup 1 --no-cpu-baseline --relaxed-steps 0 > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || { tail -20 "$OUT/trace.err"; exit 1; }
 echo "trace pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_fetch" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --relaxed-steps 0 --max-iters 200 > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || { tail -20 "$OUT/pmc_fetch.err"; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_fetch" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --relaxed-steps 0 > "$OUT/bench_pmc_fetch.json" 2> "$OUT/pmc_fetch.err" || { tail -20 "$OUT/pmc_fetch.err"; exit 1; }
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_write" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --relaxed-steps 0 --max-iters 200 > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" || { tail -20 "$OUT/pmc_write.err"; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_write" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --relaxed-steps 0 > "$OUT/bench_pmc_write.json" 2> "$OUT/pmc_write.err" || { tail -20 "$OUT/pmc_write.err"; exit 1; }
 echo "write pass done"
 # L2 hit rate and wave stall split of the two sweeps (diagnostics; TCC 2 slots + SQ 4 slots)
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -T --kernel-include-regex "k_constraint|k_body" -d "$OUT/pmc_l2" -- python3 "$BENCH" --steps 1 --warmup 0 --no-cpu-baseline --relaxed-steps 0 --max-iters 200 > "$OUT/bench_pmc_l2.json" 2> "$OUT/pmc_l2.err" || { tail -20 "$OUT/pmc_l2.err"; echo "l2 pass failed (diagnostic only)"; }

@@ -15,7 +15,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KERNELS = ("k_constraint", "k_body")
+# k_constraint: the full sweep, or in a tiered iteration the hot range + the scan of the cold tail; k_constraint_listed:
+# the woken contacts of the tail (a short launch every tiered iteration)
+KERNELS = ("k_constraint", "k_body", "k_constraint_listed")
 
 
 def find(sub, pat):
@@ -82,7 +84,7 @@ if traffic:
         if k in eff:
             traffic[k]["trace_avg_effective_us"] = eff[k] / 1e3
     traffic["_source"] = ("scripts/profile_bench.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py "
-                          "--steps 1 --warmup 0 --max-iters 200`, 2 x FETCH_SIZE + WRITE_SIZE per effective launch"
+                          "--steps 1 --warmup 0` (the whole solve: untiered first iterations and tiered rest, as in the timed run), 2 x FETCH_SIZE + WRITE_SIZE per effective launch"
                           % os.path.basename(out.rstrip("/")).replace("prof_", ""))
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print("\n## HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
