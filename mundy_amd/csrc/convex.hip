@@ -718,12 +718,14 @@ __device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverS
                                                  const unsigned long long* __restrict__ tier_counters,
                                                  const TierCheck& check) {
   __shared__ double scratch[2 * kBlock / 64];
-  // (tiered solves) the last check.blocks workgroups of the grid scan the cold tail while the others sweep
+  // (tiered solves) the first check.blocks workgroups of the grid scan the cold tail (a latency-bound loop of dependent
+  // gathers), dispatched ahead of the bandwidth-bound sweep of the others
   const unsigned nblk = gridDim.x - check.blocks;
-  if (blockIdx.x >= nblk) {
-    if (MODE == X_SOLVE && !st->done) tier_check_range(check, op.pairs, op.drift, blockIdx.x - nblk, check.blocks);
+  if (blockIdx.x < check.blocks) {
+    if (MODE == X_SOLVE && !st->done) tier_check_range(check, op.pairs, op.drift, blockIdx.x, check.blocks);
     return;
   }
+  const unsigned bid = blockIdx.x - check.blocks;  // this workgroup's place among the sweeping ones
   const double* xt = X0;
   const double* gt = G0;
   double* xn = X1;
@@ -748,7 +750,7 @@ __device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverS
   DD num{0.0, 0.0}, den{0.0, 0.0};
   const size_t nwork = LISTED ? static_cast<size_t>(tier_counters[0]) : op.c_end - op.c_first;
   const size_t ntiles = (nwork + kBlock - 1) / kBlock;
-  for (size_t lin = blockIdx.x; lin < ntiles; lin += nblk) {
+  for (size_t lin = bid; lin < ntiles; lin += nblk) {
     size_t c;
     if (LISTED) {
       const size_t k = lin * kBlock + threadIdx.x;
@@ -799,7 +801,7 @@ __device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverS
     const DD s2 = block_sum(den, scratch);
     if (threadIdx.x == 0) {  // kRed planes of values: the final pass reads them coalesced
       const size_t stride = op.part_stride ? op.part_stride : nblk;
-      store_partial(partials, stride, op.part_offset + blockIdx.x, m, s1, s2);
+      store_partial(partials, stride, op.part_offset + bid, m, s1, s2);
     }
   }
 }
@@ -1598,6 +1600,12 @@ constexpr unsigned kSnapshotAfter = 8;
 //   from the two body-row buffers, everything is scattered back to the caller's numbering, inc is restored.
 constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g above this (far above rounding noise)
 constexpr size_t kTierMinContacts = 65536;  // smaller problems are launch-bound: not worth the bookkeeping
+#ifndef MHIP_TIER_SCAN_BLOCKS
+#define MHIP_TIER_SCAN_BLOCKS 2048
+#endif
+// workgroups that scan the cold tail.  The scan is a chain of dependent gathers: it needs the waves (10^6 rods, whole
+// step: 128 workgroups 260 ms, 256: 204, 512: 180.3, 1024: 178.5, 2048: 178.9; scripts/ab_tier_scan.sh)
+constexpr unsigned kTierScanBlocks = MHIP_TIER_SCAN_BLOCKS;
 
 struct TierGeo {
   int2* pairs;
@@ -1948,7 +1956,7 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   const unsigned ghot = t.H ? constraint_grid(t.H) : 0u;
   // the tail: scanned by extra workgroups of the hot launch (a latency-bound scan under a bandwidth-bound sweep), its
   // awake contacts then evaluated by a small grid-stride launch
-  const unsigned gcheck = t.H < C ? grid_for(C - t.H) : 0u;
+  const unsigned gcheck = t.H < C ? (grid_for(C - t.H) < kTierScanBlocks ? grid_for(C - t.H) : kTierScanBlocks) : 0u;
   const unsigned glist = t.H < C ? (grid_for(C - t.H) < 256u ? grid_for(C - t.H) : 256u) : 0u;
   OpView hot = op->view, listed = op->view;
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
