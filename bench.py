@@ -139,6 +139,8 @@ def parse():
                         "without it such a run exits with code 3")
     p.add_argument("--xcd-tile", type=int, default=-1, help="tile -> XCD mapping of the sweeps (time only)")
     p.add_argument("--lanes-per-body", type=int, default=-1, help="lanes per body of the body sweep (time only)")
+    p.add_argument("--no-cold-tier", action="store_true",
+                   help="sweep every contact every iteration (time only: the iterates are the same bits)")
     p.add_argument("--relaxed-steps", type=int, default=2,
                    help="N = 1: after the headline steps, advance the packing by this many full steps and time --steps "
                         "more from THAT state (labelled `relaxed_packing`; SURVEY 8d.3 allows one relaxation pre-pass)")
@@ -201,6 +203,8 @@ def main():
                                       friction=args.friction)
     if args.xcd_tile >= 0 or args.lanes_per_body > 0:
         stepper.work_mapping = (args.xcd_tile, args.lanes_per_body)
+    if args.no_cold_tier:
+        stepper.tiering = 0
     pristine = stepper.snapshot()
     prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 

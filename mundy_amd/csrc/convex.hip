@@ -398,8 +398,9 @@ struct OpView {
   const double* arec;                   // their records, same layout as `half`
   const unsigned long long* snap_mask;  // [N] the masks the snapshot was taken from
   // Tiered solves (see "Cold tier" below): the body rows ping-pong between vel (even parity) and vel_alt like the
-  // iterate does, so that the rows of the last TWO iterates exist; drift [N] accumulates, per body, an upper bound of
-  // how far any of its contact-point velocities has moved (times dt) since the solve began.  null = off.
+  // iterate does, so that the rows of the last TWO iterates exist when the solve ends; drift [N] accumulates, per body,
+  // an upper bound of how far any of its contact-point velocities has moved (times dt) since the bookkeeping began.
+  // null = off.
   double* vel_alt;
   double* drift;
 };
@@ -454,15 +455,14 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 //   n_c 24 B translation-only
 // compulsory bytes (rods): per half edge 4 (entry) + 32 (record), 16 per contact for its iterate (gathered by both
 // of its half edges); per body 4 (row pointer) + 16 (mobilities) + 24 (axis) + 48 (velocity row) + 24 (omega).
-template <int MODE, int KIN, int G, int U, bool PACKED>
+template <int MODE, int KIN, int G, int U, bool PACKED, bool TRACK = false>
 __global__ void __launch_bounds__(kBlock)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
   const double* xt = X0;
   const double* gt = G0;
   double step = 0.0;
-  double* vel_new = op.vel;         // rows this sweep writes
-  const double* vel_old = op.vel;   // rows of the previous iterate (tiered solves only)
+  double* vel_new = op.vel;  // rows this sweep writes (tiered solves: the buffer of the new iterate's parity)
   if (MODE == X_SOLVE) {
     if (st->done) return;
     const bool odd = st->flips & 1u;
@@ -470,10 +470,7 @@ __global__ void __launch_bounds__(kBlock)
       xt = X1;
       gt = G1;
     }
-    if (op.vel_alt) {
-      vel_new = odd ? op.vel : op.vel_alt;
-      vel_old = odd ? op.vel_alt : op.vel;
-    }
+    if (op.vel_alt) vel_new = odd ? op.vel : op.vel_alt;
     step = st->step;
   }
   const bool step_is_zero = fabs(-step) < kZeroTol;
@@ -491,16 +488,16 @@ __global__ void __launch_bounds__(kBlock)
   // not one more dependent memory level at the end of the chain
   double mt = 0.0, mr = 0.0;
   V3 axis{0.0, 0.0, 0.0};
-  const bool track = MODE == X_SOLVE && op.drift != nullptr;
-  double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0;  // the body's previous row (drift bookkeeping)
+  // drift bookkeeping of tiered solves: how far this body's row moves in this sweep, from the changes of its
+  // multipliers (F_new - F_old = sum +/- (lam - x_old) n over the entries walked: an entry that is not walked has
+  // lam = x_old = 0) -- no second pass over the rows
+  // (a template parameter: carried as a run-time flag the bookkeeping cost the untracked sweep 6 % in registers)
+  constexpr bool track = TRACK && MODE == X_SOLVE && PACKED && KIN != KIN_RIGID;
+  V3 dF{0.0, 0.0, 0.0}, dS{0.0, 0.0, 0.0};
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
     if (KIN == KIN_ROD) axis = load3(op.axis, b);
-    if (track) {
-      const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
-      o0 = vo[0]; o1 = vo[1]; o2 = vo[2];
-    }
   }
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
@@ -511,7 +508,7 @@ __global__ void __launch_bounds__(kBlock)
   auto process = [&](const int32_t* __restrict__ ent, const double* __restrict__ rec, const int32_t* kk,
                      const bool eager) {
     int32_t e[U];
-    double lam[U];
+    double lam[U], xo[U];
     double2 h0[U], h1[U], h2[U];
     auto fetch = [&](int u) {
       const size_t k = static_cast<size_t>(kk[u]);
@@ -533,20 +530,30 @@ __global__ void __launch_bounds__(kBlock)
       if (eager && kk[u] >= 0) fetch(u);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      lam[u] = (e[u] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(e[u] >> 1), xt, gt, step, step_is_zero, sp)
+    for (int u = 0; u < U; ++u) {
+      xo[u] = 0.0;
+      lam[u] = (e[u] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(e[u] >> 1), xt, gt, step, step_is_zero, sp, &xo[u])
                            : 0.0;
+    }
     // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so (when the
-    // records are not fetched eagerly) its record is never fetched
+    // records are not fetched eagerly) its record is never fetched (unless its multiplier just dropped to zero and the
+    // drift bookkeeping wants the change)
     if (!eager) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (lam[u] != 0.0) fetch(u);
+        if (lam[u] != 0.0 || (track && xo[u] != 0.0)) fetch(u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (lam[u] == 0.0) continue;
+      if (lam[u] == 0.0 && !(track && xo[u] != 0.0)) continue;
       const V3 n{h0[u].x, h0[u].y, h1[u].x};
+      if (track) {  // change of this body's force (and of S) against the previous iterate: plain sums, a bound only
+        const double dl = (e[u] & 1) ? lam[u] - xo[u] : xo[u] - lam[u];
+        const V3 df{dl * n.x, dl * n.y, dl * n.z};
+        dF = dF + df;
+        if (KIN == KIN_ROD) dS = dS + h1[u].y * df;
+      }
+      if (lam[u] == 0.0) continue;
       V3 f{lam[u] * n.x, lam[u] * n.y, lam[u] * n.z};
       if (!(e[u] & 1)) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
       dd_add(Fdd, f);
@@ -610,6 +617,13 @@ __global__ void __launch_bounds__(kBlock)
       dd_add(Tdd.z, dd_shfl_xor(Tdd.z, off));
     }
   }
+  if (track) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      dF = dF + V3{__shfl_xor(dF.x, off, 64), __shfl_xor(dF.y, off, 64), __shfl_xor(dF.z, off, 64)};
+      if (KIN == KIN_ROD) dS = dS + V3{__shfl_xor(dS.x, off, 64), __shfl_xor(dS.y, off, 64), __shfl_xor(dS.z, off, 64)};
+    }
+  }
   if (sub != 0) return;
   const V3 F = dd_value(Fdd), T = dd_value(Tdd);  // the one rounding of each sum
   double2* v = reinterpret_cast<double2*>(vel_new + 6 * b);
@@ -627,9 +641,13 @@ __global__ void __launch_bounds__(kBlock)
   v[2] = make_double2(W.y, W.z);
   if (track) {
     // |change of n . (U + coef Z)| <= |dU|_1 + |coef| |dZ|_1 with |coef| <= 1/2 (rods; spheres carry no Z): what any
-    // contact of this body can have moved by, times dt as the gradient sees it
-    double d = fabs(Ub.x - o0.x) + fabs(Ub.y - o0.y) + fabs(Ub.z - o1.x);
-    if (KIN != KIN_TRANS) d += 0.5 * (fabs(W.x - o1.y) + fabs(W.y - o2.x) + fabs(W.z - o2.y));
+    // contact of this body can have moved by, times dt as the gradient sees it.  dU = mt dF, dZ = (mr (u x dS)) x u.
+    double d = mt * (fabs(dF.x) + fabs(dF.y) + fabs(dF.z));
+    if (KIN == KIN_ROD) {
+      const V3 tq = cross(axis, dS);
+      const V3 dZ = cross(V3{mr * tq.x, mr * tq.y, mr * tq.z}, axis);
+      d += 0.5 * (fabs(dZ.x) + fabs(dZ.y) + fabs(dZ.z));
+    }
     op.drift[b] += op.dt * d;
   }
 }
@@ -682,25 +700,44 @@ struct TierCheck {
 __device__ inline void tier_check_range(const TierCheck& tc, const int2* __restrict__ pairs,
                                         const double* __restrict__ drift, unsigned block, unsigned nblocks) {
   const int lane = threadIdx.x & 63;
-  for (size_t base = tc.H + block * (size_t)blockDim.x; base < tc.C; base += (size_t)nblocks * blockDim.x) {
-    const size_t c = base + threadIdx.x;
-    bool woke = false;
-    if (c < tc.C) {
-      const double level = tc.wake[c - tc.H];
-      if (level > -1.7976931348623157e308) {
-        const int2 ij = pairs[c];
-        woke = !(drift[ij.x] + drift[ij.y] < level);
+  constexpr int kChains = 4;  // tiles in flight per workgroup: the gathers of one tile overlap the next one's
+  const size_t span = (size_t)blockDim.x * kChains;
+  for (size_t base = tc.H + block * span; base < tc.C; base += (size_t)nblocks * span) {
+    double level[kChains];
+    int2 ij[kChains];
+    bool live[kChains];
+#pragma unroll
+    for (int u = 0; u < kChains; ++u) {
+      const size_t c = base + (size_t)u * blockDim.x + threadIdx.x;
+      live[u] = false;
+      level[u] = 0.0;
+      ij[u] = make_int2(0, 0);
+      if (c < tc.C) {
+        level[u] = tc.wake[c - tc.H];
+        live[u] = level[u] > -1.7976931348623157e308;
+        if (live[u]) ij[u] = pairs[c];
       }
     }
-    const unsigned long long m = __ballot(woke);
-    if (m) {
-      const int leader = __ffsll(static_cast<long long>(m)) - 1;
-      unsigned long long at = 0;
-      if (lane == leader) at = atomicAdd(&tc.counters[0], static_cast<unsigned long long>(__popcll(m)));
-      at = __shfl(at, leader, 64);
-      if (woke) {
-        tc.list[at + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int32_t>(c);
-        tc.wake[c - tc.H] = -__builtin_huge_val();
+    double di[kChains], dj[kChains];
+#pragma unroll
+    for (int u = 0; u < kChains; ++u) {
+      di[u] = live[u] ? drift[ij[u].x] : 0.0;
+      dj[u] = live[u] ? drift[ij[u].y] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kChains; ++u) {
+      const size_t c = base + (size_t)u * blockDim.x + threadIdx.x;
+      const bool woke = live[u] && !(di[u] + dj[u] < level[u]);
+      const unsigned long long m = __ballot(woke);
+      if (m) {
+        const int leader = __ffsll(static_cast<long long>(m)) - 1;
+        unsigned long long at = 0;
+        if (lane == leader) at = atomicAdd(&tc.counters[0], static_cast<unsigned long long>(__popcll(m)));
+        at = __shfl(at, leader, 64);
+        if (woke) {
+          tc.list[at + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int32_t>(c);
+          tc.wake[c - tc.H] = -__builtin_huge_val();
+        }
       }
     }
   }
@@ -715,17 +752,9 @@ __device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverS
                                                  double* __restrict__ G0, double* __restrict__ G1,
                                                  const double* __restrict__ q, const Space& sp, int resid_kind,
                                                  double* __restrict__ partials, const int32_t* __restrict__ list,
-                                                 const unsigned long long* __restrict__ tier_counters,
-                                                 const TierCheck& check) {
+                                                 const unsigned long long* __restrict__ tier_counters) {
   __shared__ double scratch[2 * kBlock / 64];
-  // (tiered solves) the first check.blocks workgroups of the grid scan the cold tail (a latency-bound loop of dependent
-  // gathers), dispatched ahead of the bandwidth-bound sweep of the others
-  const unsigned nblk = gridDim.x - check.blocks;
-  if (blockIdx.x < check.blocks) {
-    if (MODE == X_SOLVE && !st->done) tier_check_range(check, op.pairs, op.drift, blockIdx.x, check.blocks);
-    return;
-  }
-  const unsigned bid = blockIdx.x - check.blocks;  // this workgroup's place among the sweeping ones
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;
   const double* xt = X0;
   const double* gt = G0;
   double* xn = X1;
@@ -806,13 +835,112 @@ __device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverS
   }
 }
 
+// (Kept as its own body rather than an instantiation of constraint_sweep: as one, the same sweep ran 10 % slower --
+// 0.144 against 0.130 ms at 10^6 rods -- for reasons the ISA diff of the loop does not show.)
 template <int MODE, int KIN, bool PACKED>
 __global__ void __launch_bounds__(kBlock)
     k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
                  int resid_kind, double* __restrict__ partials, TierCheck check = TierCheck{}) {
-  constraint_sweep<MODE, KIN, PACKED, false>(op, st, X0, X1, G0, G1, q, sp, resid_kind, partials, nullptr, nullptr, check);
+  __shared__ double scratch[2 * kBlock / 64];
+  // (tiered solves) the first check.blocks workgroups of the grid scan the cold tail (a latency-bound loop of dependent
+  // gathers), dispatched ahead of the bandwidth-bound sweep of the others
+  const unsigned nblk = gridDim.x - check.blocks;
+  if (blockIdx.x < check.blocks) {
+    if (MODE == X_SOLVE && !st->done) tier_check_range(check, op.pairs, op.drift, blockIdx.x, check.blocks);
+    return;
+  }
+  const unsigned bid = blockIdx.x - check.blocks;  // this workgroup's place among the sweeping ones
+  const double* xt = X0;
+  const double* gt = G0;
+  double* xn = X1;
+  double* gn = G1;
+  double step = 0.0;
+  if (MODE == X_SOLVE) {
+    if (st->done) return;
+    if (st->flips & 1u) {
+      xt = X1; gt = G1; xn = X0; gn = G0;
+    }
+    step = st->step;
+  }
+  if (MODE == X_INIT) gn = G0;  // g_tmp = A x_tmp + q
+  if (MODE == X_INIT && PACKED) {  // X0 = packed buffer of the first iterate, G0 = the caller's plain x
+    xt = G0;
+    xn = X0;
+  }
+  const double* vel = op.vel;  // the rows the body sweep of this iteration wrote
+  if (MODE == X_SOLVE && op.vel_alt && !(st->flips & 1u)) vel = op.vel_alt;
+  const bool step_is_zero = fabs(-step) < kZeroTol;
+  double rmax = kLowest;
+  DD num{0.0, 0.0}, den{0.0, 0.0};
+  const size_t ntiles = (op.c_end - op.c_first + kBlock - 1) / kBlock;
+  for (size_t lin = bid; lin < ntiles; lin += nblk) {
+    const size_t c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
+    if (c >= op.c_end) continue;
+    const int2 ij = op.pairs[c];
+    double x_old = 0.0, g_old = 0.0;
+    const double xc = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
+    const V3 n = load3(op.normal, c);
+    const double2* vi2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.x);
+    const double2* vj2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.y);
+    const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
+    V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
+    if (KIN == KIN_RIGID) {
+      const double2 a2 = vi2[2], b2 = vj2[2];
+      vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
+      vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    }
+    if (KIN == KIN_ROD) {
+      const double2 a2 = vi2[2], b2 = vj2[2];
+      const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+      vi = vi + ci * V3{a1.y, a2.x, a2.y};
+      vj = vj + cj * V3{b1.y, b2.x, b2.y};
+    }
+    // sdot = -n . (v_src - v_tgt)  (NgpLcp.cpp:526-528)
+    const double sdot = -n.x * (vi.x - vj.x) - n.y * (vi.y - vj.y) - n.z * (vi.z - vj.z);
+    const double y = op.dt * sdot;
+    if (MODE == X_APPLY) {
+      gn[c] = y;
+    } else {
+      const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
+      if (PACKED) {
+        reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
+        if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
+          // masks start all-ones (every contact "active"); flip this contact's two bits when its state changes
+          const bool was = (MODE == X_INIT) ? true : !(x_old == 0.0 && g_old >= 0.0 && g_old <= 1.7976931348623157e308);
+          const bool now = !(xc == 0.0 && g >= 0.0 && g <= 1.7976931348623157e308);
+          if (was != now) {
+            const unsigned pi = op.pos[2 * c], pj = op.pos[2 * c + 1];
+            if (pi < 64u) atomicXor(&op.body_mask[ij.x], 1ull << pi);
+            if (pj < 64u) atomicXor(&op.body_mask[ij.y], 1ull << pj);
+          }
+        }
+      } else {
+        gn[c] = g;
+        if (MODE == X_SOLVE) xn[c] = xc;
+      }
+      if (op.counted == nullptr || op.counted[c]) {
+        const double r = residual_term(resid_kind, xc, g, sp);
+        if (r > rmax) rmax = r;
+        if (MODE == X_SOLVE) {
+          const double dx = xc - x_old;
+          dd_add(num, dx * dx);            // diff_dot(x, x_old)              (convex.hpp:507)
+          dd_add(den, dx * (g - g_old));   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+        }
+      }
+    }
+  }
+  if (MODE != X_APPLY) {
+    const double m = block_max(rmax, scratch);
+    const DD s1 = block_sum(num, scratch);
+    const DD s2 = block_sum(den, scratch);
+    if (threadIdx.x == 0) {  // kRed planes of values: the final pass reads them coalesced
+      const size_t stride = op.part_stride ? op.part_stride : nblk;
+      store_partial(partials, stride, op.part_offset + bid, m, s1, s2);
+    }
+  }
 }
+
 // the woken contacts of a tiered solve's cold tail, from their list (its own name: the profiles tell the sweeps apart)
 template <int KIN>
 __global__ void __launch_bounds__(kBlock)
@@ -820,7 +948,7 @@ __global__ void __launch_bounds__(kBlock)
                         const double* __restrict__ q, Space sp, int resid_kind, double* __restrict__ partials,
                         const int32_t* __restrict__ list, const unsigned long long* __restrict__ tier_counters) {
   constraint_sweep<X_SOLVE, KIN, true, true>(op, st, P0, P1, nullptr, nullptr, q, sp, resid_kind, partials, list,
-                                             tier_counters, TierCheck{});
+                                             tier_counters);
 }
 
 constexpr int kFinalBlock = 1024;  // threads of the single-workgroup final passes
@@ -1471,7 +1599,9 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   const SolverState* st = op->state.as<SolverState>();
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
-    if (packed && M == X_SOLVE)                                                                    \
+    if (packed && M == X_SOLVE && op->view.drift != nullptr && R != KIN_RIGID)                     \
+      k_body<M, R, GG, UU, true, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);  \
+    else if (packed && M == X_SOLVE)                                                               \
       k_body<M, R, GG, UU, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);        \
     else                                                                                           \
       k_body<M, R, GG, UU, false><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);       \

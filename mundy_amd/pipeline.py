@@ -85,6 +85,7 @@ class ContactStepper:
         self.lam = None
         self.contacts = None
         self.work_mapping = None  # (xcd_tile, lanes_per_body) for ContactOperator.set_work_mapping: time only
+        self.tiering = None       # ContactOperator.set_tiering mode (None: the library default): time only
         # BUILD OPTION (None = off, the reference's behaviour: every neighbour pair is a constraint, NgpLcp.cpp:346-373):
         # only pairs within contact_cutoff of touching become constraints of this step (ballot compaction of the
         # candidate list); the dropped pairs are checked afterwards (they must satisfy g >= 0, i.e. stay inactive) and
@@ -237,6 +238,8 @@ class ContactStepper:
                                           rb=c.get("rb"), mob_rot=self.mob_rot, priority=c["sep"])
         if self.work_mapping is not None:
             self.op.set_work_mapping(*self.work_mapping)
+        if self.tiering is not None:
+            self.op.set_tiering(self.tiering)
         if getattr(self, "profile_next", False):
             self.op.set_profiling(True)  # per-kernel HIP-event timing of the fused iteration (bench.py roofline)
         nc = pairs.shape[0]
