@@ -76,11 +76,11 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
     if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
         # cold tier: over the tiered iterations only the hot share h of the contacts is swept in full; a
         # contact of the cold tail costs its pair 8 + wake level 8; the drift table (8 B per body) is read by the tail
-        # scan; the body sweep additionally reads each body's previous row (48) and updates its drift (8 + 8)
+        # scan; the body sweep additionally updates each body's drift (8 + 8)
         w = min(1.0, tier["tiered_iterations"] / float(iterations))
         h = tier["mean_hot_fraction"]
         con = (1.0 - w) * con + w * ((88.0 * h + 16.0 * (1.0 - h)) * contacts + 56.0 * bodies)
-        body += w * 64.0 * bodies
+        body += w * 16.0 * bodies
     return {"k_constraint": con, "k_body": body}
 
 
