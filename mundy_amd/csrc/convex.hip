@@ -1554,7 +1554,7 @@ struct mhip_contact_op {
   DeviceBuffer aptr, aent, arec, snap_mask, acnt;  // active lists (see OpView)
   int device = -1;  // the device current at create: where every buffer of this operator lives
   int tiering = 1;         // the fused solve may use the cold tier (mhip_contact_op_set_tiering); 2: test hook
-  int lanes_per_body = 2;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (16 lanes: 2) half-edge chains in flight
+  int lanes_per_body = 2;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (2 and 16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
   struct Stage {
@@ -1608,7 +1608,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   } while (0)
 #define BODY(M, R)                                    \
   do {                                                \
-    if (G == 2) BODY4(M, R, 2, 4);                    \
+    if (G == 2) BODY4(M, R, 2, 2);                    \
     else if (G == 8) BODY4(M, R, 8, 4);               \
     else if (G == 16) BODY4(M, R, 16, 2);             \
     else BODY4(M, R, 4, 4);                           \
@@ -2361,7 +2361,8 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
     // per sweep; walking only the entries the activity masks flag: (8,4) 0.144, (4,4) 0.137, (2,8) 0.142, (1,8) 0.156.
     // With double-double sums (one rounding per sum): (4,4) 0.138 ms, (2,4) 0.151, (8,4) 0.182, (8,2) 0.156, (4,8) 0.149.
     // With the compact active lists (a sweep streams the active third of a list): (2,4) 0.103 ms, (4,4) 0.108, (8,4)
-    // 0.162, (16,2) 0.255; whole step from the relaxed packing 26.6 ms with two lanes against 28.8 with four.
+    // 0.162, (16,2) 0.255; whole step from the relaxed packing 26.6 ms with two lanes against 28.8 with four; with the
+    // drift bookkeeping of the cold tier (2,2) 0.100, (2,3) 0.103, (2,4) 0.103, (2,6) 0.114.
     // The layout only moves time: the sums, hence the iterates, are the same for every G (tests).
     const double mean_deg = N ? 2.0 * (double)C / (double)N : 0.0;
     op->lanes_per_body = mean_deg <= 24.0 ? 2 : (mean_deg <= 48.0 ? 4 : (mean_deg <= 96.0 ? 8 : 16));
