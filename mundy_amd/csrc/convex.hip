@@ -2662,13 +2662,14 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       enqueued = op->host_state->iter;
     }
     if (op->host_state->done || enqueued >= config->max_iters) break;
-    if (enqueued >= kSnapshotAfter) {
-      if (!tier.disabled) {
-        const unsigned left = config->max_iters - enqueued;
-        if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, s)) return e;
-      }
-      if (int e = op_snapshot_active(op, s)) return e;
+    // cold tier: the drift bookkeeping starts with the first iteration, the first classification comes with the first
+    // snapshot (short solves -- a relaxed packing needs ~100 iterations -- get their tiers early)
+    if (!tier.disabled && (enqueued >= kSnapshotAfter || !tier.tracking)) {
+      const unsigned left = config->max_iters - enqueued;
+      if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, s)) return e;
     }
+    if (enqueued >= kSnapshotAfter)
+      if (int e = op_snapshot_active(op, s)) return e;
     iter_before = op->host_state->iter;
     const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
     for (unsigned k = 0; k < todo; ++k) {
