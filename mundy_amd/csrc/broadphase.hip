@@ -13,7 +13,8 @@
 //   k_lbvh_build    one thread per internal node: Karras' binary radix tree from the longest common prefixes
 //   k_lbvh_refit_pass (x2), _top   bottom-up box union, second arriver at a node proceeds (workgroup-scope tickets)
 //   k_lbvh_ropes    skip pointers -> stackless pre-order traversal
-//   k_lbvh_pairs<COUNT>, scan, k_lbvh_pairs<FILL>   per body: traverse, exact predicate at the leaves
+//   k_lbvh_pairs<COUNT>, scan, k_lbvh_pairs<FILL>   per body: traverse, exact predicate at the leaves (rows of up to 32
+//                   partners are parked in a slab by the first pass: one traversal)
 // Both: rows of <= 32 partners are sorted and emitted by their thread; longer rows (a large body among small ones) go
 // through the workgroup radix sort of sort.hip -> pairs sorted by (i, j) without a global sort.
 // The predicate is evaluated with the lower body index first, exactly as the CPU oracle does, so pair sets are
@@ -649,12 +650,16 @@ __global__ void __launch_bounds__(kBlock)
   else leaf_rope[x - (n - 1)] = rope;
 }
 
-// one thread per body (in key order: the lanes of a wave walk neighbouring paths): stackless traversal
+// one thread per body (in key order: the lanes of a wave walk neighbouring paths): stackless traversal.
+// The tree is walked ONCE for most bodies: the counting pass parks a body's first kSlab partners in a slab
+// (slab[slot * n + q]: lanes of a wave write neighbouring words), the filling pass copies them into the row and walks
+// the tree again only for the bodies with more partners than that.
+constexpr int kSlab = kShortSegment;
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
     k_lbvh_pairs(int n, BpArgs A, const SearchRec* __restrict__ recs, const BvhNode* __restrict__ nodes,
                  const int32_t* __restrict__ leaf_rope, int32_t* __restrict__ counts,
-                 const int32_t* __restrict__ row_ptr, RowSink out) {
+                 const int32_t* __restrict__ row_ptr, RowSink out, int32_t* __restrict__ slab) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
   const SearchRec me = recs[q];
@@ -663,11 +668,19 @@ __global__ void __launch_bounds__(kBlock)
     if (!FILL) counts[i] = 0;
     return;
   }
-  double qlo[3], qhi[3];
-  rec_box(A, me, qlo, qhi);
   int cnt = 0;
   const int32_t base = FILL ? row_ptr[i] : 0;
-  int node = (n == 1) ? 0 : 0;  // n == 1: node 0 is the only leaf
+  if (FILL) {
+    const int have = row_ptr[i + 1] - base;
+    if (have <= kSlab) {  // the counting pass kept the whole row
+      for (int a = 0; a < have; ++a) out.col[base + a] = slab[static_cast<size_t>(a) * n + q];
+      finish_row(out, i, base, have);
+      return;
+    }
+  }
+  double qlo[3], qhi[3];
+  rec_box(A, me, qlo, qhi);
+  int node = 0;  // n == 1: node 0 is the only leaf
   while (node >= 0) {
     if (node < n - 1) {
       const BvhNode nd = nodes[node];
@@ -682,6 +695,7 @@ __global__ void __launch_bounds__(kBlock)
         const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
         if (hit) {
           if (FILL) out.col[base + cnt] = j;
+          else if (cnt < kSlab) slab[static_cast<size_t>(cnt) * n + q] = j;
           ++cnt;
         }
       }
@@ -794,7 +808,7 @@ struct mhip_broadphase {
   DeviceBuffer recs, cell_of, slot_cell, cell_cnt, cell_ptr, cursor, counts, row_ptr, col, pairs, old_center, params,
       partials, scanws, flag, longrows, coltmp;
   // LBVH
-  DeviceBuffer keys, keys_tmp, order, order_tmp, sortws, nodes, right, parent, ticket, pending, leaf_rope, slot_of;
+  DeviceBuffer keys, keys_tmp, order, order_tmp, sortws, nodes, right, parent, ticket, pending, leaf_rope, slot_of, slab;
   // seam S3: source / target sets, identities, exclusion lists (copies owned by the handle)
   size_t sets_n = 0, ident_n = 0, excl_n = 0;
   bool has_source = false, has_target = false, has_ident = false, has_excl = false;
@@ -822,7 +836,7 @@ int mhip_broadphase_destroy(mhip_broadphase_t h) {
   for (DeviceBuffer* b : {&h->recs, &h->cell_of, &h->slot_cell, &h->cell_cnt, &h->cell_ptr, &h->cursor, &h->counts,
                           &h->row_ptr, &h->col, &h->pairs, &h->old_center, &h->params, &h->partials, &h->scanws,
                           &h->flag, &h->longrows, &h->coltmp, &h->keys, &h->keys_tmp, &h->order, &h->order_tmp,
-                          &h->sortws, &h->nodes, &h->right, &h->parent, &h->ticket, &h->pending, &h->leaf_rope, &h->slot_of,
+                          &h->sortws, &h->nodes, &h->right, &h->parent, &h->ticket, &h->pending, &h->leaf_rope, &h->slot_of, &h->slab,
                           &h->is_source, &h->is_target, &h->entity_id, &h->owner_rank, &h->ex_ptr, &h->ex_idx})
     b->release();
   if (h->host_scalar) (void)hipHostFree(h->host_scalar);
@@ -1062,8 +1076,9 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
     k_lbvh_ropes<<<grid_exact(2 * n - 1), kBlock, 0, s>>>(nn, nodes, h->right.as<int32_t>(), h->parent.as<int32_t>(),
                                                          h->leaf_rope.as<int32_t>());
     MHIP_LAUNCH_CHECK();
+    if (int e = h->slab.reserve((static_cast<size_t>(kSlab) * n + 2) * sizeof(int32_t))) return e;
     k_lbvh_pairs<false><<<gb, kBlock, 0, s>>>(nn, A, h->recs.as<SearchRec>(), nodes, h->leaf_rope.as<int32_t>(),
-                                             h->counts.as<int32_t>(), nullptr, none);
+                                             h->counts.as<int32_t>(), nullptr, none, h->slab.as<int32_t>());
     MHIP_LAUNCH_CHECK();
   }
 
@@ -1089,7 +1104,8 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
                                          h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
   } else {
     k_lbvh_pairs<true><<<gb, kBlock, 0, s>>>(nn, A, h->recs.as<SearchRec>(), h->nodes.as<BvhNode>(),
-                                            h->leaf_rope.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
+                                            h->leaf_rope.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink,
+                                            h->slab.as<int32_t>());
   }
   MHIP_LAUNCH_CHECK();
   // rows with more than kShortSegment partners: workgroup radix sort, then their pairs
