@@ -647,7 +647,7 @@ int mhip_migrate_exchange(mhip_comm_t c, size_t width, const double* records, do
   MHIP_REQUIRE(width >= 1, MHIP_ERR_INVALID_ARGUMENT, "width must be at least 1");
   MHIP_REQUIRE(mp.n == 0 || records != nullptr, MHIP_ERR_INVALID_ARGUMENT, "records is null");
   MHIP_REQUIRE(mp.n_new == 0 || out != nullptr, MHIP_ERR_INVALID_ARGUMENT, "out is null");
-  MHIP_REQUIRE(out != records, MHIP_ERR_INVALID_ARGUMENT, "the exchange cannot run in place");
+  MHIP_REQUIRE(out == nullptr || out != records, MHIP_ERR_INVALID_ARGUMENT, "the exchange cannot run in place");
   hipStream_t s = as_stream(stream);
   if (int e = mp.stage.reserve((mp.n * width + 2) * sizeof(double))) return e;
   double* packed = mp.stage.as<double>();  // the owned rows grouped by destination, each group in its present order

@@ -67,6 +67,14 @@ def test_three_ranks_40_steps_bodies_migrate_and_the_curve_is_recut_by_work():
                    "DIST_BUFFER": "0.3"})
 
 
+@pytest.mark.parametrize("bodies", [2, 7])
+def test_migration_when_ranks_own_nothing(bodies):
+    # the curve cut, the migration plan and the exchange with ranks that own no body at all (3 ranks, 2 or 7 bodies):
+    # every rank still takes part in every collective, nobody is lost, the trajectory is the single-rank one
+    _run(3, None, {"DIST_STEPS": "6", "DIST_MIGRATE": "1", "DIST_MIGRATE_ANY": "1", "DIST_BODIES": str(bodies),
+                   "DIST_PHI": "0.5"})
+
+
 def test_distributed_mixed_shapes_equals_single_rank():
     # BASELINE configs[4] as a parity case: spheres + spherocylinders + ellipsoids, Hilbert-partitioned over 2 ranks
     _run(2, 29620, {"DIST_MIXED": "1", "DIST_BODIES": "9000"})
