@@ -1736,6 +1736,10 @@ constexpr size_t kTierMinContacts = 65536;  // smaller problems are launch-bound
 // workgroups that scan the cold tail.  The scan is a chain of dependent gathers: it needs the waves (10^6 rods, whole
 // step: 128 workgroups 260 ms, 256: 204, 512: 180.3, 1024: 178.5, 2048: 178.9; scripts/ab_tier_scan.sh)
 constexpr unsigned kTierScanBlocks = MHIP_TIER_SCAN_BLOCKS;
+#ifndef MHIP_TIER_LIST_BLOCKS
+#define MHIP_TIER_LIST_BLOCKS 256
+#endif
+constexpr unsigned kTierListBlocks = MHIP_TIER_LIST_BLOCKS;  // workgroups of the listed sweep (grid-stride)
 
 struct TierGeo {
   int2* pairs;
@@ -2087,7 +2091,7 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   // the tail: scanned by extra workgroups of the hot launch (a latency-bound scan under a bandwidth-bound sweep), its
   // awake contacts then evaluated by a small grid-stride launch
   const unsigned gcheck = t.H < C ? (grid_for(C - t.H) < kTierScanBlocks ? grid_for(C - t.H) : kTierScanBlocks) : 0u;
-  const unsigned glist = t.H < C ? (grid_for(C - t.H) < 256u ? grid_for(C - t.H) : 256u) : 0u;
+  const unsigned glist = t.H < C ? (grid_for(C - t.H) < kTierListBlocks ? grid_for(C - t.H) : kTierListBlocks) : 0u;
   OpView hot = op->view, listed = op->view;
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
   listed.part_offset = ghot; listed.part_stride = kStageStride;
