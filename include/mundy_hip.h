@@ -340,8 +340,8 @@ int mhip_contact_op_set_work_mapping(mhip_contact_op_t handle, int xcd_tile, int
  * the solve therefore renumbers the contacts hot-first and sweeps the cold tail only through those bounds (16 streamed
  * bytes per sleeping contact instead of 88); a contact that reaches its bound is evaluated like any other again.  Same
  * iterates, bit for bit, and the same iteration count as with tiering off (every sum is a double-double pair rounded
- * once, so the partition of the contacts does not reach the sums).  LCP solves of spheres and rods with at least 65 536
- * contacts; mode 0 = off, 1 = on (default), 2 = test hook: leave the tiers after the first tiered iteration, as the
+ * once, so the partition of the contacts does not reach the sums).  LCP solves (any of the three operator forms) with at
+ * least 65 536 contacts; mode 0 = off, 1 = on (default), 2 = test hook: leave the tiers after the first tiered iteration, as the
  * solve does before a BB step outside [0, finite].
  * tier_stats: iterations that ran tiered, mean share of hot contacts over them, renumberings, contacts woken. */
 int mhip_contact_op_set_tiering(mhip_contact_op_t handle, int mode);

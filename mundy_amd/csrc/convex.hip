@@ -403,6 +403,7 @@ struct OpView {
   // null = off.
   double* vel_alt;
   double* drift;
+  const double* arm_max;  // [N] (vector-arm operator, tiered solves) longest lever arm of each body's contacts
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
@@ -492,7 +493,7 @@ __global__ void __launch_bounds__(kBlock)
   // multipliers (F_new - F_old = sum +/- (lam - x_old) n over the entries walked: an entry that is not walked has
   // lam = x_old = 0) -- no second pass over the rows
   // (a template parameter: carried as a run-time flag the bookkeeping cost the untracked sweep 6 % in registers)
-  constexpr bool track = TRACK && MODE == X_SOLVE && PACKED && KIN != KIN_RIGID;
+  constexpr bool track = TRACK && MODE == X_SOLVE && PACKED;
   V3 dF{0.0, 0.0, 0.0}, dS{0.0, 0.0, 0.0};
   if (sub == 0) {
     mt = op.mt[b];
@@ -552,6 +553,7 @@ __global__ void __launch_bounds__(kBlock)
         const V3 df{dl * n.x, dl * n.y, dl * n.z};
         dF = dF + df;
         if (KIN == KIN_ROD) dS = dS + h1[u].y * df;
+        if (KIN == KIN_RIGID) dS = dS + cross(V3{h1[u].y, h2[u].x, h2[u].y}, df);  // change of the torque
       }
       if (lam[u] == 0.0) continue;
       V3 f{lam[u] * n.x, lam[u] * n.y, lam[u] * n.z};
@@ -621,7 +623,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) {
       dF = dF + V3{__shfl_xor(dF.x, off, 64), __shfl_xor(dF.y, off, 64), __shfl_xor(dF.z, off, 64)};
-      if (KIN == KIN_ROD) dS = dS + V3{__shfl_xor(dS.x, off, 64), __shfl_xor(dS.y, off, 64), __shfl_xor(dS.z, off, 64)};
+      if (KIN != KIN_TRANS) dS = dS + V3{__shfl_xor(dS.x, off, 64), __shfl_xor(dS.y, off, 64), __shfl_xor(dS.z, off, 64)};
     }
   }
   if (sub != 0) return;
@@ -648,6 +650,8 @@ __global__ void __launch_bounds__(kBlock)
       const V3 dZ = cross(V3{mr * tq.x, mr * tq.y, mr * tq.z}, axis);
       d += 0.5 * (fabs(dZ.x) + fabs(dZ.y) + fabs(dZ.z));
     }
+    // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|, dW = mr dT
+    if (KIN == KIN_RIGID) d += op.arm_max[b] * mr * (fabs(dS.x) + fabs(dS.y) + fabs(dS.z));
     op.drift[b] += op.dt * d;
   }
 }
@@ -1574,7 +1578,7 @@ struct mhip_contact_op {
     double* saved_vel = nullptr;
     int set = 0;            // geometry / iterate set in use
     size_t H = 0;           // hot contacts [0, H), cold tail [H, C)
-    DeviceBuffer geo[2], iter[2], misc, vel2, drift;
+    DeviceBuffer geo[2], iter[2], misc, vel2, drift, arm;
     OpView saved{};         // the operator's own view, restored when the tiers are left
     // statistics of the last solve
     size_t tiered_iterations = 0, retiers = 0, wakeups = 0;
@@ -1599,7 +1603,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   const SolverState* st = op->state.as<SolverState>();
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
-    if (packed && M == X_SOLVE && op->view.drift != nullptr && R != KIN_RIGID)                     \
+    if (packed && M == X_SOLVE && op->view.drift != nullptr)                                       \
       k_body<M, R, GG, UU, true, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);  \
     else if (packed && M == X_SOLVE)                                                               \
       k_body<M, R, GG, UU, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);        \
@@ -1713,7 +1717,7 @@ constexpr unsigned kSnapshotAfter = 8;
 // of both BB sums.  What must never be missed is the iteration in which its gradient turns non-positive -- and that
 // can be bounded: the gradient is sep + dt * sdot, sdot is a contraction of the two bodies' contact-point velocities
 // with the unit normal, so between two iterates it moves by at most the bodies' drifts (k_body accumulates
-// drift[b] += dt (|dU|_1 + |dZ|_1 / 2) every sweep).  A contact that goes cold at gradient g0 > 0 with the drifts at
+// drift[b] += dt (|dU|_1 + |dZ|_1 / 2) every sweep; with vector arms dt (|dU|_1 + |dW|_1 max|r|)).  A contact that goes cold at gradient g0 > 0 with the drifts at
 // D0 has g > g0 / 2 > 0 for as long as  drift[i] + drift[j] < D0 + g0 / 2  =: its wake level.
 //   At a convergence poll the contacts are RENUMBERED hot-first (stable partition): geometry, q, the slot table and
 //   both packed iterates are copied into that order, the incidence entries are remapped, the compact active lists
@@ -1743,13 +1747,14 @@ constexpr unsigned kTierListBlocks = MHIP_TIER_LIST_BLOCKS;  // workgroups of th
 
 struct TierGeo {
   int2* pairs;
-  double *normal, *arc_s, *arc_t, *q;
+  double *normal, *arc_s, *arc_t, *q, *ra, *rb;
   int32_t* orig;
   unsigned char* pos;
 };
 inline size_t tier_align(size_t b) { return (b + 255) & ~static_cast<size_t>(255); }
-inline size_t tier_geo_bytes(size_t C) {
-  return tier_align(C * 8) + tier_align(3 * C * 8) + 3 * tier_align(C * 8) + tier_align(C * 4) + tier_align(2 * C) + 256;
+inline size_t tier_geo_bytes(size_t C, bool arms) {
+  return tier_align(C * 8) + tier_align(3 * C * 8) + 3 * tier_align(C * 8) + tier_align(C * 4) + tier_align(2 * C) +
+         (arms ? 2 * tier_align(3 * C * 8) : 0) + 256;
 }
 inline TierGeo tier_geo_at(void* base, size_t C) {
   char* p = static_cast<char*>(base);
@@ -1760,7 +1765,9 @@ inline TierGeo tier_geo_at(void* base, size_t C) {
   g.arc_t = reinterpret_cast<double*>(p); p += tier_align(C * 8);
   g.q = reinterpret_cast<double*>(p); p += tier_align(C * 8);
   g.orig = reinterpret_cast<int32_t*>(p); p += tier_align(C * 4);
-  g.pos = reinterpret_cast<unsigned char*>(p);
+  g.pos = reinterpret_cast<unsigned char*>(p); p += tier_align(2 * C);
+  g.ra = reinterpret_cast<double*>(p); p += tier_align(3 * C * 8);  // (only reserved for the vector-arm operator)
+  g.rb = reinterpret_cast<double*>(p);
   return g;
 }
 struct TierMisc {
@@ -1797,6 +1804,19 @@ __global__ void __launch_bounds__(kBlock) k_tier_budget(size_t N, const double* 
     drift_prev[b] = d;
   }
 }
+// vector-arm operator: arm_max[b] = the longest lever arm among body b's half-edge records (n, r)
+__global__ void __launch_bounds__(kBlock) k_tier_arm_max(size_t N, const int32_t* __restrict__ inc_ptr,
+                                                        const double* __restrict__ half, double* __restrict__ arm_max) {
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x) {
+    double m = 0.0;
+    for (int32_t k = inc_ptr[b]; k < inc_ptr[b + 1]; ++k) {
+      const double* H = half + static_cast<size_t>(k) * 6;
+      const double r = sqrt(H[3] * H[3] + H[4] * H[4] + H[5] * H[5]);
+      if (r > m) m = r;
+    }
+    arm_max[b] = m * (1.0 + 1e-12);
+  }
+}
 // flags[c] = 1: hot.  H_old = C when the solve is not tiered yet (nobody is asleep).
 __global__ void __launch_bounds__(kBlock)
     k_tier_classify(size_t C, const int2* __restrict__ pairs, const double2* __restrict__ Pcur,
@@ -1821,8 +1841,9 @@ __global__ void __launch_bounds__(kBlock)
 template <int KIN>
 __global__ void __launch_bounds__(kBlock)
     k_tier_permute(size_t C, size_t H, int cur_is_p1, const int2* __restrict__ pairs, const double* __restrict__ normal,
-                   const double* __restrict__ arc_s, const double* __restrict__ arc_t, const double* __restrict__ q,
-                   const int32_t* __restrict__ orig, const unsigned char* __restrict__ pos, TierGeo dst,
+                   const double* __restrict__ arc_s, const double* __restrict__ arc_t, const double* __restrict__ ra,
+                   const double* __restrict__ rb, const double* __restrict__ q, const int32_t* __restrict__ orig,
+                   const unsigned char* __restrict__ pos, TierGeo dst,
                    const double2* __restrict__ P0s, const double2* __restrict__ P1s, double2* __restrict__ P0d,
                    double2* __restrict__ P1d, const int32_t* __restrict__ flags, const int32_t* __restrict__ rank,
                    int32_t* __restrict__ new_of, const double* __restrict__ wake_old, size_t H_old,
@@ -1838,6 +1859,10 @@ __global__ void __launch_bounds__(kBlock)
     if (KIN == KIN_ROD) {
       dst.arc_s[nc] = arc_s[c];
       dst.arc_t[nc] = arc_t[c];
+    }
+    if (KIN == KIN_RIGID) {
+      store3(dst.ra, nc, load3(ra, c));
+      store3(dst.rb, nc, load3(rb, c));
     }
     dst.q[nc] = q[c];
     dst.orig[nc] = orig ? orig[c] : static_cast<int32_t>(c);
@@ -1913,7 +1938,7 @@ __global__ void __launch_bounds__(kBlock)
 
 bool tier_eligible(const mhip_contact_op* op, const Space& sp, int resid_kind) {
   const OpView& v = op->view;
-  return (op->kin == KIN_ROD || op->kin == KIN_TRANS) && v.C >= kTierMinContacts && v.body_mask != nullptr &&
+  return v.C >= kTierMinContacts && v.body_mask != nullptr &&
          v.counted == nullptr && v.body_first == 0 && v.body_count == v.N && sp.kind == MHIP_SPACE_LOWER_BOUND &&
          sp.lo == 0.0 && resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF;
 }
@@ -1943,6 +1968,12 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     MHIP_HIP(hipMemsetAsync(m.drift_prev, 0, N * sizeof(double), s));
     // the body rows start to ping-pong: the current rows must sit in the buffer of the current parity
     if (cur_is_p1) MHIP_HIP(hipMemcpyAsync(t.vel2.ptr, v.vel, 6 * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (op->kin == KIN_RIGID) {  // the drift of a body with vector arms is scaled by its longest arm
+      if (int e = t.arm.reserve((N + 8) * sizeof(double))) return e;
+      k_tier_arm_max<<<grid_for(N), kBlock, 0, s>>>(N, v.inc_ptr, v.half, t.arm.as<double>());
+      MHIP_LAUNCH_CHECK();
+      v.arm_max = t.arm.as<double>();
+    }
     t.saved_vel = v.vel;
     v.vel_alt = t.vel2.as<double>();
     v.drift = t.drift.as<double>();
@@ -1978,7 +2009,7 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     return MHIP_SUCCESS;  // (almost) everything is hot: nothing to gain yet
   }
   const int dst_set = t.active ? (t.set ^ 1) : 0;
-  if (int e = t.geo[dst_set].reserve(tier_geo_bytes(C))) return e;
+  if (int e = t.geo[dst_set].reserve(tier_geo_bytes(C, op->kin == KIN_RIGID))) return e;
   if (int e = t.iter[dst_set].reserve(2 * (C + 1) * sizeof(double2))) return e;
   const TierGeo dst = tier_geo_at(t.geo[dst_set].ptr, C);
   double2* P0d = t.iter[dst_set].as<double2>();
@@ -1989,12 +2020,13 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   else
     t.saved = v;
 #define PERMUTE(K)                                                                                                    \
-  k_tier_permute<K><<<grid_for(C), kBlock, 0, s>>>(C, H, cur_is_p1 ? 1 : 0, v.pairs, v.normal, v.arc_s, v.arc_t, cur.q, \
+  k_tier_permute<K><<<grid_for(C), kBlock, 0, s>>>(C, H, cur_is_p1 ? 1 : 0, v.pairs, v.normal, v.arc_s, v.arc_t, v.ra, \
+                                                   v.rb, cur.q,                                                      \
                                                    orig_src, v.pos, dst, reinterpret_cast<const double2*>(cur.P0),   \
                                                    reinterpret_cast<const double2*>(cur.P1), P0d, P1d, m.flags,      \
                                                    m.rank, m.new_of, wake_old, H_old, m.wake[dst_set],               \
                                                    t.drift.as<double>())
-  if (op->kin == KIN_ROD) PERMUTE(KIN_ROD); else PERMUTE(KIN_TRANS);
+  if (op->kin == KIN_ROD) PERMUTE(KIN_ROD); else if (op->kin == KIN_RIGID) PERMUTE(KIN_RIGID); else PERMUTE(KIN_TRANS);
 #undef PERMUTE
   MHIP_LAUNCH_CHECK();
   k_tier_remap_inc<<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>(), m.new_of);
@@ -2004,6 +2036,10 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   v.normal = dst.normal;
   v.arc_s = dst.arc_s;
   v.arc_t = dst.arc_t;
+  if (op->kin == KIN_RIGID) {
+    v.ra = dst.ra;
+    v.rb = dst.rb;
+  }
   v.pos = dst.pos;
   cur.P0 = reinterpret_cast<double*>(P0d);
   cur.P1 = reinterpret_cast<double*>(P1d);
@@ -2047,6 +2083,8 @@ int tier_release(mhip_contact_op* op, TierPairs& cur, bool final, double* P0, do
     const unsigned grid = grid_for(C - t.H);
     if (op->kin == KIN_ROD)
       k_tier_refresh_sleepers<KIN_ROD><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
+    else if (op->kin == KIN_RIGID)
+      k_tier_refresh_sleepers<KIN_RIGID><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
     else
       k_tier_refresh_sleepers<KIN_TRANS><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
     MHIP_LAUNCH_CHECK();
@@ -2105,7 +2143,7 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
       k_constraint_listed<K><<<glist, kBlock, 0, s>>>(listed, st, cur.P0, cur.P1, cur.q, sp, resid_kind, parts,    \
                                                      m.list, m.counters);                                          \
   } while (0)
-  if (op->kin == KIN_ROD) TIERED(KIN_ROD); else TIERED(KIN_TRANS);
+  if (op->kin == KIN_ROD) TIERED(KIN_ROD); else if (op->kin == KIN_RIGID) TIERED(KIN_RIGID); else TIERED(KIN_TRANS);
 #undef TIERED
   MHIP_LAUNCH_CHECK();
   *nparts = ghot + glist;
@@ -2236,7 +2274,7 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
 // pinned state block, timing events -- are the same size step after step.  A destroyed operator therefore leaves them
 // in one process-wide spare set that the next create adopts: no hipMalloc / hipFree in the steady state (hipFree
 // alone cost 1.6 ms per step at 10^6 rods).  mhip_release_cached_workspaces() frees the spare set.
-constexpr int kOpBuffers = 28;
+constexpr int kOpBuffers = 29;
 struct OpWorkspaces {
   DeviceBuffer buf[kOpBuffers];
   SolverState* host_state = nullptr;
@@ -2252,7 +2290,7 @@ static DeviceBuffer* op_buffers(mhip_contact_op* op, int k) {
                                    &op->body_mask, &op->pos,   &op->sort_tmp, &op->sort_list, &op->aptr,    &op->aent,
                                    &op->arec,    &op->snap_mask, &op->acnt,
                                    &op->tier.geo[0], &op->tier.geo[1], &op->tier.iter[0], &op->tier.iter[1],
-                                   &op->tier.misc, &op->tier.vel2, &op->tier.drift};
+                                   &op->tier.misc, &op->tier.vel2, &op->tier.drift, &op->tier.arm};
   return all[k];
 }
 static void free_workspaces(OpWorkspaces& w) {

@@ -538,7 +538,7 @@ def test_fill_and_deep_copy(ops):
         assert torch.equal(u[1:n + 1], t[1:n + 1]) and float(u[0]) == 0.0 and float(u[-1]) == 0.0
 
 
-@pytest.mark.parametrize("maker,n", [(_sphere_problem, 60000), (_rod_problem_arclength, 12000)])
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 60000), (_rod_problem_arclength, 12000), (_rod_problem, 12000)])
 def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
     # the fused solve keeps inactive contacts in a cold tier from the first convergence poll on (renumbered hot-first,
     # the tail swept only through drift bounds): x, g and the previous iterate, the iteration count and the body
