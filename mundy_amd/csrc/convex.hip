@@ -404,6 +404,11 @@ struct OpView {
   double* vel_alt;
   double* drift;
   const double* arm_max;  // [N] (vector-arm operator, tiered solves) longest lever arm of each body's contacts
+  // tiered solves: a body whose drift reaches fire_at[b] has a sleeping contact to wake: the body sweep lists it in
+  // fired (tier_counters[1] = length).  null = nobody sleeps.
+  const double* fire_at;
+  int32_t* fired;
+  unsigned long long* tier_counters;
 };
 
 // XCD-aware work mapping (MI355X: 8 XCDs, each with a private 4 MiB L2; workgroups are dealt round-robin over the XCDs,
@@ -652,7 +657,10 @@ __global__ void __launch_bounds__(kBlock)
     }
     // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|, dW = mr dT
     if (KIN == KIN_RIGID) d += op.arm_max[b] * mr * (fabs(dS.x) + fabs(dS.y) + fabs(dS.z));
-    op.drift[b] += op.dt * d;
+    const double D = op.drift[b] + op.dt * d;
+    op.drift[b] = D;
+    if (op.fire_at != nullptr && !(D < op.fire_at[b]))  // one of its sleeping contacts has used up its share of slack
+      op.fired[atomicAdd(&op.tier_counters[1], 1ull)] = static_cast<int32_t>(b);
   }
 }
 
@@ -691,59 +699,50 @@ __device__ inline double contact_dt_sdot(const OpView& op, const double* __restr
   return op.dt * sdot;
 }
 
-// Cold tail of a tiered solve ("Cold tier" below): the scan of [H, C) by workgroups `block` of `nblocks`.  Contacts
-// whose bodies have drifted up to their wake level are listed (one atomic per wavefront) and marked awake (level =
-// -inf); k_constraint<LISTED> evaluates the list, this iteration and after.
+// Cold tail of a tiered solve ("Cold tier" below).  A sleeping contact (i, j) holds two thresholds, thr[0] for drift[i]
+// and thr[1] for drift[j] (each body gets half the contact's slack); fire_at[b] is the smallest threshold among b's
+// sleeping contacts.  The body sweep lists the bodies whose drift has reached fire_at; the first `blocks` workgroups of
+// the constraint sweep's grid then walk those bodies' incidence lists, wake the contacts whose threshold is reached
+// (they go to `list`: k_constraint_listed evaluates them, this iteration and after) and reset fire_at to the smallest
+// threshold left.  A handful of bodies per iteration: nothing scans the tail.
 struct TierCheck {
-  size_t H, C;
-  double* wake;        // [C - H]
-  int32_t* list;       // awake contacts of the tail
-  unsigned long long* counters;  // [0] = length of list
-  unsigned blocks;     // workgroups at the end of the grid that scan instead of sweeping
+  size_t H;                      // cold tail = contacts [H, C)
+  double* wake;                  // [C - H][2] thresholds; thr[0] = -inf: awake
+  int32_t* list;                 // awake contacts of the tail
+  unsigned long long* counters;  // [0] = length of list, [1] = length of fired
+  const int32_t* fired;          // bodies listed by the body sweep
+  double* fire_at;               // [N]
+  unsigned blocks;               // workgroups at the front of the grid that do this instead of sweeping
 };
-__device__ inline void tier_check_range(const TierCheck& tc, const int2* __restrict__ pairs,
-                                        const double* __restrict__ drift, unsigned block, unsigned nblocks) {
-  const int lane = threadIdx.x & 63;
-  constexpr int kChains = 4;  // tiles in flight per workgroup: the gathers of one tile overlap the next one's
-  const size_t span = (size_t)blockDim.x * kChains;
-  for (size_t base = tc.H + block * span; base < tc.C; base += (size_t)nblocks * span) {
-    double level[kChains];
-    int2 ij[kChains];
-    bool live[kChains];
-#pragma unroll
-    for (int u = 0; u < kChains; ++u) {
-      const size_t c = base + (size_t)u * blockDim.x + threadIdx.x;
-      live[u] = false;
-      level[u] = 0.0;
-      ij[u] = make_int2(0, 0);
-      if (c < tc.C) {
-        level[u] = tc.wake[c - tc.H];
-        live[u] = level[u] > -1.7976931348623157e308;
-        if (live[u]) ij[u] = pairs[c];
+__device__ inline void tier_fire_range(const TierCheck& tc, const int32_t* __restrict__ inc_ptr,
+                                       const int32_t* __restrict__ inc, const double* __restrict__ drift,
+                                       unsigned block, unsigned nblocks) {
+  const size_t count = static_cast<size_t>(tc.counters[1]);
+  const double ninf = -__builtin_huge_val();
+  for (size_t q = block * (size_t)blockDim.x + threadIdx.x; q < count; q += (size_t)nblocks * blockDim.x) {
+    const size_t b = static_cast<size_t>(tc.fired[q]);
+    const double D = drift[b];
+    double left = __builtin_huge_val();
+    for (int32_t k = inc_ptr[b]; k < inc_ptr[b + 1]; ++k) {
+      const int32_t e = inc[k];
+      const size_t c = static_cast<size_t>(e >> 1);
+      if (c < tc.H) continue;
+      double* thr = tc.wake + 2 * (c - tc.H);
+      const double mine = thr[e & 1];
+      if (!(thr[0] > ninf)) continue;  // awake already
+      if (D < mine) {
+        if (mine < left) left = mine;
+        continue;
+      }
+      // wake it; the contact's other body may be doing the same right now: slot 0 decides who lists it
+      const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(thr),
+                                                static_cast<unsigned long long>(__double_as_longlong(ninf)));
+      if (__longlong_as_double(static_cast<long long>(old)) > ninf) {
+        thr[1] = ninf;
+        tc.list[atomicAdd(&tc.counters[0], 1ull)] = static_cast<int32_t>(c);
       }
     }
-    double di[kChains], dj[kChains];
-#pragma unroll
-    for (int u = 0; u < kChains; ++u) {
-      di[u] = live[u] ? drift[ij[u].x] : 0.0;
-      dj[u] = live[u] ? drift[ij[u].y] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < kChains; ++u) {
-      const size_t c = base + (size_t)u * blockDim.x + threadIdx.x;
-      const bool woke = live[u] && !(di[u] + dj[u] < level[u]);
-      const unsigned long long m = __ballot(woke);
-      if (m) {
-        const int leader = __ffsll(static_cast<long long>(m)) - 1;
-        unsigned long long at = 0;
-        if (lane == leader) at = atomicAdd(&tc.counters[0], static_cast<unsigned long long>(__popcll(m)));
-        at = __shfl(at, leader, 64);
-        if (woke) {
-          tc.list[at + __popcll(m & ((1ull << lane) - 1ull))] = static_cast<int32_t>(c);
-          tc.wake[c - tc.H] = -__builtin_huge_val();
-        }
-      }
-    }
+    tc.fire_at[b] = left;
   }
 }
 
@@ -847,11 +846,10 @@ __global__ void __launch_bounds__(kBlock)
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
                  int resid_kind, double* __restrict__ partials, TierCheck check = TierCheck{}) {
   __shared__ double scratch[2 * kBlock / 64];
-  // (tiered solves) the first check.blocks workgroups of the grid scan the cold tail (a latency-bound loop of dependent
-  // gathers), dispatched ahead of the bandwidth-bound sweep of the others
+  // (tiered solves) the first check.blocks workgroups of the grid wake the sleeping contacts of the bodies that fired
   const unsigned nblk = gridDim.x - check.blocks;
   if (blockIdx.x < check.blocks) {
-    if (MODE == X_SOLVE && !st->done) tier_check_range(check, op.pairs, op.drift, blockIdx.x, check.blocks);
+    if (MODE == X_SOLVE && !st->done) tier_fire_range(check, op.inc_ptr, op.inc, op.drift, blockIdx.x, check.blocks);
     return;
   }
   const unsigned bid = blockIdx.x - check.blocks;  // this workgroup's place among the sweeping ones
@@ -996,13 +994,15 @@ __global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, size_t str
 template <int MODE>
 __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const double* __restrict__ partials, size_t si,
                                                          size_t sk, SolverState* __restrict__ st, int resid_kind,
-                                                         double tol, unsigned max_iters, int tiered = 0) {
+                                                         double tol, unsigned max_iters, int tiered = 0,
+                                                         unsigned long long* __restrict__ tier_counters = nullptr) {
   __shared__ double scratch[2 * kFinalBlock / 64];
   if (MODE == X_SOLVE && st->done) return;
   double rmax;
   DD numdd, dendd;
   reduce_records(nparts, partials, si, sk, scratch, rmax, numdd, dendd);
   if (threadIdx.x != 0) return;
+  if (tier_counters) tier_counters[1] = 0;  // the fired bodies of this iteration have been dealt with
   const double num = dd_value(numdd);  // the BB dot products, each rounded once
   double den = dd_value(dendd);
   const double res = (resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF) ? rmax / kSmallStep : rmax;
@@ -1718,28 +1718,27 @@ constexpr unsigned kSnapshotAfter = 8;
 // can be bounded: the gradient is sep + dt * sdot, sdot is a contraction of the two bodies' contact-point velocities
 // with the unit normal, so between two iterates it moves by at most the bodies' drifts (k_body accumulates
 // drift[b] += dt (|dU|_1 + |dZ|_1 / 2) every sweep; with vector arms dt (|dU|_1 + |dW|_1 max|r|)).  A contact that goes cold at gradient g0 > 0 with the drifts at
-// D0 has g > g0 / 2 > 0 for as long as  drift[i] + drift[j] < D0 + g0 / 2  =: its wake level.
+// D0 has g > g0 / 2 > 0 for as long as  drift[i] + drift[j] < D0 + g0 / 2 -- in particular while each body stays below
+// a threshold of its own, drift[i] < D0_i + g0 / 4 and drift[j] < D0_j + g0 / 4.
 //   At a convergence poll the contacts are RENUMBERED hot-first (stable partition): geometry, q, the slot table and
 //   both packed iterates are copied into that order, the incidence entries are remapped, the compact active lists
-//   rebuilt.  A contact goes to the cold tail when x == 0 in the last two iterates and half its gradient exceeds what
-//   its two bodies are expected to drift until the next poll (their drift over the last period, scaled to the length
-//   of the next one).  The ordinary sweep then runs over [0, H) only.  The tail [H, C) is scanned by k_tier_check -- 16
-//   streamed bytes and two L2-resident gathers per sleeping contact -- which lists the contacts that have reached
-//   their level; k_constraint<LISTED> evaluates the listed ones, from then on every iteration, exactly as the ordinary
-//   sweep would (a sleeper's stale pair says x = 0, g > 0, which is all an evaluation uses of an inactive contact:
-//   Proj(0 - step g) = 0 and dx = 0).  Every sum is a double-double pair rounded once, so the partition does not reach
-//   the iterates: same bits, same iteration count as the untiered solve (tests).
+//   rebuilt.  A contact goes to the cold tail when x == 0 in the last two iterates and a quarter of its gradient
+//   exceeds what either of its bodies is expected to drift until the next poll (its drift over the last period, scaled
+//   to the length of the next one).  (Sharing the slack in proportion to the two expectations instead tiers 64
+//   iterations earlier on the raw packing but wakes 2.3 x as many contacts: same step time, relaxed steps 5 % slower.)  The ordinary sweep then runs over [0, H) only.  Nothing scans the tail: every body
+//   knows the smallest threshold among its sleeping contacts (fire_at), the body sweep -- which has just updated the
+//   body's drift -- lists the bodies that reached it, and a few workgroups at the front of the constraint sweep's grid
+//   walk those bodies' incidence lists and wake the contacts concerned (TierCheck).  k_constraint_listed evaluates the
+//   awake contacts of the tail, from then on every iteration, exactly as the ordinary sweep would (a sleeper's stale
+//   pair says x = 0, g > 0, which is all an evaluation uses of an inactive contact: Proj(0 - step g) = 0 and dx = 0).
+//   Every sum is a double-double pair rounded once, so the partition does not reach the iterates: same bits, same
+//   iteration count as the untiered solve (tests).
 //   Leaving the tiers (end of the solve, or a BB step outside [0, finite], which would need the sleepers' exact
 //   gradients -- k_finalize pauses the solve for that): the sleepers' gradients are evaluated for the last two iterates
 //   from the two body-row buffers, everything is scattered back to the caller's numbering, inc is restored.
 constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g above this (far above rounding noise)
 constexpr size_t kTierMinContacts = 65536;  // smaller problems are launch-bound: not worth the bookkeeping
-#ifndef MHIP_TIER_SCAN_BLOCKS
-#define MHIP_TIER_SCAN_BLOCKS 2048
-#endif
-// workgroups that scan the cold tail.  The scan is a chain of dependent gathers: it needs the waves (10^6 rods, whole
-// step: 128 workgroups 260 ms, 256: 204, 512: 180.3, 1024: 178.5, 2048: 178.9; scripts/ab_tier_scan.sh)
-constexpr unsigned kTierScanBlocks = MHIP_TIER_SCAN_BLOCKS;
+constexpr unsigned kTierFireBlocks = 8;  // workgroups that wake the sleeping contacts of fired bodies (a multiple of 8: XCDs)
 #ifndef MHIP_TIER_LIST_BLOCKS
 #define MHIP_TIER_LIST_BLOCKS 256
 #endif
@@ -1771,13 +1770,14 @@ inline TierGeo tier_geo_at(void* base, size_t C) {
   return g;
 }
 struct TierMisc {
-  int32_t *flags, *rank, *new_of, *list;
-  double* wake[2];
-  double *budget, *drift_prev;
-  unsigned long long* counters;  // [0]: contacts of the tail that are awake (= length of list)
+  int32_t *flags, *rank, *new_of, *list, *fired;
+  double* wake[2];  // [C][2] thresholds of the cold tail (see TierCheck)
+  double *budget, *drift_prev, *fire_at;
+  unsigned long long* counters;  // [0]: awake contacts of the tail (= length of list); [1]: bodies fired this iteration
 };
 inline size_t tier_misc_bytes(size_t C, size_t N) {
-  return 4 * tier_align((C + 2) * 4) + 2 * tier_align((C + 2) * 8) + 2 * tier_align((N + 2) * 8) + 256;
+  return 4 * tier_align((C + 2) * 4) + tier_align((N + 2) * 4) + 2 * tier_align((2 * C + 4) * 8) +
+         3 * tier_align((N + 2) * 8) + 256;
 }
 inline TierMisc tier_misc_at(void* base, size_t C, size_t N) {
   char* p = static_cast<char*>(base);
@@ -1786,10 +1786,12 @@ inline TierMisc tier_misc_at(void* base, size_t C, size_t N) {
   m.rank = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
   m.new_of = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
   m.list = reinterpret_cast<int32_t*>(p); p += tier_align((C + 2) * 4);
-  m.wake[0] = reinterpret_cast<double*>(p); p += tier_align((C + 2) * 8);
-  m.wake[1] = reinterpret_cast<double*>(p); p += tier_align((C + 2) * 8);
+  m.fired = reinterpret_cast<int32_t*>(p); p += tier_align((N + 2) * 4);
+  m.wake[0] = reinterpret_cast<double*>(p); p += tier_align((2 * C + 4) * 8);
+  m.wake[1] = reinterpret_cast<double*>(p); p += tier_align((2 * C + 4) * 8);
   m.budget = reinterpret_cast<double*>(p); p += tier_align((N + 2) * 8);
   m.drift_prev = reinterpret_cast<double*>(p); p += tier_align((N + 2) * 8);
+  m.fire_at = reinterpret_cast<double*>(p); p += tier_align((N + 2) * 8);
   m.counters = reinterpret_cast<unsigned long long*>(p);
   return m;
 }
@@ -1825,14 +1827,15 @@ __global__ void __launch_bounds__(kBlock)
                     int32_t* __restrict__ flags) {
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
     const int2 ij = pairs[c];
-    const double need = budget[ij.x] + budget[ij.y];
+    const double need_i = budget[ij.x], need_j = budget[ij.y];
     bool cold;
-    if (c >= H_old && wake_old[c - H_old] > -1.7976931348623157e308) {
-      // asleep (its pair is stale): stays cold while what is left of its level covers the coming period
-      cold = wake_old[c - H_old] - (drift[ij.x] + drift[ij.y]) > need;
+    if (c >= H_old && wake_old[2 * (c - H_old)] > -1.7976931348623157e308) {
+      // asleep (its pair is stale): stays cold while what is left of either threshold covers the coming period
+      cold = wake_old[2 * (c - H_old)] - drift[ij.x] > need_i && wake_old[2 * (c - H_old) + 1] - drift[ij.y] > need_j;
     } else {
       const double2 a = Pcur[c], b = Pprev[c];
-      cold = a.x == 0.0 && b.x == 0.0 && a.y > kTierMinGap && a.y <= 1.7976931348623157e308 && 0.5 * a.y > need;
+      cold = a.x == 0.0 && b.x == 0.0 && a.y > kTierMinGap && a.y <= 1.7976931348623157e308 && 0.25 * a.y > need_i &&
+             0.25 * a.y > need_j;
     }
     flags[c] = cold ? 0 : 1;
   }
@@ -1847,7 +1850,7 @@ __global__ void __launch_bounds__(kBlock)
                    const double2* __restrict__ P0s, const double2* __restrict__ P1s, double2* __restrict__ P0d,
                    double2* __restrict__ P1d, const int32_t* __restrict__ flags, const int32_t* __restrict__ rank,
                    int32_t* __restrict__ new_of, const double* __restrict__ wake_old, size_t H_old,
-                   double* __restrict__ wake_new, const double* __restrict__ drift) {
+                   double* __restrict__ wake_new, const double* __restrict__ drift, double* __restrict__ fire_at) {
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
     const bool hot = flags[c] != 0;
     const size_t r = static_cast<size_t>(rank[c]);
@@ -1870,14 +1873,22 @@ __global__ void __launch_bounds__(kBlock)
     dst.pos[2 * nc + 1] = pos[2 * c + 1];
     double2 a0 = P0s[c], a1 = P1s[c];
     if (!hot) {
-      const bool asleep = c >= H_old && wake_old[c - H_old] > -1.7976931348623157e308;
-      if (asleep) {
-        wake_new[nc - H] = wake_old[c - H_old];  // its level stands; the pair keeps saying x = 0, g > 0
-      } else {
+      const bool asleep = c >= H_old && wake_old[2 * (c - H_old)] > -1.7976931348623157e308;
+      double ti, tj;
+      if (asleep) {  // its thresholds stand; the pair keeps saying x = 0, g > 0
+        ti = wake_old[2 * (c - H_old)];
+        tj = wake_old[2 * (c - H_old) + 1];
+      } else {       // half the gradient is slack, each body gets half of that
         const double g = cur_is_p1 ? a1.y : a0.y;
-        wake_new[nc - H] = drift[ij.x] + drift[ij.y] + 0.5 * g;
+        ti = drift[ij.x] + 0.25 * g;
+        tj = drift[ij.y] + 0.25 * g;
         a0 = a1 = make_double2(0.0, g);
       }
+      wake_new[2 * (nc - H)] = ti;
+      wake_new[2 * (nc - H) + 1] = tj;
+      // (thresholds are positive doubles: their bit patterns order like the values)
+      atomicMin(reinterpret_cast<unsigned long long*>(fire_at + ij.x), static_cast<unsigned long long>(__double_as_longlong(ti)));
+      atomicMin(reinterpret_cast<unsigned long long*>(fire_at + ij.y), static_cast<unsigned long long>(__double_as_longlong(tj)));
     }
     P0d[nc] = a0;
     P1d[nc] = a1;
@@ -1903,7 +1914,7 @@ __global__ void __launch_bounds__(kBlock)
   double2* Pcur = cur ? P1 : P0;
   double2* Pprev = cur ? P0 : P1;
   for (size_t c = H + blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
-    if (!(wake[c - H] > -1.7976931348623157e308)) continue;  // awake: its pairs are exact already
+    if (!(wake[2 * (c - H)] > -1.7976931348623157e308)) continue;  // awake: its pairs are exact already
     const int2 ij = op.pairs[c];
     Pcur[c] = make_double2(0.0, 1.0 * q[c] + 1.0 * contact_dt_sdot<KIN>(op, vcur, c, ij));
     Pprev[c] = make_double2(0.0, 1.0 * q[c] + 1.0 * contact_dt_sdot<KIN>(op, vprev, c, ij));
@@ -2019,13 +2030,14 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     orig_src = tier_geo_at(t.geo[t.set].ptr, C).orig;
   else
     t.saved = v;
+  if (int e = mhip_fill(N, m.fire_at, __builtin_huge_val(), reinterpret_cast<mhip_stream_t>(s))) return e;
 #define PERMUTE(K)                                                                                                    \
   k_tier_permute<K><<<grid_for(C), kBlock, 0, s>>>(C, H, cur_is_p1 ? 1 : 0, v.pairs, v.normal, v.arc_s, v.arc_t, v.ra, \
                                                    v.rb, cur.q,                                                      \
                                                    orig_src, v.pos, dst, reinterpret_cast<const double2*>(cur.P0),   \
                                                    reinterpret_cast<const double2*>(cur.P1), P0d, P1d, m.flags,      \
                                                    m.rank, m.new_of, wake_old, H_old, m.wake[dst_set],               \
-                                                   t.drift.as<double>())
+                                                   t.drift.as<double>(), m.fire_at)
   if (op->kin == KIN_ROD) PERMUTE(KIN_ROD); else if (op->kin == KIN_RIGID) PERMUTE(KIN_RIGID); else PERMUTE(KIN_TRANS);
 #undef PERMUTE
   MHIP_LAUNCH_CHECK();
@@ -2041,6 +2053,9 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     v.rb = dst.rb;
   }
   v.pos = dst.pos;
+  v.fire_at = m.fire_at;
+  v.fired = m.fired;
+  v.tier_counters = m.counters;
   cur.P0 = reinterpret_cast<double*>(P0d);
   cur.P1 = reinterpret_cast<double*>(P1d);
   cur.q = dst.q;
@@ -2107,6 +2122,9 @@ int tier_release(mhip_contact_op* op, TierPairs& cur, bool final, double* P0, do
   v.xcd_aware = keep.xcd_aware;
   v.vel_alt = keep.vel_alt;
   v.drift = keep.drift;
+  v.fire_at = nullptr;
+  v.fired = nullptr;
+  v.tier_counters = nullptr;
   v.aptr = nullptr;
   t.active = false;
   cur.P0 = P0;
@@ -2126,14 +2144,14 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   double* parts = op->partials.as<double>();
   const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
   const unsigned ghot = t.H ? constraint_grid(t.H) : 0u;
-  // the tail: scanned by extra workgroups of the hot launch (a latency-bound scan under a bandwidth-bound sweep), its
-  // awake contacts then evaluated by a small grid-stride launch
-  const unsigned gcheck = t.H < C ? (grid_for(C - t.H) < kTierScanBlocks ? grid_for(C - t.H) : kTierScanBlocks) : 0u;
+  // the tail: the bodies that fired in this iteration's body sweep are dealt with by the first workgroups of the hot
+  // launch, the awake contacts then evaluated by a small grid-stride launch
+  const unsigned gcheck = t.H < C ? kTierFireBlocks : 0u;
   const unsigned glist = t.H < C ? (grid_for(C - t.H) < kTierListBlocks ? grid_for(C - t.H) : kTierListBlocks) : 0u;
   OpView hot = op->view, listed = op->view;
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
   listed.part_offset = ghot; listed.part_stride = kStageStride;
-  const TierCheck tc{t.H, C, m.wake[t.set], m.list, m.counters, gcheck};
+  const TierCheck tc{t.H, m.wake[t.set], m.list, m.counters, m.fired, m.fire_at, gcheck};
 #define TIERED(K)                                                                                                   \
   do {                                                                                                              \
     if (ghot + gcheck)                                                                                              \
@@ -2731,7 +2749,8 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       double* pp = parts;
       fold_partials(np, ps, pp, st, 1, s);
       k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters,
-                                                        tier.active ? op->tiering : 0);
+                                                        tier.active ? op->tiering : 0,
+                                                        tier.active ? op->view.tier_counters : nullptr);
       MHIP_LAUNCH_CHECK();
     }
     enqueued += todo;
