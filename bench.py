@@ -74,13 +74,13 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
     con = 88.0 * contacts + 48.0 * bodies
     body = 2 * 36.0 * act + 16.0 * act + 136.0 * bodies
     if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
-        # cold tier: over the tiered iterations only the hot share h of the contacts is swept in full; a
-        # contact of the cold tail costs its pair 8 + wake level 8; the drift table (8 B per body) is read by the tail
-        # scan; the body sweep additionally updates each body's drift (8 + 8)
+        # cold tier: over the tiered iterations only the hot share h of the contacts is swept (plus the few
+        # thousand awake contacts of the cold tail, not counted here); nothing scans the sleepers.  The body sweep additionally
+        # updates each body's drift (8 + 8) and reads its firing threshold (8)
         w = min(1.0, tier["tiered_iterations"] / float(iterations))
         h = tier["mean_hot_fraction"]
-        con = (1.0 - w) * con + w * ((88.0 * h + 16.0 * (1.0 - h)) * contacts + 56.0 * bodies)
-        body += w * 16.0 * bodies
+        con = (1.0 - w) * con + w * (88.0 * h * contacts + 48.0 * bodies)
+        body += w * 24.0 * bodies
     return {"k_constraint": con, "k_body": body}
 
 

@@ -36,18 +36,18 @@ def test_default_line_has_the_contract_keys():
     # the body sweep's bytes are those its activity masks require, with the active fraction measured in the run
     kb = r if r["kernel"].startswith("k_body") else d["k_body"]
     assert 0.0 < kb["active_contact_fraction"] < 1.0
-    # (+ 16 B per body -- its drift, read and written -- over the share of the iterations that ran with the cold tier)
+    # (+ 24 B per body -- its drift, read and written, and its firing threshold -- over the tiered share of the iterations)
     ct = d["cold_tier"]
     share = min(1.0, ct["tiered_iterations"] / d["config"]["bbpgd_iters_per_step"][-1])
     assert kb["bytes_per_launch"] == pytest.approx(
         88.0 * kb["active_contact_fraction"] * d["config"]["contacts_per_gpu"] +
-        (136.0 + 16.0 * share) * d["config"]["bodies_per_gpu"], rel=1e-3)
-    # the constraint sweep's: 88 B per contact swept in full, 16 per contact of the cold tail, over the tiered iterations
+        (136.0 + 24.0 * share) * d["config"]["bodies_per_gpu"], rel=1e-3)
+    # the constraint sweep's: 88 B per contact swept (hot range + awake part of the tail) over the tiered iterations
     kc = r if r["kernel"].startswith("k_constraint") else d["k_constraint"]
     C, N, h = d["config"]["contacts_per_gpu"], d["config"]["bodies_per_gpu"], ct["mean_hot_fraction"]
     assert ct["tiered_iterations"] > 0 and 0.0 < h < 1.0 and ct["renumberings"] >= 1
     assert kc["bytes_per_launch"] == pytest.approx(
-        (1 - share) * (88.0 * C + 48.0 * N) + share * ((88.0 * h + 16.0 * (1 - h)) * C + 56.0 * N), rel=1e-3)
+        (1 - share) * (88.0 * C + 48.0 * N) + share * (88.0 * h * C + 48.0 * N), rel=1e-3)
     # the second, labelled figure: the same step from the relaxed packing
     rp = d["relaxed_packing"]
     assert "NOT the headline" in rp["what"] and all(rp["converged"]) and rp["timesteps_per_sec"] > 0
