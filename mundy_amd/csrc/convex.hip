@@ -706,7 +706,7 @@ __device__ inline double contact_dt_sdot(const OpView& op, const double* __restr
 // (they go to `list`: k_constraint_listed evaluates them, this iteration and after) and reset fire_at to the smallest
 // threshold left.  A handful of bodies per iteration: nothing scans the tail.
 struct TierCheck {
-  size_t H;                      // cold tail = contacts [H, C)
+  size_t H, I;                   // cold tail = contacts [H, I)
   double* wake;                  // [C - H][2] thresholds; thr[0] = -inf: awake
   int32_t* list;                 // awake contacts of the tail
   unsigned long long* counters;  // [0] = length of list, [1] = length of fired
@@ -726,7 +726,7 @@ __device__ inline void tier_fire_range(const TierCheck& tc, const int32_t* __res
     for (int32_t k = inc_ptr[b]; k < inc_ptr[b + 1]; ++k) {
       const int32_t e = inc[k];
       const size_t c = static_cast<size_t>(e >> 1);
-      if (c < tc.H) continue;
+      if (c < tc.H || c >= tc.I) continue;
       double* thr = tc.wake + 2 * (c - tc.H);
       const double mine = thr[e & 1];
       if (!(thr[0] > ninf)) continue;  // awake already
@@ -1577,8 +1577,11 @@ struct mhip_contact_op {
     unsigned polled_at = 0; // iterations run at the last poll
     double* saved_vel = nullptr;
     int set = 0;            // geometry / iterate set in use
-    size_t H = 0;           // hot contacts [0, H), cold tail [H, C)
-    DeviceBuffer geo[2], iter[2], misc, vel2, drift, arm;
+    size_t H = 0;           // hot contacts [0, H), cold tail [H, I)
+    size_t I = 0;           // contacts [I, C) never go cold (the staged solver's boundary contacts: a ghost body's drift
+                            // is not known here); the fused solve has I = C
+    bool pingpong = false;  // the body rows alternate between two buffers (fused solve)
+    DeviceBuffer geo[2], iter[2], misc, vel2, drift, arm, xprev;
     OpView saved{};         // the operator's own view, restored when the tiers are left
     // statistics of the last solve
     size_t tiered_iterations = 0, retiers = 0, wakeups = 0;
@@ -1843,7 +1846,7 @@ __global__ void __launch_bounds__(kBlock)
 // src numbering -> hot-first numbering (stable): geometry, q, slot table, both packed iterates, wake levels
 template <int KIN>
 __global__ void __launch_bounds__(kBlock)
-    k_tier_permute(size_t C, size_t H, int cur_is_p1, const int2* __restrict__ pairs, const double* __restrict__ normal,
+    k_tier_permute(size_t C, size_t I, size_t H, int cur_is_p1, const int2* __restrict__ pairs, const double* __restrict__ normal,
                    const double* __restrict__ arc_s, const double* __restrict__ arc_t, const double* __restrict__ ra,
                    const double* __restrict__ rb, const double* __restrict__ q, const int32_t* __restrict__ orig,
                    const unsigned char* __restrict__ pos, TierGeo dst,
@@ -1852,9 +1855,10 @@ __global__ void __launch_bounds__(kBlock)
                    int32_t* __restrict__ new_of, const double* __restrict__ wake_old, size_t H_old,
                    double* __restrict__ wake_new, const double* __restrict__ drift, double* __restrict__ fire_at) {
   for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
-    const bool hot = flags[c] != 0;
-    const size_t r = static_cast<size_t>(rank[c]);
-    const size_t nc = hot ? r : H + (c - r);
+    const bool fixed = c >= I;  // beyond the range that is partitioned: stays where it is, never cold
+    const bool hot = fixed || flags[c] != 0;
+    const size_t r = fixed ? 0 : static_cast<size_t>(rank[c]);
+    const size_t nc = fixed ? c : (hot ? r : H + (c - r));
     new_of[c] = static_cast<int32_t>(nc);
     const int2 ij = pairs[c];
     dst.pairs[nc] = ij;
@@ -1901,24 +1905,26 @@ __global__ void __launch_bounds__(kBlock) k_tier_remap_inc(size_t n, int32_t* __
     inc[k] = (map[e >> 1] << 1) | (e & 1);
   }
 }
-// leaving the tiers: the gradient of every sleeping contact at the last two iterates, from the two row buffers
+// leaving the tiers: the gradient of every sleeping contact at the last two iterates, from the rows of those iterates
+// (cur_is_1: which of the packed pairs holds the latest iterate)
 template <int KIN>
 __global__ void __launch_bounds__(kBlock)
-    k_tier_refresh_sleepers(OpView op /*tier view*/, size_t H, const SolverState* __restrict__ st,
-                            const double* __restrict__ q, const double* __restrict__ wake, double2* __restrict__ P0,
-                            double2* __restrict__ P1) {
-  const unsigned f = st->flips;
-  const unsigned cur = (st->converged && !st->converged_at_init) ? ((f + 1u) & 1u) : (f & 1u);
-  const double* vcur = cur ? op.vel_alt : op.vel;
-  const double* vprev = cur ? op.vel : op.vel_alt;
-  double2* Pcur = cur ? P1 : P0;
-  double2* Pprev = cur ? P0 : P1;
-  for (size_t c = H + blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < op.C; c += (size_t)gridDim.x * blockDim.x) {
+    k_tier_refresh_sleepers(OpView op /*tier view*/, size_t H, size_t I, int cur_is_1, const double* __restrict__ vcur,
+                            const double* __restrict__ vprev, const double* __restrict__ q,
+                            const double* __restrict__ wake, double2* __restrict__ P0, double2* __restrict__ P1) {
+  double2* Pcur = cur_is_1 ? P1 : P0;
+  double2* Pprev = cur_is_1 ? P0 : P1;
+  for (size_t c = H + blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < I; c += (size_t)gridDim.x * blockDim.x) {
     if (!(wake[2 * (c - H)] > -1.7976931348623157e308)) continue;  // awake: its pairs are exact already
     const int2 ij = op.pairs[c];
     Pcur[c] = make_double2(0.0, 1.0 * q[c] + 1.0 * contact_dt_sdot<KIN>(op, vcur, c, ij));
     Pprev[c] = make_double2(0.0, 1.0 * q[c] + 1.0 * contact_dt_sdot<KIN>(op, vprev, c, ij));
   }
+}
+// x of the previous iterate as a plain vector (tier numbering): what the body sweep needs to rebuild that iterate's rows
+__global__ void __launch_bounds__(kBlock) k_tier_prev_x(size_t n, const double2* __restrict__ Pprev,
+                                                       double* __restrict__ x) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = Pprev[i].x;
 }
 // tier numbering -> the caller's: the solver's four vectors (final) ...
 __global__ void __launch_bounds__(kBlock)
@@ -1960,14 +1966,16 @@ struct TierPairs {
   const double* q;
 };
 
-// At a poll (the stream is idle, host_state is current).  First call of a solve: the drift bookkeeping starts (body
-// rows ping-pong, drift accumulates).  Later calls: classify against the drift of the period just run, and renumber
+// At a poll (the stream is idle, host_state is current).  First call of a solve: the drift bookkeeping starts (drift
+// accumulates; with pingpong the body rows alternate between two buffers).  Only contacts [0, I) may go cold.  Later calls: classify against the drift of the period just run, and renumber
 // hot-first when that pays.  iters_done = iterations run so far, next_period = iterations until the next poll.
 // `cur` = the pairs / q in use; on return the ones to use from now on.
-int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsigned next_period, hipStream_t s) {
+int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsigned next_period, size_t I, bool pingpong,
+                hipStream_t s) {
   mhip_contact_op::Tier& t = op->tier;
   OpView& v = op->view;
   const size_t C = v.C, N = v.N;
+  if (I > C) I = C;
   if (int e = t.misc.reserve(tier_misc_bytes(C, N))) return e;
   if (int e = op->scanws.reserve(scan_workspace_bytes(C + 2) + 64)) return e;
   const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
@@ -1978,7 +1986,8 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     MHIP_HIP(hipMemsetAsync(t.drift.ptr, 0, N * sizeof(double), s));
     MHIP_HIP(hipMemsetAsync(m.drift_prev, 0, N * sizeof(double), s));
     // the body rows start to ping-pong: the current rows must sit in the buffer of the current parity
-    if (cur_is_p1) MHIP_HIP(hipMemcpyAsync(t.vel2.ptr, v.vel, 6 * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (pingpong && cur_is_p1)
+      MHIP_HIP(hipMemcpyAsync(t.vel2.ptr, v.vel, 6 * N * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (op->kin == KIN_RIGID) {  // the drift of a body with vector arms is scaled by its longest arm
       if (int e = t.arm.reserve((N + 8) * sizeof(double))) return e;
       k_tier_arm_max<<<grid_for(N), kBlock, 0, s>>>(N, v.inc_ptr, v.half, t.arm.as<double>());
@@ -1986,7 +1995,8 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
       v.arm_max = t.arm.as<double>();
     }
     t.saved_vel = v.vel;
-    v.vel_alt = t.vel2.as<double>();
+    t.pingpong = pingpong;
+    v.vel_alt = pingpong ? t.vel2.as<double>() : nullptr;
     v.drift = t.drift.as<double>();
     t.tracking = true;
     t.polled_at = iters_done;
@@ -2002,13 +2012,14 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   const double2* Pp = reinterpret_cast<const double2*>(cur_is_p1 ? cur.P0 : cur.P1);
   const double* wake_old = t.active ? m.wake[t.set] : m.wake[0];
   const size_t H_old = t.active ? t.H : C;
-  k_tier_classify<<<grid_for(C), kBlock, 0, s>>>(C, v.pairs, Pc, Pp, m.budget, t.drift.as<double>(), wake_old, H_old,
+  if (I == 0) return MHIP_SUCCESS;
+  k_tier_classify<<<grid_for(I), kBlock, 0, s>>>(I, v.pairs, Pc, Pp, m.budget, t.drift.as<double>(), wake_old, H_old,
                                                  m.flags);
   MHIP_LAUNCH_CHECK();
-  if (int e = exclusive_scan_i32(m.flags, m.rank, C, op->scanws.ptr, s)) return e;
+  if (int e = exclusive_scan_i32(m.flags, m.rank, I, op->scanws.ptr, s)) return e;
   int32_t H32 = 0;
   unsigned long long awake = 0;
-  MHIP_HIP(hipMemcpyAsync(&H32, m.rank + C, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipMemcpyAsync(&H32, m.rank + I, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (t.active) MHIP_HIP(hipMemcpyAsync(&awake, m.counters, sizeof(awake), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
   const size_t H = static_cast<size_t>(H32);
@@ -2016,7 +2027,7 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     // renumbering costs about four constraint sweeps: only when what is swept in full (the hot range and the awake
     // part of the tail, the latter through scattered accesses) can shrink by a tenth
     if (10 * H >= 9 * (t.H + static_cast<size_t>(awake))) return MHIP_SUCCESS;
-  } else if (10 * H > 9 * C) {
+  } else if (10 * H > 9 * I) {
     return MHIP_SUCCESS;  // (almost) everything is hot: nothing to gain yet
   }
   const int dst_set = t.active ? (t.set ^ 1) : 0;
@@ -2032,7 +2043,7 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     t.saved = v;
   if (int e = mhip_fill(N, m.fire_at, __builtin_huge_val(), reinterpret_cast<mhip_stream_t>(s))) return e;
 #define PERMUTE(K)                                                                                                    \
-  k_tier_permute<K><<<grid_for(C), kBlock, 0, s>>>(C, H, cur_is_p1 ? 1 : 0, v.pairs, v.normal, v.arc_s, v.arc_t, v.ra, \
+  k_tier_permute<K><<<grid_for(C), kBlock, 0, s>>>(C, I, H, cur_is_p1 ? 1 : 0, v.pairs, v.normal, v.arc_s, v.arc_t, v.ra, \
                                                    v.rb, cur.q,                                                      \
                                                    orig_src, v.pos, dst, reinterpret_cast<const double2*>(cur.P0),   \
                                                    reinterpret_cast<const double2*>(cur.P1), P0d, P1d, m.flags,      \
@@ -2063,6 +2074,7 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   t.active = true;
   t.set = dst_set;
   t.H = H;
+  t.I = I;
   t.retiers += 1;
   return MHIP_SUCCESS;
 }
@@ -2073,7 +2085,7 @@ int tier_stop_tracking(mhip_contact_op* op, hipStream_t s) {
   if (!t.tracking) return MHIP_SUCCESS;
   const SolverState& hs = *op->host_state;
   const unsigned curv = (hs.converged && !hs.converged_at_init) ? ((hs.flips + 1u) & 1u) : (hs.flips & 1u);
-  if (curv == 1u)
+  if (t.pingpong && curv == 1u)
     MHIP_HIP(hipMemcpyAsync(t.saved_vel, t.vel2.ptr, 6 * op->view.N * sizeof(double), hipMemcpyDeviceToDevice, s));
   op->view.vel_alt = nullptr;
   op->view.drift = nullptr;
@@ -2094,14 +2106,47 @@ int tier_release(mhip_contact_op* op, TierPairs& cur, bool final, double* P0, do
   const SolverState* st = op->state.as<SolverState>();
   double2* T0 = reinterpret_cast<double2*>(cur.P0);
   double2* T1 = reinterpret_cast<double2*>(cur.P1);
-  if (t.H < C) {
-    const unsigned grid = grid_for(C - t.H);
-    if (op->kin == KIN_ROD)
-      k_tier_refresh_sleepers<KIN_ROD><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
-    else if (op->kin == KIN_RIGID)
-      k_tier_refresh_sleepers<KIN_RIGID><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
-    else
-      k_tier_refresh_sleepers<KIN_TRANS><<<grid, kBlock, 0, s>>>(v, t.H, st, cur.q, m.wake[t.set], T0, T1);
+  if (t.H < t.I) {
+    const SolverState& hs = *op->host_state;
+    const bool conv = hs.converged && !hs.converged_at_init;
+    const unsigned cur1 = conv ? ((hs.flips + 1u) & 1u) : (hs.flips & 1u);  // which pair holds the latest iterate
+    const double *vcur, *vprev;
+    if (t.pingpong) {
+      vcur = cur1 ? v.vel_alt : v.vel;
+      vprev = cur1 ? v.vel : v.vel_alt;
+    } else {
+      // one row buffer (the staged solver's, filled by the halo as well): the rows of the previous iterate are rebuilt
+      // from its multipliers -- the same sums of the same terms, each a double-double pair rounded once: the same bits.
+      // Sleepers only touch owned bodies, whose rows the body sweep computes.
+      if (int e = t.vel2.reserve((10 * N + 16) * sizeof(double))) return e;
+      if (int e = t.xprev.reserve((C + 2) * sizeof(double))) return e;
+      k_tier_prev_x<<<grid_for(C), kBlock, 0, s>>>(C, cur1 ? T0 : T1, t.xprev.as<double>());
+      MHIP_LAUNCH_CHECK();
+      double* rows = t.vel2.as<double>();
+      double* const keep_vel = v.vel;
+      double* const keep_omega = v.omega;
+      double* const keep_drift = v.drift;
+      const int32_t* const keep_aptr = v.aptr;
+      v.vel = rows;
+      v.omega = rows + 6 * N;  // (the integrator's angular velocities belong to the latest iterate: untouched)
+      v.drift = nullptr;
+      v.aptr = nullptr;
+      const int e = op_launch_body(op, X_APPLY, t.xprev.as<double>(), t.xprev.as<double>(), nullptr, nullptr,
+                                   Space{MHIP_SPACE_UNCONSTRAINED, 0.0, 0.0}, s);
+      v.vel = keep_vel;
+      v.omega = keep_omega;
+      v.drift = keep_drift;
+      v.aptr = keep_aptr;
+      if (e) return e;
+      vcur = v.vel;
+      vprev = rows;
+    }
+    const unsigned grid = grid_for(t.I - t.H);
+#define REFRESH(K)                                                                                              \
+  k_tier_refresh_sleepers<K><<<grid, kBlock, 0, s>>>(v, t.H, t.I, static_cast<int>(cur1), vcur, vprev, cur.q,   \
+                                                     m.wake[t.set], T0, T1)
+    if (op->kin == KIN_ROD) REFRESH(KIN_ROD); else if (op->kin == KIN_RIGID) REFRESH(KIN_RIGID); else REFRESH(KIN_TRANS);
+#undef REFRESH
     MHIP_LAUNCH_CHECK();
   }
   if (final)
@@ -2146,12 +2191,12 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   const unsigned ghot = t.H ? constraint_grid(t.H) : 0u;
   // the tail: the bodies that fired in this iteration's body sweep are dealt with by the first workgroups of the hot
   // launch, the awake contacts then evaluated by a small grid-stride launch
-  const unsigned gcheck = t.H < C ? kTierFireBlocks : 0u;
-  const unsigned glist = t.H < C ? (grid_for(C - t.H) < kTierListBlocks ? grid_for(C - t.H) : kTierListBlocks) : 0u;
+  const unsigned gcheck = t.H < t.I ? kTierFireBlocks : 0u;
+  const unsigned glist = t.H < t.I ? (grid_for(t.I - t.H) < kTierListBlocks ? grid_for(t.I - t.H) : kTierListBlocks) : 0u;
   OpView hot = op->view, listed = op->view;
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
   listed.part_offset = ghot; listed.part_stride = kStageStride;
-  const TierCheck tc{t.H, m.wake[t.set], m.list, m.counters, m.fired, m.fire_at, gcheck};
+  const TierCheck tc{t.H, t.I, m.wake[t.set], m.list, m.counters, m.fired, m.fire_at, gcheck};
 #define TIERED(K)                                                                                                   \
   do {                                                                                                              \
     if (ghot + gcheck)                                                                                              \
@@ -2292,7 +2337,7 @@ int mhip_gemv(size_t n, const double* A, const double* x, double* y, mhip_stream
 // pinned state block, timing events -- are the same size step after step.  A destroyed operator therefore leaves them
 // in one process-wide spare set that the next create adopts: no hipMalloc / hipFree in the steady state (hipFree
 // alone cost 1.6 ms per step at 10^6 rods).  mhip_release_cached_workspaces() frees the spare set.
-constexpr int kOpBuffers = 29;
+constexpr int kOpBuffers = 30;
 struct OpWorkspaces {
   DeviceBuffer buf[kOpBuffers];
   SolverState* host_state = nullptr;
@@ -2308,7 +2353,7 @@ static DeviceBuffer* op_buffers(mhip_contact_op* op, int k) {
                                    &op->body_mask, &op->pos,   &op->sort_tmp, &op->sort_list, &op->aptr,    &op->aent,
                                    &op->arec,    &op->snap_mask, &op->acnt,
                                    &op->tier.geo[0], &op->tier.geo[1], &op->tier.iter[0], &op->tier.iter[1],
-                                   &op->tier.misc, &op->tier.vel2, &op->tier.drift, &op->tier.arm};
+                                   &op->tier.misc, &op->tier.vel2, &op->tier.drift, &op->tier.arm, &op->tier.xprev};
   return all[k];
 }
 static void free_workspaces(OpWorkspaces& w) {
@@ -2726,7 +2771,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
     // snapshot (short solves -- a relaxed packing needs ~100 iterations -- get their tiers early)
     if (!tier.disabled && (enqueued >= kSnapshotAfter || !tier.tracking)) {
       const unsigned left = config->max_iters - enqueued;
-      if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, s)) return e;
+      if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, C, /*pingpong=*/true, s)) return e;
     }
     if (enqueued >= kSnapshotAfter)
       if (int e = op_snapshot_active(op, s)) return e;
