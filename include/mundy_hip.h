@@ -341,8 +341,9 @@ int mhip_contact_op_set_work_mapping(mhip_contact_op_t handle, int xcd_tile, int
  * bytes per sleeping contact instead of 88); a contact that reaches its bound is evaluated like any other again.  Same
  * iterates, bit for bit, and the same iteration count as with tiering off (every sum is a double-double pair rounded
  * once, so the partition of the contacts does not reach the sums).  LCP solves (any of the three operator forms) with at
- * least 65 536 contacts; mode 0 = off, 1 = on (default), 2 = test hook: leave the tiers after the first tiered iteration, as the
- * solve does before a BB step outside [0, finite].
+ * least 65 536 contacts, in the fused solve and -- for the contacts between two bodies the rank owns -- in the staged /
+ * distributed one; mode 0 = off, 1 = on (default), 2 = test hook: leave the tiers mid-solve, as the solve does before a BB
+ * step outside [0, finite], 3 = test hook: no minimum size (2 has none either).
  * tier_stats: iterations that ran tiered, mean share of hot contacts over them, renumberings, contacts woken. */
 int mhip_contact_op_set_tiering(mhip_contact_op_t handle, int mode);
 int mhip_contact_op_tier_stats(mhip_contact_op_t handle, size_t* tiered_iterations, double* mean_hot_fraction,

@@ -1568,6 +1568,14 @@ struct mhip_contact_op {
     mhip_pgd_config cfg{0, 0, 0};
     bool active = false;
     unsigned part_used = 0;  // partial slots written by this iteration's constraint sweeps
+    // cold tier of the staged solve: the packed pairs / q in use, the interior range [0, interior) whose contacts may
+    // sleep (both bodies owned: their drifts are known here), whether a bad BB step pauses the solve (the same on every
+    // rank: it must not depend on anything local)
+    double *P0 = nullptr, *P1 = nullptr;
+    const double* q_cur = nullptr;
+    size_t interior = 0;
+    bool interior_known = false, pause_on_bad_step = false;
+    unsigned polls = 0;
   } stage;
   // cold tier of the fused solve (see "Cold tier")
   struct Tier {
@@ -1953,11 +1961,14 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// what does not depend on the size or the partition of the problem (the same on every rank of a distributed solve)
+bool tier_problem_kind(const Space& sp, int resid_kind) {
+  return sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0 && resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF;
+}
 bool tier_eligible(const mhip_contact_op* op, const Space& sp, int resid_kind) {
   const OpView& v = op->view;
-  return v.C >= kTierMinContacts && v.body_mask != nullptr &&
-         v.counted == nullptr && v.body_first == 0 && v.body_count == v.N && sp.kind == MHIP_SPACE_LOWER_BOUND &&
-         sp.lo == 0.0 && resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF;
+  return (v.C >= kTierMinContacts || op->tiering >= 2) && v.body_mask != nullptr && v.counted == nullptr &&
+         v.body_first == 0 && v.body_count == v.N && tier_problem_kind(sp, resid_kind);
 }
 
 // the packed pair a tiered (or not yet tiered) solve is iterating on
@@ -2831,10 +2842,11 @@ int mhip_contact_op_tier_stats(mhip_contact_op_t op, size_t* tiered_iterations, 
 
 /* 1 (default): mhip_bbpgd_solve_contact may keep inactive contacts in a cold tier; 0: every contact is swept every
  * iteration; 2 (for tests): as 1, and the solve is paused after its first tiered iteration as it would be before a BB
- * step outside [0, finite], i.e. it leaves the tiers and goes on untiered.  Time only: the iterates are the same bits. */
+ * step outside [0, finite], i.e. it leaves the tiers and goes on untiered; 3 (for tests): as 1 whatever the number of
+ * contacts (so is 2).  Time only: the iterates are the same bits. */
 int mhip_contact_op_set_tiering(mhip_contact_op_t op, int mode) {
   MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
-  MHIP_REQUIRE(mode >= 0 && mode <= 2, MHIP_ERR_INVALID_ARGUMENT, "tiering mode must be 0, 1 or 2, got %d", mode);
+  MHIP_REQUIRE(mode >= 0 && mode <= 3, MHIP_ERR_INVALID_ARGUMENT, "tiering mode must be 0 ... 3, got %d", mode);
   op->tiering = mode;
   return MHIP_SUCCESS;
 }
@@ -3041,16 +3053,46 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
     MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), as_stream(stream)));
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   MHIP_HIP(hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState), as_stream(stream)));
+  // cold tier (see "Cold tier"): interior contacts only, one row buffer
+  op->stage.P0 = op->iterate.as<double>();
+  op->stage.P1 = op->stage.P0 + 2 * C;
+  op->stage.q_cur = q;
+  op->stage.interior = 0;
+  op->stage.interior_known = false;
+  op->stage.polls = 0;
+  op->stage.pause_on_bad_step = op->tiering != 0 && tier_problem_kind(sp, config->residual_kind);
+  mhip_contact_op::Tier& tier = op->tier;
+  if (tier.active) {  // a staged solve that ended in an error left the operator in the tier numbering
+    const TierGeo geo = tier_geo_at(tier.geo[tier.set].ptr, C);
+    k_tier_remap_inc<<<grid_for(2 * C), kBlock, 0, as_stream(stream)>>>(2 * C, op->inc.as<int32_t>(), geo.orig);
+    MHIP_LAUNCH_CHECK();
+    op->view.pairs = tier.saved.pairs;   // (the caller's arrays; everything else of the view is the caller's to set)
+    op->view.normal = tier.saved.normal;
+    op->view.ra = tier.saved.ra;
+    op->view.rb = tier.saved.rb;
+    op->view.arc_s = tier.saved.arc_s;
+    op->view.arc_t = tier.saved.arc_t;
+    op->view.pos = tier.saved.pos;
+    op->view.aptr = nullptr;
+  }
+  op->view.vel_alt = nullptr;
+  op->view.drift = nullptr;
+  op->view.fire_at = nullptr;
+  op->view.fired = nullptr;
+  op->view.tier_counters = nullptr;
+  tier.active = tier.tracking = false;
+  tier.disabled = !op->stage.pause_on_bad_step || op->view.body_mask == nullptr ||
+                  !(C >= kTierMinContacts || op->tiering >= 2);
+  tier.tiered_iterations = tier.retiers = tier.wakeups = 0;
+  tier.hot_sum = 0.0;
   return MHIP_SUCCESS;
 }
 
 int mhip_bbpgd_stage_body(mhip_contact_op_t op, int init, mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   auto& st = op->stage;
-  double* P0 = op->iterate.as<double>();
-  double* P1 = P0 + 2 * op->view.C;
   if (init) return op_launch_body(op, X_INIT, st.x, st.x, nullptr, nullptr, st.sp, as_stream(stream));
-  return op_launch_body(op, X_SOLVE, P0, P1, nullptr, nullptr, st.sp, as_stream(stream), true);
+  return op_launch_body(op, X_SOLVE, st.P0, st.P1, nullptr, nullptr, st.sp, as_stream(stream), true);
 }
 
 int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_first, size_t c_count,
@@ -3058,18 +3100,62 @@ int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_f
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   MHIP_REQUIRE(c_first + c_count <= op->view.C, MHIP_ERR_INVALID_ARGUMENT,
                "constraint range [%zu, %zu) exceeds the %zu constraints", c_first, c_first + c_count, op->view.C);
-  if (c_count == 0) return MHIP_SUCCESS;
   auto& st = op->stage;
+  // the first range of an iteration that starts at 0 is the interior one (both bodies of its contacts are owned)
+  if (c_first == 0 && !st.interior_known) {
+    st.interior = c_count;
+    st.interior_known = true;
+  }
+  mhip_contact_op::Tier& tier = op->tier;
+  if (tier.active) {
+    // tiered: the ranges the tiers were built for are [0, interior) -- of which only the hot part is swept, with the
+    // workgroups that wake the contacts of fired bodies in front -- and [interior, C)
+    MHIP_REQUIRE(!init && ((c_first == 0 && c_count == tier.I) || (c_first == tier.I && c_first + c_count == op->view.C)),
+                 MHIP_ERR_RUNTIME, "constraint range [%zu, %zu) does not match the ranges of the tiered solve", c_first,
+                 c_first + c_count);
+    hipStream_t s = as_stream(stream);
+    const SolverState* sst = op->state.as<SolverState>();
+    double* parts = op->partials.as<double>();
+    const TierMisc m = tier_misc_at(tier.misc.ptr, op->view.C, op->view.N);
+    OpView vw = op->view;
+    vw.part_offset = st.part_used;
+    vw.part_stride = kStageStride;
+    unsigned grid = 0, extra = 0;
+    TierCheck tc{};
+    if (c_first == 0) {
+      vw.c_first = 0;
+      vw.c_end = tier.H;
+      grid = tier.H ? constraint_grid(tier.H) : 0u;
+      if (tier.H < tier.I) {
+        extra = kTierFireBlocks;
+        tc = TierCheck{tier.H, tier.I, m.wake[tier.set], m.list, m.counters, m.fired, m.fire_at, extra};
+      }
+    } else {
+      if (c_count == 0) return MHIP_SUCCESS;
+      vw.c_first = c_first;
+      vw.c_end = c_first + c_count;
+      grid = constraint_grid(c_count);
+    }
+    if (grid + extra == 0) return MHIP_SUCCESS;
+    MHIP_REQUIRE(st.part_used + grid <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
+#define STAGED(K)                                                                                                    \
+  k_constraint<X_SOLVE, K, true><<<grid + extra, kBlock, 0, s>>>(vw, sst, st.P0, st.P1, nullptr, nullptr, st.q_cur, \
+                                                                st.sp, st.cfg.residual_kind, parts, tc)
+    if (op->kin == KIN_ROD) STAGED(KIN_ROD); else if (op->kin == KIN_RIGID) STAGED(KIN_RIGID); else STAGED(KIN_TRANS);
+#undef STAGED
+    MHIP_LAUNCH_CHECK();
+    st.part_used += grid;
+    return MHIP_SUCCESS;
+  }
+  if (c_count == 0) return MHIP_SUCCESS;
   const unsigned grid = constraint_grid(c_count);
   MHIP_REQUIRE(st.part_used + grid <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
-  double* P0 = op->iterate.as<double>();
-  double* P1 = P0 + 2 * op->view.C;
   op->view.c_first = c_first;
   op->view.c_end = c_first + c_count;
   op->view.part_offset = st.part_used;
   op->view.part_stride = kStageStride;
-  const int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, P0, P1, init ? st.x : nullptr, nullptr, st.q, st.sp,
-                                     st.cfg.residual_kind, grid, as_stream(stream), true);
+  const int e = op_launch_constraint(op, init ? X_INIT : X_SOLVE, st.P0, st.P1, init ? st.x : nullptr, nullptr, st.q_cur,
+                                     st.sp, st.cfg.residual_kind, grid, as_stream(stream), true);
   op->view.c_first = 0;
   op->view.c_end = op->view.C;
   op->view.part_offset = 0;
@@ -3083,6 +3169,25 @@ int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local, mhip_
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   MHIP_REQUIRE(local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local record is null");
   hipStream_t s = as_stream(stream);
+  if (op->tier.active && !init && op->tier.H < op->tier.I) {  // the awake contacts of the cold tail
+    mhip_contact_op::Tier& tier = op->tier;
+    const TierMisc m = tier_misc_at(tier.misc.ptr, op->view.C, op->view.N);
+    const size_t tail = tier.I - tier.H;
+    const unsigned glist = grid_for(tail) < kTierListBlocks ? grid_for(tail) : kTierListBlocks;
+    MHIP_REQUIRE(op->stage.part_used + glist <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
+    OpView vw = op->view;
+    vw.part_offset = op->stage.part_used;
+    vw.part_stride = kStageStride;
+    const SolverState* sst = op->state.as<SolverState>();
+    auto& st = op->stage;
+#define LISTED(K)                                                                                                  \
+  k_constraint_listed<K><<<glist, kBlock, 0, s>>>(vw, sst, st.P0, st.P1, st.q_cur, st.sp, st.cfg.residual_kind,     \
+                                                 op->partials.as<double>(), m.list, m.counters)
+    if (op->kin == KIN_ROD) LISTED(KIN_ROD); else if (op->kin == KIN_RIGID) LISTED(KIN_RIGID); else LISTED(KIN_TRANS);
+#undef LISTED
+    MHIP_LAUNCH_CHECK();
+    op->stage.part_used += glist;
+  }
   unsigned np = op->stage.part_used;
   size_t ps = kStageStride;
   double* pp = op->partials.as<double>();
@@ -3110,8 +3215,12 @@ int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gath
     k_finalize<X_INIT><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, kRed, 1, st, cfg.residual_kind,
                                                                          cfg.tol, cfg.max_iters);
   else
-    k_finalize<X_SOLVE><<<1, final_block(nparts), 0, as_stream(stream)>>>(nparts, gathered, kRed, 1, st,
-                                                                          cfg.residual_kind, cfg.tol, cfg.max_iters);
+    k_finalize<X_SOLVE><<<1, final_block(nparts), 0, as_stream(stream)>>>(
+        nparts, gathered, kRed, 1, st, cfg.residual_kind, cfg.tol, cfg.max_iters,
+        // (test hook, mode 2: every rank pauses at the first iteration after its third snapshot poll -- a condition that
+        // is the same on all ranks, as a bad step would be)
+        op->stage.pause_on_bad_step ? ((op->tiering == 2 && op->stage.polls >= 3) ? 2 : 1) : 0,
+        op->tier.active ? op->view.tier_counters : nullptr);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -3121,6 +3230,27 @@ int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result, int* 
   hipStream_t s = as_stream(stream);
   MHIP_HIP(hipMemcpyAsync(op->host_state, op->state.ptr, sizeof(SolverState), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
+  if (op->host_state->done == 2 && op->stage.active) {
+    // paused before a BB step outside [0, finite] (every rank pauses at the same iteration: the step is global): the
+    // sleepers' exact gradients are needed, so the tiers are left for good and the solve goes on
+    mhip_contact_op::Tier& tier = op->tier;
+    if (tier.active) {
+      TierPairs cur{op->stage.P0, op->stage.P1, op->stage.q_cur};
+      double* P0 = op->iterate.as<double>();
+      if (int e = tier_release(op, cur, false, P0, P0 + 2 * op->view.C, op->stage.q, nullptr, nullptr, nullptr, nullptr, s))
+        return e;
+      op->stage.P0 = cur.P0;
+      op->stage.P1 = cur.P1;
+      op->stage.q_cur = cur.q;
+    } else if (int e = tier_stop_tracking(op, s)) {
+      return e;
+    }
+    tier.disabled = true;
+    op->stage.pause_on_bad_step = false;
+    op->host_state->done = 0;
+    MHIP_HIP(hipMemcpyAsync(&op->state.as<SolverState>()->done, &op->host_state->done, sizeof(int), hipMemcpyHostToDevice, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+  }
   result->num_iters = op->host_state->iter;
   result->residual = op->host_state->residual;
   result->converged = op->host_state->converged;
@@ -3130,22 +3260,44 @@ int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result, int* 
 
 int mhip_bbpgd_stage_snapshot_active(mhip_contact_op_t op, mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
-  return op_snapshot_active(op, as_stream(stream));
+  hipStream_t s = as_stream(stream);
+  auto& st = op->stage;
+  st.polls += 1;
+  mhip_contact_op::Tier& tier = op->tier;
+  // cold tier: needs the interior range (learnt from the sweeps of the iterations run so far) and host_state (the
+  // caller has just polled).  Only contacts between two owned bodies may sleep: a ghost's drift is not known here.
+  if (!tier.disabled && st.interior_known && !op->host_state->done) {
+    TierPairs cur{st.P0, st.P1, st.q_cur};
+    const unsigned period = op->host_state->iter > tier.polled_at ? op->host_state->iter - tier.polled_at : 1u;
+    if (int e = tier_update(op, cur, op->host_state->iter, period, st.interior, /*pingpong=*/false, s)) return e;
+    st.P0 = cur.P0;
+    st.P1 = cur.P1;
+    st.q_cur = cur.q;
+  }
+  return op_snapshot_active(op, s);
 }
 
 int mhip_bbpgd_stage_end(mhip_contact_op_t op, mhip_solve_result* result, mhip_stream_t stream) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   auto& st = op->stage;
   hipStream_t s = as_stream(stream);
-  if (op->view.C > 0) {
-    const double2* P0 = op->iterate.as<double2>();
-    k_finish_packed<<<grid_for(op->view.C), kBlock, 0, s>>>(op->view.C, op->state.as<SolverState>(), P0,
-                                                            P0 + op->view.C, st.x, st.g, st.x_tmp, st.g_tmp);
-    MHIP_LAUNCH_CHECK();
-  }
   int done = 0;
   mhip_solve_result r{};
-  if (int e = mhip_bbpgd_stage_poll(op, result ? result : &r, &done, stream)) return e;
+  if (int e = mhip_bbpgd_stage_poll(op, result ? result : &r, &done, stream)) return e;  // host_state for the tiers
+  if (op->tier.active) {
+    TierPairs cur{st.P0, st.P1, st.q_cur};
+    double* P0 = op->iterate.as<double>();
+    if (int e = tier_release(op, cur, true, P0, P0 + 2 * op->view.C, st.q, st.x, st.g, st.x_tmp, st.g_tmp, s)) return e;
+  } else {
+    if (int e = tier_stop_tracking(op, s)) return e;
+    if (op->view.C > 0) {
+      const double2* P0 = op->iterate.as<double2>();
+      k_finish_packed<<<grid_for(op->view.C), kBlock, 0, s>>>(op->view.C, op->state.as<SolverState>(), P0,
+                                                              P0 + op->view.C, st.x, st.g, st.x_tmp, st.g_tmp);
+      MHIP_LAUNCH_CHECK();
+    }
+  }
+  MHIP_HIP(hipStreamSynchronize(s));
   st.active = false;
   return MHIP_SUCCESS;
 }

@@ -354,6 +354,7 @@ class DistributedContactStepper:
         self.splitters = None            # [world - 1] last lattice cell (Hilbert position) of every rank but the last
         self._rebalances = 0
         self._body_weight = None
+        self.tiering = None              # ContactOperator.set_tiering mode (None: the library default): time only
         self.dt, self.viscosity, self.buffer = float(dt), float(viscosity), float(search_buffer)
         self.cfg = cfg or ops.PGDConfig(max_iters=10000, tol=1e-5)
         self.poll_every = int(poll_every)
@@ -544,6 +545,8 @@ class DistributedContactStepper:
                 self.op = ops.ContactOperator(pairs, con["normal"], mob_t, self.dt, mob_rot=mob_r,
                                               rod=(con["s"], con["t"], seg), priority=con["sep"])
         op = self.op
+        if self.tiering is not None:
+            op.set_tiering(self.tiering)
         tick("narrow_phase_operator")
         self.vel = torch.zeros((nl, 6), dtype=torch.float64, device=dev)
         self._keep = (pairs, counted, con, mob_t, mob_r, seg)

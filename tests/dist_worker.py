@@ -41,12 +41,16 @@ def main():
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]),
                                          a, comm=D.Comm(), search_buffer=buf, cfg=cfg, poll_every=8,
                                          domain=(0.0, b["box"]), curve_level=4, recut_every=3)
+    # DIST_TIER: cold tier mode of every rank's operator (3 = tier whatever the size, 2 = and leave the tiers mid-solve)
+    if os.environ.get("DIST_TIER"):
+        st.tiering = int(os.environ["DIST_TIER"])
     stats = st.step(integrate=False)
+    tier_stats = st.op.tier_stats() if st.op is not None else {}
     gid = st.local["gid"].cpu().numpy().astype(np.int64)
     pairs = st.pairs.cpu().numpy()
     out = dict(stats=stats, gpairs=gid[pairs], counted=st.counted.cpu().numpy().astype(bool),
                g=st.grad.cpu().numpy(), x=st.lam.cpu().numpy(),
-               vel=st.op.body_velocity()[st.n_lo:st.n_lo + st.n].cpu().numpy(), first=a)
+               vel=st.op.body_velocity()[st.n_lo:st.n_lo + st.n].cpu().numpy(), first=a, tier=tier_stats)
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(out, gathered, dst=0)
     ok = True
@@ -68,6 +72,9 @@ def main():
         srt = np.argsort(key(allp))
         checks = {}
         checks["pair set == single-rank neighbour list"] = np.array_equal(allp[srt], rp)
+        if os.environ.get("DIST_TIER"):   # the staged solve of every rank did renumber its contacts hot-first
+            checks["cold tier active on every rank: renumberings %s" % [o["tier"].get("renumberings") for o in gathered]] = \
+                all(o["tier"].get("renumberings", 0) >= 1 for o in gathered)
         checks["all ranks converged"] = all(o["stats"]["converged"] for o in gathered) and rs.converged
         iters = [o["stats"]["num_iters"] for o in gathered]
         checks["same iteration count on every rank"] = len(set(iters)) == 1

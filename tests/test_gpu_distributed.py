@@ -67,6 +67,15 @@ def test_three_ranks_40_steps_bodies_migrate_and_the_curve_is_recut_by_work():
                    "DIST_BUFFER": "0.3"})
 
 
+@pytest.mark.parametrize("world,mode", [(2, 3), (3, 3), (3, 2)])
+def test_cold_tier_of_the_staged_solver(world, mode):
+    # the staged (multi-rank) driver keeps interior contacts -- both bodies owned by the rank -- in the cold tier: each
+    # rank renumbers its own contacts, wakes them through its own bodies' drifts, and on return rebuilds the previous
+    # iterate's rows for the sleepers' x_tmp / g_tmp.  Mode 3 tiers whatever the size; mode 2 also makes every rank leave
+    # the tiers mid-solve.  Bit for bit the single-rank solve, and a 6-step trajectory on top
+    _run(world, None, {"DIST_TIER": str(mode), "DIST_BODIES": "9000", "DIST_STEPS": "6"})
+
+
 @pytest.mark.parametrize("bodies", [2, 7])
 def test_migration_when_ranks_own_nothing(bodies):
     # the curve cut, the migration plan and the exchange with ranks that own no body at all (3 ranks, 2 or 7 bodies):
