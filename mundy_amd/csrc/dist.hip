@@ -784,6 +784,8 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
         profile->timed_iterations += 1;
       }
     }
+    // (after a pause -- mhip_bbpgd_stage_poll has handled it -- the rest of the chunk did nothing: count what ran)
+    if (!done && result->num_iters < enqueued) enqueued = result->num_iters;
     if (done || enqueued >= config->max_iters) break;
     if (enqueued >= 8)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
       if (int e = mhip_bbpgd_stage_snapshot_active(op, stream)) return e;

@@ -572,6 +572,7 @@ class DistributedContactStepper:
             self.prof["iters"] += int(dprof.timed_iterations)
         tick("solve")
         self.lam, self.grad, self.contacts, self.pairs, self.counted = x, g, con, pairs, counted
+        self.lam_prev, self.grad_prev = x_tmp, g_tmp     # the iterate before (what a warm restart continues from)
         if integrate:
             a, b = self.n_lo, self.n_lo + self.n
             own_c, own_q = L["center"][a:b], L["quat"][a:b]

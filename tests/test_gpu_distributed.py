@@ -165,6 +165,25 @@ def test_nccl_transport_single_rank():
         s3 = st3.step(integrate=False)
         assert not s3["converged"] and s3["num_iters"] == 7
         st3.op.close()
+        # the cold tier of the staged solver leaves all four solver vectors where the untiered staged solve leaves them:
+        # converged, stopped at an even and at an odd iteration cap, tiers kept to the end (3) or left mid-solve (2)
+        for cap in (20000, 61, 62):
+            got = {}
+            for mode in (0, 3, 2):
+                st5 = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]),
+                                                  0, comm=comm, cfg=ops.PGDConfig(max_iters=cap, tol=1e-6),
+                                                  poll_every=8)
+                st5.tiering = mode
+                s5 = st5.step(integrate=False)
+                got[mode] = (s5["num_iters"], st5.lam.clone(), st5.grad.clone(), st5.lam_prev.clone(),
+                             st5.grad_prev.clone(), st5.vel.clone())
+                if mode and cap > 100:
+                    assert st5.op.tier_stats()["renumberings"] > 0
+                st5.op.close()
+            for mode in (3, 2):
+                assert got[mode][0] == got[0][0], (cap, mode)
+                for u, v in zip(got[mode][1:], got[0][1:]):
+                    assert torch.equal(u, v), (cap, mode)
         comm.close()
         # if the library's RCCL communicator cannot be made, every rank falls back -- together -- to the host-callback
         # transport over a gloo group: same step, same result
