@@ -141,6 +141,8 @@ def parse():
     p.add_argument("--lanes-per-body", type=int, default=-1, help="lanes per body of the body sweep (time only)")
     p.add_argument("--no-cold-tier", action="store_true",
                    help="sweep every contact every iteration (time only: the iterates are the same bits)")
+    p.add_argument("--cold-tier-any-size", action="store_true",
+                   help="cold tier even below the size (1.5M contacts) from which it pays -- for tests of the accounting")
     p.add_argument("--relaxed-steps", type=int, default=2,
                    help="N = 1: after the headline steps, advance the packing by this many full steps and time --steps "
                         "more from THAT state (labelled `relaxed_packing`; SURVEY 8d.3 allows one relaxation pre-pass)")
@@ -205,6 +207,8 @@ def main():
         stepper.work_mapping = (args.xcd_tile, args.lanes_per_body)
     if args.no_cold_tier:
         stepper.tiering = 0
+    elif args.cold_tier_any_size:
+        stepper.tiering = 3
     pristine = stepper.snapshot()
     prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 

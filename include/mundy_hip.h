@@ -337,11 +337,13 @@ int mhip_contact_op_set_work_mapping(mhip_contact_op_t handle, int xcd_tile, int
 /* Cold tier of mhip_bbpgd_solve_contact (time only, never results).  Two thirds of the contacts of a packing are inactive
  * (x = 0, g > 0) for most of a solve; such a contact adds exact zeros to every sum of an iteration, and how far its
  * gradient can have moved is bounded by its two bodies' accumulated velocity changes.  From the first convergence poll on
- * the solve therefore renumbers the contacts hot-first and sweeps the cold tail only through those bounds (16 streamed
- * bytes per sleeping contact instead of 88); a contact that reaches its bound is evaluated like any other again.  Same
+ * the solve therefore renumbers the contacts hot-first and leaves the cold tail alone (a body whose accumulated change
+ * reaches the smallest bound of its sleeping contacts wakes those that have reached theirs; a woken contact is evaluated
+ * like any other again).  Same
  * iterates, bit for bit, and the same iteration count as with tiering off (every sum is a double-double pair rounded
  * once, so the partition of the contacts does not reach the sums).  LCP solves (any of the three operator forms) with at
- * least 65 536 contacts, in the fused solve and -- for the contacts between two bodies the rank owns -- in the staged /
+ * least 1.5 million contacts (below that the solve is launch-bound and the bookkeeping costs more than the shorter
+ * sweep saves), in the fused solve and -- for the contacts between two bodies the rank owns -- in the staged /
  * distributed one; mode 0 = off, 1 = on (default), 2 = test hook: leave the tiers mid-solve, as the solve does before a BB
  * step outside [0, finite], 3 = test hook: no minimum size (2 has none either).
  * tier_stats: iterations that ran tiered, mean share of hot contacts over them, renumberings, contacts woken. */

@@ -1575,7 +1575,7 @@ struct mhip_contact_op {
     const double* q_cur = nullptr;
     size_t interior = 0;
     bool interior_known = false, pause_on_bad_step = false;
-    unsigned polls = 0;
+    unsigned polls = 0, iter_at_poll = 0;
   } stage;
   // cold tier of the fused solve (see "Cold tier")
   struct Tier {
@@ -1748,7 +1748,10 @@ constexpr unsigned kSnapshotAfter = 8;
 //   gradients -- k_finalize pauses the solve for that): the sleepers' gradients are evaluated for the last two iterates
 //   from the two body-row buffers, everything is scattered back to the caller's numbering, inc is restored.
 constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g above this (far above rounding noise)
-constexpr size_t kTierMinContacts = 65536;  // smaller problems are launch-bound: not worth the bookkeeping
+// smaller problems are launch-bound, the extra launch per iteration and the renumbering passes cost more than the
+// shorter sweep saves (rods, fused solve, tier on / off: 0.22M contacts 9.2 / 7.5 ms, 0.94M 18.5 / 16.8 ms, 1.9M 32.6 /
+// 34.2 ms, 3.8M 94 / 108 ms, 7.6M 150 / 190 ms; scripts/tier_crossover.py)
+constexpr size_t kTierMinContacts = 1500000;
 constexpr unsigned kTierFireBlocks = 8;  // workgroups that wake the sleeping contacts of fired bodies (a multiple of 8: XCDs)
 #ifndef MHIP_TIER_LIST_BLOCKS
 #define MHIP_TIER_LIST_BLOCKS 256
@@ -3060,6 +3063,7 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.interior = 0;
   op->stage.interior_known = false;
   op->stage.polls = 0;
+  op->stage.iter_at_poll = 0;
   op->stage.pause_on_bad_step = op->tiering != 0 && tier_problem_kind(sp, config->residual_kind);
   mhip_contact_op::Tier& tier = op->tier;
   if (tier.active) {  // a staged solve that ended in an error left the operator in the tier numbering
@@ -3230,6 +3234,14 @@ int mhip_bbpgd_stage_poll(mhip_contact_op_t op, mhip_solve_result* result, int* 
   hipStream_t s = as_stream(stream);
   MHIP_HIP(hipMemcpyAsync(op->host_state, op->state.ptr, sizeof(SolverState), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
+  if (op->stage.active) {
+    if (op->tier.active && op->host_state->iter > op->stage.iter_at_poll) {  // (statistics: iterations that ran tiered)
+      const unsigned ran = op->host_state->iter - op->stage.iter_at_poll;
+      op->tier.tiered_iterations += ran;
+      op->tier.hot_sum += ran * (static_cast<double>(op->tier.H + (op->view.C - op->tier.I)) / static_cast<double>(op->view.C));
+    }
+    op->stage.iter_at_poll = op->host_state->iter;
+  }
   if (op->host_state->done == 2 && op->stage.active) {
     // paused before a BB step outside [0, finite] (every rank pauses at the same iteration: the step is global): the
     // sleepers' exact gradients are needed, so the tiers are left for good and the solve goes on

@@ -13,11 +13,15 @@ c, q, r, L = (b[k][order] for k in ("center", "quat", "radius", "length"))
 cfg = ops.PGDConfig(max_iters=10000, tol=1e-5)
 st = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=D.Comm(), cfg=cfg, poll_every=32)
 ref = pipeline.ContactStepper("spherocylinder", dev(c), dev(r), dev(q), dev(L), search_buffer=0.1, cfg=cfg)
-for name, fn in (("staged", lambda: st.step(integrate=False)), ("fused", lambda: ref.step(integrate=False))):
+st0 = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=D.Comm(), cfg=cfg, poll_every=32)
+st0.tiering = 0
+for name, fn in (("staged", lambda: st.step(integrate=False)), ("staged, cold tier off", lambda: st0.step(integrate=False)),
+                 ("fused", lambda: ref.step(integrate=False))):
     fn(); torch.cuda.synchronize()
     t = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t
     it = out["num_iters"] if isinstance(out, dict) else out.num_iters
     print("%s: %.1f ms/step, %d iterations, %.3f ms/iteration" % (name, 1e3 * dt, it, 1e3 * dt / max(it, 1)))
+print("staged cold tier:", st.op.tier_stats())
 print("fused stage ms:", {k: round(v, 2) for k, v in ref.step(integrate=False, timed=True).timings_ms.items()})
 st.profile = True
 st.prof.update(body_ms=0.0, con_ms=0.0, iters=0)

@@ -20,6 +20,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
     b = synth.spherocylinders(n, seed=1000 + case, volume_fraction=phi, length=L)
     st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]), dev(b["length"]),
                                  dt=dt, search_buffer=buf, cfg=ops.PGDConfig(max_iters=50000, tol=tol))
+    st.tiering = 3      # the cold tier whatever the size (by default only from 1.5M contacts on): the harder path
     s = st.step(integrate=False)
     aabb = oracle.compute_aabb_spherocylinders(b["center"], b["quat"], b["radius"], b["length"])
     brad = oracle.bounding_radius_spherocylinders(b["radius"], b["length"])

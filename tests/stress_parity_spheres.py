@@ -21,6 +21,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
     box = [s["box"]] * 3 if periodic else None
     st = pipeline.ContactStepper("sphere", dev(c), dev(r), search_buffer=buf, search_kind=kind, periodic_box=box,
                                  cfg=ops.PGDConfig(max_iters=50000, tol=tol))
+    st.tiering = 3      # the cold tier whatever the size (by default only from 1.5M contacts on): the harder path
     res = st.step(integrate=False)
     lo, hi, R = oracle.grow(oracle.compute_aabb_spheres(c, r), r, buf)
     pairs = oracle.search(kind, lo, hi, c, R, box=box)

@@ -20,8 +20,11 @@ def _run(extra):
     return json.loads(lines[0])
 
 
-def test_default_line_has_the_contract_keys():
-    d = _run([])
+@pytest.mark.parametrize("tier", ["default", "any-size"])
+def test_default_line_has_the_contract_keys(tier):
+    # (30000 rods are below the size from which the cold tier pays: the default run sweeps every contact; the second
+    # run switches the tier on regardless, for the byte accounting of the tiered iterations)
+    d = _run([] if tier == "default" else ["--cold-tier-any-size"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -45,7 +48,10 @@ def test_default_line_has_the_contract_keys():
     # the constraint sweep's: 88 B per contact swept (hot range + awake part of the tail) over the tiered iterations
     kc = r if r["kernel"].startswith("k_constraint") else d["k_constraint"]
     C, N, h = d["config"]["contacts_per_gpu"], d["config"]["bodies_per_gpu"], ct["mean_hot_fraction"]
-    assert ct["tiered_iterations"] > 0 and 0.0 < h < 1.0 and ct["renumberings"] >= 1
+    if tier == "default":
+        assert ct["tiered_iterations"] == 0 and ct["renumberings"] == 0
+    else:
+        assert ct["tiered_iterations"] > 0 and 0.0 < h < 1.0 and ct["renumberings"] >= 1
     assert kc["bytes_per_launch"] == pytest.approx(
         (1 - share) * (88.0 * C + 48.0 * N) + share * (88.0 * h * C + 48.0 * N), rel=1e-3)
     # the second, labelled figure: the same step from the relaxed packing

@@ -549,10 +549,10 @@ def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
     from gpu_util import dev
     P = maker(oracle, n, seed=41)
     C = len(P["pairs"])
-    assert C >= 65536, C
+    assert 65536 <= C < 1_500_000, C       # (below the size from which the tier is on by default: mode 3 = any size)
     q = dev(P["sep"])
     results = {}
-    for mode in (0, 1, 2):
+    for mode in (0, 3, 2):
         op = _gpu_op(ops, P)
         op.set_tiering(mode)
         out = []
@@ -563,7 +563,7 @@ def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
             out.append((st, res, op.body_velocity().clone(), stats))
             if mode == 0:
                 assert stats["tiered_iterations"] == 0
-            elif mode == 1:
+            elif mode == 3:
                 # (drift bookkeeping from the poll at 8 iterations, tiers from the poll at 24 or 56)
                 assert stats["tiered_iterations"] >= min(res.num_iters, max_iters) - 56 > 0, stats
                 assert stats["renumberings"] >= 1, stats
@@ -576,7 +576,11 @@ def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
             np.testing.assert_allclose((y + q).cpu().numpy(), st[1].cpu().numpy(), atol=1e-9)
         results[mode] = out
         op.close()
-    for mode in (1, 2):
+    op = _gpu_op(ops, P)                     # default mode at this size: every contact swept
+    ops.solve_lcp(op, q, dev(np.zeros(C)), ops.PGDConfig(max_iters=100, tol=1e-6))
+    assert op.tier_stats()["tiered_iterations"] == 0
+    op.close()
+    for mode in (3, 2):
         for (st0, r0, v0, _), (st1, r1, v1, _) in zip(results[0], results[mode]):
             assert (r0.num_iters, r0.converged, r0.residual) == (r1.num_iters, r1.converged, r1.residual)
             for a, b in zip(st0, st1):
