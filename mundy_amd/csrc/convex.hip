@@ -701,155 +701,157 @@ __device__ inline double contact_dt_sdot(const OpView& op, const double* __restr
 
 // Cold tail of a tiered solve ("Cold tier" below).  A sleeping contact (i, j) holds two thresholds, thr[0] for drift[i]
 // and thr[1] for drift[j] (each body gets half the contact's slack); fire_at[b] is the smallest threshold among b's
-// sleeping contacts.  The body sweep lists the bodies whose drift has reached fire_at; the first `blocks` workgroups of
-// the constraint sweep's grid then walk those bodies' incidence lists, wake the contacts whose threshold is reached
-// (they go to `list`: k_constraint_listed evaluates them, this iteration and after) and reset fire_at to the smallest
-// threshold left.  A handful of bodies per iteration: nothing scans the tail.
+// sleeping contacts.  The body sweep lists the bodies whose drift has reached fire_at.  The first `blocks` workgroups
+// of the constraint sweep's grid ("service" workgroups) do the tail's work in the shadow of the hot sweep: they evaluate
+// the contacts that were awake when the iteration started (list[0, counters[2])), then walk the fired bodies'
+// incidence lists, wake the contacts whose threshold is reached -- listed, and evaluated on the spot by the lane that
+// woke them -- and reset fire_at to the smallest threshold left.  A handful of bodies per iteration: nothing scans the
+// tail, and the tail costs no launch of its own.
 struct TierCheck {
   size_t H, I;                   // cold tail = contacts [H, I)
   double* wake;                  // [C - H][2] thresholds; thr[0] = -inf: awake
   int32_t* list;                 // awake contacts of the tail
-  unsigned long long* counters;  // [0] = length of list, [1] = length of fired
+  unsigned long long* counters;  // [0] = length of list, [1] = length of fired, [2] = length of list when the iteration began
   const int32_t* fired;          // bodies listed by the body sweep
   double* fire_at;               // [N]
   unsigned blocks;               // workgroups at the front of the grid that do this instead of sweeping
 };
-__device__ inline void tier_fire_range(const TierCheck& tc, const int32_t* __restrict__ inc_ptr,
-                                       const int32_t* __restrict__ inc, const double* __restrict__ drift,
-                                       unsigned block, unsigned nblocks) {
-  const size_t count = static_cast<size_t>(tc.counters[1]);
-  const double ninf = -__builtin_huge_val();
-  for (size_t q = block * (size_t)blockDim.x + threadIdx.x; q < count; q += (size_t)nblocks * blockDim.x) {
-    const size_t b = static_cast<size_t>(tc.fired[q]);
-    const double D = drift[b];
-    double left = __builtin_huge_val();
-    for (int32_t k = inc_ptr[b]; k < inc_ptr[b + 1]; ++k) {
-      const int32_t e = inc[k];
-      const size_t c = static_cast<size_t>(e >> 1);
-      if (c < tc.H || c >= tc.I) continue;
-      double* thr = tc.wake + 2 * (c - tc.H);
-      const double mine = thr[e & 1];
-      if (!(thr[0] > ninf)) continue;  // awake already
-      if (D < mine) {
-        if (mine < left) left = mine;
-        continue;
-      }
-      // wake it; the contact's other body may be doing the same right now: slot 0 decides who lists it
-      const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(thr),
-                                                static_cast<unsigned long long>(__double_as_longlong(ninf)));
-      if (__longlong_as_double(static_cast<long long>(old)) > ninf) {
-        thr[1] = ninf;
-        tc.list[atomicAdd(&tc.counters[0], 1ull)] = static_cast<int32_t>(c);
-      }
+
+// one contact of the tail evaluated as the sweep evaluates a hot one (same expressions: same bits); a sleeper's stale
+// pair says x = 0, g > 0 -- all an evaluation uses of an inactive contact
+template <int KIN>
+__device__ __forceinline__ void tier_evaluate(const OpView& op, const double* __restrict__ vel,
+                                              const double* __restrict__ xt, double* __restrict__ xn,
+                                              const double* __restrict__ q, const Space& sp, double step,
+                                              bool step_is_zero, int resid_kind, size_t c, double& rmax, DD& num,
+                                              DD& den) {
+  const int2 ij = op.pairs[c];
+  double x_old = 0.0, g_old = 0.0;
+  const double xc = iterate_x<X_SOLVE, true>(c, xt, nullptr, step, step_is_zero, sp, &x_old, &g_old);
+  const double y = contact_dt_sdot<KIN>(op, vel, c, ij);
+  const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
+  reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
+  if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
+    const bool was = !(x_old == 0.0 && g_old >= 0.0 && g_old <= 1.7976931348623157e308);
+    const bool now = !(xc == 0.0 && g >= 0.0 && g <= 1.7976931348623157e308);
+    if (was != now) {
+      const unsigned pi = op.pos[2 * c], pj = op.pos[2 * c + 1];
+      if (pi < 64u) atomicXor(&op.body_mask[ij.x], 1ull << pi);
+      if (pj < 64u) atomicXor(&op.body_mask[ij.y], 1ull << pj);
     }
-    tc.fire_at[b] = left;
+  }
+  if (op.counted == nullptr || op.counted[c]) {
+    const double r = residual_term(resid_kind, xc, g, sp);
+    if (r > rmax) rmax = r;
+    const double dx = xc - x_old;
+    dd_add(num, dx * dx);            // diff_dot(x, x_old)              (convex.hpp:507)
+    dd_add(den, dx * (g - g_old));   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
   }
 }
 
-// The constraint sweep (k_constraint, k_constraint_listed).  LISTED: the contacts swept are those of `list`
-// (tier_counters[0] of them): the woken contacts of a tiered solve's cold tail ("Cold tier" below), evaluated like any
-// other; sleeping ones add exact zeros, among them 0 to the max.
-template <int MODE, int KIN, bool PACKED, bool LISTED>
-__device__ __forceinline__ void constraint_sweep(const OpView& op, const SolverState* __restrict__ st,
-                                                 double* __restrict__ X0, double* __restrict__ X1,
-                                                 double* __restrict__ G0, double* __restrict__ G1,
-                                                 const double* __restrict__ q, const Space& sp, int resid_kind,
-                                                 double* __restrict__ partials, const int32_t* __restrict__ list,
-                                                 const unsigned long long* __restrict__ tier_counters) {
-  __shared__ double scratch[2 * kBlock / 64];
-  const unsigned nblk = gridDim.x, bid = blockIdx.x;
+// what a service workgroup does (block = its index among the tc.blocks of them); its partial record goes to `slot`.
+// Waking and evaluating alternate in rounds -- a lane wakes at most kTierRoundClaims contacts into the workgroup's LDS
+// queue, then the workgroup evaluates the queue -- so that the walk of the incidence lists and the evaluation do not
+// hold their registers at the same time (evaluating on the spot took 82 VGPRs against the sweep's 66).
+constexpr int kTierRoundClaims = 8;
+constexpr int kTierQueue = kTierRoundClaims * kBlock;
+template <int KIN>
+__device__ __forceinline__ void tier_service(const OpView& op, const SolverState* __restrict__ st, double* __restrict__ X0,
+                                             double* __restrict__ X1, const double* __restrict__ q, const Space& sp,
+                                             int resid_kind, double* __restrict__ partials, const TierCheck& tc,
+                                             unsigned block, size_t slot, double* scratch, int32_t* queue,
+                                             unsigned* queued) {
+  if (st->done) return;
   const double* xt = X0;
-  const double* gt = G0;
   double* xn = X1;
-  double* gn = G1;
-  double step = 0.0;
-  if (MODE == X_SOLVE) {
-    if (st->done) return;
-    if (st->flips & 1u) {
-      xt = X1; gt = G1; xn = X0; gn = G0;
-    }
-    step = st->step;
+  if (st->flips & 1u) {
+    xt = X1; xn = X0;
   }
-  if (MODE == X_INIT) gn = G0;  // g_tmp = A x_tmp + q
-  if (MODE == X_INIT && PACKED) {  // X0 = packed buffer of the first iterate, G0 = the caller's plain x
-    xt = G0;
-    xn = X0;
-  }
+  const double step = st->step;
   const double* vel = op.vel;  // the rows the body sweep of this iteration wrote
-  if (MODE == X_SOLVE && op.vel_alt && !(st->flips & 1u)) vel = op.vel_alt;
+  if (op.vel_alt && !(st->flips & 1u)) vel = op.vel_alt;
   const bool step_is_zero = fabs(-step) < kZeroTol;
-  double rmax = LISTED ? 0.0 : kLowest;
+  double rmax = 0.0;  // (sleeping contacts add exact zeros, among them 0 to the max)
   DD num{0.0, 0.0}, den{0.0, 0.0};
-  const size_t nwork = LISTED ? static_cast<size_t>(tier_counters[0]) : op.c_end - op.c_first;
-  const size_t ntiles = (nwork + kBlock - 1) / kBlock;
-  for (size_t lin = bid; lin < ntiles; lin += nblk) {
-    size_t c;
-    if (LISTED) {
-      const size_t k = lin * kBlock + threadIdx.x;
-      if (k >= nwork) continue;
-      c = static_cast<size_t>(list[k]);
-    } else {
-      c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
-      if (c >= op.c_end) continue;
-    }
-    const int2 ij = op.pairs[c];
-    double x_old = 0.0, g_old = 0.0;
-    const double xc = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
-    const double y = contact_dt_sdot<KIN>(op, vel, c, ij);
-    if (MODE == X_APPLY) {
-      gn[c] = y;
-    } else {
-      const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
-      if (PACKED) {
-        reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
-        if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
-          // masks start all-ones (every contact "active"); flip this contact's two bits when its state changes
-          const bool was = (MODE == X_INIT) ? true : !(x_old == 0.0 && g_old >= 0.0 && g_old <= 1.7976931348623157e308);
-          const bool now = !(xc == 0.0 && g >= 0.0 && g <= 1.7976931348623157e308);
-          if (was != now) {
-            const unsigned pi = op.pos[2 * c], pj = op.pos[2 * c + 1];
-            if (pi < 64u) atomicXor(&op.body_mask[ij.x], 1ull << pi);
-            if (pj < 64u) atomicXor(&op.body_mask[ij.y], 1ull << pj);
-          }
+  // this workgroup's share of the contacts woken in earlier iterations: evaluated in the first round below
+  const size_t awake = static_cast<size_t>(tc.counters[2]);
+  const size_t share = (awake + tc.blocks - 1) / tc.blocks;
+  const size_t old_lo = block * share < awake ? block * share : awake;
+  unsigned n_old = static_cast<unsigned>((old_lo + share < awake ? old_lo + share : awake) - old_lo);
+  // the bodies that fired in this iteration's body sweep: one per lane, a chunk of blockDim at a time
+  const size_t count = static_cast<size_t>(tc.counters[1]);
+  const double ninf = -__builtin_huge_val();
+  size_t f0 = block * (size_t)blockDim.x;
+  for (;;) {
+    const bool have = f0 + threadIdx.x < count;
+    const size_t b = have ? static_cast<size_t>(tc.fired[f0 + threadIdx.x]) : 0;
+    const double D = have ? op.drift[b] : 0.0;
+    int32_t k = have ? op.inc_ptr[b] : 0;
+    const int32_t kend = have ? op.inc_ptr[b + 1] : 0;
+    double left = __builtin_huge_val();
+    do {
+      if (threadIdx.x == 0) *queued = 0u;
+      __syncthreads();
+      for (int claims = 0; k < kend && claims < kTierRoundClaims; ++k) {
+        const int32_t e = op.inc[k];
+        const size_t c = static_cast<size_t>(e >> 1);
+        if (c < tc.H || c >= tc.I) continue;
+        double* thr = tc.wake + 2 * (c - tc.H);
+        const double mine = thr[e & 1];
+        if (!(thr[0] > ninf)) continue;  // awake already
+        if (D < mine) {
+          if (mine < left) left = mine;
+          continue;
         }
-      } else {
-        gn[c] = g;
-        if (MODE == X_SOLVE) xn[c] = xc;
-      }
-      if (op.counted == nullptr || op.counted[c]) {
-        const double r = residual_term(resid_kind, xc, g, sp);
-        if (r > rmax) rmax = r;
-        if (MODE == X_SOLVE) {
-          const double dx = xc - x_old;
-          dd_add(num, dx * dx);            // diff_dot(x, x_old)              (convex.hpp:507)
-          dd_add(den, dx * (g - g_old));   // diff_dot(x, x_old, g, g_old)    (convex.hpp:508)
+        // wake it; the contact's other body may be doing the same right now: slot 0 decides who lists and evaluates it
+        const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long*>(thr),
+                                                  static_cast<unsigned long long>(__double_as_longlong(ninf)));
+        if (__longlong_as_double(static_cast<long long>(old)) > ninf) {
+          thr[1] = ninf;
+          tc.list[atomicAdd(&tc.counters[0], 1ull)] = static_cast<int32_t>(c);
+          queue[atomicAdd(queued, 1u)] = static_cast<int32_t>(c);
+          ++claims;
         }
       }
-    }
+      __syncthreads();
+      const unsigned total = n_old + *queued;
+      for (unsigned i = threadIdx.x; i < total; i += blockDim.x) {
+        const int32_t c = i < n_old ? tc.list[old_lo + i] : queue[i - n_old];
+        tier_evaluate<KIN>(op, vel, xt, xn, q, sp, step, step_is_zero, resid_kind, static_cast<size_t>(c), rmax, num,
+                           den);
+      }
+      n_old = 0;
+    } while (__syncthreads_or(k < kend));  // (the barrier also keeps the queue reads ahead of the next reset)
+    if (have) tc.fire_at[b] = left;
+    f0 += (size_t)tc.blocks * blockDim.x;
+    if (f0 >= count) break;
   }
-  if (MODE != X_APPLY) {
-    const double m = block_max(rmax, scratch);
-    const DD s1 = block_sum(num, scratch);
-    const DD s2 = block_sum(den, scratch);
-    if (threadIdx.x == 0) {  // kRed planes of values: the final pass reads them coalesced
-      const size_t stride = op.part_stride ? op.part_stride : nblk;
-      store_partial(partials, stride, op.part_offset + bid, m, s1, s2);
-    }
-  }
+  const double m = block_max(rmax, scratch);
+  const DD s1 = block_sum(num, scratch);
+  const DD s2 = block_sum(den, scratch);
+  if (threadIdx.x == 0) store_partial(partials, op.part_stride, slot, m, s1, s2);
 }
 
 // (Kept as its own body rather than an instantiation of constraint_sweep: as one, the same sweep ran 10 % slower --
 // 0.144 against 0.130 ms at 10^6 rods -- for reasons the ISA diff of the loop does not show.)
+// (the waves-per-SIMD floor keeps the service path, which the compiler would otherwise schedule into 97 VGPRs, within
+// the sweep's own register budget)
 template <int MODE, int KIN, bool PACKED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     k_constraint(OpView op, const SolverState* __restrict__ st, double* __restrict__ X0, double* __restrict__ X1,
                  double* __restrict__ G0, double* __restrict__ G1, const double* __restrict__ q, Space sp,
                  int resid_kind, double* __restrict__ partials, TierCheck check = TierCheck{}) {
   __shared__ double scratch[2 * kBlock / 64];
-  // (tiered solves) the first check.blocks workgroups of the grid wake the sleeping contacts of the bodies that fired
+  // (tiered solves) the first check.blocks workgroups of the grid serve the cold tail; their partial records follow
+  // the sweeping workgroups' (the launch sets part_stride)
   const unsigned nblk = gridDim.x - check.blocks;
   if (blockIdx.x < check.blocks) {
-    if (MODE == X_SOLVE && !st->done) tier_fire_range(check, op.inc_ptr, op.inc, op.drift, blockIdx.x, check.blocks);
+    if (MODE == X_SOLVE && PACKED) {
+      __shared__ int32_t queue[kTierQueue];
+      __shared__ unsigned queued;
+      tier_service<KIN>(op, st, X0, X1, q, sp, resid_kind, partials, check, blockIdx.x,
+                        op.part_offset + nblk + blockIdx.x, scratch, queue, &queued);
+    }
     return;
   }
   const unsigned bid = blockIdx.x - check.blocks;  // this workgroup's place among the sweeping ones
@@ -943,16 +945,6 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// the woken contacts of a tiered solve's cold tail, from their list (its own name: the profiles tell the sweeps apart)
-template <int KIN>
-__global__ void __launch_bounds__(kBlock)
-    k_constraint_listed(OpView op, const SolverState* __restrict__ st, double* __restrict__ P0, double* __restrict__ P1,
-                        const double* __restrict__ q, Space sp, int resid_kind, double* __restrict__ partials,
-                        const int32_t* __restrict__ list, const unsigned long long* __restrict__ tier_counters) {
-  constraint_sweep<X_SOLVE, KIN, true, true>(op, st, P0, P1, nullptr, nullptr, q, sp, resid_kind, partials, list,
-                                             tier_counters);
-}
-
 constexpr int kFinalBlock = 1024;  // threads of the single-workgroup final passes
 // ordered reduction of nparts (max, num, den) records of kRed doubles; element (i, k) sits at partials[i * si + k * sk]
 // (block partials: si = 1, sk = plane distance; the all-gathered per-rank records: si = kRed, sk = 1)
@@ -1002,7 +994,10 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
   DD numdd, dendd;
   reduce_records(nparts, partials, si, sk, scratch, rmax, numdd, dendd);
   if (threadIdx.x != 0) return;
-  if (tier_counters) tier_counters[1] = 0;  // the fired bodies of this iteration have been dealt with
+  if (tier_counters) {
+    tier_counters[1] = 0;                 // the fired bodies of this iteration have been dealt with
+    tier_counters[2] = tier_counters[0];  // the contacts awake when the next iteration begins
+  }
   const double num = dd_value(numdd);  // the BB dot products, each rounded once
   double den = dd_value(dendd);
   const double res = (resid_kind == MHIP_RESIDUAL_PROJECTED_DIFF) ? rmax / kSmallStep : rmax;
@@ -1738,9 +1733,10 @@ constexpr unsigned kSnapshotAfter = 8;
 //   to the length of the next one).  (Sharing the slack in proportion to the two expectations instead tiers 64
 //   iterations earlier on the raw packing but wakes 2.3 x as many contacts: same step time, relaxed steps 5 % slower.)  The ordinary sweep then runs over [0, H) only.  Nothing scans the tail: every body
 //   knows the smallest threshold among its sleeping contacts (fire_at), the body sweep -- which has just updated the
-//   body's drift -- lists the bodies that reached it, and a few workgroups at the front of the constraint sweep's grid
-//   walk those bodies' incidence lists and wake the contacts concerned (TierCheck).  k_constraint_listed evaluates the
-//   awake contacts of the tail, from then on every iteration, exactly as the ordinary sweep would (a sleeper's stale
+//   body's drift -- lists the bodies that reached it, and a few "service" workgroups at the front of the constraint
+//   sweep's grid walk those bodies' incidence lists and wake the contacts concerned (TierCheck).  The same workgroups
+//   evaluate the awake contacts of the tail, from then on every iteration, exactly as the ordinary sweep would (a
+//   separate launch for them cost 10 us an iteration, a twentieth of it; a sleeper's stale
 //   pair says x = 0, g > 0, which is all an evaluation uses of an inactive contact: Proj(0 - step g) = 0 and dx = 0).
 //   Every sum is a double-double pair rounded once, so the partition does not reach the iterates: same bits, same
 //   iteration count as the untiered solve (tests).
@@ -1752,11 +1748,10 @@ constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g a
 // shorter sweep saves (rods, fused solve, tier on / off: 0.22M contacts 9.2 / 7.5 ms, 0.94M 18.5 / 16.8 ms, 1.9M 32.6 /
 // 34.2 ms, 3.8M 94 / 108 ms, 7.6M 150 / 190 ms; scripts/tier_crossover.py)
 constexpr size_t kTierMinContacts = 1500000;
-constexpr unsigned kTierFireBlocks = 8;  // workgroups that wake the sleeping contacts of fired bodies (a multiple of 8: XCDs)
-#ifndef MHIP_TIER_LIST_BLOCKS
-#define MHIP_TIER_LIST_BLOCKS 256
+#ifndef MHIP_TIER_SERVICE_BLOCKS
+#define MHIP_TIER_SERVICE_BLOCKS 16
 #endif
-constexpr unsigned kTierListBlocks = MHIP_TIER_LIST_BLOCKS;  // workgroups of the listed sweep (grid-stride)
+constexpr unsigned kTierFireBlocks = MHIP_TIER_SERVICE_BLOCKS;  // service workgroups in front of the hot sweep (a multiple of 8: XCDs)
 
 struct TierGeo {
   int2* pairs;
@@ -2192,9 +2187,8 @@ int tier_release(mhip_contact_op* op, TierPairs& cur, bool final, double* P0, do
   return tier_stop_tracking(op, s);
 }
 
-// the constraint sweeps of a tiered iteration: [0, H) as ever; the tail [H, C) is scanned for contacts that have
-// reached their wake level, and the awake ones are evaluated from their list.  Block partials of the two evaluating
-// sweeps share the planes (hot slots first).  *nparts = partial records written.
+// the constraint sweep of a tiered iteration: [0, H) as ever, with the service workgroups of the tail [H, I) in front
+// (their partial records follow the sweeping workgroups').  *nparts = partial records written.
 int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space sp, int resid_kind, unsigned* nparts,
                                 hipStream_t s) {
   mhip_contact_op::Tier& t = op->tier;
@@ -2203,27 +2197,20 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   double* parts = op->partials.as<double>();
   const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
   const unsigned ghot = t.H ? constraint_grid(t.H) : 0u;
-  // the tail: the bodies that fired in this iteration's body sweep are dealt with by the first workgroups of the hot
-  // launch, the awake contacts then evaluated by a small grid-stride launch
+  // the tail is served by the first workgroups of the hot launch
   const unsigned gcheck = t.H < t.I ? kTierFireBlocks : 0u;
-  const unsigned glist = t.H < t.I ? (grid_for(t.I - t.H) < kTierListBlocks ? grid_for(t.I - t.H) : kTierListBlocks) : 0u;
-  OpView hot = op->view, listed = op->view;
+  OpView hot = op->view;
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
-  listed.part_offset = ghot; listed.part_stride = kStageStride;
   const TierCheck tc{t.H, t.I, m.wake[t.set], m.list, m.counters, m.fired, m.fire_at, gcheck};
-#define TIERED(K)                                                                                                   \
-  do {                                                                                                              \
-    if (ghot + gcheck)                                                                                              \
-      k_constraint<X_SOLVE, K, true><<<ghot + gcheck, kBlock, 0, s>>>(hot, st, cur.P0, cur.P1, nullptr, nullptr,   \
-                                                                     cur.q, sp, resid_kind, parts, tc);            \
-    if (glist)                                                                                                      \
-      k_constraint_listed<K><<<glist, kBlock, 0, s>>>(listed, st, cur.P0, cur.P1, cur.q, sp, resid_kind, parts,    \
-                                                     m.list, m.counters);                                          \
-  } while (0)
-  if (op->kin == KIN_ROD) TIERED(KIN_ROD); else if (op->kin == KIN_RIGID) TIERED(KIN_RIGID); else TIERED(KIN_TRANS);
+#define TIERED(K)                                                                                                 \
+  k_constraint<X_SOLVE, K, true><<<ghot + gcheck, kBlock, 0, s>>>(hot, st, cur.P0, cur.P1, nullptr, nullptr,     \
+                                                                 cur.q, sp, resid_kind, parts, tc)
+  if (ghot + gcheck) {
+    if (op->kin == KIN_ROD) TIERED(KIN_ROD); else if (op->kin == KIN_RIGID) TIERED(KIN_RIGID); else TIERED(KIN_TRANS);
+    MHIP_LAUNCH_CHECK();
+  }
 #undef TIERED
-  MHIP_LAUNCH_CHECK();
-  *nparts = ghot + glist;
+  *nparts = ghot + gcheck;
   return MHIP_SUCCESS;
 }
 
@@ -3141,14 +3128,14 @@ int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_f
       grid = constraint_grid(c_count);
     }
     if (grid + extra == 0) return MHIP_SUCCESS;
-    MHIP_REQUIRE(st.part_used + grid <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
+    MHIP_REQUIRE(st.part_used + grid + extra <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
 #define STAGED(K)                                                                                                    \
   k_constraint<X_SOLVE, K, true><<<grid + extra, kBlock, 0, s>>>(vw, sst, st.P0, st.P1, nullptr, nullptr, st.q_cur, \
                                                                 st.sp, st.cfg.residual_kind, parts, tc)
     if (op->kin == KIN_ROD) STAGED(KIN_ROD); else if (op->kin == KIN_RIGID) STAGED(KIN_RIGID); else STAGED(KIN_TRANS);
 #undef STAGED
     MHIP_LAUNCH_CHECK();
-    st.part_used += grid;
+    st.part_used += grid + extra;  // (the service workgroups' records follow the sweeping ones')
     return MHIP_SUCCESS;
   }
   if (c_count == 0) return MHIP_SUCCESS;
@@ -3173,25 +3160,6 @@ int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local, mhip_
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   MHIP_REQUIRE(local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local record is null");
   hipStream_t s = as_stream(stream);
-  if (op->tier.active && !init && op->tier.H < op->tier.I) {  // the awake contacts of the cold tail
-    mhip_contact_op::Tier& tier = op->tier;
-    const TierMisc m = tier_misc_at(tier.misc.ptr, op->view.C, op->view.N);
-    const size_t tail = tier.I - tier.H;
-    const unsigned glist = grid_for(tail) < kTierListBlocks ? grid_for(tail) : kTierListBlocks;
-    MHIP_REQUIRE(op->stage.part_used + glist <= kStageStride, MHIP_ERR_RUNTIME, "too many constraint sweeps in one iteration");
-    OpView vw = op->view;
-    vw.part_offset = op->stage.part_used;
-    vw.part_stride = kStageStride;
-    const SolverState* sst = op->state.as<SolverState>();
-    auto& st = op->stage;
-#define LISTED(K)                                                                                                  \
-  k_constraint_listed<K><<<glist, kBlock, 0, s>>>(vw, sst, st.P0, st.P1, st.q_cur, st.sp, st.cfg.residual_kind,     \
-                                                 op->partials.as<double>(), m.list, m.counters)
-    if (op->kin == KIN_ROD) LISTED(KIN_ROD); else if (op->kin == KIN_RIGID) LISTED(KIN_RIGID); else LISTED(KIN_TRANS);
-#undef LISTED
-    MHIP_LAUNCH_CHECK();
-    op->stage.part_used += glist;
-  }
   unsigned np = op->stage.part_used;
   size_t ps = kStageStride;
   double* pp = op->partials.as<double>();

@@ -15,9 +15,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-# k_constraint: the full sweep, or in a tiered iteration the hot range + the scan of the cold tail; k_constraint_listed:
-# the woken contacts of the tail (a short launch every tiered iteration)
-KERNELS = ("k_constraint", "k_body", "k_constraint_listed")
+# k_constraint: the full sweep, or in a tiered iteration the hot range with the cold tail's service workgroups in front
+KERNELS = ("k_constraint", "k_body")
 
 
 def find(sub, pat):
