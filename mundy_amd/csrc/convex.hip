@@ -1570,7 +1570,7 @@ struct mhip_contact_op {
     const double* q_cur = nullptr;
     size_t interior = 0;
     bool interior_known = false, pause_on_bad_step = false;
-    unsigned polls = 0, iter_at_poll = 0;
+    unsigned polls = 0, iter_at_poll = 0, snap_at = 0;
   } stage;
   // cold tier of the fused solve (see "Cold tier")
   struct Tier {
@@ -1588,6 +1588,7 @@ struct mhip_contact_op {
     OpView saved{};         // the operator's own view, restored when the tiers are left
     // statistics of the last solve
     size_t tiered_iterations = 0, retiers = 0, wakeups = 0;
+    unsigned service_blocks = 16;  // workgroups serving the cold tail in front of the hot sweep (set at polls)
     double hot_sum = 0.0;   // sum over tiered iterations of H / C
   } tier;
   // optional per-kernel timing (mhip_contact_op_set_profiling)
@@ -1748,6 +1749,7 @@ constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g a
 // shorter sweep saves (rods, fused solve, tier on / off: 0.22M contacts 9.2 / 7.5 ms, 0.94M 18.5 / 16.8 ms, 1.9M 32.6 /
 // 34.2 ms, 3.8M 94 / 108 ms, 7.6M 150 / 190 ms; scripts/tier_crossover.py)
 constexpr size_t kTierMinContacts = 1500000;
+constexpr unsigned kTierHorizon = 64;  // iterations a sleeper's slack is sized for, at least
 #ifndef MHIP_TIER_SERVICE_BLOCKS
 #define MHIP_TIER_SERVICE_BLOCKS 16
 #endif
@@ -1969,6 +1971,12 @@ bool tier_eligible(const mhip_contact_op* op, const Space& sp, int resid_kind) {
          v.body_first == 0 && v.body_count == v.N && tier_problem_kind(sp, resid_kind);
 }
 
+// service workgroups of a tiered sweep for an awake list of the given length (known at polls; a multiple of 8: XCDs)
+unsigned tier_service_blocks(size_t awake) {
+  const size_t want = kTierFireBlocks + 8 * (awake / (8 * 2 * kBlock));  // about two rounds per workgroup
+  return static_cast<unsigned>(want < 256 ? want : 256);
+}
+
 // the packed pair a tiered (or not yet tiered) solve is iterating on
 struct TierPairs {
   double *P0, *P1;
@@ -2012,9 +2020,18 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
     return MHIP_SUCCESS;
   }
   const unsigned last_period = iters_done - t.polled_at;
+  // (a poll that comes too soon after the last one only lengthens the window the drift rate is measured over: half the
+  // horizon, less at the start of a solve, where the drifts are largest and a short window errs on the safe side)
+  const unsigned min_window = iters_done / 2 < kTierHorizon / 2 ? iters_done / 2 : kTierHorizon / 2;
+  if (last_period == 0 || last_period < min_window) return MHIP_SUCCESS;
   t.polled_at = iters_done;
-  if (last_period == 0) return MHIP_SUCCESS;
-  const double scale = static_cast<double>(next_period) / static_cast<double>(last_period);
+  // the drift a body is expected to collect while its contacts sleep: the rate of the period just run over the
+  // iterations until the next poll -- but at least kTierHorizon of them: a sleeper is meant to last until the next
+  // RENUMBERING, which comes only when it pays, and BB steps are bursty, so the budget of a short polling period (the
+  // caller's choice in the staged driver) predicts too little.  (10^6 rods, staged, polled every 16 / 32 / 64
+  // iterations: 1 130 000 / 136 000 / 3 700 contacts woken and 259 / 170 / 156 ms per step before this floor.)
+  const unsigned horizon = next_period > kTierHorizon ? next_period : kTierHorizon;
+  const double scale = static_cast<double>(horizon) / static_cast<double>(last_period);
   k_tier_budget<<<grid_for(N), kBlock, 0, s>>>(N, t.drift.as<double>(), m.drift_prev, scale, m.budget);
   MHIP_LAUNCH_CHECK();
   const double2* Pc = reinterpret_cast<const double2*>(cur_is_p1 ? cur.P1 : cur.P0);
@@ -2033,6 +2050,8 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   MHIP_HIP(hipStreamSynchronize(s));
   const size_t H = static_cast<size_t>(H32);
   if (t.active) {
+    // (a long awake list gets more service workgroups: each evaluates its share in rounds of a workgroup's width)
+    t.service_blocks = tier_service_blocks(static_cast<size_t>(awake));
     // renumbering costs about four constraint sweeps: only when what is swept in full (the hot range and the awake
     // part of the tail, the latter through scattered accesses) can shrink by a tenth
     if (10 * H >= 9 * (t.H + static_cast<size_t>(awake))) return MHIP_SUCCESS;
@@ -2081,6 +2100,7 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   cur.q = dst.q;
   t.wakeups += static_cast<size_t>(awake);
   t.active = true;
+  t.service_blocks = kTierFireBlocks;
   t.set = dst_set;
   t.H = H;
   t.I = I;
@@ -2198,7 +2218,7 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   const TierMisc m = tier_misc_at(t.misc.ptr, C, N);
   const unsigned ghot = t.H ? constraint_grid(t.H) : 0u;
   // the tail is served by the first workgroups of the hot launch
-  const unsigned gcheck = t.H < t.I ? kTierFireBlocks : 0u;
+  const unsigned gcheck = t.H < t.I ? t.service_blocks : 0u;
   OpView hot = op->view;
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
   const TierCheck tc{t.H, t.I, m.wake[t.set], m.list, m.counters, m.fired, m.fire_at, gcheck};
@@ -3051,6 +3071,7 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.interior_known = false;
   op->stage.polls = 0;
   op->stage.iter_at_poll = 0;
+  op->stage.snap_at = 0;
   op->stage.pause_on_bad_step = op->tiering != 0 && tier_problem_kind(sp, config->residual_kind);
   mhip_contact_op::Tier& tier = op->tier;
   if (tier.active) {  // a staged solve that ended in an error left the operator in the tier numbering
@@ -3118,7 +3139,7 @@ int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_f
       vw.c_end = tier.H;
       grid = tier.H ? constraint_grid(tier.H) : 0u;
       if (tier.H < tier.I) {
-        extra = kTierFireBlocks;
+        extra = tier.service_blocks;
         tc = TierCheck{tier.H, tier.I, m.wake[tier.set], m.list, m.counters, m.fired, m.fire_at, extra};
       }
     } else {
@@ -3189,9 +3210,9 @@ int mhip_bbpgd_stage_finalize(mhip_contact_op_t op, int init, const double* gath
   else
     k_finalize<X_SOLVE><<<1, final_block(nparts), 0, as_stream(stream)>>>(
         nparts, gathered, kRed, 1, st, cfg.residual_kind, cfg.tol, cfg.max_iters,
-        // (test hook, mode 2: every rank pauses at the first iteration after its third snapshot poll -- a condition that
+        // (test hook, mode 2: every rank pauses at the first iteration after its tenth snapshot poll -- a condition that
         // is the same on all ranks, as a bad step would be)
-        op->stage.pause_on_bad_step ? ((op->tiering == 2 && op->stage.polls >= 3) ? 2 : 1) : 0,
+        op->stage.pause_on_bad_step ? ((op->tiering == 2 && op->stage.polls >= 10) ? 2 : 1) : 0,
         op->tier.active ? op->view.tier_counters : nullptr);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -3244,6 +3265,7 @@ int mhip_bbpgd_stage_snapshot_active(mhip_contact_op_t op, mhip_stream_t stream)
   auto& st = op->stage;
   st.polls += 1;
   mhip_contact_op::Tier& tier = op->tier;
+  const size_t retiers_before = tier.retiers;
   // cold tier: needs the interior range (learnt from the sweeps of the iterations run so far) and host_state (the
   // caller has just polled).  Only contacts between two owned bodies may sleep: a ghost's drift is not known here.
   if (!tier.disabled && st.interior_known && !op->host_state->done) {
@@ -3254,6 +3276,13 @@ int mhip_bbpgd_stage_snapshot_active(mhip_contact_op_t op, mhip_stream_t stream)
     st.P1 = cur.P1;
     st.q_cur = cur.q;
   }
+  // the snapshot itself (a pass over the incidence lists, 0.2 ms at 10^6 rods) pays once per few dozen iterations: a
+  // caller that polls more often gets it at every other or every fourth poll
+  const unsigned it = op->host_state->iter;
+  const bool renumbered = tier.retiers != retiers_before;  // (the lists follow the numbering)
+  if (!renumbered && op->view.aptr != nullptr && st.snap_at != 0 && it - st.snap_at < (it / 2 < 32u ? it / 2 : 32u))
+    return MHIP_SUCCESS;
+  st.snap_at = it;
   return op_snapshot_active(op, s);
 }
 

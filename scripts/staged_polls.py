@@ -1,0 +1,23 @@
+import sys, time
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, ".")
+from mundy_amd import distributed as D, ops, pipeline, synth
+n = 1_000_000
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29737", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+b = synth.spherocylinders(n)
+order = D.hilbert_order(b["center"], 0.0, b["box"], level=7)
+c, q, r, L = (b[k][order] for k in ("center", "quat", "radius", "length"))
+cfg = ops.PGDConfig(max_iters=10000, tol=1e-5)
+comm = D.Comm()
+for poll in (16, 32, 64, 128):
+    st = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=comm, cfg=cfg, poll_every=poll)
+    st.step(integrate=False); torch.cuda.synchronize()
+    t = time.perf_counter(); out = st.step(integrate=False); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("poll_every %d: %.1f ms/step, %d iterations, tier %s" % (poll, 1e3 * dt, out["num_iters"], st.op.tier_stats()), flush=True)
+    st.op.close()
+ref = pipeline.ContactStepper("spherocylinder", dev(c), dev(r), dev(q), dev(L), search_buffer=0.1, cfg=cfg)
+ref.step(integrate=False); torch.cuda.synchronize()
+t = time.perf_counter(); out = ref.step(integrate=False); torch.cuda.synchronize(); dt = time.perf_counter() - t
+print("fused: %.1f ms/step, tier %s" % (1e3 * dt, ref.op.tier_stats()))
+dist.destroy_process_group()

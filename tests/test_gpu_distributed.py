@@ -168,7 +168,7 @@ def test_nccl_transport_single_rank():
         # the cold tier of the staged solver leaves all four solver vectors where the untiered staged solve leaves them:
         # converged, stopped at an even and at an odd iteration cap, tiers kept to the end (3) or left mid-solve (2)
         for cap in (20000, 61, 62):
-            got = {}
+            got, tiered = {}, {}
             for mode in (0, 3, 2):
                 st5 = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]),
                                                   0, comm=comm, cfg=ops.PGDConfig(max_iters=cap, tol=1e-6),
@@ -177,9 +177,12 @@ def test_nccl_transport_single_rank():
                 s5 = st5.step(integrate=False)
                 got[mode] = (s5["num_iters"], st5.lam.clone(), st5.grad.clone(), st5.lam_prev.clone(),
                              st5.grad_prev.clone(), st5.vel.clone())
+                tiered[mode] = st5.op.tier_stats()
                 if mode and cap > 100:
-                    assert st5.op.tier_stats()["renumberings"] > 0
+                    assert tiered[mode]["renumberings"] > 0
                 st5.op.close()
+            if cap > 100:   # mode 2 did leave the tiers mid-solve
+                assert 0 < tiered[2]["tiered_iterations"] < tiered[3]["tiered_iterations"], tiered
             for mode in (3, 2):
                 assert got[mode][0] == got[0][0], (cap, mode)
                 for u, v in zip(got[mode][1:], got[0][1:]):
