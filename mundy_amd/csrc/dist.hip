@@ -764,7 +764,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
   };
 
   if (int e = iteration(1, nullptr)) return e;
-  unsigned enqueued = 0, last_todo = 0, iter_before = 0;
+  unsigned enqueued = 0, last_todo = 0, iter_before = 0, chunk = 8;
   int done = 0;
   for (;;) {
     if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
@@ -790,7 +790,11 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     if (enqueued >= 8)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
       if (int e = mhip_bbpgd_stage_snapshot_active(op, stream)) return e;
     iter_before = result->num_iters;
-    const unsigned todo = (config->max_iters - enqueued < poll_every) ? config->max_iters - enqueued : poll_every;
+    // (stretches of 8, 16, 32, ... iterations up to poll_every, as in the fused driver: an easy solve is found converged
+    // early, a long one is polled as rarely as the caller allows)
+    const unsigned stretch = chunk < poll_every ? chunk : poll_every;
+    if (chunk < poll_every) chunk *= 2;
+    const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
     for (unsigned k = 0; k < todo; ++k) {
       hipEvent_t* ev = (prof && k % kStride == 0) ? &c->events[(size_t)kEv * (k / kStride)] : nullptr;
       if (int e = iteration(0, ev)) return e;

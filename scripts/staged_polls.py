@@ -10,7 +10,7 @@ order = D.hilbert_order(b["center"], 0.0, b["box"], level=7)
 c, q, r, L = (b[k][order] for k in ("center", "quat", "radius", "length"))
 cfg = ops.PGDConfig(max_iters=10000, tol=1e-5)
 comm = D.Comm()
-for poll in (16, 32, 64, 128):
+for poll in [int(a) for a in sys.argv[1:]] or (16, 32, 64, 128):
     st = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=comm, cfg=cfg, poll_every=poll)
     st.step(integrate=False); torch.cuda.synchronize()
     t = time.perf_counter(); out = st.step(integrate=False); torch.cuda.synchronize(); dt = time.perf_counter() - t

@@ -15,13 +15,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(world, port=None, extra_env=None):
     import socket
-    with socket.socket() as sk:   # a fixed port can still sit in TIME_WAIT from an earlier run
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(extra_env or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    for attempt in range(3):
+        with socket.socket() as sk:   # a fixed port can still sit in TIME_WAIT from an earlier run
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        # (the probed port can be taken by somebody else before the launcher binds it: nothing has run yet, ask again)
+        if p.returncode == 0 or "EADDRINUSE" not in p.stderr:
+            break
     print(p.stdout[-5000:], p.stderr[-3000:])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     tag = "_mixed" if (extra_env or {}).get("DIST_MIXED") == "1" else ""
