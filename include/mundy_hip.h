@@ -172,7 +172,9 @@ int mhip_contact_mixed_periodic(size_t c, const int32_t* pairs, const int32_t* k
  * Search method (GenNeighborLinks::set_search_method, :443-447; the reference's default is stk::search::MORTON_LBVH):
  * the uniform cell grid (cell edge = twice the largest reach; fastest when bodies are of similar size), a linear BVH over
  * 63-bit Morton keys (adapts to each body's size: size-disperse systems), or AUTO = LBVH when the largest reach exceeds
- * twice the mean reach (free boundaries; the periodic search always runs on the grid).  Same lists either way.
+ * twice the mean reach.  Periodic systems: the tree holds every volume translated into the primary cell and is walked
+ * once per image of the query that can meet it; a cell with an edge below four times the largest reach goes to the grid
+ * whatever was asked for (mhip_broadphase_method_used tells).  Same lists either way.
  * ---------------------------------------------------------------------------------------------------------------- */
 enum { MHIP_SEARCH_SPHERES = 0, MHIP_SEARCH_AABB = 1 };
 enum { MHIP_SEARCH_METHOD_AUTO = 0, MHIP_SEARCH_METHOD_GRID = 1, MHIP_SEARCH_METHOD_MORTON_LBVH = 2 };

@@ -19,6 +19,7 @@
 // through the workgroup radix sort of sort.hip -> pairs sorted by (i, j) without a global sort.
 // The predicate is evaluated with the lower body index first, exactly as the CPU oracle does, so pair sets are
 // bit-identical whichever structure found them.  Integer/comparison work only: HBM/L2-bound, no MFMA.
+#include <algorithm>
 #include <cstdlib>
 #include <initializer_list>
 
@@ -496,6 +497,20 @@ __device__ inline void rec_box(const BpArgs& A, const SearchRec& r, double lo[3]
       hi[k] = r.a[k] + r.b[0] + pad;
     }
   }
+  if (A.periodic) {
+    // Periodic tree: every box translated by the lattice vector that takes its midpoint into the primary cell (the
+    // bin point the Morton key is made of); a query then walks the tree once per image of its own box that can meet the
+    // tree at all.  The translation rounds, so the box is padded by a few ulps: boxes only prune, the exact predicate
+    // (minimum image of the untranslated volumes) decides at the leaves.
+    const double mid[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    const V3 w = periodic_wrap(A.pm, V3{mid[0], mid[1], mid[2]});
+    for (int k = 0; k < 3; ++k) {
+      const double t = comp(w, k) - mid[k];
+      const double pad = 8.9e-16 * (fabs(lo[k]) + fabs(hi[k]) + fabs(t) + comp(A.pm.scale, k));
+      lo[k] = (lo[k] + t) - pad;
+      hi[k] = (hi[k] + t) + pad;
+    }
+  }
 }
 __global__ void __launch_bounds__(kBlock)
     k_lbvh_leaves(size_t n, BpArgs A, const double* __restrict__ aabb, const double* __restrict__ center,
@@ -678,28 +693,76 @@ __global__ void __launch_bounds__(kBlock)
       return;
     }
   }
-  double qlo[3], qhi[3];
-  rec_box(A, me, qlo, qhi);
-  int node = 0;  // n == 1: node 0 is the only leaf
-  while (node >= 0) {
-    if (node < n - 1) {
-      const BvhNode nd = nodes[node];
-      const bool meet = !(qhi[0] < nd.lo[0] || qhi[1] < nd.lo[1] || qhi[2] < nd.lo[2] || nd.hi[0] < qlo[0] ||
-                          nd.hi[1] < qlo[1] || nd.hi[2] < qlo[2]);
-      node = meet ? nd.left : nd.rope;
-    } else {
-      const int k = node - (n - 1);
-      const SearchRec o = recs[k];
-      const int j = static_cast<int>(o.id);
-      if (pair_allowed(A, i, j)) {
-        const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
-        if (hit) {
-          if (FILL) out.col[base + cnt] = j;
-          else if (cnt < kSlab) slab[static_cast<size_t>(cnt) * n + q] = j;
-          ++cnt;
-        }
+  double blo[3], bhi[3];
+  rec_box(A, me, blo, bhi);
+  // periodic: one walk per image of the query box that meets the tree's root box -- for a body away from the faces of
+  // the cell that is the unshifted one only; a leaf counts in the walk of the image its midpoint is nearest to (the
+  // predicate's own image but for ties at half a box edge, where no volume the builder admits can overlap)
+  const int nimg = A.periodic ? 27 : 1;
+  double rlo[3], rhi[3], bmid[3];
+  if (A.periodic) {
+    for (int a = 0; a < 3; ++a) bmid[a] = 0.5 * (blo[a] + bhi[a]);
+    if (n > 1) {
+      for (int a = 0; a < 3; ++a) {
+        rlo[a] = nodes[0].lo[a];
+        rhi[a] = nodes[0].hi[a];
       }
-      node = leaf_rope[k];
+    } else {
+      rec_box(A, recs[0], rlo, rhi);
+    }
+  }
+  for (int img = 0; img < nimg; ++img) {
+    double qlo[3], qhi[3];
+    int sh[3] = {0, 0, 0};
+    if (A.periodic) {
+      sh[0] = img % 3 - 1;
+      sh[1] = (img / 3) % 3 - 1;
+      sh[2] = img / 9 - 1;
+      bool meets = true;
+      for (int a = 0; a < 3; ++a) {
+        const double L = comp(A.pm.scale, a);
+        const double pad = sh[a] ? 8.9e-16 * (fabs(blo[a]) + fabs(bhi[a]) + L) : 0.0;
+        qlo[a] = (blo[a] + sh[a] * L) - pad;
+        qhi[a] = (bhi[a] + sh[a] * L) + pad;
+        meets = meets && !(qhi[a] < rlo[a] || rhi[a] < qlo[a]);
+      }
+      if (!meets) continue;
+    } else {
+      for (int a = 0; a < 3; ++a) {
+        qlo[a] = blo[a];
+        qhi[a] = bhi[a];
+      }
+    }
+    int node = 0;  // n == 1: node 0 is the only leaf
+    while (node >= 0) {
+      if (node < n - 1) {
+        const BvhNode nd = nodes[node];
+        const bool meet = !(qhi[0] < nd.lo[0] || qhi[1] < nd.lo[1] || qhi[2] < nd.lo[2] || nd.hi[0] < qlo[0] ||
+                            nd.hi[1] < qlo[1] || nd.hi[2] < qlo[2]);
+        node = meet ? nd.left : nd.rope;
+      } else {
+        const int k = node - (n - 1);
+        const SearchRec o = recs[k];
+        const int j = static_cast<int>(o.id);
+        bool mine = true;
+        if (A.periodic) {  // is this the image the leaf belongs to?
+          double olo[3], ohi[3];
+          rec_box(A, o, olo, ohi);
+          for (int a = 0; a < 3; ++a) {
+            const double d = 0.5 * (olo[a] + ohi[a]) - bmid[a];
+            mine = mine && static_cast<int>(round(d * comp(A.pm.scale_inv, a))) == sh[a];
+          }
+        }
+        if (mine && pair_allowed(A, i, j)) {
+          const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
+          if (hit) {
+            if (FILL) out.col[base + cnt] = j;
+            else if (cnt < kSlab) slab[static_cast<size_t>(cnt) * n + q] = j;
+            ++cnt;
+          }
+        }
+        node = leaf_rope[k];
+      }
     }
   }
   if (!FILL) {
@@ -925,8 +988,6 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   if (config->periodic) {
     MHIP_REQUIRE(config->box[0] > 0 && config->box[1] > 0 && config->box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
                  "periodic box must be positive");
-    MHIP_REQUIRE(config->method != MHIP_SEARCH_METHOD_MORTON_LBVH, MHIP_ERR_INVALID_ARGUMENT,
-                 "the periodic search runs on the cell grid (the LBVH covers free boundaries)");
   }
   MHIP_REQUIRE((!h->has_source && !h->has_target) || h->sets_n == n, MHIP_ERR_INVALID_ARGUMENT,
                "source / target sets were given for %zu bodies, the build has %zu", h->sets_n, n);
@@ -981,14 +1042,20 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   // Which structure: the grid's cell edge is twice the LARGEST reach, so its work grows with (max / mean reach)^3; the
   // BVH adapts to every body's own size.  Measured on MI355X (profiles/r02_broadphase_methods.txt).
   int method = config->method;
-  if (method == MHIP_SEARCH_METHOD_AUTO) {
-    method = MHIP_SEARCH_METHOD_GRID;
-    if (!config->periodic && n >= 2) {
-      MHIP_HIP(hipMemcpyAsync(h->host_summary, summary, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
-      MHIP_HIP(hipStreamSynchronize(s));
-      const double mean_reach = h->host_summary[7] / static_cast<double>(n);
-      if (h->host_summary[6] > kLbvhReachSpread * mean_reach) method = MHIP_SEARCH_METHOD_MORTON_LBVH;
+  if (n >= 2 && (method == MHIP_SEARCH_METHOD_AUTO || (method == MHIP_SEARCH_METHOD_MORTON_LBVH && config->periodic))) {
+    MHIP_HIP(hipMemcpyAsync(h->host_summary, summary, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    const double max_reach = h->host_summary[6], mean_reach = h->host_summary[7] / static_cast<double>(n);
+    if (method == MHIP_SEARCH_METHOD_AUTO)
+      method = max_reach > kLbvhReachSpread * mean_reach ? MHIP_SEARCH_METHOD_MORTON_LBVH : MHIP_SEARCH_METHOD_GRID;
+    // the periodic tree assigns a leaf to ONE image of the query (the nearest midpoint): that is the predicate's image
+    // as long as no two volumes can overlap across half a box edge; a cell that small is the grid's case
+    if (config->periodic && method == MHIP_SEARCH_METHOD_MORTON_LBVH) {
+      const double edge = std::min(config->box[0], std::min(config->box[1], config->box[2]));
+      if (!(4.0 * max_reach < edge)) method = MHIP_SEARCH_METHOD_GRID;
     }
+  } else if (method == MHIP_SEARCH_METHOD_AUTO) {
+    method = MHIP_SEARCH_METHOD_GRID;
   }
   h->method_used = method;
   int32_t* long_count = h->longrows.as<int32_t>();

@@ -1662,9 +1662,12 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
 
 // block partials of the constraint sweep -> at most kFoldGroups triples (planes) ready for the single-workgroup pass
 // `stride` is the distance between the three planes on entry and on return
+#ifndef MHIP_FOLD_ABOVE
+#define MHIP_FOLD_ABOVE 4096
+#endif
 inline void fold_partials(unsigned& nparts, size_t& stride, double*& parts, const SolverState* st, int check_done,
                           hipStream_t s) {
-  if (nparts <= 4096) return;  // one workgroup reads a few thousand triples as fast as a second launch would
+  if (nparts <= MHIP_FOLD_ABOVE) return;  // one workgroup reads a few thousand triples as fast as a second launch would
   double* folded = parts + kRed * stride;
   k_fold_partials<<<kFoldGroups, kBlock, 0, s>>>((int)nparts, stride, parts, st, check_done, folded);
   parts = folded;

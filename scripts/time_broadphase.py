@@ -11,14 +11,15 @@ def zorder(c, *arrs, cell=3.0):
     return [c[perm].contiguous()] + [a[perm].contiguous() for a in arrs]
 
 
-for name in ("rods", "spheres", "disperse spheres"):
+for name in ("rods", "spheres", "disperse spheres", "periodic spheres", "periodic disperse"):
     if name == "rods":
         b = synth.spherocylinders(n)
         c, q, r, L = zorder(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]))
         aabb, brad = ops.compute_aabb_spherocylinders(c, q, r, L), ops.bounding_radius_spherocylinders(r, L)
         kind = ops.SEARCH_AABB
-    elif name == "spheres":
+    elif name in ("spheres", "periodic spheres"):
         b = synth.spheres(n)
+        pbox = [b["box"]] * 3
         c, r = zorder(dev(b["center"]), dev(b["radius"]))
         aabb, brad = ops.compute_aabb_spheres(c, r), r
         kind = ops.SEARCH_SPHERES
@@ -30,8 +31,12 @@ for name in ("rods", "spheres", "disperse spheres"):
         c, r = zorder(dev(rng.uniform(0, box, (m, 3))), dev(rr), cell=box / 64)
         aabb, brad = ops.compute_aabb_spheres(c, r), r
         kind = ops.SEARCH_SPHERES
+        pbox = [box] * 3
     for mname, method in (("grid", ops.SEARCH_METHOD_GRID), ("lbvh", ops.SEARCH_METHOD_MORTON_LBVH), ("auto", ops.SEARCH_METHOD_AUTO)):
-        links = ops.GenNeighborLinks().set_search_buffer(0.1).set_search_kind(kind).set_search_method(method).concretize()
+        links = ops.GenNeighborLinks().set_search_buffer(0.1).set_search_kind(kind).set_search_method(method)
+        if name.startswith("periodic"):
+            links = links.set_periodic_box(pbox)
+        links = links.concretize()
         links.generate(aabb, c, brad, force=True)
         torch.cuda.synchronize()
         ts = []

@@ -217,9 +217,65 @@ def test_lbvh_lists_equal_grid_and_bruteforce(ops, oracle, kind, symmetric):
         np.testing.assert_array_equal(host(g.pairs), exp)
         np.testing.assert_array_equal(host(g.col), exp[:, 1])
         g.close()
-    with pytest.raises(ValueError, match="cell grid"):
-        (ops.GenNeighborLinks().set_search_kind(kind).set_search_method(ops.SEARCH_METHOD_MORTON_LBVH)
-         .set_periodic_box([10.0, 12.0, 9.0]).concretize().generate(dev(aabb), dev(c), dev(brad)))
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_periodic_lbvh_lists_equal_grid_and_bruteforce(ops, oracle, kind, symmetric):
+    # periodic cell: the tree holds the volumes translated into the primary cell and is walked once per image of the
+    # query that can meet it.  Bodies given as arbitrary unwrapped images, some sitting exactly on the faces and corners
+    # of the cell; same pairs, same order as the grid and the brute-force oracle (minimum-image predicate)
+    from gpu_util import dev, host, random_rods
+    rng = np.random.default_rng(70 + 2 * kind + symmetric)
+    box = np.array([9.0, 11.0, 13.0])
+    c, q, r, L = random_rods(rng, 3000, box)
+    c[:64] = rng.integers(0, 2, (64, 3)) * box                 # corners of the cell
+    c[64:256, 0] = 0.0                                          # a face
+    c[256:300, 1] = box[1]
+    c += rng.integers(-2, 3, c.shape) * box
+    aabb = oracle.compute_aabb_spherocylinders(c, q, r, L)
+    brad = oracle.bounding_radius_spherocylinders(r, L)
+    lo, hi, R = oracle.grow(aabb, brad, 0.15)
+    exp = oracle.search(kind, lo, hi, c, R, box=box, symmetric=symmetric, method="brute")
+    assert len(exp) > 5000
+    for method in (ops.SEARCH_METHOD_GRID, ops.SEARCH_METHOD_MORTON_LBVH):
+        g = (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(0.15).set_search_method(method)
+             .set_enforce_source_target_symmetry(symmetric).set_periodic_box(box).concretize())
+        g.generate(dev(aabb), dev(c), dev(brad))
+        assert g.method_used() == method
+        np.testing.assert_array_equal(host(g.pairs), exp)
+        g.close()
+    # a cell with an edge below four times the largest reach is the grid's case, whatever was asked for
+    small = np.array([3.0, 11.0, 13.0])
+    g = (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(0.15)
+         .set_search_method(ops.SEARCH_METHOD_MORTON_LBVH).set_periodic_box(small).concretize())
+    g.generate(dev(aabb[:500]), dev(c[:500]), dev(brad[:500]))
+    assert g.method_used() == ops.SEARCH_METHOD_GRID
+    np.testing.assert_array_equal(host(g.pairs), oracle.search(kind, lo[:500], hi[:500], c[:500], R[:500], box=small,
+                                                                method="brute"))
+    g.close()
+
+
+def test_periodic_size_disperse_spheres_pick_the_lbvh(ops, oracle):
+    # log-normal radii in a periodic cell: AUTO goes to the tree (largest reach > 2 x mean reach) and returns the list of
+    # the grid
+    from gpu_util import dev, host
+    rng = np.random.default_rng(5)
+    c, r = _polydisperse(rng, 20_000, sigma=0.6)
+    box = np.full(3, (4.0 / 3.0 * np.pi * (r ** 3).sum() / 0.30) ** (1.0 / 3.0))
+    assert 4.0 * (r.max() + 0.05) < box[0] and r.max() > 4.0 * r.mean()
+    aabb = oracle.compute_aabb_spheres(c, r)
+    lists = {}
+    for name, method in (("grid", ops.SEARCH_METHOD_GRID), ("auto", ops.SEARCH_METHOD_AUTO)):
+        g = (ops.GenNeighborLinks().set_search_kind(ops.SEARCH_SPHERES).set_search_buffer(0.05).set_search_method(method)
+             .set_periodic_box(box).concretize())
+        g.generate(dev(aabb), dev(c), dev(r))
+        lists[name] = host(g.pairs).copy()
+        if name == "auto":
+            assert g.method_used() == ops.SEARCH_METHOD_MORTON_LBVH
+        g.close()
+    assert len(lists["grid"]) > 10_000
+    np.testing.assert_array_equal(lists["auto"], lists["grid"])
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 65, 1000])
