@@ -404,7 +404,8 @@ def main_mixed(args, ops, pipeline, synth, dev):
                    "converged": [bool(s.converged) for s in stats], "parallelism": "single GPU"},
         "contact_pairs_per_sec": round(contacts * args.steps / elapsed, 1),
         "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
-        "roofline": roof, "cpu_baseline": None,
+        "roofline": roof,
+        "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline_mixed(b, st, pristine, args, int(np.mean(iters))),
         "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
         "narrow_phase_roofline": ell_roof,
         "ellipsoid_aabb": "reference (centre -/+ q*radii, compute_aabb.hpp:82-103: not conservative for general orientations)",
@@ -578,6 +579,50 @@ def cpu_baseline(b, stepper, args, gpu_iters):
                       "OpenMP) once + %d BBPGD iterations on %d OpenMP threads (%.3fs/iter), solve extrapolated to the "
                       "GPU's %d iterations; contacts %d" % (t["aabb"], t["search"], t["narrow"], k, threads, per_iter,
                                                            gpu_iters, len(pairs))}
+
+
+def cpu_baseline_mixed(b, st, pristine, args, gpu_iters):
+    """The CPU oracle on a bounded sample of the mixed workload: full-size AABBs and cell-list search once; the narrow
+    phase (the reference's 9-start L-BFGS for the ellipsoid classes, ~10^3 objective evaluations per pair) on every
+    `stride`-th pair of the list, scaled by the stride; `--cpu-iters` BBPGD iterations of the full-size LCP (contact
+    geometry taken from the GPU step of the same input -- the parity tests hold the two bit-identical), extrapolated to
+    the GPU's iteration count."""
+    import oracle
+    oracle.build()
+    threads = host_core_share(oracle.num_threads())
+    oracle.set_num_threads(threads)
+    t = {}
+    t0 = time.perf_counter()
+    aabb, brad = oracle.aabb_mixed(b["kind"], b["center"], b["quat"], b["shape"], fast=True)
+    t["aabb"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lo, hi, R = oracle.grow(aabb, brad, args.buffer)
+    pairs = oracle.search(oracle.SEARCH_AABB, lo, hi, b["center"], R, fast=True)
+    t["search"] = time.perf_counter() - t0
+    stride = 16
+    sample = np.ascontiguousarray(pairs[::stride])
+    t0 = time.perf_counter()
+    oracle.contact_mixed(sample, b["kind"], b["center"], b["quat"], b["shape"], fast=True)
+    t["narrow_sample"] = time.perf_counter() - t0
+    narrow = t["narrow_sample"] * len(pairs) / max(1, len(sample))
+    st.restore(pristine)      # original body order: the GPU's pair list is the oracle's
+    st.step(integrate=False, force_rebuild=True)
+    gp = st.links.pairs.cpu().numpy()
+    same = len(gp) == len(pairs) and bool(np.array_equal(gp, pairs))
+    c = {k: v.cpu().numpy() for k, v in st.contacts.items() if v is not None}
+    k = max(2, args.cpu_iters)
+    t0 = time.perf_counter()
+    oracle.solve_cqpp_contact(gp, c["normal"], c["ra"], c["rb"], st.mob_trans.cpu().numpy(), st.mob_rot.cpu().numpy(),
+                              st.dt, c["sep"], np.zeros(len(gp)), max_iters=k, tol=args.tol, threads=True, fast=True)
+    t["solve_sample"] = time.perf_counter() - t0
+    per_iter = t["solve_sample"] / (k + 1)
+    step_s = t["aabb"] + t["search"] + narrow + per_iter * (gpu_iters + 1)
+    return {"value": round(1.0 / step_s, 6), "unit": "timesteps/s", "cores": threads, "kind": "port",
+            "sample": "full-size AABB (%.2fs, OpenMP) and cell-list search (%.2fs, 1 thread) once; narrow phase on every "
+                      "%dth pair (%d pairs, %.2fs on %d OpenMP threads; x%d = %.1fs); %d BBPGD iterations of the full LCP "
+                      "(%.3fs/iter) extrapolated to the GPU's %d; contacts %d (pair list equal to the GPU's: %s)"
+                      % (t["aabb"], t["search"], stride, len(sample), t["narrow_sample"], threads, stride, narrow, k,
+                         per_iter, gpu_iters, len(pairs), same)}
 
 
 if __name__ == "__main__":

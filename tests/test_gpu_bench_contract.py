@@ -79,6 +79,11 @@ def test_mixed_line_names_configs4():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert "configs[4]" in d["config"]["workload"] and "mixed" in d["metric"]
     assert d["config"]["converged"] == [True] and d["stage_ms"]["narrowphase"] > 0 and d["roofline"]["bound"] == "hbm"
+    # the fp64-vector roofline of the ellipsoid classes and the CPU oracle timed on a bounded sample of the same input
+    assert d["narrow_phase_roofline"]["bound"] == "fp64-vector" and 0.0 < d["narrow_phase_roofline"]["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and 0.0 < c["value"] < d["value"]
+    assert "pair list equal to the GPU's: True" in c["sample"]
 
 
 def _torchrun(extra, env=None):
