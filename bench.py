@@ -63,16 +63,16 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
                     Proj(0 - step g) = 0 and adds nothing), streamed from the compact active lists: per ACTIVE half
                     edge incidence entry 4 + (n, s - 1/2) record 32 = 36 B; per ACTIVE contact its packed iterate 16 B
                     (gathered by both of its half edges, counted once); per body row pointer 4 + active-list pointer 4
-                    + mask 8 + snapshot mask 8 + mobilities 16 + axis 24 + velocity row 48 + angular velocity 24 =
-                    136 B.  `active_contacts` is measured in the run (state at the end of the solve); None = every
-                    contact (the pre-mask count).
+                    + mask 8 + snapshot mask 8 + mobilities 16 + axis 24 + velocity row 48 = 112 B (the angular
+                    velocity, 24 B, is written once per solve, by a sweep of the final iterate).  `active_contacts` is
+                    measured in the run (state at the end of the solve); None = every contact (the pre-mask count).
     SURVEY 8(d)'s own figure, 368 C + 96 N per iteration, charges a gathered row to every contact that reads it and
     assumes vector lever arms; this implementation streams scalar arclengths and serves the 48 MB row table from L2 /
     Infinity Cache, so that figure divided by the measured time exceeds the HBM peak (1.39 x at 10^6 rods) -- it is
     unusable as a denominator here and is not printed."""
     act = contacts if active_contacts is None else active_contacts
     con = 88.0 * contacts + 48.0 * bodies
-    body = 2 * 36.0 * act + 16.0 * act + 136.0 * bodies
+    body = 2 * 36.0 * act + 16.0 * act + 112.0 * bodies
     if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
         # cold tier (DESIGN 4): over the tiered iterations only the hot share h of the contacts is swept (plus the few
         # thousand awake contacts of the cold tail, not counted here); nothing scans the sleepers.  The body sweep additionally

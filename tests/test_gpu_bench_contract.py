@@ -44,7 +44,7 @@ def test_default_line_has_the_contract_keys(tier):
     share = min(1.0, ct["tiered_iterations"] / d["config"]["bbpgd_iters_per_step"][-1])
     assert kb["bytes_per_launch"] == pytest.approx(
         88.0 * kb["active_contact_fraction"] * d["config"]["contacts_per_gpu"] +
-        (136.0 + 24.0 * share) * d["config"]["bodies_per_gpu"], rel=1e-3)
+        (112.0 + 24.0 * share) * d["config"]["bodies_per_gpu"], rel=1e-3)
     # the constraint sweep's: 88 B per contact swept (hot range + awake part of the tail) over the tiered iterations
     kc = r if r["kernel"].startswith("k_constraint") else d["k_constraint"]
     C, N, h = d["config"]["contacts_per_gpu"], d["config"]["bodies_per_gpu"], ct["mean_hot_fraction"]
