@@ -586,6 +586,18 @@ int mhip_comm_create_host(mhip_comm_t* comm, int rank, int world, mhip_comm_exch
                           mhip_comm_all_gather_fn all_gather, void* user);
 int mhip_comm_destroy(mhip_comm_t comm);
 int mhip_comm_info(mhip_comm_t comm, int* rank, int* world, int* is_rccl);
+/* Mailbox (ranks of ONE node): the 5-double reduction record every rank contributes to every BBPGD iteration
+ * (NGPSpheresLCP.cpp:371, :450-452: 1 all_reduce_max + 3 all_reduce_sum there) travels through slots in the ranks'
+ * device memory instead of a collective launch: every rank owns a box of fine-grained memory that all the others map
+ * (hipIpc handles, exchanged through the communicator's own all-gather); a rank writes its record into its slot of
+ * every box -- posted writes over xGMI -- and polls its own box, all inside the kernel that forms the record.  Every
+ * 8-byte word carries 32 bits of data and the number of the exchange, so each store validates itself and the writes
+ * may arrive in any order.  Collective call.  *opened = 1: every rank has mapped every box and two trial exchanges went
+ * through everywhere (mhip_bbpgd_solve_contact_distributed then uses it); 0: somebody could not (another node, no peer
+ * access) and everybody keeps the transport's all-gather.  A record that does not arrive within 3 s ends the solve in
+ * MHIP_ERR_RUNTIME on the ranks that waited for it (bounded polling: no wave waits forever). */
+int mhip_comm_mailbox_open(mhip_comm_t comm, int* opened /*[host]*/, mhip_stream_t stream);
+int mhip_comm_mailbox_close(mhip_comm_t comm);
 /* recv[r][0..count) = rank r's send[0..count); later work on `stream` sees recv */
 int mhip_comm_all_gather(mhip_comm_t comm, const double* send, size_t count, double* recv, mhip_stream_t stream);
 /* One grouped point-to-point exchange: message k goes to send_peer[k] / comes from recv_peer[k]; empty messages are

@@ -177,6 +177,8 @@ SIGNATURES = {
     "mhip_comm_create_host": [C.POINTER(_vp), _i, _i, EXCHANGE_FN, ALL_GATHER_FN, _vp],
     "mhip_comm_destroy": [_vp],
     "mhip_comm_info": [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "mhip_comm_mailbox_open": [_vp, C.POINTER(_i), _vp],
+    "mhip_comm_mailbox_close": [_vp],
     "mhip_comm_all_gather": [_vp, _vp, _sz, _vp, _vp],
     "mhip_comm_exchange_start": [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i),
                                  C.POINTER(_vp), C.POINTER(_sz), _vp],

@@ -1037,13 +1037,23 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
 // 8e step 3; the sums travel as double-double pairs so that the rank count does not reach the rounded result)
 __global__ void __launch_bounds__(kFinalBlock) k_reduce_local(int nparts, const double* __restrict__ partials,
                                                              size_t stride, const SolverState* __restrict__ st,
-                                                             int check_done, double* __restrict__ out) {
+                                                             int check_done, double* __restrict__ out,
+                                                             MailboxArgs mb = MailboxArgs{}) {
   __shared__ double scratch[2 * kFinalBlock / 64];
   if (check_done && st->done) return;
   double rmax;
   DD num, den;
   reduce_records(nparts, partials, 1, stride, scratch, rmax, num, den);
-  if (threadIdx.x == 0) store_partial(out, 1, 0, rmax, num, den);
+  __shared__ double record[kRed];
+  if (threadIdx.x == 0) {
+    store_partial(out, 1, 0, rmax, num, den);
+    store_partial(record, 1, 0, rmax, num, den);
+  }
+  // ranks of one node: the record goes to everybody's mailbox and everybody's records are collected, in this launch
+  if (mb.peers != nullptr) {
+    __syncthreads();
+    mailbox_exchange_wave(mb, record);
+  }
 }
 
 // ---- the scrap app's BBPGD variant: resolve_collisions, scrap/lcp_spheres/NgpLcp.cpp:558-759 ----------
@@ -2296,6 +2306,21 @@ int solve_generic(size_t n, const Apply& apply, const double* q, Space sp, const
 
 #define REQ(p) MHIP_REQUIRE((p) != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT, "%s: %s is null", __func__, #p)
 
+namespace mhip {
+int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const MailboxArgs& mb, hipStream_t s) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  MHIP_REQUIRE(local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local record is null");
+  unsigned np = op->stage.part_used;
+  size_t ps = kStageStride;
+  double* pp = op->partials.as<double>();
+  fold_partials(np, ps, pp, op->state.as<SolverState>(), init ? 0 : 1, s);
+  k_reduce_local<<<1, final_block(np), 0, s>>>((int)np, pp, ps, op->state.as<SolverState>(), init ? 0 : 1, local, mb);
+  MHIP_LAUNCH_CHECK();
+  op->stage.part_used = 0;
+  return MHIP_SUCCESS;
+}
+}  // namespace mhip
+
 extern "C" {
 
 int mhip_deep_copy(size_t n, double* dst, const double* src, mhip_stream_t stream) {
@@ -3189,17 +3214,7 @@ int mhip_bbpgd_stage_constraint_range(mhip_contact_op_t op, int init, size_t c_f
 }
 
 int mhip_bbpgd_stage_reduce(mhip_contact_op_t op, int init, double* local, mhip_stream_t stream) {
-  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
-  MHIP_REQUIRE(local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local record is null");
-  hipStream_t s = as_stream(stream);
-  unsigned np = op->stage.part_used;
-  size_t ps = kStageStride;
-  double* pp = op->partials.as<double>();
-  fold_partials(np, ps, pp, op->state.as<SolverState>(), init ? 0 : 1, s);
-  k_reduce_local<<<1, final_block(np), 0, s>>>((int)np, pp, ps, op->state.as<SolverState>(), init ? 0 : 1, local);
-  MHIP_LAUNCH_CHECK();
-  op->stage.part_used = 0;
-  return MHIP_SUCCESS;
+  return mhip::stage_reduce_exchange(op, init, local, mhip::MailboxArgs{}, as_stream(stream));
 }
 
 int mhip_bbpgd_stage_constraint(mhip_contact_op_t op, int init, double* local, mhip_stream_t stream) {

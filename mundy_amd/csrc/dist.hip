@@ -7,9 +7,15 @@
 // (mundy_mesh/GenNeighborLinkers.hpp:658, :687-711); per iteration stk::all_reduce_max + 3 x stk::all_reduce_sum
 // (scrap/lcp_spheres/NGPSpheresLCP.cpp:371, :450-452) and the ghost refresh left as a TODO at :1057.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is looked up at run time
 
+#include <cctype>
 #include <initializer_list>
+#include <string>
 #include <vector>
 
 #include "mhip_internal.hpp"
@@ -88,6 +94,17 @@ struct mhip_comm {
   std::vector<const double*> send_buf;
   std::vector<double*> recv_buf;
   std::vector<size_t> send_count, recv_count;
+  // Mailbox (mhip_comm_mailbox_open): the per-iteration record exchange of the ranks of ONE node through slots in each
+  // other's device memory -- every rank owns a box of fine-grained memory, IPC-mapped by all the others; a rank writes
+  // its record into its slot of every box and polls its own.  No collective launch on the critical path of an iteration.
+  struct Mailbox {
+    bool open = false;
+    void* own = nullptr;             // this rank's box
+    std::vector<void*> mapped;       // the other ranks' boxes as mapped here (null at this rank's place)
+    DeviceBuffer peers;              // [world] device array of box pointers
+    unsigned long long seq = 0;      // exchanges so far: the same number on every rank
+    DeviceBuffer status;             // [0] != 0: an exchange timed out (sticky)
+  } mbox;
   // work buffers of the distributed solve
   DeviceBuffer send_rows, triples;
   std::vector<hipEvent_t> events;
@@ -157,9 +174,160 @@ static int host_all_gather(mhip_comm* c, const double* in, size_t count, std::ve
   MHIP_HIP(hipStreamSynchronize(s));
   return MHIP_SUCCESS;
 }
+// the exchange as a launch of its own (the trial exchanges of mhip_comm_mailbox_open; the solve has it inside the
+// kernel that forms the record, mhip_bbpgd_stage_reduce_exchange)
+__global__ void __launch_bounds__(64) k_mailbox_exchange(MailboxArgs m, const double* __restrict__ local) {
+  mailbox_exchange_wave(m, local);
+}
+constexpr unsigned long long kMailboxTimeoutTicks = 300000000ull;  // 3 s of the 100 MHz wall clock
+
+MailboxArgs mailbox_next(mhip_comm* c, int width, double* gathered) {
+  c->mbox.seq += 1;
+  MailboxArgs m;
+  m.peers = c->mbox.peers.as<unsigned long long*>();
+  m.world = c->world;
+  m.rank = c->rank;
+  m.width = width;
+  m.seq = c->mbox.seq;
+  m.gathered = gathered;
+  m.status = c->mbox.status.as<unsigned long long>();
+  m.timeout = kMailboxTimeoutTicks;
+  return m;
+}
+int mailbox_exchange(mhip_comm* c, int width, const double* local, double* gathered, hipStream_t s) {
+  k_mailbox_exchange<<<1, 64, 0, s>>>(mailbox_next(c, width, gathered), local);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+// after a stream synchronisation: did an exchange time out?
+int mailbox_check(mhip_comm* c, hipStream_t s) {
+  unsigned long long bad = 0;
+  MHIP_HIP(hipMemcpyAsync(&bad, c->mbox.status.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  MHIP_REQUIRE(bad == 0, MHIP_ERR_RUNTIME,
+               "rank %d: a peer's reduction record did not arrive in the mailbox within 3 s (exchange %llu)", c->rank,
+               c->mbox.seq);
+  return MHIP_SUCCESS;
+}
+void mailbox_close(mhip_comm* c) {
+  for (void* p : c->mbox.mapped)
+    if (p) (void)hipIpcCloseMemHandle(p);
+  if (c->mbox.own) (void)hipFree(c->mbox.own);
+  c->mbox.peers.release();
+  c->mbox.status.release();
+  c->mbox = mhip_comm::Mailbox{};
+}
+
 }  // namespace mhip
 
 extern "C" {
+
+/* Opens the mailbox of a communicator whose ranks all run on this node (see mundy_hip.h).  Collective. */
+int mhip_comm_mailbox_open(mhip_comm_t c, int* opened, mhip_stream_t stream) {
+  MHIP_REQUIRE(c != nullptr && opened != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  *opened = 0;
+  if (c->mbox.open || c->mbox.own) mailbox_close(c);
+  hipStream_t s = as_stream(stream);
+  const int world = c->world;
+  const size_t bytes = 2 * (size_t)world * kSlotWords * sizeof(unsigned long long);
+  constexpr size_t kHandleDoubles = (sizeof(hipIpcMemHandle_t) + 7) / 8;
+  // this rank's box: fine-grained device memory (coherent for the peers that write into it while a kernel polls it)
+  double mine_ok = 0.0;
+  hipIpcMemHandle_t handle;
+  memset(&handle, 0, sizeof(handle));
+  void* own = nullptr;
+  if (hipExtMallocWithFlags(&own, bytes, hipDeviceMallocFinegrained) == hipSuccess && own != nullptr) {
+    if (hipMemsetAsync(own, 0, bytes, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess &&
+        (world == 1 || hipIpcGetMemHandle(&handle, own) == hipSuccess)) {
+      mine_ok = 1.0;
+    } else {
+      (void)hipFree(own);
+      own = nullptr;
+    }
+  }
+  (void)hipGetLastError();
+  c->mbox.own = own;
+  // the handles travel through the ordinary transport (bytes in doubles: copied, never computed with)
+  if (int e = c->triples.reserve((kHandleDoubles + 8) * (size_t)(world + 1) * sizeof(double))) return e;
+  double* send = c->triples.as<double>();
+  double* recv = send + kHandleDoubles + 8;
+  std::vector<double> hsend(kHandleDoubles + 1, 0.0), hrecv((kHandleDoubles + 1) * (size_t)world, 0.0);
+  memcpy(hsend.data(), &handle, sizeof(handle));
+  hsend[kHandleDoubles] = mine_ok;
+  MHIP_HIP(hipMemcpyAsync(send, hsend.data(), hsend.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  if (int e = mhip_comm_all_gather(c, send, kHandleDoubles + 1, recv, stream)) return e;
+  MHIP_HIP(hipMemcpyAsync(hrecv.data(), recv, hrecv.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  MHIP_HIP(hipStreamSynchronize(s));
+  bool all = true;
+  for (int r = 0; r < world; ++r) all = all && hrecv[(kHandleDoubles + 1) * (size_t)r + kHandleDoubles] == 1.0;
+  // map everybody's box (everybody tries, then everybody agrees: all calls below are made by every rank)
+  double map_ok = all ? 1.0 : 0.0;
+  c->mbox.mapped.assign(world, nullptr);
+  std::vector<unsigned long long*> peers(world, nullptr);
+  if (all) {
+    for (int r = 0; r < world; ++r) {
+      if (r == c->rank) {
+        peers[r] = static_cast<unsigned long long*>(own);
+        continue;
+      }
+      hipIpcMemHandle_t h;
+      memcpy(&h, &hrecv[(kHandleDoubles + 1) * (size_t)r], sizeof(h));
+      void* p = nullptr;
+      if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess && p != nullptr) {
+        c->mbox.mapped[r] = p;
+        peers[r] = static_cast<unsigned long long*>(p);
+      } else {
+        (void)hipGetLastError();
+        map_ok = 0.0;
+      }
+    }
+    if (c->mbox.peers.reserve(world * sizeof(void*)) != MHIP_SUCCESS || c->mbox.status.reserve(64) != MHIP_SUCCESS ||
+        hipMemcpyAsync(c->mbox.peers.ptr, peers.data(), world * sizeof(void*), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(c->mbox.status.ptr, 0, 64, s) != hipSuccess)
+      map_ok = 0.0;
+  }
+  double* flag = send;
+  double* flags = recv;
+  auto agree = [&](double ok, bool* everybody) -> int {
+    MHIP_HIP(hipMemcpyAsync(flag, &ok, sizeof(double), hipMemcpyHostToDevice, s));
+    if (int e = mhip_comm_all_gather(c, flag, 1, flags, stream)) return e;
+    std::vector<double> h(world);
+    MHIP_HIP(hipMemcpyAsync(h.data(), flags, world * sizeof(double), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    *everybody = true;
+    for (double v : h) *everybody = *everybody && v == 1.0;
+    return MHIP_SUCCESS;
+  };
+  if (int e = agree(map_ok, &all)) return e;
+  if (all) {  // the thing itself, twice (both slot sets)
+    c->mbox.seq = 0;
+    double trial_ok = 1.0;
+    for (int round = 0; round < 2 && trial_ok == 1.0; ++round) {
+      const double v = 1000.0 * (round + 1) + c->rank;
+      MHIP_HIP(hipMemcpyAsync(flag, &v, sizeof(double), hipMemcpyHostToDevice, s));
+      if (int e = mailbox_exchange(c, 1, flag, flags, s)) return e;
+      std::vector<double> h(world);
+      MHIP_HIP(hipMemcpyAsync(h.data(), flags, world * sizeof(double), hipMemcpyDeviceToHost, s));
+      MHIP_HIP(hipStreamSynchronize(s));
+      for (int r = 0; r < world; ++r)
+        if (h[r] != 1000.0 * (round + 1) + r) trial_ok = 0.0;
+    }
+    if (int e = agree(trial_ok, &all)) return e;
+  }
+  if (all) {
+    c->mbox.open = true;
+    *opened = 1;
+  } else {
+    mailbox_close(c);
+  }
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_mailbox_close(mhip_comm_t c) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  mailbox_close(c);
+  return MHIP_SUCCESS;
+}
 
 int mhip_comm_unique_id(unsigned char* id) {
   MHIP_REQUIRE(id != nullptr, MHIP_ERR_INVALID_ARGUMENT, "id is null");
@@ -224,6 +392,7 @@ int mhip_comm_destroy(mhip_comm_t c) {
   c->ghost.regions.release();
   for (DeviceBuffer* b : {&c->migrate.dest, &c->migrate.sortkey, &c->migrate.order, &c->migrate.hist, &c->migrate.stage})
     b->release();
+  mailbox_close(c);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   if (c->ready) (void)hipEventDestroy(c->ready);
@@ -757,9 +926,14 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
       if (int e = mhip_comm_exchange_finish(c, stream)) return e;
     if (ev) MHIP_HIP(hipEventRecord(ev[4], s));
     if (int e = mhip_bbpgd_stage_constraint_range(op, init, interior_contacts, C - interior_contacts, stream)) return e;
-    if (int e = mhip_bbpgd_stage_reduce(op, init, local3, stream)) return e;
-    if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
-    if (int e = mhip_comm_all_gather(c, local3, kRed, gathered, stream)) return e;
+    if (c->mbox.open) {  // the record is posted, and everybody's collected, by the kernel that forms it
+      if (int e = stage_reduce_exchange(op, init, local3, mailbox_next(c, kRed, gathered), s)) return e;
+      if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
+    } else {
+      if (int e = mhip_bbpgd_stage_reduce(op, init, local3, stream)) return e;
+      if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
+      if (int e = mhip_comm_all_gather(c, local3, kRed, gathered, stream)) return e;
+    }
     return mhip_bbpgd_stage_finalize(op, init, gathered, c->world, stream);
   };
 
@@ -768,6 +942,8 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
   int done = 0;
   for (;;) {
     if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
+    if (c->mbox.open)
+      if (int e = mailbox_check(c, s)) return e;
     if (prof && last_todo) {
       unsigned eff = result->num_iters - iter_before + ((result->converged && result->num_iters < config->max_iters) ? 1u : 0u);
       if (eff > last_todo) eff = last_todo;

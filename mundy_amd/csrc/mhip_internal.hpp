@@ -267,6 +267,67 @@ struct TraceRange {
 
 int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, void* workspace, hipStream_t stream);
 
+// ---- mailbox (dist.hip: mhip_comm_mailbox_open): the ranks of one node exchange a small record per solver iteration
+// through slots in each other's device memory (IPC-mapped, fine-grained).  PUSH: a rank writes its record into its
+// slot of EVERY rank's box (posted writes over xGMI), then polls its OWN box (local reads).  A record of `width`
+// doubles travels as 2 * width 8-byte words, each (32 bits of data, 32-bit flag = the exchange number): every word is
+// one atomic store and validates itself, so no ordering between stores is needed (writes to a peer may arrive in any
+// order) -- the low-latency protocol of the collective libraries.  Box layout: [parity of the exchange][rank][kSlotWords].
+constexpr int kSlotWords = 16;  // words per slot: records of up to 8 doubles
+struct MailboxArgs {
+  unsigned long long* const* peers = nullptr;  // [world] device pointers: every rank's box (null: no mailbox)
+  int world = 1, rank = 0, width = 0;
+  unsigned long long seq = 0;            // number of this exchange (the same on every rank, counted from 1)
+  double* gathered = nullptr;            // [world][width] out
+  unsigned long long* status = nullptr;  // [0] != 0: an exchange timed out (sticky)
+  unsigned long long timeout = 0;        // ticks of the 100 MHz wall clock
+};
+// convex.hip: mhip_bbpgd_stage_reduce with the exchange inside the launch that forms the record
+int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const MailboxArgs& mb, hipStream_t s);
+// Called by the first wave of a workgroup (threads 0 .. 63); `mine` = this rank's record, readable by every lane of the
+// wave (shared or global memory).  Two slot sets alternate: a rank can post exchange k + 2 only after it has read
+// everybody's k + 1, which the others posted after reading everybody's k -- nobody still reads the slots of k when they
+// are written again.  All accesses are relaxed system-scope atomics on fine-grained memory (uncached: nothing to write
+// back or invalidate -- a release / acquire pair at system scope would flush the whole L2 every iteration).  The wait
+// is bounded: a rank that never posts ends in an error on the host (status[0]), not in waves that never finish.
+__device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double* mine) {
+  if (threadIdx.x >= 64) return;
+  const int nw = 2 * m.width;
+  const unsigned flag = static_cast<unsigned>(m.seq);
+  const size_t set = (m.seq & 1ull) * (size_t)m.world * kSlotWords;
+  // post: word w of my record into my slot of rank r's box, for every (r, w)
+  for (int t = threadIdx.x; t < m.world * nw; t += 64) {
+    const int r = t / nw, w = t % nw;
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(mine[w >> 1]));
+    const unsigned half = static_cast<unsigned>((w & 1) ? (bits >> 32) : (bits & 0xffffffffull));
+    unsigned long long* dst = m.peers[r] + set + (size_t)m.rank * kSlotWords + w;
+    __hip_atomic_store(dst, (static_cast<unsigned long long>(flag) << 32) | half, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // collect: word w of rank r's record from my own box
+  unsigned long long* box = m.peers[m.rank] + set;
+  for (int t = threadIdx.x; t < m.world * m.width; t += 64) {
+    const int r = t / m.width, k = t % m.width;
+    unsigned long long lo = 0, hi = 0;
+    const unsigned long long t0 = wall_clock64();
+    bool ok = true;
+    for (;;) {
+      lo = __hip_atomic_load(&box[(size_t)r * kSlotWords + 2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      hi = __hip_atomic_load(&box[(size_t)r * kSlotWords + 2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (static_cast<unsigned>(lo >> 32) == flag && static_cast<unsigned>(hi >> 32) == flag) break;
+      if (__hip_atomic_load(&m.status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
+          wall_clock64() - t0 > m.timeout) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(&m.status[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long bits = (hi << 32) | (lo & 0xffffffffull);
+    m.gathered[(size_t)r * m.width + k] = ok ? __longlong_as_double(static_cast<long long>(bits)) : __builtin_nan("");
+  }
+}
+
 // sort.hip: stable LSD radix sort of (u64 key, u32 value) records over the key bits [0, 8 * passes), passes even (the
 // result is back in keys / vals); segment sorts (ascending, unsigned) -- see sort.hip
 constexpr int kShortSegment = 32;  // segments up to this length are sorted by one thread

@@ -136,9 +136,10 @@ class Comm:
     tests, where several ranks share one GPU and RCCL refuses duplicate devices), it is the message layer behind the
     library's host-callback transport.  All halo traffic and reductions of the step go through the library."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, mailbox=True):
         lib = capi.load()
         self.group = group
+        self.mailbox = False
         self.enabled = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
@@ -186,6 +187,24 @@ class Comm:
             self._callbacks = (capi.EXCHANGE_FN(self._exchange_cb), capi.ALL_GATHER_FN(self._all_gather_cb))
             capi.check(lib.mhip_comm_create_host(C.byref(self._h), self.rank, self.world, self._callbacks[0],
                                                  self._callbacks[1], None))
+        if mailbox and torch.cuda.is_available():
+            self.mailbox = self._open_mailbox()
+
+    def _open_mailbox(self):
+        """The per-iteration reduction record through slots in the ranks' device memory instead of a collective launch
+        (mhip_comm_mailbox_open): ranks of one node only."""
+        import socket
+        import zlib
+        if self.enabled and self.world > 1:
+            dev = torch.device("cuda") if self.direct else torch.device("cpu")
+            host = torch.tensor([zlib.crc32(socket.gethostname().encode())], dtype=torch.int64, device=dev)
+            hosts = [torch.zeros_like(host) for _ in range(self.world)]
+            dist.all_gather(hosts, host, group=self.group)
+            if any(int(h) != int(host) for h in hosts):
+                return False      # ranks on several nodes: the transport's all-gather stays
+        opened = C.c_int(0)
+        capi.check(capi.load().mhip_comm_mailbox_open(self._h, C.byref(opened), _stream()))
+        return bool(opened.value)
 
     def close(self):
         if self._h:

@@ -15,10 +15,16 @@ st = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=D.Comm(
 ref = pipeline.ContactStepper("spherocylinder", dev(c), dev(r), dev(q), dev(L), search_buffer=0.1, cfg=cfg)
 st0 = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=D.Comm(), cfg=cfg, poll_every=32)
 st0.tiering = 0
-for name, fn in (("staged", lambda: st.step(integrate=False)), ("staged, cold tier off", lambda: st0.step(integrate=False)),
+st1 = D.DistributedContactStepper(dev(c), dev(q), dev(r), dev(L), 0, comm=D.Comm(mailbox=False), cfg=cfg, poll_every=32)
+assert st.comm.mailbox and not st1.comm.mailbox
+for name, fn in (("staged (records through the mailbox)", lambda: st.step(integrate=False)),
+                 ("staged, records through ncclAllGather", lambda: st1.step(integrate=False)),
+                 ("staged, cold tier off", lambda: st0.step(integrate=False)),
                  ("fused", lambda: ref.step(integrate=False))):
-    fn(); torch.cuda.synchronize()
-    t = time.perf_counter(); out = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    fn(); fn(); torch.cuda.synchronize(); ts = []
+    for _ in range(5):
+        t = time.perf_counter(); out = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    dt = float(np.median(ts))
     it = out["num_iters"] if isinstance(out, dict) else out.num_iters
     print("%s: %.1f ms/step, %d iterations, %.3f ms/iteration" % (name, 1e3 * dt, it, 1e3 * dt / max(it, 1)))
 print("staged cold tier:", st.op.tier_stats())

@@ -93,6 +93,11 @@ int main(int argc, char** argv) {
   }
   mhip_comm_t comm = nullptr;
   check(mhip_comm_create_rccl(&comm, id, rank, world));
+  {  // the per-iteration reduction records through the node's mailbox (slots in the ranks' device memory)
+    int opened = 0;
+    check(mhip_comm_mailbox_open(comm, &opened, nullptr));
+    std::printf("MAILBOX rank %d opened %d\n", rank, opened);
+  }
 
   const size_t base = n / world, rem = n % world;
   const size_t first = rank * base + (static_cast<size_t>(rank) < rem ? rank : rem);

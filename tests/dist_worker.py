@@ -31,15 +31,20 @@ def main():
     a, e = int(starts[rank]), int(starts[rank + 1])
     cfg = ops.PGDConfig(max_iters=20000, tol=tol)
     D.Comm().self_check()
+
+    def make_comm():   # DIST_NO_MAILBOX: the reduction records through the transport's all-gather, as on several nodes
+        comm = D.Comm(mailbox=not os.environ.get("DIST_NO_MAILBOX"))
+        assert comm.mailbox == (not os.environ.get("DIST_NO_MAILBOX")), "mailbox %s" % comm.mailbox
+        return comm
     if mixed:
         g_kind, g_shape = b["kind"][order], b["shape"][order]
-        st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), None, None, a, comm=D.Comm(),
+        st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), None, None, a, comm=make_comm(),
                                          search_buffer=buf, cfg=cfg, poll_every=8, kind=dev(g_kind[a:e]),
                                          shape=dev(g_shape[a:e]))
     else:
         g_radius, g_length = b["radius"][order], b["length"][order]
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]),
-                                         a, comm=D.Comm(), search_buffer=buf, cfg=cfg, poll_every=8,
+                                         a, comm=make_comm(), search_buffer=buf, cfg=cfg, poll_every=8,
                                          domain=(0.0, b["box"]), curve_level=4, recut_every=3)
     # DIST_TIER: cold tier mode of every rank's operator (3 = tier whatever the size, 2 = and leave the tiers mid-solve)
     if os.environ.get("DIST_TIER"):

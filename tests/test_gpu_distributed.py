@@ -36,6 +36,12 @@ def _run(world, port=None, extra_env=None):
     assert "DIST_RESULT PASS" in p.stdout
 
 
+def test_reduction_records_through_the_transport_instead_of_the_mailbox():
+    # by default the ranks of a node exchange the per-iteration record through the host-shared mailbox (every other test
+    # here asserts that it opened); this one takes the transport's all-gather, as ranks on several nodes would
+    _run(3, extra_env={"DIST_NO_MAILBOX": "1"})
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_equals_single_rank(world):
     _run(world, 29610 + world)
