@@ -1767,6 +1767,9 @@ constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g a
 // shorter sweep saves (rods, fused solve, tier on / off: 0.22M contacts 9.2 / 7.5 ms, 0.94M 18.5 / 16.8 ms, 1.9M 32.6 /
 // 34.2 ms, 3.8M 94 / 108 ms, 7.6M 150 / 190 ms; scripts/tier_crossover.py)
 constexpr size_t kTierMinContacts = 1500000;
+#ifndef MHIP_TIER_RETIER_PERCENT
+#define MHIP_TIER_RETIER_PERCENT 6  // (10: 149.1 ms per step at 10^6 rods, 6: 147.3 -- a third renumbering at iteration 248)
+#endif
 constexpr unsigned kTierHorizon = 64;  // iterations a sleeper's slack is sized for, at least
 #ifndef MHIP_TIER_SERVICE_BLOCKS
 #define MHIP_TIER_SERVICE_BLOCKS 16
@@ -2067,12 +2070,16 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   if (t.active) MHIP_HIP(hipMemcpyAsync(&awake, m.counters, sizeof(awake), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
   const size_t H = static_cast<size_t>(H32);
+#ifdef MHIP_TIER_DEBUG
+  fprintf(stderr, "tier_update: iter %u last_period %u next %u scale %.2f  H %zu of I %zu (%.3f)  active %d awake %llu\n",
+          iters_done, last_period, next_period, scale, H, I, (double)H / (double)I, (int)t.active, awake);
+#endif
   if (t.active) {
     // (a long awake list gets more service workgroups: each evaluates its share in rounds of a workgroup's width)
     t.service_blocks = tier_service_blocks(static_cast<size_t>(awake));
     // renumbering costs about four constraint sweeps: only when what is swept in full (the hot range and the awake
-    // part of the tail, the latter through scattered accesses) can shrink by a tenth
-    if (10 * H >= 9 * (t.H + static_cast<size_t>(awake))) return MHIP_SUCCESS;
+    // part of the tail, the latter through scattered accesses) can shrink by MHIP_TIER_RETIER_PERCENT percent
+    if (100 * H >= (100 - MHIP_TIER_RETIER_PERCENT) * (t.H + static_cast<size_t>(awake))) return MHIP_SUCCESS;
   } else if (10 * H > 9 * I) {
     return MHIP_SUCCESS;  // (almost) everything is hot: nothing to gain yet
   }
