@@ -512,7 +512,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                        "bodies_moved_by_work_recut_rank0": moved["sent"],
                        "converged": [bool(s["converged"]) for s in stats],
                        "parallelism": "hilbert domain decomposition dd%d: ghost-body halo per rebuild; per BBPGD "
-                                      "iteration ghost-velocity send/recv + 5-double all-gather (RCCL)" % world,
+                                      "iteration ghost-velocity send/recv + 5-double record per rank (%s)"
+                                      % (world, "mailbox: IPC-mapped device slots" if comm.mailbox else "ncclAllGather"),
                        "transport": comm.transport,
                        # the per-iteration 5-double record: slots in the ranks' device memory, or the transport's all-gather
                        "reduction_records": "mailbox" if comm.mailbox else "all-gather"},
