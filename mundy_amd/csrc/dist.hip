@@ -229,7 +229,9 @@ int mhip_comm_mailbox_open(mhip_comm_t c, int* opened, mhip_stream_t stream) {
   if (c->mbox.open || c->mbox.own) mailbox_close(c);
   hipStream_t s = as_stream(stream);
   const int world = c->world;
-  const size_t bytes = 2 * (size_t)world * kSlotWords * sizeof(unsigned long long);
+  // the slots, then one scratch word per rank (written through the copy engine when the box is mapped: see below)
+  const size_t slot_bytes = 2 * (size_t)world * kSlotWords * sizeof(unsigned long long);
+  const size_t bytes = slot_bytes + (size_t)world * sizeof(unsigned long long);
   constexpr size_t kHandleDoubles = (sizeof(hipIpcMemHandle_t) + 7) / 8;
   // this rank's box: fine-grained device memory (coherent for the peers that write into it while a kernel polls it)
   double mine_ok = 0.0;
@@ -276,6 +278,16 @@ int mhip_comm_mailbox_open(mhip_comm_t c, int* opened, mhip_stream_t stream) {
       if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess && p != nullptr) {
         c->mbox.mapped[r] = p;
         peers[r] = static_cast<unsigned long long*>(p);
+        // a first write through the runtime's copy path: a mapping this device cannot reach fails HERE, as an error
+        // code, not later as a fault of the kernel that stores into it
+        const unsigned long long probe = 0x6d626f78ull + static_cast<unsigned long long>(c->rank);
+        unsigned long long back = 0;
+        char* word = static_cast<char*>(p) + slot_bytes + (size_t)c->rank * sizeof(unsigned long long);
+        if (hipMemcpy(word, &probe, sizeof(probe), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(&back, word, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess || back != probe) {
+          (void)hipGetLastError();
+          map_ok = 0.0;
+        }
       } else {
         (void)hipGetLastError();
         map_ok = 0.0;
