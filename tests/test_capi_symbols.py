@@ -111,3 +111,14 @@ def test_gen_neighbor_links_builder_misuse():
     with pytest.raises(RuntimeError, match="more than once"):
         g.concretize()
     g.close()
+
+
+def test_library_reads_no_tuning_switch_from_the_environment(lib):
+    # the product has no run-time tuning switches -- the only environment variable the library looks at is
+    # MHIP_TRACE (roctx ranges on / off); A/B macros exist at compile time only (MHIP_EXTRA_HIPCC_FLAGS of the build)
+    src = os.path.join(ROOT, "mundy_amd", "csrc")
+    calls = []
+    for f in sorted(os.listdir(src)):
+        text = open(os.path.join(src, f)).read()
+        calls += [(f, m) for m in re.findall(r"getenv\(\s*\"([^\"]+)\"", text)]
+    assert calls == [("runtime.hip", "MHIP_TRACE")], calls
