@@ -594,7 +594,7 @@ int mhip_comm_info(mhip_comm_t comm, int* rank, int* world, int* is_rccl);
  * 8-byte word carries 32 bits of data and the number of the exchange, so each store validates itself and the writes
  * may arrive in any order.  Collective call.  *opened = 1: every rank has mapped every box and two trial exchanges went
  * through everywhere (mhip_bbpgd_solve_contact_distributed then uses it); 0: somebody could not (another node, no peer
- * access) and everybody keeps the transport's all-gather.  A record that does not arrive within 3 s ends the solve in
+ * access) and everybody keeps the transport's all-gather.  A record that does not arrive within 20 s ends the solve in
  * MHIP_ERR_RUNTIME on the ranks that waited for it (bounded polling: no wave waits forever). */
 int mhip_comm_mailbox_open(mhip_comm_t comm, int* opened /*[host]*/, mhip_stream_t stream);
 int mhip_comm_mailbox_close(mhip_comm_t comm);
