@@ -294,6 +294,22 @@ def main():
                    "timesteps_per_sec": round(args.steps / r_el, 4), "ms_per_step": round(1e3 * r_el / args.steps, 3),
                    "contacts": rstats[-1].num_contacts, "bbpgd_iters_per_step": [s.num_iters for s in rstats],
                    "converged": [bool(s.converged) for s in rstats]}
+        # ... and a short trajectory from there as a simulation runs it: consecutive steps, the neighbour list rebuilt
+        # only when the rebuild rule asks for it (GenNeighborLinkers.hpp:603-615: a body moved more than half the buffer)
+        stepper.restore(pristine_relaxed)
+        stepper.links.invalidate()
+        stepper.step(integrate=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        tstats = [stepper.step(integrate=True) for _ in range(8)]
+        torch.cuda.synchronize()
+        t_el = time.perf_counter() - t2
+        relaxed["trajectory"] = {"what": "8 consecutive steps from the relaxed packing, neighbour list reused until the "
+                                         "rebuild rule fires", "ms_per_step": round(1e3 * t_el / 8, 3),
+                                 "timesteps_per_sec": round(8 / t_el, 4),
+                                 "rebuilds": int(sum(1 for s in tstats if s.rebuilt)),
+                                 "bbpgd_iters_per_step": [s.num_iters for s in tstats],
+                                 "converged": [bool(s.converged) for s in tstats]}
 
     # ---- CPU baseline: the oracle (CPU restatement of the reference path) on this box's host cores, rank 0 ---------
     cpu = None

@@ -58,6 +58,8 @@ def test_default_line_has_the_contract_keys(tier):
     rp = d["relaxed_packing"]
     assert "NOT the headline" in rp["what"] and all(rp["converged"]) and rp["timesteps_per_sec"] > 0
     assert max(rp["bbpgd_iters_per_step"]) < min(d["config"]["bbpgd_iters_per_step"])
+    tr = rp["trajectory"]     # consecutive steps with the rebuild rule deciding about the neighbour list
+    assert len(tr["bbpgd_iters_per_step"]) == 8 and all(tr["converged"]) and 0 <= tr["rebuilds"] <= 8
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0.0 < r["frac"] < 1.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=1e-3)
     c = d["cpu_baseline"]
