@@ -34,7 +34,10 @@ def main():
 
     def make_comm():   # DIST_NO_MAILBOX: the reduction records through the transport's all-gather, as on several nodes
         comm = D.Comm(mailbox=not os.environ.get("DIST_NO_MAILBOX"))
-        assert comm.mailbox == (not os.environ.get("DIST_NO_MAILBOX")), "mailbox %s" % comm.mailbox
+        assert not (comm.mailbox and os.environ.get("DIST_NO_MAILBOX"))
+        # (a box that refuses fine-grained IPC memory leaves everybody on the all-gather: the solve must not care;
+        # test_mailbox_opens_between_the_ranks_of_the_test_box is the one that insists)
+        print("MAILBOX rank %d opened %d" % (rank, int(comm.mailbox)), flush=True)
         return comm
     if mixed:
         g_kind, g_shape = b["kind"][order], b["shape"][order]

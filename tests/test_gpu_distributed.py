@@ -34,12 +34,21 @@ def _run(world, port=None, extra_env=None):
         f.write(p.stdout[-20000:])
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_RESULT PASS" in p.stdout
+    return p.stdout
 
 
 def test_reduction_records_through_the_transport_instead_of_the_mailbox():
-    # by default the ranks of a node exchange the per-iteration record through the host-shared mailbox (every other test
-    # here asserts that it opened); this one takes the transport's all-gather, as ranks on several nodes would
-    _run(3, extra_env={"DIST_NO_MAILBOX": "1"})
+    # by default the ranks of a node exchange the per-iteration record through the mailbox (slots in each other's device
+    # memory); this one takes the transport's all-gather, as ranks on several nodes would
+    out = _run(3, extra_env={"DIST_NO_MAILBOX": "1"})
+    assert out.count("MAILBOX rank") == 3 and "opened 1" not in out
+
+
+def test_mailbox_opens_between_the_ranks_of_the_test_box():
+    # three processes sharing the GPU: every rank maps the others' boxes (hipIpc), the trial exchanges go through, and
+    # the solve that used it equals the single-rank solve like any other
+    out = _run(3)
+    assert out.count("MAILBOX rank") == 3 and "opened 0" not in out
 
 
 @pytest.mark.parametrize("world", [2, 3])
