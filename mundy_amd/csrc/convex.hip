@@ -696,7 +696,7 @@ __device__ inline double contact_dt_sdot(const OpView& op, const double* __restr
   }
   if (KIN == KIN_ROD) {
     const double2 a2 = vi2[2], b2 = vj2[2];
-    const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+    const double ci = rod_arm_coef(op.arc_s[c]), cj = rod_arm_coef(op.arc_t[c]);
     vi = vi + ci * V3{a1.y, a2.x, a2.y};
     vj = vj + cj * V3{b1.y, b2.x, b2.y};
   }
@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     }
     if (KIN == KIN_ROD) {
       const double2 a2 = vi2[2], b2 = vj2[2];
-      const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+      const double ci = rod_arm_coef(op.arc_s[c]), cj = rod_arm_coef(op.arc_t[c]);
       vi = vi + ci * V3{a1.y, a2.x, a2.y};
       vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
@@ -1107,7 +1107,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (KIN == KIN_ROD) {
       const double2 a2 = vi2[2], b2 = vj2[2];
-      const double ci = op.arc_s[c] - 0.5, cj = op.arc_t[c] - 0.5;
+      const double ci = rod_arm_coef(op.arc_s[c]), cj = rod_arm_coef(op.arc_t[c]);
       vi = vi + ci * V3{a1.y, a2.x, a2.y};
       vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
@@ -1297,7 +1297,7 @@ __global__ void __launch_bounds__(kBlock)
       const V3 r = (e & 1) ? load3(rb, c) : load3(ra, c);
       H[3] = r.x; H[4] = r.y; H[5] = r.z;
     }
-    if (KIN == KIN_ROD) H[3] = ((e & 1) ? arc_t[c] : arc_s[c]) - 0.5;
+    if (KIN == KIN_ROD) H[3] = rod_arm_coef((e & 1) ? arc_t[c] : arc_s[c]);
   }
 }
 

@@ -188,8 +188,10 @@ __global__ void __launch_bounds__(kBlock)
     if (cp2) store3(cp2, c, r.cp2);
     if (ra) store3(ra, c, r.cp1 - load3(center, ij.x));
     if (rb) store3(rb, c, r.cp2 - (PERIODIC ? load3(center, ij.y) + shift : load3(center, ij.y)));
-    if (s) s[c] = r.s;
-    if (t) t[c] = r.t;
+    // arclengths of the contact points cp1 / cp2, i.e. of the CLAMPED closest points: in the colinear branch the
+    // distance routine's own s / t are unclamped line parameters (mhip_distance_segment_segment returns those raw)
+    if (s) s[c] = contact_arclength(r.s);
+    if (t) t[c] = contact_arclength(r.t);
   }
 }
 

@@ -113,6 +113,16 @@ __host__ __device__ inline V3 qrot(Quat q, V3 v) {
 
 constexpr double kZeroTol = 1e-15;  // get_zero_tolerance<double>() (mundy_math/Tolerance.hpp:38-50)
 
+// Arclength of a rod's CONTACT POINT from the parameter the distance routines hand back.  distance(Point,
+// LineSegment) clamps the closest point to an endpoint but leaves its parameter t unclamped
+// (mundy_geom/distance/PointLineSegment.hpp:156-166), and the colinear branch of segment-segment returns that t
+// (LineSegmentLineSegment.hpp:236-265); the contact point of the assembly is the clamped closest point
+// (scrap/.../SpherocylinderSpherocylinderLinker.cpp:246-247), whose arclength is t clamped to [0, 1].
+__host__ __device__ inline double contact_arclength(double t) { return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t); }
+// coefficient of the rod-compressed lever arm, (arclength - 1/2) (p1 - p0): |coef| <= 1/2 whatever the caller passed
+__host__ __device__ inline double rod_arm_coef(double t) { return contact_arclength(t) - 0.5; }
+
+
 __device__ inline V3 load3(const double* p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
 __device__ inline void store3(double* p, size_t i, V3 v) {
   p[3 * i] = v.x;

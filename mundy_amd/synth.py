@@ -71,6 +71,20 @@ def spherocylinders(n, radius=0.5, length=2.0, volume_fraction=0.40, seed=1234, 
                 length=np.full(n, float(length)), box=L)
 
 
+def aligned_spherocylinders(n, radius=0.5, length=2.0, volume_fraction=0.40, seed=1234, axis=(0.0, 0.0, 1.0)):
+    """n PARALLEL spherocylinders (a nematic packing: every pair takes the colinear branch of the segment-segment
+    distance, LineSegmentLineSegment.hpp:215-265 -- end-to-end pairs with an unclamped parameter, side-by-side pairs
+    with overlapping projections).  Centres uniform in the box of the requested volume fraction; one common axis."""
+    b = spherocylinders(n, radius, length, volume_fraction, seed)
+    u = np.asarray(axis, dtype=np.float64)
+    u = u / np.linalg.norm(u)
+    # quat_from_parallel_transport(zhat, u)  (Quaternion.hpp:1489-1505)
+    w = np.sqrt(0.5 * (1.0 + u[2]))
+    q = np.array([w, 0.5 * (-u[1]) / w, 0.5 * u[0] / w, 0.0])
+    b["quat"] = np.ascontiguousarray(np.tile(q, (n, 1)))
+    return b
+
+
 def mixed_bodies(n, volume_fraction=0.40, seed=1234, sphere_radius=0.5, rod=(0.5, 2.0), ellipsoid=(0.8, 0.5, 0.4)):
     """BASELINE configs[4]: n bodies, kind = index mod 3 (0 sphere, 1 spherocylinder, 2 ellipsoid), centres uniform
     in the box that gives the requested volume fraction, orientations uniform (unit quaternions from 4 normal

@@ -1255,6 +1255,14 @@ struct ContactOp {
 // rounding (one ulp of the arm), not bitwise.  This is the association the device path evaluates (its half-edge
 // records hold (n, s - 1/2)); with kSumCompensated the two produce the same bits.  Like the 6-DOF form of ContactOp it
 // has no counterpart in the reference (its LCP app is spheres only): parity unpinned.
+//
+// s, t are the arclengths OF THE CONTACT POINTS.  distance(Point, LineSegment) clamps the closest point but leaves its
+// parameter unclamped (PointLineSegment.hpp:156-166) and the colinear branch of segment-segment hands that parameter
+// back (LineSegmentLineSegment.hpp:236-265), while the contact points of the assembly are the clamped closest points
+// (SpherocylinderSpherocylinderLinker.cpp:246-247): the arm coefficient is clamp(s, 0, 1) - 1/2, so that this form
+// equals ContactOp with ra = cp1 - c_i, rb = cp2 - c_j on aligned rods too (round-2 review: the unclamped parameter
+// put the contact point of an end-to-end pair off the rod).
+inline double contact_arclength(double t) { return t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t); }
 struct ContactOpRod {
   const int32_t* pairs;   // [C][2]
   const double* normal;   // [C][3]
@@ -1278,7 +1286,7 @@ struct ContactOpRod {
       const double lam = x[c];
       const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
       const V3 f{lam * n.x, lam * n.y, lam * n.z};
-      const double ci = arc_s[c] - 0.5, cj = arc_t[c] - 0.5;
+      const double ci = contact_arclength(arc_s[c]) - 0.5, cj = contact_arclength(arc_t[c]) - 0.5;
       for (int k = 0; k < 3; ++k) {
         Fa[3 * i + k].add(-f[k]);
         Fa[3 * j + k].add(f[k]);
@@ -1303,7 +1311,7 @@ struct ContactOpRod {
     for (size_t c = 0; c < C; ++c) {
       const int32_t i = pairs[2 * c], j = pairs[2 * c + 1];
       const V3 n{normal[3 * c], normal[3 * c + 1], normal[3 * c + 2]};
-      const double ci = arc_s[c] - 0.5, cj = arc_t[c] - 0.5;
+      const double ci = contact_arclength(arc_s[c]) - 0.5, cj = contact_arclength(arc_t[c]) - 0.5;
       const V3 zi{Z[3 * i], Z[3 * i + 1], Z[3 * i + 2]}, zj{Z[3 * j], Z[3 * j + 1], Z[3 * j + 2]};
       const V3 vi = V3{U[3 * i], U[3 * i + 1], U[3 * i + 2]} + zi * ci;
       const V3 vj = V3{U[3 * j], U[3 * j + 1], U[3 * j + 2]} + zj * cj;

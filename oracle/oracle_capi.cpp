@@ -160,8 +160,10 @@ void o_contact_spherocylinders(size_t C, const int32_t* pairs, const double* seg
     if (cp2) st3(cp2, c, rc.cp2);
     if (ra) st3(ra, c, rc.cp1 - ld3(center, i));
     if (rb) st3(rb, c, rc.cp2 - (box ? ld3(center, j) + shift : ld3(center, j)));
-    if (s) s[c] = rc.s;
-    if (t) t[c] = rc.t;
+    // arclengths of the contact points (the clamped closest points the linker uses,
+    // SpherocylinderSpherocylinderLinker.cpp:246-247), not the raw line parameters of the colinear branch
+    if (s) s[c] = contact_arclength(rc.s);
+    if (t) t[c] = contact_arclength(rc.t);
   }
 }
 
