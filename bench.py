@@ -160,11 +160,48 @@ def parse():
     return p.parse_args()
 
 
+def launch_plan(gpus, env, argv, device_count=None):
+    """--gpus N must MEAN N.  Called before anything touches the GPU.  Returns None when this process is one of the N
+    ranks it should be (N == WORLD_SIZE, or N == 1 without a launcher), the command line of the launcher to start as a
+    CHILD when N > 1 and no launcher started us (never an exec: a process that has initialised the GPU must not be
+    replaced on this pool, and this way the rule holds whatever gets added above), and raises SystemExit(2) on any
+    mismatch a launcher left us with -- a scaling run must never be recorded from fewer ranks than it names."""
+    if gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; launch as\n  python -m "
+                             "torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                             "--master-port P bench.py --gpus %d ...\n" % (gpus, world, gpus, gpus))
+            raise SystemExit(2)
+        return None
+    if gpus == 1:
+        return None
+    if device_count is not None and device_count < gpus and env.get("MUNDY_BENCH_BACKEND", "nccl") == "nccl":
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s)\n" % (gpus, device_count))
+        raise SystemExit(2)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    # (torch.cuda.device_count() does not initialise the GPU on this image; nothing before this line has either)
+    plan = launch_plan(args.gpus, os.environ, sys.argv[1:], device_count=torch.cuda.device_count())
+    if plan is not None:
+        import subprocess
+        sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(plan)))
+        sys.stderr.flush()
+        raise SystemExit(subprocess.call(plan))   # the ranks inherit stdout: rank 0's JSON line is the output
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: mundy_amd has no CPU path")
     # MUNDY_BENCH_BACKEND=gloo lets several ranks share one GPU (development boxes have one): same code path, the halo

@@ -130,6 +130,19 @@ def negotiate_direct_transport(group, rank, make_id, create, device):
     return flag.item() == 0.0, err
 
 
+# the two calls that make the library's RCCL communicator; module-level so that the tests can put a failing one in
+# their place (monkeypatch) -- the product reads no environment variable to decide anything
+def _rccl_unique_id(lib):
+    ident = C.create_string_buffer(capi.COMM_ID_BYTES)
+    capi.check(lib.mhip_comm_unique_id(ident))
+    return ident.raw
+
+
+def _rccl_create(lib, handle, raw, rank, world):
+    ident = C.create_string_buffer(raw, capi.COMM_ID_BYTES)
+    capi.check(lib.mhip_comm_create_rccl(C.byref(handle), ident, rank, world))
+
+
 class Comm:
     """One rank's communicator of the C library (mhip_comm_*, csrc/dist.hip).  torch.distributed is only the launcher:
     it carries the RCCL unique id from rank 0 to the others, and, when the process group is not nccl (gloo in the
@@ -151,20 +164,11 @@ class Comm:
             # the library's own RCCL communicator.  Should creating it fail on ANY rank (decided together, so that all
             # ranks take the same road) the step still runs, staged through host memory over a gloo group -- slow, and
             # said so loudly; it is not a second compute path, only a second wire.  bench.py refuses to time it.
-            forced = os.environ.get("MUNDY_TEST_FAIL_RCCL", "")   # the tests' way into the fallback branch
-
             def make_id():
-                if forced in ("1", "rank0"):
-                    raise RuntimeError("RCCL refused (forced by MUNDY_TEST_FAIL_RCCL)")
-                ident = C.create_string_buffer(capi.COMM_ID_BYTES)
-                capi.check(lib.mhip_comm_unique_id(ident))
-                return ident.raw
+                return _rccl_unique_id(lib)
 
             def create(raw):
-                if forced == "1" or forced == "rank%d" % self.rank:
-                    raise RuntimeError("RCCL refused (forced by MUNDY_TEST_FAIL_RCCL)")
-                ident = C.create_string_buffer(raw, capi.COMM_ID_BYTES)
-                capi.check(lib.mhip_comm_create_rccl(C.byref(self._h), ident, self.rank, self.world))
+                _rccl_create(lib, self._h, raw, self.rank, self.world)
 
             ok, err = negotiate_direct_transport(group, self.rank, make_id, create, torch.device("cuda"))
             if not ok:

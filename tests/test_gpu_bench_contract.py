@@ -88,16 +88,19 @@ def test_mixed_line_names_configs4():
     assert "pair list equal to the GPU's: True" in c["sample"]
 
 
-def _torchrun(extra, env=None):
+def _torchrun(extra, fail_rccl=False):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # fail_rccl: bench.py run through a wrapper that puts a refusing function in the place of the library's
+    # communicator constructor (the product reads no environment variable for this)
+    script = os.path.join(ROOT, "tests", "bench_rccl_refused.py") if fail_rccl else os.path.join(ROOT, "bench.py")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--distributed",
+           "127.0.0.1", "--master-port", str(port), script, "--gpus", "1", "--distributed",
            "--bodies", "30000", "--steps", "1", "--warmup", "1"] + extra
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
-                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", **(env or {})))
+                          env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
 
 
 def test_partitioned_line_is_configs3_and_refuses_a_host_staged_halo():
@@ -110,11 +113,11 @@ def test_partitioned_line_is_configs3_and_refuses_a_host_staged_halo():
     assert d["value"] == pytest.approx(1e3 / d["ms_per_step"], rel=1e-3)
     assert d["config"]["contact_imbalance_max_over_mean"] == 1.0
     # ... a run whose RCCL communicator could not be made falls back to the host-staged transport and prints NO line
-    p = _torchrun([], env={"MUNDY_TEST_FAIL_RCCL": "1"})
+    p = _torchrun([], fail_rccl=True)
     assert p.returncode != 0 and "refusing to print a scaling line" in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     # ... unless told to (development boxes), and then the line says which wire ran
-    p = _torchrun(["--allow-host-transport"], env={"MUNDY_TEST_FAIL_RCCL": "1"})
+    p = _torchrun(["--allow-host-transport"], fail_rccl=True)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["transport"] == "host"

@@ -209,11 +209,15 @@ def test_nccl_transport_single_rank():
         comm.close()
         # if the library's RCCL communicator cannot be made, every rank falls back -- together -- to the host-callback
         # transport over a gloo group: same step, same result
-        os.environ["MUNDY_TEST_FAIL_RCCL"] = "1"
+        def refuse(*a, **k):
+            raise RuntimeError("RCCL refused (injected by the test)")
+
+        real = D._rccl_create
+        D._rccl_create = refuse
         try:
             comm2 = D.Comm()
         finally:
-            del os.environ["MUNDY_TEST_FAIL_RCCL"]
+            D._rccl_create = real
         assert comm2.transport == "host" and not comm2.direct
         st4 = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), 0,
                                           comm=comm2, cfg=cfg)
