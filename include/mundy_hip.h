@@ -223,6 +223,13 @@ int mhip_broadphase_set_identities(mhip_broadphase_t handle, size_t n, const uin
 int mhip_broadphase_get_ident_pairs(mhip_broadphase_t handle, uint64_t* source_id, int32_t* source_proc,
                                     uint64_t* target_id, int32_t* target_proc, mhip_stream_t stream);
 int mhip_broadphase_method_used(mhip_broadphase_t handle, int* method /*[host]*/);
+/* Periodic cells: the predicate tests a pair at the NEAREST image of its centres / box midpoints only -- the minimum
+ * image of PeriodicScaledMetric::sep (periodicity.hpp:812-816), as every periodic distance of the reference does.  That
+ * finds every overlap as long as the smallest cell edge exceeds four times the largest reach (half extent + buffer) of
+ * the bodies; in a smaller cell two volumes can also meet through a second image, and such pairs are NOT reported.
+ * *complete [host] = 1 when the last build's cell met the condition (always 1 in free space), 0 otherwise: a caller
+ * that needs the multi-image list has to replicate the cell.  No synchronisation (the build has read the figure). */
+int mhip_broadphase_minimum_image_complete(mhip_broadphase_t handle, int* complete /*[host]*/);
 /* The list in MuNDy's link layout, so that it can be handed to LinkData without the host-serial
  * request_link loop of GenNeighborLinkers.hpp:714-738:
  *   export_coo  one row per link, as the fields LinkCOOData keeps per link entity (LinkMetaData.hpp:102-106): the link's

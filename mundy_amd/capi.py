@@ -108,6 +108,7 @@ SIGNATURES = {
     "mhip_broadphase_set_identities": [_vp, _sz, _vp, _vp, _vp],
     "mhip_broadphase_get_ident_pairs": [_vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_broadphase_method_used": [_vp, C.POINTER(_i)],
+    "mhip_broadphase_minimum_image_complete": [_vp, C.POINTER(_i)],
     "mhip_links_export_coo": [_vp, C.c_uint64, _i, _i, _vp, _vp, _vp, _vp],
     "mhip_links_export_crs": [_vp, C.c_uint64, C.c_uint, _vp, _vp, _vp, _vp, _vp],
     "mhip_deep_copy": [_sz, _vp, _vp, _vp],

@@ -868,6 +868,7 @@ struct mhip_broadphase {
   bool built = false;
   size_t n = 0, num_pairs = 0;
   int method_used = MHIP_SEARCH_METHOD_GRID;
+  bool min_image_complete = true;  // last build: no two volumes could have met through any image but the nearest
   DeviceBuffer recs, cell_of, slot_cell, cell_cnt, cell_ptr, cursor, counts, row_ptr, col, pairs, old_center, params,
       partials, scanws, flag, longrows, coltmp;
   // LBVH
@@ -957,6 +958,12 @@ int mhip_broadphase_set_exclusions(mhip_broadphase_t h, size_t n, const int32_t*
     if (int e = copy_in(h->ex_idx, ex_idx, num_entries * sizeof(int32_t), s)) return e;
   }
   h->built = false;
+  return MHIP_SUCCESS;
+}
+
+int mhip_broadphase_minimum_image_complete(mhip_broadphase_t h, int* complete) {
+  MHIP_REQUIRE(h != nullptr && complete != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  *complete = h->min_image_complete ? 1 : 0;
   return MHIP_SUCCESS;
 }
 
@@ -1152,7 +1159,15 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   // ---- row offsets, the one host read of the pair total ---------------------------------------------------------
   if (int e = exclusive_scan_i32(h->counts.as<int32_t>(), h->row_ptr.as<int32_t>(), n, h->scanws.ptr, s)) return e;
   MHIP_HIP(hipMemcpyAsync(h->host_scalar, h->row_ptr.as<int32_t>() + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (config->periodic && n > 0)
+    MHIP_HIP(hipMemcpyAsync(h->host_summary, summary, 8 * sizeof(double), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
+  // the periodic predicate looks at the NEAREST image of a pair only (PeriodicScaledMetric::sep, periodicity.hpp:
+  // 812-816, like every periodic distance of the reference): two volumes whose midpoints are d apart along an edge E
+  // meet again at E - d >= E/2, which their reaches (<= 2 x the largest) cannot span when 4 x largest reach < E
+  h->min_image_complete = true;
+  if (config->periodic && n > 0)
+    h->min_image_complete = 4.0 * h->host_summary[6] < std::min(config->box[0], std::min(config->box[1], config->box[2]));
   const int32_t total = h->host_scalar[0];
   MHIP_REQUIRE(total >= 0, MHIP_ERR_RUNTIME, "pair count overflowed 32 bits");
   h->num_pairs = static_cast<size_t>(total);

@@ -102,8 +102,7 @@ struct mhip_comm {
     void* own = nullptr;             // this rank's box
     std::vector<void*> mapped;       // the other ranks' boxes as mapped here (null at this rank's place)
     DeviceBuffer peers;              // [world] device array of box pointers
-    unsigned long long seq = 0;      // exchanges so far: the same number on every rank
-    DeviceBuffer status;             // [0] != 0: an exchange timed out (sticky)
+    DeviceBuffer status;             // [0] != 0: an exchange timed out (sticky); [1] = exchanges made (device-counted)
   } mbox;
   // work buffers of the distributed solve
   DeviceBuffer send_rows, triples;
@@ -182,13 +181,11 @@ __global__ void __launch_bounds__(64) k_mailbox_exchange(MailboxArgs m, const do
 constexpr unsigned long long kMailboxTimeoutTicks = 2000000000ull;  // 20 s of the 100 MHz wall clock (ranks enter a solve at different times: the narrow phase of a mixed system is uneven)
 
 MailboxArgs mailbox_next(mhip_comm* c, int width, double* gathered) {
-  c->mbox.seq += 1;
   MailboxArgs m;
   m.peers = c->mbox.peers.as<unsigned long long*>();
   m.world = c->world;
   m.rank = c->rank;
   m.width = width;
-  m.seq = c->mbox.seq;
   m.gathered = gathered;
   m.status = c->mbox.status.as<unsigned long long>();
   m.timeout = kMailboxTimeoutTicks;
@@ -201,12 +198,12 @@ int mailbox_exchange(mhip_comm* c, int width, const double* local, double* gathe
 }
 // after a stream synchronisation: did an exchange time out?
 int mailbox_check(mhip_comm* c, hipStream_t s) {
-  unsigned long long bad = 0;
-  MHIP_HIP(hipMemcpyAsync(&bad, c->mbox.status.ptr, sizeof(bad), hipMemcpyDeviceToHost, s));
+  unsigned long long st[2] = {0, 0};
+  MHIP_HIP(hipMemcpyAsync(st, c->mbox.status.ptr, sizeof(st), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
-  MHIP_REQUIRE(bad == 0, MHIP_ERR_RUNTIME,
+  MHIP_REQUIRE(st[0] == 0, MHIP_ERR_RUNTIME,
                "rank %d: a peer's reduction record did not arrive in the mailbox within 20 s (exchange %llu)", c->rank,
-               c->mbox.seq);
+               st[1] + 1);
   return MHIP_SUCCESS;
 }
 void mailbox_close(mhip_comm* c) {
@@ -311,8 +308,7 @@ int mhip_comm_mailbox_open(mhip_comm_t c, int* opened, mhip_stream_t stream) {
     return MHIP_SUCCESS;
   };
   if (int e = agree(map_ok, &all)) return e;
-  if (all) {  // the thing itself, twice (both slot sets)
-    c->mbox.seq = 0;
+  if (all) {  // the thing itself, twice (both slot sets); the exchange counter starts at 0 (status was just zeroed)
     double trial_ok = 1.0;
     for (int round = 0; round < 2 && trial_ok == 1.0; ++round) {
       const double v = 1000.0 * (round + 1) + c->rank;

@@ -287,9 +287,9 @@ constexpr int kSlotWords = 16;  // words per slot: records of up to 8 doubles
 struct MailboxArgs {
   unsigned long long* const* peers = nullptr;  // [world] device pointers: every rank's box (null: no mailbox)
   int world = 1, rank = 0, width = 0;
-  unsigned long long seq = 0;            // number of this exchange (the same on every rank, counted from 1)
   double* gathered = nullptr;            // [world][width] out
-  unsigned long long* status = nullptr;  // [0] != 0: an exchange timed out (sticky)
+  // [0] != 0: an exchange timed out (sticky); [1] = exchanges REALLY made so far (device-resident: see below)
+  unsigned long long* status = nullptr;
   unsigned long long timeout = 0;        // ticks of the 100 MHz wall clock
 };
 // convex.hip: mhip_bbpgd_stage_reduce with the exchange inside the launch that forms the record
@@ -297,14 +297,20 @@ int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const M
 // Called by the first wave of a workgroup (threads 0 .. 63); `mine` = this rank's record, readable by every lane of the
 // wave (shared or global memory).  Two slot sets alternate: a rank can post exchange k + 2 only after it has read
 // everybody's k + 1, which the others posted after reading everybody's k -- nobody still reads the slots of k when they
-// are written again.  All accesses are relaxed system-scope atomics on fine-grained memory (uncached: nothing to write
+// are written again.  That argument needs every exchange number to be exchanged, so the number lives ON THE DEVICE
+// (status[1], advanced by the wave that exchanges): launches enqueued behind a converged solve return before the
+// exchange (`done` is the same on every rank), and a host-side count of enqueued launches would let an odd number of
+// skipped ones hand the next real exchange the slot set of the last one while a slow peer still reads it.
+// All accesses are relaxed system-scope atomics on fine-grained memory (uncached: nothing to write
 // back or invalidate -- a release / acquire pair at system scope would flush the whole L2 every iteration).  The wait
 // is bounded: a rank that never posts ends in an error on the host (status[0]), not in waves that never finish.
 __device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double* mine) {
   if (threadIdx.x >= 64) return;
   const int nw = 2 * m.width;
-  const unsigned flag = static_cast<unsigned>(m.seq);
-  const size_t set = (m.seq & 1ull) * (size_t)m.world * kSlotWords;
+  // exchanges on one rank are launches on one stream, one wave each: nothing else touches status[1] meanwhile
+  const unsigned long long seq = __hip_atomic_load(&m.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  const unsigned flag = static_cast<unsigned>(seq);
+  const size_t set = (seq & 1ull) * (size_t)m.world * kSlotWords;
   // post: word w of my record into my slot of rank r's box, for every (r, w)
   for (int t = threadIdx.x; t < m.world * nw; t += 64) {
     const int r = t / nw, w = t % nw;
@@ -336,6 +342,9 @@ __device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double*
     const unsigned long long bits = (hi << 32) | (lo & 0xffffffffull);
     m.gathered[(size_t)r * m.width + k] = ok ? __longlong_as_double(static_cast<long long>(bits)) : __builtin_nan("");
   }
+  // (every lane has read status[1] above: the wave runs in lockstep and the barrier keeps the store below the loops)
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) __hip_atomic_store(&m.status[1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sort.hip: stable LSD radix sort of (u64 key, u32 value) records over the key bits [0, 8 * passes), passes even (the

@@ -362,6 +362,13 @@ class GenNeighborLinks:
         capi.check(capi.load().mhip_broadphase_method_used(self._h, C.byref(m)))
         return m.value
 
+    def minimum_image_complete(self):
+        """False when the last build's periodic cell was so small (an edge <= 4 x the largest reach) that volumes can
+        also meet through a second image -- pairs the minimum-image predicate does not report"""
+        m = C.c_int(0)
+        capi.check(capi.load().mhip_broadphase_minimum_image_complete(self._h, C.byref(m)))
+        return bool(m.value)
+
     def export_coo(self, first_link_id=0, source_rank=3, target_rank=3):
         """MuNDy's LinkCOOData rows (LinkMetaData.hpp:102-106): (link ids [P], linked entity ids [P, 2], linked entity
         ranks [P, 2] uint8; 3 = stk::topology::ELEM_RANK)"""

@@ -242,7 +242,7 @@ def test_periodic_lbvh_lists_equal_grid_and_bruteforce(ops, oracle, kind, symmet
         g = (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(0.15).set_search_method(method)
              .set_enforce_source_target_symmetry(symmetric).set_periodic_box(box).concretize())
         g.generate(dev(aabb), dev(c), dev(brad))
-        assert g.method_used() == method
+        assert g.method_used() == method and g.minimum_image_complete()
         np.testing.assert_array_equal(host(g.pairs), exp)
         g.close()
     # a cell with an edge below four times the largest reach is the grid's case, whatever was asked for
@@ -251,6 +251,8 @@ def test_periodic_lbvh_lists_equal_grid_and_bruteforce(ops, oracle, kind, symmet
          .set_search_method(ops.SEARCH_METHOD_MORTON_LBVH).set_periodic_box(small).concretize())
     g.generate(dev(aabb[:500]), dev(c[:500]), dev(brad[:500]))
     assert g.method_used() == ops.SEARCH_METHOD_GRID
+    # ... and the handle says that the minimum-image list is not the multi-image list there (mundy_hip.h)
+    assert not g.minimum_image_complete()
     np.testing.assert_array_equal(host(g.pairs), oracle.search(kind, lo[:500], hi[:500], c[:500], R[:500], box=small,
                                                                 method="brute"))
     g.close()
