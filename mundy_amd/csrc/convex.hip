@@ -337,6 +337,33 @@ int launch_copy(size_t n, double* dst, const double* src, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------------------
 // contact operator
 // ------------------------------------------------------------------------------------------------------------------
+// Streams that are read once per launch (entries, records, contact geometry) are loaded non-temporally so that they do
+// not push the GATHERED tables (packed iterates, body rows) out of L2 / Infinity Cache between the two sweeps.
+// MHIP_NT: bit 0 = the body sweep's compact streams, bit 1 = the constraint sweep's per-contact streams.  Measured on the
+// 10^6-rod solve (profiles/r03_ab_nt.txt): k_body 0.0943 -> 0.0904 ms, k_constraint 0.0768 -> 0.0730 ms, step 148.5 ->
+// 141.7 ms.  (The per-body rows -- row pointers, masks, mobilities, axes -- loaded that way cost k_body 4 %: neighbouring
+// lanes share their lines.)
+#ifndef MHIP_NT
+#define MHIP_NT 3
+#endif
+typedef double mhip_d2v __attribute__((ext_vector_type(2)));
+typedef int mhip_i2v __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ inline double ld_s(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ inline int32_t ld_s(const int32_t* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ inline double2 ld_s(const double2* p) {
+  if (!NT) return *p;
+  const mhip_d2v v = __builtin_nontemporal_load(reinterpret_cast<const mhip_d2v*>(p));
+  return make_double2(v.x, v.y);
+}
+template <bool NT> __device__ inline int2 ld_s(const int2* p) {
+  if (!NT) return *p;
+  const mhip_i2v v = __builtin_nontemporal_load(reinterpret_cast<const mhip_i2v*>(p));
+  return make_int2(v.x, v.y);
+}
+template <bool NT> __device__ inline V3 ld_s3(const double* p, size_t i) {
+  return {ld_s<NT>(p + 3 * i), ld_s<NT>(p + 3 * i + 1), ld_s<NT>(p + 3 * i + 2)};
+}
+
 struct SolverState {  // device resident
   double step, residual, num, den;
   unsigned iter;   // reported iteration count
@@ -431,14 +458,14 @@ __device__ inline size_t xcd_tile(size_t lin, size_t ntiles, unsigned T) {
 // operator-owned ping-pong pair, so the body sweep's gather of a half edge's iterate is ONE 16-byte access instead of
 // two 8-byte accesses into separate arrays (the gathers, not the streams, are what k_body waits on).  xt then points
 // at the packed array of the current iterate; in X_INIT it is the caller's plain x in both layouts.
-template <int MODE, bool PACKED>
+template <int MODE, bool PACKED, bool NT = false>
 __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, const double* __restrict__ gt,
                                    double step, bool step_is_zero, const Space& sp, double* x_old = nullptr,
                                    double* g_old = nullptr) {
   if (MODE == X_SOLVE) {
     double xv, gv;
     if (PACKED) {
-      const double2 p = reinterpret_cast<const double2*>(xt)[c];
+      const double2 p = ld_s<NT>(reinterpret_cast<const double2*>(xt) + c);
       xv = p.x;
       gv = p.y;
     } else {
@@ -464,10 +491,25 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 #ifndef MHIP_KBODY_WAVES
 #define MHIP_KBODY_WAVES 1
 #endif
-template <int MODE, int KIN, int G, int U, bool PACKED, bool TRACK = false>
+// entries per lane and chunk of the flat stream over the compact active lists (0: per-body chains there too).
+// Measured (profiles/r03_ab_nt.txt, 10^6 rods): 0 -> 0.0986 ms, 1 -> 0.1028, 2 -> 0.0944, 4 -> 0.1071 (48 KB of LDS)
+#ifndef MHIP_KBODY_FLAT
+#define MHIP_KBODY_FLAT 2
+#endif
+// FLATP > 0 (packed solves with a snapshot of the active lists): the compact lists are not walked body by body --
+// the workgroup's 256 threads STREAM the entries of its 256 / G bodies flat, FLATP x 256 at a time (every lane has the
+// same work whatever its body's share of the list; entry, record and the gather of the iterate are FLATP independent
+// chains per lane; no lane waits for its body's row pointer first), leave (n, coef, +/-lambda, +/-dlambda) of every
+// entry in LDS, and the G lanes of a body then add up their body's slice of that image -- the double-double sums see
+// the same terms (rounded once: any order gives the same bits).  What the snapshot does not cover (entries that became
+// active since, lists beyond 64 entries, steps outside [0, finite]) takes the per-body chains as before.
+template <int MODE, int KIN, int G, int U, bool PACKED, bool TRACK = false, int FLATP = 0>
 __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
+  constexpr bool FLAT = FLATP > 0 && MODE == X_SOLVE && PACKED;
+  constexpr int kFlatPlanes = (KIN == KIN_RIGID) ? 4 : 3;
+  __shared__ double2 flat_img[FLAT ? kFlatPlanes * FLATP * kBlock : 1];
   const double* xt = X0;
   const double* gt = G0;
   double step = 0.0;
@@ -487,8 +529,10 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   const size_t tile = xcd_tile(blockIdx.x, gridDim.x, op.xcd_aware);
   const size_t t = tile * (size_t)blockDim.x + threadIdx.x;
   const int sub = static_cast<int>(t % G);
-  if (t / G >= op.body_count) return;  // whole groups leave together (G divides the wave size)
-  const size_t b = op.body_first + t / G;
+  const bool has_body = t / G < op.body_count;
+  if (!FLAT && !has_body) return;  // whole groups leave together (G divides the wave size)
+  // (FLAT: lanes without a body still stream entries and meet the workgroup's barriers; b is clamped for them)
+  const size_t b = op.body_first + (has_body ? t / G : op.body_count - 1);
   constexpr int HW = (KIN == KIN_RIGID) ? 6 : (KIN == KIN_ROD ? 4 : 3);
   // force and torque sums in double-double: their rounded values do not depend on the order of the list, on G or on U
   DD3 Fdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, Tdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
@@ -581,14 +625,99 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     if (head < 64) mm &= (1ull << head) - 1ull;
     if (op.aptr != nullptr) {  // the snapshot's active entries, streamed; what became active since stays in mm
       const int32_t ab = op.aptr[b], ae = op.aptr[b + 1];
-      for (int32_t k0 = ab + sub; k0 < ae; k0 += G * U) {
-        int32_t kc[U];
+      if constexpr (FLAT) {
+        // the tile's bodies and their share [E0, E1) of the compact arrays (uniform over the workgroup)
+        const size_t tb0r = tile * (size_t)(kBlock / G);
+        const size_t tb0 = (tb0r < op.body_count) ? tb0r : op.body_count;  // (the grid is rounded up to whole XCD rounds)
+        const size_t tb1 = (tb0 + kBlock / G < op.body_count) ? tb0 + kBlock / G : op.body_count;
+        const int32_t E0 = op.aptr[op.body_first + tb0], E1 = op.aptr[op.body_first + tb1];
+        constexpr int kChunk = FLATP * kBlock;
+        constexpr bool NTS = (MHIP_NT & 1) != 0;
+        double2* const pl0 = flat_img;
+        double2* const pl1 = flat_img + kChunk;
+        double2* const pl2 = flat_img + 2 * kChunk;
+        double2* const pl3 = flat_img + (kFlatPlanes - 1) * kChunk;  // (+/-lambda, +/-dlambda)
+        for (int32_t base = E0; base < E1; base += kChunk) {
+          // phase A: FLATP entries per lane, all their loads in flight together
+          int32_t fe[FLATP];
+          double2 r0[FLATP], r1[FLATP], r2[FLATP];
 #pragma unroll
-        for (int u = 0; u < U; ++u) kc[u] = (k0 + u * G < ae) ? k0 + u * G : -1;
-        process(op.aent, op.arec, kc, true);
+          for (int p = 0; p < FLATP; ++p) {
+            const int32_t k = base + p * kBlock + static_cast<int32_t>(threadIdx.x);
+            fe[p] = (k < E1) ? ld_s<NTS>(op.aent + k) : -1;
+            r0[p] = r1[p] = r2[p] = make_double2(0.0, 0.0);
+            if (k < E1) {
+              if (KIN == KIN_TRANS) {
+                const double* H = op.arec + static_cast<size_t>(k) * HW;
+                r0[p] = make_double2(ld_s<NTS>(H), ld_s<NTS>(H + 1));
+                r1[p] = make_double2(ld_s<NTS>(H + 2), 0.0);
+              } else {
+                const double2* H2 = reinterpret_cast<const double2*>(op.arec + static_cast<size_t>(k) * HW);
+                r0[p] = ld_s<NTS>(H2);
+                r1[p] = ld_s<NTS>(H2 + 1);
+                if (KIN == KIN_RIGID) r2[p] = ld_s<NTS>(H2 + 2);
+              }
+            }
+          }
+          double sl[FLATP], sdl[FLATP];
+#pragma unroll
+          for (int p = 0; p < FLATP; ++p) {
+            double xo = 0.0;
+            const double lam = (fe[p] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(fe[p] >> 1), xt, gt, step,
+                                                                      step_is_zero, sp, &xo)
+                                            : 0.0;
+            // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472); the same sign on the multiplier's change
+            sl[p] = (fe[p] & 1) ? lam : -lam;
+            sdl[p] = (fe[p] & 1) ? lam - xo : xo - lam;
+          }
+#pragma unroll
+          for (int p = 0; p < FLATP; ++p) {
+            const int slot = p * kBlock + static_cast<int>(threadIdx.x);
+            pl0[slot] = r0[p];
+            pl1[slot] = r1[p];
+            if (KIN == KIN_RIGID) pl2[slot] = r2[p];
+            pl3[slot] = make_double2(sl[p], sdl[p]);
+          }
+          __syncthreads();
+          // phase B: a body's lanes add up its slice of the image
+          if (has_body) {
+            const int32_t lo = (ab > base) ? ab : base;
+            const int32_t hi = (ae < base + kChunk) ? ae : base + kChunk;
+            for (int32_t k = lo + sub; k < hi; k += G) {
+              const int slot = k - base;
+              const double2 a0 = pl0[slot], a1 = pl1[slot], a3 = pl3[slot];
+              const V3 n{a0.x, a0.y, a1.x};
+              V3 arm{0.0, 0.0, 0.0};
+              if (KIN == KIN_RIGID) {
+                const double2 a2 = pl2[slot];
+                arm = V3{a1.y, a2.x, a2.y};
+              }
+              if (track && a3.y != 0.0) {
+                const V3 df{a3.y * n.x, a3.y * n.y, a3.y * n.z};
+                dF = dF + df;
+                if (KIN == KIN_ROD) dS = dS + a1.y * df;
+                if (KIN == KIN_RIGID) dS = dS + cross(arm, df);
+              }
+              if (a3.x == 0.0) continue;
+              const V3 f{a3.x * n.x, a3.x * n.y, a3.x * n.z};
+              dd_add(Fdd, f);
+              if (KIN == KIN_RIGID) dd_add(Tdd, cross(arm, f));
+              if (KIN == KIN_ROD) dd_add(Tdd, a1.y * f);
+            }
+          }
+          __syncthreads();
+        }
+      } else {
+        for (int32_t k0 = ab + sub; k0 < ae; k0 += G * U) {
+          int32_t kc[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) kc[u] = (k0 + u * G < ae) ? k0 + u * G : -1;
+          process(op.aent, op.arec, kc, true);
+        }
       }
       mm &= ~op.snap_mask[b];
     }
+    if (FLAT && !has_body) mm = 0ull;
     int32_t kk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) kk[u] = -1;
@@ -610,6 +739,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     if (nm) process(op.inc, op.half, kk, true);
     full_from = beg + head;
   }
+  if (FLAT && !has_body) return;  // (no barrier follows; whole groups leave together)
   for (int32_t k0 = full_from + sub; k0 < end; k0 += G * U) {
     int32_t kk[U];
 #pragma unroll
@@ -886,10 +1016,11 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
   for (size_t lin = bid; lin < ntiles; lin += nblk) {
     const size_t c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
     if (c >= op.c_end) continue;
-    const int2 ij = op.pairs[c];
+    constexpr bool NTC = (MHIP_NT & 2) != 0 && MODE == X_SOLVE && PACKED;
+    const int2 ij = ld_s<NTC>(op.pairs + c);
     double x_old = 0.0, g_old = 0.0;
-    const double xc = iterate_x<MODE, PACKED>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
-    const V3 n = load3(op.normal, c);
+    const double xc = iterate_x<MODE, PACKED, NTC>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
+    const V3 n = ld_s3<NTC>(op.normal, c);
     const double2* vi2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.x);
     const double2* vj2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.y);
     const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
@@ -901,7 +1032,7 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     }
     if (KIN == KIN_ROD) {
       const double2 a2 = vi2[2], b2 = vj2[2];
-      const double ci = rod_arm_coef(op.arc_s[c]), cj = rod_arm_coef(op.arc_t[c]);
+      const double ci = rod_arm_coef(ld_s<NTC>(op.arc_s + c)), cj = rod_arm_coef(ld_s<NTC>(op.arc_t + c));
       vi = vi + ci * V3{a1.y, a2.x, a2.y};
       vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
@@ -911,7 +1042,7 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     if (MODE == X_APPLY) {
       gn[c] = y;
     } else {
-      const double g = 1.0 * q[c] + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
+      const double g = 1.0 * ld_s<NTC>(q + c) + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
       if (PACKED) {
         reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
         if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
@@ -1618,14 +1749,18 @@ namespace {
 int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double* X1, const double* G0,
                    const double* G1, Space sp, hipStream_t s, bool packed = false) {
   if (op->view.N == 0) return MHIP_SUCCESS;
-  const int G = (op->lanes_per_body == 2 || op->lanes_per_body == 8 || op->lanes_per_body == 16) ? op->lanes_per_body : 4;
+  const int G = (op->lanes_per_body == 1 || op->lanes_per_body == 2 || op->lanes_per_body == 8 || op->lanes_per_body == 16) ? op->lanes_per_body : 4;
   if (op->view.body_count == 0) return MHIP_SUCCESS;
   const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
   op->last_stream = s;
   const SolverState* st = op->state.as<SolverState>();
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
-    if (packed && M == X_SOLVE && op->view.drift != nullptr)                                       \
+    if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
+      k_body<M, R, GG, UU, true, true, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+    else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr)             \
+      k_body<M, R, GG, UU, true, false, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+    else if (packed && M == X_SOLVE && op->view.drift != nullptr)                                  \
       k_body<M, R, GG, UU, true, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);  \
     else if (packed && M == X_SOLVE)                                                               \
       k_body<M, R, GG, UU, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);        \
@@ -1635,6 +1770,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
 #define BODY(M, R)                                    \
   do {                                                \
     if (G == 2) BODY4(M, R, 2, 2);                    \
+    else if (G == 1) BODY4(M, R, 1, 2);               \
     else if (G == 8) BODY4(M, R, 8, 4);               \
     else if (G == 16) BODY4(M, R, 16, 2);             \
     else BODY4(M, R, 4, 4);                           \
@@ -2681,9 +2817,9 @@ int mhip_contact_op_set_work_mapping(mhip_contact_op_t op, int xcd_tile, int lan
   MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
   MHIP_REQUIRE(xcd_tile >= -1 && xcd_tile <= 4096, MHIP_ERR_INVALID_ARGUMENT,
                "xcd_tile must be in [0, 4096] (or -1 to keep the current value), got %d", xcd_tile);
-  MHIP_REQUIRE(lanes_per_body == -1 || lanes_per_body == 2 || lanes_per_body == 4 || lanes_per_body == 8 ||
-                   lanes_per_body == 16,
-               MHIP_ERR_INVALID_ARGUMENT, "lanes_per_body must be 2, 4, 8 or 16 (or -1 to keep), got %d", lanes_per_body);
+  MHIP_REQUIRE(lanes_per_body == -1 || lanes_per_body == 1 || lanes_per_body == 2 || lanes_per_body == 4 ||
+                   lanes_per_body == 8 || lanes_per_body == 16,
+               MHIP_ERR_INVALID_ARGUMENT, "lanes_per_body must be 1, 2, 4, 8 or 16 (or -1 to keep), got %d", lanes_per_body);
   MHIP_REQUIRE(!op->stage.active, MHIP_ERR_RUNTIME, "a staged solve is in progress");
   if (xcd_tile >= 0) op->view.xcd_aware = xcd_tile;
   if (lanes_per_body > 0) op->lanes_per_body = lanes_per_body;
