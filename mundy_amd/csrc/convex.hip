@@ -458,27 +458,34 @@ __device__ inline size_t xcd_tile(size_t lin, size_t ntiles, unsigned T) {
 // operator-owned ping-pong pair, so the body sweep's gather of a half edge's iterate is ONE 16-byte access instead of
 // two 8-byte accesses into separate arrays (the gathers, not the streams, are what k_body waits on).  xt then points
 // at the packed array of the current iterate; in X_INIT it is the caller's plain x in both layouts.
+// (two steps, so that a sweep can issue the loads of several contacts before it uses the first)
+template <int MODE, bool PACKED, bool NT = false>
+__device__ inline double2 iterate_load(size_t c, const double* __restrict__ xt, const double* __restrict__ gt) {
+  if (MODE == X_SOLVE) {
+    if (PACKED) return ld_s<NT>(reinterpret_cast<const double2*>(xt) + c);
+    return make_double2(xt[c], gt[c]);
+  }
+  return make_double2(xt[c], 0.0);
+}
+template <int MODE>
+__device__ inline double iterate_value(double2 p, double step, bool step_is_zero, const Space& sp) {
+  if (MODE == X_SOLVE) {
+    // wrapped_axpbyz(1, x_tmp, -step, g_tmp, x, space) with its beta ~ 0 branch (convex.hpp:228-247, :647)
+    const double v = step_is_zero ? 1.0 * p.x : 1.0 * p.x + (-step) * p.y;
+    return sp.project(v);
+  }
+  return p.x;
+}
 template <int MODE, bool PACKED, bool NT = false>
 __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, const double* __restrict__ gt,
                                    double step, bool step_is_zero, const Space& sp, double* x_old = nullptr,
                                    double* g_old = nullptr) {
+  const double2 p = iterate_load<MODE, PACKED, NT>(c, xt, gt);
   if (MODE == X_SOLVE) {
-    double xv, gv;
-    if (PACKED) {
-      const double2 p = ld_s<NT>(reinterpret_cast<const double2*>(xt) + c);
-      xv = p.x;
-      gv = p.y;
-    } else {
-      xv = xt[c];
-      gv = gt[c];
-    }
-    if (x_old) *x_old = xv;
-    if (g_old) *g_old = gv;
-    // wrapped_axpbyz(1, x_tmp, -step, g_tmp, x, space) with its beta ~ 0 branch (convex.hpp:228-247, :647)
-    const double v = step_is_zero ? 1.0 * xv : 1.0 * xv + (-step) * gv;
-    return sp.project(v);
+    if (x_old) *x_old = p.x;
+    if (g_old) *g_old = p.y;
   }
-  return xt[c];
+  return iterate_value<MODE>(p, step, step_is_zero, sp);
 }
 
 // Body sweep.  G lanes cooperate on one body: lane `sub` walks the body's half-edge records sub, sub+G, ... (a
@@ -582,11 +589,16 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
       h0[u] = h1[u] = h2[u] = make_double2(0.0, 0.0);
       if (eager && kk[u] >= 0) fetch(u);
     }
+    // (the iterate of an empty slot is read from contact 0 and dropped: an unconditional load can be issued next to
+    // the others, a conditional one waits for the one before it)
+    double2 pit[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      pit[u] = iterate_load<MODE, PACKED>(e[u] >= 0 ? static_cast<size_t>(e[u] >> 1) : 0, xt, gt);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      xo[u] = 0.0;
-      lam[u] = (e[u] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(e[u] >> 1), xt, gt, step, step_is_zero, sp, &xo[u])
-                           : 0.0;
+      xo[u] = (e[u] >= 0 && MODE == X_SOLVE) ? pit[u].x : 0.0;
+      lam[u] = (e[u] >= 0) ? iterate_value<MODE>(pit[u], step, step_is_zero, sp) : 0.0;
     }
     // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so (when the
     // records are not fetched eagerly) its record is never fetched (unless its multiplier just dropped to zero and the
@@ -620,9 +632,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
                       sp.lo == 0.0 && step >= 0.0 && step <= 1.7976931348623157e308;
   int32_t full_from = beg;  // incidence slots from here on are walked unconditionally
   if (masked) {
-    const int32_t head = (end - beg < 64) ? end - beg : 64;
-    unsigned long long mm = op.body_mask[b];
-    if (head < 64) mm &= (1ull << head) - 1ull;
+    // (the compact lists first: nothing in there waits for the body's own rows -- masks, row pointers -- loaded above)
     if (op.aptr != nullptr) {  // the snapshot's active entries, streamed; what became active since stays in mm
       const int32_t ab = op.aptr[b], ae = op.aptr[b + 1];
       if constexpr (FLAT) {
@@ -659,13 +669,15 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
               }
             }
           }
+          double2 pit[FLATP];
+#pragma unroll
+          for (int p = 0; p < FLATP; ++p)
+            pit[p] = iterate_load<MODE, PACKED>(fe[p] >= 0 ? static_cast<size_t>(fe[p] >> 1) : 0, xt, gt);
           double sl[FLATP], sdl[FLATP];
 #pragma unroll
           for (int p = 0; p < FLATP; ++p) {
-            double xo = 0.0;
-            const double lam = (fe[p] >= 0) ? iterate_x<MODE, PACKED>(static_cast<size_t>(fe[p] >> 1), xt, gt, step,
-                                                                      step_is_zero, sp, &xo)
-                                            : 0.0;
+            const double xo = (fe[p] >= 0) ? pit[p].x : 0.0;
+            const double lam = (fe[p] >= 0) ? iterate_value<MODE>(pit[p], step, step_is_zero, sp) : 0.0;
             // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472); the same sign on the multiplier's change
             sl[p] = (fe[p] & 1) ? lam : -lam;
             sdl[p] = (fe[p] & 1) ? lam - xo : xo - lam;
@@ -715,8 +727,11 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
           process(op.aent, op.arec, kc, true);
         }
       }
-      mm &= ~op.snap_mask[b];
     }
+    const int32_t head = (end - beg < 64) ? end - beg : 64;
+    unsigned long long mm = op.body_mask[b];
+    if (head < 64) mm &= (1ull << head) - 1ull;
+    if (op.aptr != nullptr) mm &= ~op.snap_mask[b];
     if (FLAT && !has_body) mm = 0ull;
     int32_t kk[U];
 #pragma unroll
