@@ -1769,9 +1769,26 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   const unsigned grid = (grid_exact(op->view.body_count * (size_t)G) + 7u) & ~7u;  // multiple of 8: XCD tiles
   op->last_stream = s;
   const SolverState* st = op->state.as<SolverState>();
+  // Flat sweep over the compact lists: a workgroup's bodies should fit ONE chunk of FLATP x 256 entries (a second,
+  // mostly empty chunk is a second round of dependent loads behind two more barriers), and no more LDS than that
+  // needs (24 KB per workgroup at FLATP = 2, 36 KB at 3: five against four workgroups per CU).  The length of the
+  // lists is known from the last snapshot but one (it reaches the host with the polls); before that the whole
+  // incidence list stands in.  10^6 rods (profiles/r03_ab_nt.txt): raw packing 640 entries per workgroup, 0.0900 ms
+  // at FLATP = 2, 0.0865 at 3; relaxed packing (a fifth of that) 22.25 against 22.9 ms per step.
+  int flatp = MHIP_KBODY_FLAT;
+  if (MHIP_KBODY_FLAT == 2 && packed && mode == X_SOLVE && op->view.aptr != nullptr) {
+    const int32_t known = op->host_state ? *reinterpret_cast<const int32_t*>(op->host_state + 1) : 0;
+    const double entries = known > 0 ? static_cast<double>(known) : 2.0 * static_cast<double>(op->view.C);
+    const double per_group = entries / static_cast<double>(op->view.body_count) * (kBlock / (double)G);
+    if (per_group > 0.9 * 2 * kBlock) flatp = 3;
+  }
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
-    if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
+    if (flatp == 3 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
+      k_body<M, R, GG, UU, true, true, 3><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+    else if (flatp == 3 && packed && M == X_SOLVE && op->view.aptr != nullptr)                     \
+      k_body<M, R, GG, UU, true, false, 3><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+    else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
       k_body<M, R, GG, UU, true, true, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
     else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr)             \
       k_body<M, R, GG, UU, true, false, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
@@ -1876,6 +1893,11 @@ int op_snapshot_active(mhip_contact_op* op, hipStream_t s) {
   if (hw == 6) FILL(6); else if (hw == 4) FILL(4); else FILL(3);
 #undef FILL
   MHIP_LAUNCH_CHECK();
+  // the length of the compact lists travels to the host with the next poll (it picks the flat sweep's chunk; see
+  // op_launch_body): pinned spare words behind host_state, no synchronisation here
+  if (op->host_state != nullptr)
+    MHIP_HIP(hipMemcpyAsync(reinterpret_cast<int32_t*>(op->host_state + 1), op->aptr.as<int32_t>() + v.body_first + cnt,
+                            sizeof(int32_t), hipMemcpyDeviceToHost, s));
   v.aptr = op->aptr.as<int32_t>();
   v.aent = op->aent.as<int32_t>();
   v.arec = op->arec.as<double>();
@@ -2623,6 +2645,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
     hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&op->host_state), sizeof(SolverState) + 64);
     if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(he)));
   }
+  *reinterpret_cast<int32_t*>(op->host_state + 1) = 0;  // length of the compact active lists: not known yet
   int32_t* deg = op->cursor.as<int32_t>();
   int* bad = reinterpret_cast<int*>(op->state.as<char>() + sizeof(SolverState));
   hipError_t he = hipMemsetAsync(deg, 0, (N + 1) * sizeof(int32_t), s);
