@@ -33,6 +33,18 @@ constexpr double kLowest = -1.7976931348623157e308;  // Kokkos::Max<double> iden
 // ------------------------------------------------------------------------------------------------------------------
 // Streaming kernels move 16 bytes per lane per access when the vectors are 16-byte aligned (VEC: elements in pairs,
 // the odd tail element by one thread); element-wise arithmetic is unchanged, so results do not depend on VEC.
+#ifndef MHIP_STREAM_UNROLL
+#define MHIP_STREAM_UNROLL 4
+#endif
+// one tile per workgroup up to this many workgroups (measured, 2^27 doubles: capped at 2048 / 8192 workgroups with a
+// grid-stride loop 5.3-5.4 / 5.4-5.8 TB/s, uncapped 5.6-6.0; profiles/r03_stream_ceiling.txt)
+#ifndef MHIP_STREAM_GRID
+#define MHIP_STREAM_GRID 1048576
+#endif
+constexpr int kStreamUnroll = MHIP_STREAM_UNROLL;
+// a workgroup streams CONTIGUOUS tiles of kStreamUnroll x 256 16-byte elements (lane -> element tid + u * 256 of the
+// tile): first element of this thread in its workgroup's first tile
+__device__ inline size_t stream_first() { return blockIdx.x * (size_t)(kBlock * kStreamUnroll) + threadIdx.x; }
 template <int MODE>  // 0: a*x+b*y   1: b*y   2: a*x   3: 0
 __device__ inline double axpby_value(double alpha, double x, double beta, double y) {
   if (MODE == 0) return alpha * x + beta * y;
@@ -47,10 +59,22 @@ __global__ void __launch_bounds__(kBlock) k_axpby(size_t n, double alpha, const 
   if (VEC) {
     const double2* x2 = reinterpret_cast<const double2*>(x);
     double2* y2 = reinterpret_cast<double2*>(y);
-    for (size_t i = tid; i < n / 2; i += nth) {
-      const double2 a = (MODE == 0 || MODE == 2) ? x2[i] : make_double2(0.0, 0.0);
-      const double2 b = (MODE == 0 || MODE == 1) ? y2[i] : make_double2(0.0, 0.0);
-      y2[i] = make_double2(axpby_value<MODE>(alpha, a.x, beta, b.x), axpby_value<MODE>(alpha, a.y, beta, b.y));
+    // kStreamUnroll 16-byte accesses per lane and array in flight (all loads of a round issued before its first store)
+    const size_t n2 = n / 2;
+    for (size_t i0 = stream_first(); i0 < n2; i0 += nth * kStreamUnroll) {
+      double2 a[kStreamUnroll], b[kStreamUnroll];
+#pragma unroll
+      for (int u = 0; u < kStreamUnroll; ++u) {
+        const size_t i = i0 + u * kBlock;
+        a[u] = ((MODE == 0 || MODE == 2) && i < n2) ? x2[i] : make_double2(0.0, 0.0);
+        b[u] = ((MODE == 0 || MODE == 1) && i < n2) ? y2[i] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < kStreamUnroll; ++u) {
+        const size_t i = i0 + u * kBlock;
+        if (i < n2)
+          y2[i] = make_double2(axpby_value<MODE>(alpha, a[u].x, beta, b[u].x), axpby_value<MODE>(alpha, a[u].y, beta, b[u].y));
+      }
     }
     if ((n & 1) && tid == 0) y[n - 1] = axpby_value<MODE>(alpha, MODE == 1 || MODE == 3 ? 0.0 : x[n - 1], beta, y[n - 1]);
   } else {
@@ -67,11 +91,22 @@ __global__ void __launch_bounds__(kBlock) k_wrapped_axpbyz(size_t n, double alph
     const double2* x2 = reinterpret_cast<const double2*>(x);
     const double2* y2 = reinterpret_cast<const double2*>(y);
     double2* z2 = reinterpret_cast<double2*>(z);
-    for (size_t i = tid; i < n / 2; i += nth) {
-      const double2 a = (MODE == 0 || MODE == 2) ? x2[i] : make_double2(0.0, 0.0);
-      const double2 b = (MODE == 0 || MODE == 1) ? y2[i] : make_double2(0.0, 0.0);
-      z2[i] = make_double2(sp.project(axpby_value<MODE>(alpha, a.x, beta, b.x)),
-                           sp.project(axpby_value<MODE>(alpha, a.y, beta, b.y)));
+    const size_t n2 = n / 2;
+    for (size_t i0 = stream_first(); i0 < n2; i0 += nth * kStreamUnroll) {
+      double2 a[kStreamUnroll], b[kStreamUnroll];
+#pragma unroll
+      for (int u = 0; u < kStreamUnroll; ++u) {
+        const size_t i = i0 + u * kBlock;
+        a[u] = ((MODE == 0 || MODE == 2) && i < n2) ? x2[i] : make_double2(0.0, 0.0);
+        b[u] = ((MODE == 0 || MODE == 1) && i < n2) ? y2[i] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < kStreamUnroll; ++u) {
+        const size_t i = i0 + u * kBlock;
+        if (i < n2)
+          z2[i] = make_double2(sp.project(axpby_value<MODE>(alpha, a[u].x, beta, b[u].x)),
+                               sp.project(axpby_value<MODE>(alpha, a[u].y, beta, b[u].y)));
+      }
     }
     if ((n & 1) && tid == 0)
       z[n - 1] = sp.project(axpby_value<MODE>(alpha, (MODE == 0 || MODE == 2) ? x[n - 1] : 0.0, beta,
@@ -86,7 +121,16 @@ template <bool VEC>
 __global__ void __launch_bounds__(kBlock) k_copy(size_t n, double* __restrict__ dst, const double* __restrict__ src) {
   const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
   if (VEC) {
-    for (size_t i = tid; i < n / 2; i += nth) reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(src)[i];
+    const size_t n2 = n / 2;
+    for (size_t i0 = stream_first(); i0 < n2; i0 += nth * kStreamUnroll) {
+      double2 a[kStreamUnroll];
+#pragma unroll
+      for (int u = 0; u < kStreamUnroll; ++u)
+        a[u] = (i0 + u * kBlock < n2) ? reinterpret_cast<const double2*>(src)[i0 + u * kBlock] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < kStreamUnroll; ++u)
+        if (i0 + u * kBlock < n2) reinterpret_cast<double2*>(dst)[i0 + u * kBlock] = a[u];
+    }
     if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
   } else {
     for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
@@ -101,8 +145,8 @@ inline bool aligned16(const void* a, const void* b = nullptr, const void* c = nu
 }
 // streaming grids: enough workgroups to keep every CU's queue full, capped so the tail wave is short
 inline unsigned stream_grid(size_t work_items) {
-  const size_t g = (work_items + kBlock - 1) / kBlock;
-  return static_cast<unsigned>(g == 0 ? 1 : (g > 8192 ? 8192 : g));
+  const size_t g = (work_items + (size_t)kBlock * kStreamUnroll - 1) / ((size_t)kBlock * kStreamUnroll);
+  return static_cast<unsigned>(g == 0 ? 1 : (g > MHIP_STREAM_GRID ? MHIP_STREAM_GRID : g));
 }
 
 // residual term of one unknown (policies convex.hpp:434-496)
