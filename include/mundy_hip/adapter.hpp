@@ -340,6 +340,79 @@ inline SegmentSegmentResult distance(SharedNormalSigned, const std::vector<LineS
   return r;
 }
 
+// ---- single-object overloads (seam S4) ---------------------------------------------------------------------------------
+// The reference's free functions take ONE pair of owning primitives (they are called per thread inside user kernels:
+// distance/SphereSphere.hpp:44-76, LineSegmentLineSegment.hpp:169-197, EllipsoidEllipsoid.hpp:106-113,
+// PointEllipsoid.hpp:94-135, compute_aabb.hpp:72-127).  Host code that holds single objects gets the same signatures
+// here; each forwards to a one-element batch of the device routine (same arithmetic, one launch and one round trip
+// per call -- for a handful of objects; anything in a loop belongs in the batch overloads above).
+inline AABB<double> compute_aabb(const Sphere<double>& sphere) {
+  return compute_aabb(std::vector<Sphere<double>>{sphere})[0];
+}
+inline AABB<double> compute_aabb(const Spherocylinder<double>& spherocylinder) {
+  return compute_aabb(std::vector<Spherocylinder<double>>{spherocylinder})[0];
+}
+inline AABB<double> compute_aabb(const Ellipsoid<double>& ellipsoid) {
+  return compute_aabb(std::vector<Ellipsoid<double>>{ellipsoid})[0];
+}
+inline double distance(SharedNormalSigned t, const Sphere<double>& sphere1, const Sphere<double>& sphere2) {
+  return distance(t, std::vector<Sphere<double>>{sphere1}, std::vector<Sphere<double>>{sphere2})[0];
+}
+inline double distance(const Sphere<double>& sphere1, const Sphere<double>& sphere2) {  // SphereSphere.hpp:44-48
+  return distance(SharedNormalSigned{}, sphere1, sphere2);
+}
+inline double distance(SharedNormalSigned t, const Sphere<double>& sphere1, const Sphere<double>& sphere2,
+                       Point<double>& sep) {
+  std::vector<Point<double>> s;
+  const double d = distance(t, std::vector<Sphere<double>>{sphere1}, std::vector<Sphere<double>>{sphere2}, &s)[0];
+  sep = s[0];
+  return d;
+}
+inline double distance(const Sphere<double>& sphere1, const Sphere<double>& sphere2, Point<double>& sep) {
+  return distance(SharedNormalSigned{}, sphere1, sphere2, sep);  // SphereSphere.hpp:66-76
+}
+inline double distance(SharedNormalSigned t, const LineSegment<double>& line_segment1,
+                       const LineSegment<double>& line_segment2, Point<double>& closest_point1,
+                       Point<double>& closest_point2, double& arch_length1, double& arch_length2, Point<double>& sep) {
+  const SegmentSegmentResult r = distance(t, std::vector<LineSegment<double>>{line_segment1},
+                                          std::vector<LineSegment<double>>{line_segment2});
+  closest_point1 = r.closest_point1[0];
+  closest_point2 = r.closest_point2[0];
+  arch_length1 = r.arch_length1[0];   // the reference's raw parameters: unclamped in the colinear branch
+  arch_length2 = r.arch_length2[0];
+  sep = r.sep[0];
+  return r.distance[0];
+}
+inline double distance(const LineSegment<double>& line_segment1, const LineSegment<double>& line_segment2,
+                       Point<double>& closest_point1, Point<double>& closest_point2, double& arch_length1,
+                       double& arch_length2, Point<double>& sep) {  // LineSegmentLineSegment.hpp:169-178
+  return distance(SharedNormalSigned{}, line_segment1, line_segment2, closest_point1, closest_point2, arch_length1,
+                  arch_length2, sep);
+}
+inline double distance(SharedNormalSigned t, const Ellipsoid<double>& ellipsoid1, const Ellipsoid<double>& ellipsoid2,
+                       Point<double>& closest_point1, Point<double>& closest_point2, Point<double>& shared_normal1,
+                       Point<double>& shared_normal2) {  // EllipsoidEllipsoid.hpp:106-113
+  const EllipsoidEllipsoidResult r = distance(t, std::vector<Ellipsoid<double>>{ellipsoid1},
+                                              std::vector<Ellipsoid<double>>{ellipsoid2});
+  closest_point1 = r.closest_point1[0];
+  closest_point2 = r.closest_point2[0];
+  shared_normal1 = r.shared_normal1[0];
+  shared_normal2 = r.shared_normal2[0];
+  return r.distance[0];
+}
+inline double distance(SharedNormalSigned t, const Ellipsoid<double>& ellipsoid1, const Ellipsoid<double>& ellipsoid2) {
+  Point<double> a, b, c, d;
+  return distance(t, ellipsoid1, ellipsoid2, a, b, c, d);
+}
+inline double distance(SharedNormalSigned t, const Point<double>& point, const Ellipsoid<double>& ellipsoid,
+                       Point<double>& closest_point, Point<double>& ellipsoid_normal) {  // PointEllipsoid.hpp:94-135
+  std::vector<Point<double>> cp, nrm;
+  const double d = distance(t, std::vector<Point<double>>{point}, std::vector<Ellipsoid<double>>{ellipsoid}, &cp, &nrm)[0];
+  closest_point = cp[0];
+  ellipsoid_normal = nrm[0];
+  return d;
+}
+
 // ---- periodic metrics (mundy_geom/periodicity.hpp) -------------------------------------------------------------------
 namespace detail {
 inline std::vector<double> flatten(const std::vector<Point<double>>& p) {

@@ -222,6 +222,44 @@ static void test_segment_kats() {  // UnitTestSegmentSegment.cpp:417-472
   EXPECT_NEAR(d[0], 1.5, 1e-15);
   EXPECT_NEAR(sep[0][0], 1.5, 1e-15);
 }
+static void test_single_object_overloads() {
+  // seam S4: the reference's free functions on ONE pair of owning primitives (SphereSphere.hpp:44-76,
+  // LineSegmentLineSegment.hpp:169-197, EllipsoidEllipsoid.hpp:106-113, PointEllipsoid.hpp:94-135, compute_aabb.hpp:72-127)
+  using namespace geom;
+  const Quaternion<double> id(1, 0, 0, 0), x90(1.0 / std::sqrt(2.0), 1.0 / std::sqrt(2.0), 0.0, 0.0);
+  const Point<double> c(1, -2, 3);
+  expect_aabb(compute_aabb(Sphere<double>(c, 4.0)), {-3, -6, -1, 5, 2, 7});                     // UnitTestComputeAABB.cpp:167-232
+  expect_aabb(compute_aabb(Spherocylinder<double>(c, x90, 2, 3)), {-1, -5.5, 1, 3, 1.5, 5});
+  expect_aabb(compute_aabb(Ellipsoid<double>(c, x90, Point<double>(4, 5, 6))), {-3, -8, -2, 5, 4, 8});
+  const Sphere<double> s1(Point<double>(0, 0, 0), 1.0), s2(Point<double>(3, 0, 0), 0.5);
+  Point<double> sep;
+  EXPECT_NEAR(distance(s1, s2), 1.5, 1e-15);
+  EXPECT_NEAR(distance(SharedNormalSigned{}, s1, s2), 1.5, 1e-15);
+  EXPECT_NEAR(distance(s1, s2, sep), 1.5, 1e-15);
+  EXPECT_NEAR(sep[0], 1.5, 1e-15);
+  // UnitTestSegmentSegment.cpp:417-472, first known-answer case
+  const LineSegment<double> a(Point<double>(0.2257294191072674, 0.30159862841764695, 0.12784820133135649),
+                              Point<double>(0.22572948671663273, 0.30159858045792487, 0.1278481814714105));
+  const LineSegment<double> b(Point<double>(0.5220039935659887, 0.88764831847472003, -0.2219484914838093),
+                              Point<double>(0.50288066060587278, 0.66779290982621586, -0.5723507723323677));
+  Point<double> cp1, cp2;
+  double t1 = -1, t2 = -1;
+  EXPECT_NEAR(distance(a, b, cp1, cp2, t1, t2, sep), 0.74347757392471259, 1e-6);
+  EXPECT_NEAR(t1, 1.0, 1e-6);
+  EXPECT_NEAR(t2, 0.069641589451982497, 1e-6);
+  EXPECT_NEAR(cp2[1], 0.87233723836682309, 1e-6);
+  // the colinear branch hands back the UNCLAMPED parameter (PointLineSegment.hpp:156-166): rods end to end
+  const LineSegment<double> l(Point<double>(0, 0, -1), Point<double>(0, 0, 1)), m(Point<double>(0.8, 0, 1.5), Point<double>(0.8, 0, 3.5));
+  distance(SharedNormalSigned{}, l, m, cp1, cp2, t1, t2, sep);
+  EXPECT_TRUE(t1 == 1.0 && t2 == -0.25 && cp2[2] == 1.5);
+  // two spheres as ellipsoids (UnitTestEllipsoidEllipsoid.cpp:65-145), tolerance 1e-4
+  const Ellipsoid<double> e1(Point<double>(0, 0, 0), id, Point<double>(1, 1, 1)), e2(Point<double>(4, 0, 0), x90, Point<double>(2, 2, 2));
+  Point<double> n1, n2;
+  EXPECT_NEAR(distance(SharedNormalSigned{}, e1, e2, cp1, cp2, n1, n2), 1.0, 1e-4);
+  EXPECT_NEAR(distance(SharedNormalSigned{}, e1, e2), 1.0, 1e-4);
+  EXPECT_NEAR(n1[0], 1.0, 1e-4);
+  EXPECT_NEAR(distance(SharedNormalSigned{}, Point<double>(0, 5, 0), e2, cp1, n1), std::sqrt(41.0) - 2.0, 1e-4);
+}
 static void test_two_coincident_spheres() {  // UnitTestGenNeighborLinks.cpp:73-152
   DeviceVector c(std::vector<double>(6, 0.0)), r(std::vector<double>(2, 1.0)), aabb(12);
   check(mhip_compute_aabb_spheres(2, c.data(), r.data(), aabb.data(), nullptr));
@@ -386,6 +424,7 @@ int main() {
   test_error_behaviour();
   test_compute_aabb_hard_coded();
   test_segment_kats();
+  test_single_object_overloads();
   test_two_coincident_spheres();
   test_gen_neighbor_links_reference_usage();
   test_periodic_metrics();
