@@ -154,6 +154,10 @@ def parse():
                         "--mixed-phi volume fraction; shape classes binned, L-BFGS ellipsoid distances, vector-arm "
                         "operator.  N = 1 only; never the default line.")
     p.add_argument("--mixed-phi", type=float, default=0.30)
+    p.add_argument("--ellipsoid-fma", action="store_true",
+                   help="--mixed: LABELLED build option -- the ellipsoid minimisation classes from the build with "
+                        "floating-point contraction on (results at the reference's 1e-4 tolerance instead of bit parity "
+                        "with the oracle).  Never the default; the line says which arithmetic ran.")
     p.add_argument("--friction", type=float, default=None,
                    help="BUILD EXTENSION, parity unpinned: Coulomb coefficient of the cone-complementarity solver "
                         "(the reference has no frictional solver; default = its frictionless LCP).  N = 1 only.")
@@ -391,6 +395,7 @@ def main_mixed(args, ops, pipeline, synth, dev):
     roofline object is that of the BBPGD sweeps with explicit lever arms (KIN_RIGID)."""
     n = args.bodies
     b = synth.mixed_bodies(n, volume_fraction=args.mixed_phi, seed=1234)
+    ops.contact_mixed_set_contraction(args.ellipsoid_fma)
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
     st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=args.buffer, cfg=cfg,
                                  kinds=dev(b["kind"]), shape=dev(b["shape"]))
@@ -430,8 +435,34 @@ def main_mixed(args, ops, pipeline, synth, dev):
                 "frac": round(flops / narrow_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
                 "objective_evaluations": evals, "flops_per_evaluation": FLOPS_PER_EVALUATION,
                 "stage_ms": round(stage_ms["narrowphase"], 3),
-                "note": "peak counts an FMA as two flops; this build never fuses a*b+c (bit parity with the scalar "
-                        "reference order), so 0.5 x peak is what it could reach"}
+                "arithmetic": "contracted (fused multiply-adds): LABELLED build option, results at the reference's "
+                              "1e-4" if args.ellipsoid_fma else "no contraction: bit-identical to the CPU oracle",
+                "note": "peak counts an FMA as two flops; the default build never fuses a*b+c (bit parity with the "
+                        "scalar reference order), so 0.5 x peak is what it could reach"}
+    # both arithmetics side by side on this step's neighbour list: the narrow phase alone, HIP-event timed, and how far
+    # the contracted build's separations are from the default's (the reference's bar: 1e-4, UnitTestEllipsoidEllipsoid.cpp:53)
+    both = {}
+    seps = {}
+    for name, on in (("default", False), ("contracted", True)):
+        ops.contact_mixed_set_contraction(on)
+        ops.contact_mixed(st.links.pairs, st.kinds, st.center, st.quat, st.shape)   # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o = ops.contact_mixed(st.links.pairs, st.kinds, st.center, st.quat, st.shape)
+        e1.record()
+        torch.cuda.synchronize()
+        ev = ops.contact_mixed_last_evaluations()
+        ms = e0.elapsed_time(e1)
+        fl = FLOPS_PER_EVALUATION * float(sum(ev.values()))
+        both[name] = {"narrowphase_ms": round(ms, 3), "objective_evaluations": sum(ev.values()),
+                      "achieved_tflops": round(fl / (1e-3 * ms) / 1e12, 3),
+                      "frac_of_fp64_vector_peak": round(fl / (1e-3 * ms) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4)}
+        seps[name] = o["sep"]
+    ops.contact_mixed_set_contraction(args.ellipsoid_fma)
+    dsep = (seps["default"] - seps["contracted"]).abs()
+    both["separations_within_1e-4"] = round(float((dsep <= 1e-4).double().mean().item()), 6)
+    both["separations_bit_identical"] = round(float((dsep == 0).double().mean().item()), 6)
+    ell_roof["arithmetics"] = both
     roof, extra = None, {}
     if prof["iters"] > 0:
         # explicit lever arms: k_constraint streams pair 8 + normal 24 + arms 48 + packed (x, g) 16 + q 8, writes 16;

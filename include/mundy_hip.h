@@ -149,6 +149,12 @@ int mhip_compute_aabb_mixed_conservative(size_t n, const int32_t* kind, const do
 int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, const double* center, const double* quat,
                        const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                        double* rb, size_t* class_counts /*[host]*/, mhip_stream_t stream);
+/* BUILD OPTION, labelled wherever it is exposed: on = 1 makes the following mhip_contact_mixed* calls (any thread) run
+ * the S-E, R-E and E-E minimisation classes from a build with floating-point contraction ON (fused multiply-adds):
+ * their results then agree with the default build -- which is bit-identical to the CPU oracle -- only to the
+ * reference's own tolerance for ellipsoid distances, 1e-4 (UnitTestEllipsoidEllipsoid.cpp:53), on >= 99.5 % of pairs
+ * (tests/test_gpu_mixed.py).  The closed-form classes (S-S, S-R, R-R) are not affected.  Default 0. */
+int mhip_contact_mixed_set_contraction(int on);
 /* objective evaluations the L-BFGS classes (S-E, R-E, E-E) needed in the last mhip_contact_mixed* call of this host
  * thread, and in the last mhip_distance_ellipsoid_* / mhip_contact_ellipsoids call: these kernels are fp64-vector bound
  * (about 2.3 * 10^3 fp64 instructions per evaluation), so evaluations x that / time is their roofline figure */

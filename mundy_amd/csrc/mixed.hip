@@ -9,7 +9,23 @@
 // extensions, parity unpinned (see the oracle): the point - ellipsoid minimisation with the sphere's centre, resp. the
 // closest point of the rod's centreline, as the point, minus the radius.  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
 // (r,-,-) / (r,L,-) / (r1,r2,r3).
+#include <atomic>
+
 #include "ellipsoid_lockstep.hpp"
+
+// This file is compiled twice.  mixed.hip itself: everything, under the library's -ffp-contract=off (every a*b+c two
+// roundings: results bit-identical to the scalar reference order).  mixed_fma.hip (which only includes this file with
+// MHIP_MIXED_FMA_TU defined): the three MINIMISATION classes alone, under -ffp-contract=fast -- a labelled build of the
+// compute-bound kernels for callers that take the reference's own 1e-4 tolerance of the ellipsoid distances
+// (UnitTestEllipsoidEllipsoid.cpp:53) instead of bit parity with the oracle; selected at run time by
+// mhip_contact_mixed_set_contraction, never the default.
+#ifdef MHIP_MIXED_FMA_TU
+#define MHIP_LOCKSTEP_KERNEL k_contact_class_lockstep_fma
+#define MHIP_LOCKSTEP_LAUNCH launch_contact_classes_lockstep_fma
+#else
+#define MHIP_LOCKSTEP_KERNEL k_contact_class_lockstep
+#define MHIP_LOCKSTEP_LAUNCH launch_contact_classes_lockstep
+#endif
 
 namespace mhip {
 
@@ -24,6 +40,7 @@ __device__ inline BodyD load_body(const int32_t* kind, const double* c, const do
   return {kind[i], load3(c, i), load4q(q, i), load3(shape, i)};
 }
 
+#ifndef MHIP_MIXED_FMA_TU
 template <bool CONSERVATIVE>
 __global__ void __launch_bounds__(kBlock)
     k_aabb_mixed(size_t n, const int32_t* __restrict__ kind, const double* __restrict__ center,
@@ -77,6 +94,8 @@ __global__ void __launch_bounds__(kBlock)
   if (blockIdx.x == 0 && threadIdx.x == 0) class_start[which + 1] = base + pos[nc];
 }
 
+#endif  // !MHIP_MIXED_FMA_TU
+
 struct MixedOut {
   double *sep, *normal, *cp1, *cp2, *ra, *rb;
   // periodic box: body j is taken at the lattice image whose centre is nearest to body i's centre
@@ -100,6 +119,7 @@ __device__ inline void store_contact(const MixedOut& o, size_t k, bool swapped, 
   if (o.rb) store3(o.rb, k, c2 - cj);
 }
 
+#ifndef MHIP_MIXED_FMA_TU
 // the closed-form classes: sphere - sphere, sphere - rod, rod - rod
 template <int CLS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -139,13 +159,15 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+#endif  // !MHIP_MIXED_FMA_TU
+
 // The three minimisation classes (S-E, R-E, E-E) in lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one
 // lane per pair of the class, objective evaluations converged, lanes refilled from a per-class counter.  Same
 // arithmetic per lane as the nested-loop form the tests build as their checker (tests/cpp/ellipsoid_nested_ref.hip).
 // Two waves per SIMD: 20 KB of LDS history per wave (ellipsoid_lockstep.hpp).
 template <int CLS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
-    k_contact_class_lockstep(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
+    MHIP_LOCKSTEP_KERNEL(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
                              const int2* __restrict__ pairs, const int32_t* __restrict__ kind,
                              const double* __restrict__ center, const double* __restrict__ quat,
                              const double* __restrict__ shape, MixedOut out, unsigned long long* __restrict__ counter) {
@@ -238,6 +260,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
   }
 }
 
+// the three launches (S-E, R-E, E-E); cnt[k] = next pair of class k, cnt[4 + k] = its objective evaluations
+int MHIP_LOCKSTEP_LAUNCH(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
+                         const int32_t* kind, const double* center, const double* quat, const double* shape,
+                         const MixedOut& out, unsigned long long* cnt, hipStream_t s) {
+  MHIP_LOCKSTEP_KERNEL<2><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 0);
+  MHIP_LOCKSTEP_KERNEL<4><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 1);
+  MHIP_LOCKSTEP_KERNEL<5><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 2);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+#ifndef MHIP_MIXED_FMA_TU
+// (mixed_fma.hip)
+int launch_contact_classes_lockstep_fma(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
+                                        const int32_t* kind, const double* center, const double* quat,
+                                        const double* shape, const MixedOut& out, unsigned long long* cnt,
+                                        hipStream_t s);
+std::atomic<int> g_mixed_contraction{0};
+
 struct MixedScratch {
   DeviceBuffer cls, flags, pos, order, start, scanws, counters;
   int32_t* host = nullptr;
@@ -247,8 +288,11 @@ MixedScratch& mixed_scratch() {
   return s;
 }
 
+#endif  // !MHIP_MIXED_FMA_TU
+
 }  // namespace mhip
 
+#ifndef MHIP_MIXED_FMA_TU
 using namespace mhip;
 
 extern "C" {
@@ -341,9 +385,11 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
     unsigned long long* cnt = ms.counters.as<unsigned long long>();  // [k]: next pair of class k; [4 + k]: its evaluations
     MHIP_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), s));
     const unsigned gl = static_cast<unsigned>(c / 64 + 1 > 2048 ? 2048 : c / 64 + 1);  // persistent waves
-    k_contact_class_lockstep<2><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 0);
-    k_contact_class_lockstep<4><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 1);
-    k_contact_class_lockstep<5><<<gl, 64, 0, s>>>(start, order, p2, kind, center, quat, shape, out, cnt + 2);
+    if (g_mixed_contraction.load() != 0) {
+      if (int e = launch_contact_classes_lockstep_fma(gl, start, order, p2, kind, center, quat, shape, out, cnt, s)) return e;
+    } else {
+      if (int e = launch_contact_classes_lockstep(gl, start, order, p2, kind, center, quat, shape, out, cnt, s)) return e;
+    }
   }
 #undef CLASS
   MHIP_LAUNCH_CHECK();
@@ -352,6 +398,12 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
     MHIP_HIP(hipStreamSynchronize(s));
     for (int k = 0; k < 6; ++k) class_counts[k] = static_cast<size_t>(ms.host[k + 1] - ms.host[k]);
   }
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_mixed_set_contraction(int on) {
+  MHIP_REQUIRE(on == 0 || on == 1, MHIP_ERR_INVALID_ARGUMENT, "contraction must be 0 or 1, got %d", on);
+  g_mixed_contraction.store(on);
   return MHIP_SUCCESS;
 }
 
@@ -370,3 +422,4 @@ int mhip_contact_mixed_last_evaluations(unsigned long long evaluations[3], mhip_
 }
 
 }  // extern "C"
+#endif  // !MHIP_MIXED_FMA_TU

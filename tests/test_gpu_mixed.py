@@ -165,3 +165,108 @@ def test_conservative_ellipsoid_box_finds_every_overlapping_pair(ops, oracle):
     missed = overlapping - listed(False)
     print("reference ellipsoid box misses %d of %d overlapping pairs" % (len(missed), len(overlapping)))
     assert len(missed) > 0                                   # the reference box does miss some (the quirk is real)
+
+
+def test_configs4_at_full_size(ops, oracle):
+    # BASELINE configs[4] at the size it names: 10^6 mixed bodies, one full step (reorder, AABBs, neighbour list, all six
+    # shape classes, BBPGD on the vector-arm operator).  The oracle cannot redo this in seconds, so the step is checked
+    # through size-independent properties, and every ellipsoid class (the L-BFGS kernels) is re-evaluated against the
+    # oracle, in shared-sincos mode (bit for bit), on a sample of 10^4 of its pairs.
+    import torch
+    from gpu_util import assert_bits_equal, dev, host
+    from mundy_amd import pipeline, synth
+    n, tol = 1_000_000, 1e-5
+    b = synth.mixed_bodies(n, volume_fraction=0.30, seed=1234)     # bench.py --mixed
+    st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=0.1,
+                                 cfg=ops.PGDConfig(max_iters=10000, tol=tol), kinds=dev(b["kind"]), shape=dev(b["shape"]))
+    st.reorder_bodies(cell_size=3.0, lo=[0.0, 0.0, 0.0])
+    s = st.step(integrate=False, force_rebuild=True)
+    assert s.converged and s.num_contacts > 3_000_000, (s.converged, s.num_contacts)
+    pairs = st.links.pairs
+    C = pairs.shape[0]
+    # neighbour list: unique i < j rows, sorted by (i, j)
+    key = pairs[:, 0].long() * n + pairs[:, 1].long()
+    assert bool((pairs[:, 0] < pairs[:, 1]).all()) and bool((key[1:] > key[:-1]).all())
+    # LCP conditions of the solution (UnitTestConvex.cpp:559: 10 tol)
+    x, g = st.lam, st.grad
+    assert float(x.min()) >= 0.0 and float(g.min()) >= -10 * tol
+    assert float(torch.minimum(x, g).abs().max()) <= 10 * tol
+    ga = st.op.apply(x) + st.contacts["sep"]
+    assert float((ga - g).abs().max()) <= 1e-9 * max(1.0, float(g.abs().max()))
+    # A = dt D^T M D: linear and symmetric
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    u = torch.rand(C, dtype=torch.float64, device="cuda", generator=gen)
+    v = torch.rand(C, dtype=torch.float64, device="cuda", generator=gen)
+    Au, Av = st.op.apply(u).clone(), st.op.apply(v).clone()
+    lin = st.op.apply(2.0 * u - 0.5 * v)
+    scale = float(Au.abs().max())
+    assert float((lin - (2.0 * Au - 0.5 * Av)).abs().max()) <= 1e-11 * scale
+    uAv, vAu = float(torch.dot(u, Av)), float(torch.dot(v, Au))
+    assert abs(uAv - vAu) <= 1e-10 * abs(uAv) and float(torch.dot(u, Au)) >= 0.0
+    # the ellipsoid classes against the oracle on 10^4 pairs each
+    kind_d = st.kinds
+    ka, kb = kind_d[pairs[:, 0].long()], kind_d[pairs[:, 1].long()]
+    cls = torch.minimum(ka, kb) * 3 + torch.maximum(ka, kb)
+    kind_h, c_h, q_h, shape_h = host(st.kinds), host(st.center), host(st.quat), host(st.shape)
+    rng = np.random.default_rng(5)
+    with oracle.shared_trig():
+        for name, code in (("SE", 2), ("RE", 5), ("EE", 8)):
+            idx = torch.nonzero(cls == code).flatten()
+            assert idx.numel() > 100_000, (name, idx.numel())
+            pick = idx[torch.from_numpy(np.sort(rng.choice(idx.numel(), 10_000, replace=False))).cuda()]
+            sub = np.ascontiguousarray(host(pairs[pick]))
+            exp = oracle.contact_mixed(sub, kind_h, c_h, q_h, shape_h)
+            for k in ("sep", "normal", "ra", "rb"):
+                assert_bits_equal(host(st.contacts[k][pick]), exp[k], "%s %s at 10^6 bodies" % (name, k))
+    # and the exact classes on a sample as well
+    for name, code in (("SS", 0), ("SR", 1), ("RR", 4)):
+        idx = torch.nonzero(cls == code).flatten()
+        pick = idx[:: max(1, idx.numel() // 10_000)]
+        exp = oracle.contact_mixed(np.ascontiguousarray(host(pairs[pick])), kind_h, c_h, q_h, shape_h)
+        for k in ("sep", "normal", "ra", "rb"):
+            assert_bits_equal(host(st.contacts[k][pick]), exp[k], "%s %s at 10^6 bodies" % (name, k))
+    st.op.close()
+    st.links.close()
+
+
+def test_contracted_build_of_the_minimisation_classes_meets_the_reference_tolerance(ops, oracle):
+    # BUILD OPTION (labelled, never the default): S-E / R-E / E-E from the translation unit compiled with fused
+    # multiply-adds (mixed_fma.hip).  The closed-form classes must not change at all; the minimisation classes must stay
+    # within the reference's own tolerance for ellipsoid distances, 1e-4 (UnitTestEllipsoidEllipsoid.cpp:53), on at least
+    # 99.5 % of the pairs against the default build AND against the oracle; and the default must be what a fresh
+    # process gets.
+    from gpu_util import assert_bits_equal, dev, host
+    from mundy_amd import synth
+    b = synth.mixed_bodies(30_000, seed=11)
+    kind, c, q, shape = b["kind"], b["center"], b["quat"], b["shape"]
+    dk, dc, dq, ds = dev(kind), dev(c), dev(q), dev(shape)
+    aabb, brad = ops.compute_aabb_mixed(dk, dc, dq, ds)
+    links = ops.GenNeighborLinks().set_search_kind(ops.SEARCH_AABB).set_search_buffer(0.05).concretize()
+    links.generate(aabb, dc, brad)
+    pairs = host(links.pairs)
+    with oracle.shared_trig():
+        exp = oracle.contact_mixed(pairs, kind, c, q, shape)
+    exact_build = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
+    for k in ("sep", "normal", "ra", "rb"):
+        assert_bits_equal(host(exact_build[k]), exp[k], "default build " + k)
+    try:
+        ops.contact_mixed_set_contraction(True)
+        fma = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
+    finally:
+        ops.contact_mixed_set_contraction(False)
+    ka, kb = kind[pairs[:, 0]], kind[pairs[:, 1]]
+    cls = np.minimum(ka, kb) * 3 + np.maximum(ka, kb)
+    closed = np.isin(cls, (0, 1, 4))
+    for k in ("sep", "normal", "ra", "rb"):
+        assert_bits_equal(host(fma[k])[closed], exp[k][closed], "contracted build, closed-form classes, " + k)
+    for name, code in (("SE", 2), ("RE", 5), ("EE", 8)):
+        sel = cls == code
+        assert sel.sum() > 1000
+        d = np.abs(host(fma["sep"])[sel] - exp["sep"][sel])
+        assert (d <= 1e-4).mean() >= 0.995, (name, (d <= 1e-4).mean())
+        assert (d > 0).any(), name      # it IS another arithmetic
+        nrm = host(fma["normal"])[sel]
+        np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-9)
+    again = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
+    assert_bits_equal(host(again["sep"]), exp["sep"], "default restored")
+    links.close()
