@@ -52,7 +52,7 @@ FLOPS_PER_EVALUATION = 460.0
 METRIC = "timesteps/sec, 10^6 spherocylinders, frictionless LCP contact (BBPGD)"
 
 
-def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=None):
+def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=None, kin="rod"):
     """Algorithmic bytes per launch of the two sweeps of one fused BBPGD iteration (rod-compressed kinematics): every
     array the launch REQUIRES, counted once (a gathered table once per row, not once per reader) -- what HBM must move
     even with perfect caches.  This is what roofline.achieved divides.
@@ -71,27 +71,31 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
     Infinity Cache, so that figure divided by the measured time exceeds the HBM peak (1.39 x at 10^6 rods) -- it is
     unusable as a denominator here and is not printed."""
     act = contacts if active_contacts is None else active_contacts
-    con = 88.0 * contacts + 48.0 * bodies
-    body = 2 * 36.0 * act + 16.0 * act + 112.0 * bodies
+    # kin = "rigid" (mixed shapes: explicit lever arms): the constraint streams 48 B of arms instead of 16 B of
+    # arclengths (120 B per constraint), a half-edge record is (n, r) 48 B instead of (n, s - 1/2) 32 B (entry + record
+    # 52 B), a body has no axis (88 B) -- and in tiered iterations reads its longest arm (8 B) on top of the drift words
+    per_con, per_edge, per_body, tier_body = (88.0, 36.0, 112.0, 24.0) if kin == "rod" else (120.0, 52.0, 88.0, 32.0)
+    con = per_con * contacts + 48.0 * bodies
+    body = 2 * per_edge * act + 16.0 * act + per_body * bodies
     if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
         # cold tier (DESIGN 4): over the tiered iterations only the hot share h of the contacts is swept (plus the few
         # thousand awake contacts of the cold tail, not counted here); nothing scans the sleepers.  The body sweep additionally
         # updates each body's drift (8 + 8) and reads its firing threshold (8)
         w = min(1.0, tier["tiered_iterations"] / float(iterations))
         h = tier["mean_hot_fraction"]
-        con = (1.0 - w) * con + w * (88.0 * h * contacts + 48.0 * bodies)
-        body += w * 24.0 * bodies
+        con = (1.0 - w) * con + w * (per_con * h * contacts + 48.0 * bodies)
+        body += w * tier_body * bodies
     return {"k_constraint": con, "k_body": body}
 
 
 def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", active_contacts=None, tier=None,
-                     iterations=None):
-    kb = kernel_bytes(contacts, bodies, active_contacts, tier, iterations)
+                     iterations=None, kin="rod"):
+    kb = kernel_bytes(contacts, bodies, active_contacts, tier, iterations, kin)
     ms = {"k_constraint": con_ms, "k_body": body_ms}
     ent = {}
     for k in ms:
         a = kb[k] / (ms[k] * 1e-3) / 1e9
-        ent[k] = {"bound": "hbm", "kernel": k + "<X_SOLVE,KIN_ROD>" + label, "achieved": round(a, 1),
+        ent[k] = {"bound": "hbm", "kernel": k + ("<X_SOLVE,KIN_ROD>" if kin == "rod" else "<X_SOLVE,KIN_RIGID>") + label, "achieved": round(a, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "traffic": None,
                   "traffic_source": None, "avg_launch_ms": round(ms[k], 4), "launches": launches,
                   "bytes_per_launch": kb[k]}
@@ -413,6 +417,8 @@ def main_mixed(args, ops, pipeline, synth, dev):
             prof["body_ms"] += a
             prof["con_ms"] += c
             prof["iters"] += k
+            prof["tier"] = st.op.tier_stats()
+            prof["solve_iters"] = s.num_iters
         return s
 
     for _ in range(args.warmup):
@@ -422,6 +428,9 @@ def main_mixed(args, ops, pipeline, synth, dev):
     stats = [one_step(True) for _ in range(args.steps)]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    active = None   # contacts the body sweep's masks flag at the end of the solve (as in the headline line)
+    if st.lam is not None and getattr(st, "grad", None) is not None:
+        active = int((~((st.lam == 0) & (st.grad >= 0) & torch.isfinite(st.grad))).sum().item())
     stage_ms = one_step(False, timed_stages=True).timings_ms
     contacts, iters = stats[-1].num_contacts, [s.num_iters for s in stats]
     # The narrow phase of this config is its largest stage and is NOT bandwidth bound: the S-E, R-E and E-E classes run
@@ -465,18 +474,11 @@ def main_mixed(args, ops, pipeline, synth, dev):
     ell_roof["arithmetics"] = both
     roof, extra = None, {}
     if prof["iters"] > 0:
-        # explicit lever arms: k_constraint streams pair 8 + normal 24 + arms 48 + packed (x, g) 16 + q 8, writes 16;
-        # k_body per half edge entry 4 + (n, r) record 48 + iterate gather 16, per body row pointer 4 + mobilities 16 +
-        # velocity row 48
-        by = {"k_constraint": 120.0 * contacts + 48.0 * n, "k_body": 2 * 68.0 * contacts + 68.0 * n}
-        ms = {"k_constraint": prof["con_ms"] / prof["iters"], "k_body": prof["body_ms"] / prof["iters"]}
-        ent = {k: {"bound": "hbm", "kernel": k + "<X_SOLVE,KIN_RIGID>", "achieved": round(by[k] / (ms[k] * 1e-3) / 1e9, 1),
-                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                   "traffic": None, "avg_launch_ms": round(ms[k], 4), "launches": prof["iters"],
-                   "bytes_per_launch": by[k]} for k in ms}
-        dom = max(ms, key=ms.get)
-        roof = ent[dom]
-        extra = {k: v for k, v in ent.items() if k != dom}
+        # the same accounting as the headline line (kernel_bytes: what the launch REQUIRES, with the activity masks and
+        # the cold tier as measured in this run), for explicit lever arms
+        roof, extra, _, _ = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"], prof["body_ms"] / prof["iters"],
+                                             prof["iters"], active_contacts=active, tier=prof.get("tier"),
+                                             iterations=prof.get("solve_iters"), kin="rigid")
     out = {
         "metric": "timesteps/sec, 10^6 mixed sphere / spherocylinder / ellipsoid bodies, frictionless LCP contact (BBPGD)",
         "value": round(args.steps / elapsed, 4), "unit": "timesteps/s", "n_gpus": 1, "steps": args.steps,

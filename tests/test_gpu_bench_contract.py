@@ -83,6 +83,11 @@ def test_mixed_line_names_configs4():
     assert d["config"]["converged"] == [True] and d["stage_ms"]["narrowphase"] > 0 and d["roofline"]["bound"] == "hbm"
     # the fp64-vector roofline of the ellipsoid classes and the CPU oracle timed on a bounded sample of the same input
     assert d["narrow_phase_roofline"]["bound"] == "fp64-vector" and 0.0 < d["narrow_phase_roofline"]["frac"] < 1.0
+    assert 0.0 < d["roofline"]["frac"] < 1.0 and 0.0 < d["k_constraint" if "k_constraint" in d else "k_body"]["frac"] < 1.0
+    # both arithmetics of the minimisation classes side by side; the line itself ran the default (bit-exact) one
+    ar = d["narrow_phase_roofline"]["arithmetics"]
+    assert d["narrow_phase_roofline"]["arithmetic"].startswith("no contraction")
+    assert ar["separations_within_1e-4"] >= 0.995 and 0.0 < ar["contracted"]["frac_of_fp64_vector_peak"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and 0.0 < c["value"] < d["value"]
     assert "pair list equal to the GPU's: True" in c["sample"]
