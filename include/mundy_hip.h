@@ -191,10 +191,15 @@ typedef struct {
   int search_kind; /* MHIP_SEARCH_* */
   int symmetric;   /* 0: i<j ; 1: i!=j both orders */
   double buffer;   /* search buffer added to every volume */
-  int periodic;    /* 0 free space, 1 orthorhombic periodic box [0,box) */
+  int periodic;    /* 0 free space, 1 orthorhombic periodic box [0,box), 2 triclinic unit cell `cell` */
   double box[3];
   int method;       /* MHIP_SEARCH_METHOD_* (0 = AUTO) */
   int include_self; /* 0 = ExcludeSelfInteractions (GenNeighborLinkers.hpp:185-200), 1 = (i, i) is a result */
+  /* periodic == 2: the unit cell of PeriodicMetric (periodicity.hpp:233-332), row-major 3 x 3, lattice vectors as
+   * COLUMNS.  A pair is tested at the image PeriodicMetric::sep picks for the centres / box midpoints (minimum image of
+   * the fractional coordinates, :304-307).  Grid and tree work in scaled fractional coordinates (the cell becomes an
+   * orthorhombic box of the three perpendicular widths of the cell); same lists as the brute-force statement. */
+  double cell[9];
 } mhip_broadphase_config;
 
 int mhip_broadphase_create(mhip_broadphase_t* handle);

@@ -550,6 +550,12 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
   GenNeighborLinks& set_periodic_box(double lx, double ly, double lz) {
     guard("periodic box"); cfg_.periodic = 1; cfg_.box[0] = lx; cfg_.box[1] = ly; cfg_.box[2] = lz; return *this;
   }
+  /// triclinic unit cell (PeriodicMetric, periodicity.hpp:233-332): row-major 3 x 3, lattice vectors as columns
+  GenNeighborLinks& set_periodic_cell(const double cell[9]) {
+    guard("periodic cell"); cfg_.periodic = 2;
+    for (int k = 0; k < 9; ++k) cfg_.cell[k] = cell[k];
+    return *this;
+  }
   /// stk::search::SearchMethod (:443-447; the reference's default is MORTON_LBVH): MHIP_SEARCH_METHOD_*
   GenNeighborLinks& set_search_method(int method) { guard("search method"); cfg_.method = method; return *this; }
   int get_search_method() const { return cfg_.method; }
@@ -661,7 +667,7 @@ class GenNeighborLinks {  // mundy_mesh/GenNeighborLinkers.hpp:294-866 (builder 
   mhip_broadphase_t h_ = nullptr;
   // no filter set: the historical behaviour of this adapter (self pairs excluded) is kept until set_search_filter is
   // called, after which the filter decides as in the reference
-  mhip_broadphase_config cfg_{MHIP_SEARCH_SPHERES, 0, 0.0, 0, {0, 0, 0}, MHIP_SEARCH_METHOD_AUTO, 0};
+  mhip_broadphase_config cfg_{MHIP_SEARCH_SPHERES, 0, 0.0, 0, {0, 0, 0}, MHIP_SEARCH_METHOD_AUTO, 0, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
   std::shared_ptr<search_filters::SearchFilter> filter_;
   bool concretized_ = false, generated_ = false;
   size_t num_pairs_ = 0, n_ = 0;

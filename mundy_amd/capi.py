@@ -21,7 +21,7 @@ class MhipError(RuntimeError):
 
 class BroadphaseConfig(C.Structure):
     _fields_ = [("search_kind", C.c_int), ("symmetric", C.c_int), ("buffer", C.c_double), ("periodic", C.c_int),
-                ("box", C.c_double * 3), ("method", C.c_int), ("include_self", C.c_int)]
+                ("box", C.c_double * 3), ("method", C.c_int), ("include_self", C.c_int), ("cell", C.c_double * 9)]
 
 
 class Space(C.Structure):

@@ -45,6 +45,17 @@ struct BpArgs {
   int kind, symmetric, periodic;
   double buffer;
   Periodic pm;
+  // Triclinic cell (PeriodicMetric, periodicity.hpp:233-332).  The STRUCTURES (cell grid, Morton tree) then work in
+  // scaled fractional coordinates g_a = w_a (h^-1 x)_a, w_a = 1 / |row a of h^-1| = the width of the cell along its
+  // a-th reciprocal axis: there the cell is the orthorhombic box [0, w) (pm above holds w) with lattice translations
+  // along the axes, a ball of radius R spans exactly -/+ R on every axis, and a Cartesian box of half extents e spans
+  // w_a sum_k |h^-1(a, k)| e_k.  The search records hold those g-space bounding boxes (they only bin and prune); the
+  // PREDICATE is evaluated on the Cartesian volumes themselves, fetched by id, at the image PeriodicMetric::sep picks
+  // (fractional minimum image) -- the same statement the orthorhombic search makes with PeriodicScaledMetric::sep.
+  int triclinic;
+  Triclinic tm;
+  double gw[3];
+  const double *aabb_c, *center_c, *brad_c;  // the Cartesian volumes, for the predicate
   // seam S3 result shaping (GenNeighborLinkers.hpp: acts_on(source, target) :486-507, search_filters :185-245):
   int include_self;                  // 0 = ExcludeSelfInteractions (the default)
   const unsigned char* is_source;    // [n] or null (every body is a source)
@@ -87,6 +98,28 @@ __device__ inline void body_volume(const BpArgs& A, size_t i, const double* __re
     r.b[1] = 0.0; r.b[2] = 0.0;
     binp = c;
     reach = r.b[0];
+  }
+  if (A.triclinic) {
+    // into the coordinates of the structures: midpoint / centre -> g, half extents -> their g-space bounds (rounded up
+    // a little: these boxes only bin and prune)
+    const V3 f = matvec3(A.tm.hi, binp);
+    const V3 g{A.gw[0] * f.x, A.gw[1] * f.y, A.gw[2] * f.z};
+    if (A.kind == MHIP_SEARCH_AABB) {
+      const double e[3] = {0.5 * (r.b[0] - r.a[0]), 0.5 * (r.b[1] - r.a[1]), 0.5 * (r.b[2] - r.a[2])};
+      reach = 0.0;
+      for (int a = 0; a < 3; ++a) {
+        double ge = A.gw[a] * (fabs(A.tm.hi[3 * a]) * e[0] + fabs(A.tm.hi[3 * a + 1]) * e[1] + fabs(A.tm.hi[3 * a + 2]) * e[2]);
+        ge = ge * (1.0 + 1e-12) + 1e-300;
+        r.a[a] = comp(g, a) - ge;
+        r.b[a] = comp(g, a) + ge;
+        reach = dmax(reach, ge);
+      }
+    } else {
+      r.a[0] = g.x; r.a[1] = g.y; r.a[2] = g.z;  // r.b[0] = R + buffer: a ball spans -/+ R on every g axis
+      reach = r.b[0] * (1.0 + 1e-12);
+      r.b[0] = reach;
+    }
+    binp = g;
   }
   if (A.periodic) binp = periodic_wrap(A.pm, binp);
   r.id = static_cast<long long>(i);
@@ -227,6 +260,31 @@ __global__ void __launch_bounds__(kBlock)
 
 // closed overlap test, a = lower index, b = higher index
 __device__ inline bool volumes_overlap(const BpArgs& A, const SearchRec& a, const SearchRec& b) {
+  if (A.triclinic) {  // the records hold g-space boxes: the Cartesian volumes by id, PeriodicMetric::sep (:304-307)
+    const size_t ia = static_cast<size_t>(a.id), ib = static_cast<size_t>(b.id);
+    if (A.kind == MHIP_SEARCH_SPHERES) {
+      const V3 s = periodic_sep(A.tm, load3(A.center_c, ia), load3(A.center_c, ib));
+      const double d2 = dot(s, s);
+      const double rs = (A.brad_c[ia] + A.buffer) + (A.brad_c[ib] + A.buffer);
+      return d2 <= rs * rs;
+    }
+    double alo[3], ahi[3], blo[3], bhi[3];
+    for (int k = 0; k < 3; ++k) {
+      alo[k] = A.aabb_c[6 * ia + k] - A.buffer;
+      ahi[k] = A.aabb_c[6 * ia + 3 + k] + A.buffer;
+      blo[k] = A.aabb_c[6 * ib + k] - A.buffer;
+      bhi[k] = A.aabb_c[6 * ib + 3 + k] + A.buffer;
+    }
+    const V3 mi{0.5 * (alo[0] + ahi[0]), 0.5 * (alo[1] + ahi[1]), 0.5 * (alo[2] + ahi[2])};
+    const V3 mj{0.5 * (blo[0] + bhi[0]), 0.5 * (blo[1] + bhi[1]), 0.5 * (blo[2] + bhi[2])};
+    const V3 s = periodic_sep(A.tm, mi, mj);
+    for (int k = 0; k < 3; ++k) {
+      const double shift = (comp(mi, k) + comp(s, k)) - comp(mj, k);
+      const double lo = blo[k] + shift, hi = bhi[k] + shift;
+      if (ahi[k] < lo || hi < alo[k]) return false;
+    }
+    return true;
+  }
   if (A.kind == MHIP_SEARCH_SPHERES) {
     const V3 ca{a.a[0], a.a[1], a.a[2]}, cb{b.a[0], b.a[1], b.a[2]};
     const V3 s = A.periodic ? periodic_sep(A.pm, ca, cb) : (cb - ca);
@@ -992,9 +1050,16 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
     MHIP_REQUIRE(bounding_radius != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT,
                  "bounding_radius is required for MHIP_SEARCH_SPHERES");
   MHIP_REQUIRE(center != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT, "center is null");
-  if (config->periodic) {
+  MHIP_REQUIRE(config->periodic >= 0 && config->periodic <= 2, MHIP_ERR_INVALID_ARGUMENT,
+               "periodic must be 0 (free), 1 (orthorhombic box) or 2 (triclinic cell), got %d", config->periodic);
+  if (config->periodic == 1) {
     MHIP_REQUIRE(config->box[0] > 0 && config->box[1] > 0 && config->box[2] > 0, MHIP_ERR_INVALID_ARGUMENT,
                  "periodic box must be positive");
+  }
+  if (config->periodic == 2) {
+    const double det = determinant3(config->cell);
+    MHIP_REQUIRE(det == det && det != 0.0 && fabs(det) <= 1.7976931348623157e308, MHIP_ERR_INVALID_ARGUMENT,
+                 "triclinic unit cell must be invertible (determinant %g)", det);
   }
   MHIP_REQUIRE((!h->has_source && !h->has_target) || h->sets_n == n, MHIP_ERR_INVALID_ARGUMENT,
                "source / target sets were given for %zu bodies, the build has %zu", h->sets_n, n);
@@ -1019,7 +1084,22 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   A.periodic = config->periodic ? 1 : 0;
   A.buffer = config->buffer;
   const double one[3] = {1, 1, 1};
-  A.pm = make_periodic(config->periodic ? config->box : one);
+  A.pm = make_periodic(config->periodic == 1 ? config->box : one);
+  A.triclinic = 0;
+  A.aabb_c = aabb;
+  A.center_c = center;
+  A.brad_c = bounding_radius;
+  double structure_box[3] = {config->box[0], config->box[1], config->box[2]};  // edges the structures wrap around
+  if (config->periodic == 2) {
+    A.triclinic = 1;
+    A.tm = make_triclinic(config->cell);
+    for (int a = 0; a < 3; ++a) {
+      const double* row = A.tm.hi + 3 * a;
+      A.gw[a] = 1.0 / std::sqrt(row[0] * row[0] + row[1] * row[1] + row[2] * row[2]);
+      structure_box[a] = A.gw[a];
+    }
+    A.pm = make_periodic(A.gw);
+  }
   A.include_self = config->include_self ? 1 : 0;
   A.is_source = h->has_source ? h->is_source.as<unsigned char>() : nullptr;
   A.is_target = h->has_target ? h->is_target.as<unsigned char>() : nullptr;
@@ -1058,7 +1138,7 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
     // the periodic tree assigns a leaf to ONE image of the query (the nearest midpoint): that is the predicate's image
     // as long as no two volumes can overlap across half a box edge; a cell that small is the grid's case
     if (config->periodic && method == MHIP_SEARCH_METHOD_MORTON_LBVH) {
-      const double edge = std::min(config->box[0], std::min(config->box[1], config->box[2]));
+      const double edge = std::min(structure_box[0], std::min(structure_box[1], structure_box[2]));
       if (!(4.0 * max_reach < edge)) method = MHIP_SEARCH_METHOD_GRID;
     }
   } else if (method == MHIP_SEARCH_METHOD_AUTO) {
@@ -1167,7 +1247,7 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   // meet again at E - d >= E/2, which their reaches (<= 2 x the largest) cannot span when 4 x largest reach < E
   h->min_image_complete = true;
   if (config->periodic && n > 0)
-    h->min_image_complete = 4.0 * h->host_summary[6] < std::min(config->box[0], std::min(config->box[1], config->box[2]));
+    h->min_image_complete = 4.0 * h->host_summary[6] < std::min(structure_box[0], std::min(structure_box[1], structure_box[2]));
   const int32_t total = h->host_scalar[0];
   MHIP_REQUIRE(total >= 0, MHIP_ERR_RUNTIME, "pair count overflowed 32 bits");
   h->num_pairs = static_cast<size_t>(total);

@@ -305,8 +305,16 @@ class GenNeighborLinks:
         if box is None:
             self._cfg.periodic = 0
         else:
-            self._cfg.periodic = 1
-            self._cfg.box = (C.c_double * 3)(*[float(b) for b in box])
+            import numpy as np
+            a = np.asarray(box, dtype=np.float64)
+            if a.shape == (3,):
+                self._cfg.periodic = 1
+                self._cfg.box = (C.c_double * 3)(*[float(b) for b in a])
+            elif a.shape == (3, 3):   # the unit cell of PeriodicMetric: lattice vectors as columns (periodicity.hpp:233-332)
+                self._cfg.periodic = 2
+                self._cfg.cell = (C.c_double * 9)(*[float(b) for b in a.reshape(9)])
+            else:
+                raise ValueError("periodic cell must be 3 edge lengths or a 3x3 unit-cell matrix, got shape %s" % (a.shape,))
         return self
 
     def set_search_method(self, method):

@@ -259,6 +259,13 @@ def search(kind, lo, hi, center, R, box=None, symmetric=False, method="cell", fa
     lo, hi, center, R = _f(lo), _f(hi), _f(center), _f(R)
     box = None if box is None else _f(box)
     L = lib(fast)
+    if box is not None and box.shape == (3, 3):   # triclinic unit cell (lattice vectors as columns): brute force only
+        L.o_search_triclinic.restype = C.c_size_t
+        cnt = L.o_search_triclinic(C.c_int(kind), C.c_size_t(len(R)), _p(lo), _p(hi), _p(center), _p(R), _p(box),
+                                   C.c_int(1 if symmetric else 0))
+        pairs = np.empty((cnt, 2), dtype=np.int32)
+        L.o_search_fetch(_p(pairs))
+        return pairs
     L.o_search.restype = C.c_size_t
     cnt = L.o_search(C.c_int(kind), C.c_int(0 if method == "brute" else 1), C.c_size_t(len(R)), _p(lo), _p(hi),
                      _p(center), _p(R), _p(box), C.c_int(1 if symmetric else 0))

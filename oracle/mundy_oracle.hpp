@@ -1522,8 +1522,9 @@ ScrapResult scrap_resolve_collisions(const Op& A, const double* sep, double max_
 // ---------------------------------------------------------------------------------------------------------------
 enum SearchKind : int { kSearchSpheres = 0, kSearchAABB = 1 };
 
+template <class Metric>  // PeriodicScaledMetric (orthorhombic box) or PeriodicMetric (triclinic cell): both have sep()
 inline bool search_overlap(int kind, const double* lo_i, const double* hi_i, const double* lo_j, const double* hi_j,
-                           const V3& ci, double Ri, const V3& cj, double Rj, const PeriodicScaledMetric* pm) {
+                           const V3& ci, double Ri, const V3& cj, double Rj, const Metric* pm) {
   if (kind == kSearchSpheres) {
     const V3 s = pm ? pm->sep(ci, cj) : (cj - ci);
     const double d2 = dot(s, s);
@@ -1567,6 +1568,26 @@ inline void search_bruteforce(int kind, size_t n, const double* lo, const double
       const size_t a = std::min(i, j), b = std::max(i, j);
       const V3 ca{c[3 * a], c[3 * a + 1], c[3 * a + 2]}, cb{c[3 * b], c[3 * b + 1], c[3 * b + 2]};
       if (search_overlap(kind, lo + 3 * a, hi + 3 * a, lo + 3 * b, hi + 3 * b, ca, R[a], cb, R[b], pm)) {
+        pairs.push_back(static_cast<int32_t>(i));
+        pairs.push_back(static_cast<int32_t>(j));
+      }
+    }
+  }
+}
+
+// The same in a TRICLINIC cell: the predicate with PeriodicMetric::sep (periodicity.hpp:304-307: minimum
+// image of the fractional coordinates) in the place of PeriodicScaledMetric::sep.  Brute force only: it is the checker.
+inline void search_bruteforce_triclinic(int kind, size_t n, const double* lo, const double* hi, const double* c,
+                                        const double* R, const double* cell /*[9]*/, bool symmetric,
+                                        std::vector<int32_t>& pairs) {
+  pairs.clear();
+  const PeriodicMetric pm(cell);
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t j = symmetric ? 0 : i + 1; j < n; ++j) {
+      if (j == i) continue;
+      const size_t a = std::min(i, j), b = std::max(i, j);
+      const V3 ca{c[3 * a], c[3 * a + 1], c[3 * a + 2]}, cb{c[3 * b], c[3 * b + 1], c[3 * b + 2]};
+      if (search_overlap(kind, lo + 3 * a, hi + 3 * a, lo + 3 * b, hi + 3 * b, ca, R[a], cb, R[b], &pm)) {
         pairs.push_back(static_cast<int32_t>(i));
         pairs.push_back(static_cast<int32_t>(j));
       }

@@ -298,6 +298,11 @@ size_t o_search(int kind, int method, size_t n, const double* lo, const double* 
     search_celllist(kind, n, lo, hi, c, R, box, symmetric != 0, g_pairs);
   return g_pairs.size() / 2;
 }
+size_t o_search_triclinic(int kind, size_t n, const double* lo, const double* hi, const double* c, const double* R,
+                          const double* cell, int symmetric) {
+  search_bruteforce_triclinic(kind, n, lo, hi, c, R, cell, symmetric != 0, g_pairs);
+  return g_pairs.size() / 2;
+}
 void o_search_fetch(int32_t* out) { std::copy(g_pairs.begin(), g_pairs.end(), out); }
 // rebuild test, mundy/mesh/src/mundy_mesh/GenNeighborLinkers.hpp:603-615: any |c_new - c_old| > 0.5 * buffer.
 int o_moved_too_much(size_t n, const double* c_new, const double* c_old, double buffer) {

@@ -432,3 +432,54 @@ def test_self_interactions_are_a_filter(ops, oracle):
         g.generate(dev(aabb), dev(c), dev(r))
         assert host(g.pairs).tolist() == [[0, 0], [0, 1], [1, 0], [1, 1]]
         g.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_triclinic_cell_lists_equal_brute_force(ops, oracle, kind, symmetric):
+    # the neighbour search in a TRICLINIC periodic cell (PeriodicMetric, periodicity.hpp:233-332).  Grid and
+    # Morton tree work in scaled fractional coordinates, the predicate tests the Cartesian volumes at the image
+    # PeriodicMetric::sep picks; both must give the brute-force oracle's list, row for row -- bodies on faces and
+    # corners of the cell and unwrapped images included.
+    from gpu_util import dev, host
+    rng = np.random.default_rng(21 + kind)
+    n = 10_000
+    # a strongly sheared cell: lattice vectors (columns) a = (30,0,0), b = (9,28,0), c = (-7,11,26)
+    cell = np.array([[30.0, 9.0, -7.0], [0.0, 28.0, 11.0], [0.0, 0.0, 26.0]])
+    f = rng.uniform(0, 1, (n, 3))
+    f[:64] = rng.integers(0, 2, (64, 3))            # corners of the cell
+    f[64:192, 0] = 0.0                              # a face
+    f[192:256, 2] = 1.0
+    c = f @ cell.T
+    c += (rng.integers(-2, 3, (n, 3)) @ cell.T)     # unwrapped images must not matter
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    r, L = rng.uniform(0.3, 0.6, n), rng.uniform(0.5, 2.5, n)
+    aabb = oracle.compute_aabb_spherocylinders(c, q, r, L)
+    brad = oracle.bounding_radius_spherocylinders(r, L)
+    buffer = 0.15
+    lo, hi, R = oracle.grow(aabb, brad, buffer)
+    exp = oracle.search(kind, lo, hi, c, R, box=cell, symmetric=symmetric, method="brute")
+    assert len(exp) > 3 * n
+    # the orthorhombic statement on the same bodies is ANOTHER list (the shear matters)
+    ortho = oracle.search(kind, lo, hi, c, R, box=np.array([30.0, 28.0, 26.0]), symmetric=symmetric, method="brute")
+    assert len(ortho) != len(exp) or not np.array_equal(ortho, exp)
+    for method in (ops.SEARCH_METHOD_GRID, ops.SEARCH_METHOD_MORTON_LBVH):
+        g = (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(buffer).set_search_method(method)
+             .set_enforce_source_target_symmetry(symmetric).set_periodic_box(cell).concretize())
+        g.generate(dev(aabb), dev(c), dev(brad))
+        assert g.method_used() == method and g.minimum_image_complete()
+        np.testing.assert_array_equal(host(g.pairs), exp)
+        g.close()
+    # a diagonal unit cell is the orthorhombic box
+    diag = np.diag([30.0, 28.0, 26.0])
+    g = (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(buffer)
+         .set_enforce_source_target_symmetry(symmetric).set_periodic_box(diag).concretize())
+    g.generate(dev(aabb), dev(c), dev(brad))
+    np.testing.assert_array_equal(host(g.pairs), ortho)
+    g.close()
+    # a singular cell is refused
+    bad = ops.GenNeighborLinks().set_search_kind(kind).set_periodic_box(np.array([[1.0, 2, 3], [2, 4, 6], [0, 0, 1]])).concretize()
+    with pytest.raises(ValueError):
+        bad.generate(dev(aabb), dev(c), dev(brad))
+    bad.close()

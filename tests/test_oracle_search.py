@@ -68,3 +68,26 @@ def test_rebuild_rule(oracle):
     assert not oracle.moved_too_much(d, c, 1.0)
     d[3, 1] = 0.5000001
     assert oracle.moved_too_much(d, c, 1.0)
+
+
+def test_triclinic_brute_force_states_the_periodic_metric(oracle):
+    # the triclinic checker of tests/test_gpu_broadphase.py: PeriodicMetric::sep (periodicity.hpp:304-307) restated in
+    # numpy on every pair of a small system; and a diagonal cell is the orthorhombic box
+    rng = np.random.default_rng(4)
+    n = 400
+    cell = np.array([[8.0, 2.5, -1.5], [0.0, 7.0, 3.0], [0.0, 0.0, 6.5]])
+    c = rng.uniform(0, 1, (n, 3)) @ cell.T + rng.integers(-1, 2, (n, 3)) @ cell.T
+    R = rng.uniform(0.3, 0.9, n)
+    lo, hi = c - R[:, None], c + R[:, None]
+    got = oracle.search(oracle.SEARCH_SPHERES, lo, hi, c, R, box=cell, method="brute")
+    hinv = np.linalg.inv(cell)
+    i, j = np.triu_indices(n, 1)
+    f = (c[j] - c[i]) @ hinv.T
+    s = (f - np.round(f)) @ cell.T
+    hit = (s * s).sum(axis=1) <= (R[i] + R[j]) ** 2
+    exp = np.stack([i[hit], j[hit]], axis=1).astype(np.int32)
+    assert len(exp) > n
+    np.testing.assert_array_equal(got, exp)
+    box = np.array([8.0, 7.0, 6.5])
+    np.testing.assert_array_equal(oracle.search(oracle.SEARCH_AABB, lo, hi, c, R, box=np.diag(box), method="brute"),
+                                  oracle.search(oracle.SEARCH_AABB, lo, hi, c, R, box=box, method="brute"))
