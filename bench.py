@@ -314,12 +314,16 @@ def main():
 
     # ---- a second, labelled figure: the same step from a RELAXED packing (what a running simulation sees) -----------
     relaxed = None
-    if args.relaxed_steps > 0 and args.friction is None and dist is None:
+    if args.relaxed_steps > 0 and dist is None:
         stepper.restore(pristine)
         if args.reorder:
             stepper.reorder_bodies(cell_size=args.reorder_cell, lo=[0.0, 0.0, 0.0])
-        for _ in range(args.relaxed_steps):   # the relaxation pre-pass: full steps of the same path, untimed
+        # the relaxation pre-pass: full steps of the reference's (frictionless) path, untimed -- also for the friction
+        # extension, whose timed steps then start from the same relaxed packing as the headline's
+        mu_kept, stepper.friction = stepper.friction, None
+        for _ in range(args.relaxed_steps):
             stepper.step(integrate=True, force_rebuild=True)
+        stepper.friction = mu_kept
         pristine_relaxed = stepper.snapshot()
 
         def relaxed_step():

@@ -72,6 +72,9 @@ def test_friction_extension_line_is_labelled():
     d = _run(["--friction", "0.3", "--no-cpu-baseline"])
     assert "EXTENSION" in d["config"]["workload"] and "build extension" in d["metric"]
     assert d["cpu_baseline"] is None
+    # the usable configuration of the extension: the packing relaxed by two steps of the reference's frictionless path
+    rp = d["relaxed_packing"]
+    assert all(rp["converged"]) and max(rp["bbpgd_iters_per_step"]) < 2000
 
 
 def test_mixed_line_names_configs4():

@@ -94,3 +94,38 @@ def test_friction_stepper_and_errors(ops, oracle):
         ops.solve_friction_contact(ref.op, ref.contacts["sep"], 0.3)
     with pytest.raises(Exception):
         ops.solve_friction_contact(st.op, st.contacts["sep"], -0.1)
+
+
+def test_friction_at_full_size_on_the_relaxed_packing(ops, oracle):
+    # the usable configuration of the extension (BASELINE configs[2] says "frictional LCP"): 10^6 rods, the packing
+    # relaxed by two steps of the reference's frictionless path, mu = 0.3 -- the cone complementarity conditions at the
+    # solver's tolerance, and an iteration count one can run a simulation with (the raw overlapping packing, an
+    # unphysical start, needs 23 000)
+    import torch
+    from gpu_util import dev, host
+    from mundy_amd import pipeline, synth
+    from test_oracle_friction_ext import cone_checks
+    n, mu, tol = 1_000_000, 0.3, 1e-5
+    b = synth.spherocylinders(n, seed=1234)
+    st = pipeline.ContactStepper("spherocylinder", dev(b["center"]), dev(b["radius"]), dev(b["quat"]), dev(b["length"]),
+                                 search_buffer=0.1, cfg=ops.PGDConfig(max_iters=10000, tol=tol))
+    st.reorder_bodies(cell_size=3.0, lo=[0.0, 0.0, 0.0])
+    for _ in range(2):
+        assert st.step(integrate=True, force_rebuild=True).converged
+    st.friction = mu
+    s = st.step(integrate=False, force_rebuild=True)
+    assert s.converged and s.num_iters < 2000, (s.converged, s.num_iters)
+    c = st.contacts
+    ra, rb = ops.surface_lever_arms(st.links.pairs, c["normal"], c["ra"], c["rb"], st.radius)
+    # the gradient of the solution from the operator itself: g = dt (v_j - v_i) + sep n at the surface contact points
+    p = st.impulse
+    vel = st.op.body_velocity()          # rows of the last sweep = the solution's
+    i, j = st.links.pairs[:, 0].long(), st.links.pairs[:, 1].long()
+    vi = vel[i, :3] + torch.cross(vel[i, 3:], ra, dim=1)
+    vj = vel[j, :3] + torch.cross(vel[j, 3:], rb, dim=1)
+    g = st.dt * (vj - vi) + c["sep"][:, None] * c["normal"]
+    cone_checks(host(p), host(g), host(c["normal"]), mu, tol)
+    pn = (p * c["normal"]).sum(1)
+    pt = (p - pn[:, None] * c["normal"]).norm(dim=1)
+    assert int((pt > 1e-6).sum()) > 10_000          # friction is at work
+    st.op.close()
