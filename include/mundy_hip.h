@@ -616,6 +616,21 @@ int mhip_comm_info(mhip_comm_t comm, int* rank, int* world, int* is_rccl);
  * MHIP_ERR_RUNTIME on the ranks that waited for it (bounded polling: no wave waits forever). */
 int mhip_comm_mailbox_open(mhip_comm_t comm, int* opened /*[host]*/, mhip_stream_t stream);
 int mhip_comm_mailbox_close(mhip_comm_t comm);
+/* The per-iteration VELOCITY HALO of mhip_bbpgd_solve_contact_distributed without the collective library, for the
+ * ranks of ONE node (same condition as the mailbox).  on = 1: from the next mhip_ghost_plan on (collective: every rank
+ * must have made the same call) each rank keeps an inbox of fine-grained device memory, one slot per local body row,
+ * IPC-mapped by all the others.  After its body sweep a rank writes the rows its peers hold as ghosts straight into
+ * their inboxes (posted writes over xGMI; every 8-byte word carries 32 bits of data and the number of the exchange, so
+ * each store validates itself); before its boundary sweep a rank collects its ghost rows from its own inbox into the
+ * velocity table (bounded polling: a peer that never writes ends in MHIP_ERR_RUNTIME).  Replaces the gather kernel,
+ * the grouped ncclSend / ncclRecv and two stream hand-overs per iteration by two launches on the solver's own stream.
+ * Anything short of success on every rank (allocation, mapping, probing) leaves everybody on send / recv.  The solve
+ * takes this path only for the halo of the communicator's current ghost plan; same rows, same bits.
+ * Replaces: communicate_field_data (scrap/.../SpherocylinderSpherocylinderLinker.cpp:154-155) inside the iteration,
+ * the ghost refresh the reference leaves as a TODO (NGPSpheresLCP.cpp:1057). */
+int mhip_comm_halo_ipc_enable(mhip_comm_t comm, int on);
+/* *active [host] = 1 when the current ghost plan's halo will travel through the inboxes */
+int mhip_comm_halo_ipc_active(mhip_comm_t comm, int* active /*[host]*/);
 /* recv[r][0..count) = rank r's send[0..count); later work on `stream` sees recv */
 int mhip_comm_all_gather(mhip_comm_t comm, const double* send, size_t count, double* recv, mhip_stream_t stream);
 /* One grouped point-to-point exchange: message k goes to send_peer[k] / comes from recv_peer[k]; empty messages are

@@ -181,6 +181,8 @@ SIGNATURES = {
     "mhip_comm_info": [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "mhip_comm_mailbox_open": [_vp, C.POINTER(_i), _vp],
     "mhip_comm_mailbox_close": [_vp],
+    "mhip_comm_halo_ipc_enable": [_vp, _i],
+    "mhip_comm_halo_ipc_active": [_vp, C.POINTER(_i)],
     "mhip_comm_all_gather": [_vp, _vp, _sz, _vp, _vp],
     "mhip_comm_exchange_start": [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i),
                                  C.POINTER(_vp), C.POINTER(_sz), _vp],

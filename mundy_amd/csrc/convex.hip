@@ -2531,6 +2531,11 @@ int solve_generic(size_t n, const Apply& apply, const double* q, Space sp, const
 #define REQ(p) MHIP_REQUIRE((p) != nullptr || n == 0, MHIP_ERR_INVALID_ARGUMENT, "%s: %s is null", __func__, #p)
 
 namespace mhip {
+void stage_state_words(mhip_contact_op_t op, const unsigned** flips, const int** done) {
+  const SolverState* st = op->state.as<SolverState>();
+  *flips = &st->flips;
+  *done = &st->done;
+}
 int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const MailboxArgs& mb, hipStream_t s) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
   MHIP_REQUIRE(local != nullptr, MHIP_ERR_INVALID_ARGUMENT, "local record is null");

@@ -104,6 +104,22 @@ struct mhip_comm {
     DeviceBuffer peers;              // [world] device array of box pointers
     DeviceBuffer status;             // [0] != 0: an exchange timed out (sticky); [1] = exchanges made (device-counted)
   } mbox;
+  // Velocity halo without the collective library (mhip_comm_halo_ipc_enable): every rank owns an INBOX of fine-grained
+  // memory, one slot of kHaloWords 8-byte words per local body row, IPC-mapped by all the others.  After its body sweep
+  // a rank writes the rows its peers hold as ghosts straight into their inboxes (posted writes over xGMI: one kernel, no
+  // send / recv launch, no stream hand-over); before its boundary sweep a rank collects its ghost rows from its own
+  // inbox (local polling reads) into the velocity table.  Every word carries 32 bits of data and the number of the
+  // exchange, so each store validates itself and the writes may land in any order (the mailbox's protocol).
+  struct HaloIpc {
+    bool wanted = false, open = false, plan_ok = false;
+    void* own = nullptr;             // this rank's inbox
+    size_t capacity = 0;             // rows it holds
+    std::vector<void*> mapped;       // the other ranks' inboxes as mapped here
+    std::vector<unsigned long long*> base;  // [world] inbox pointers as seen from this rank
+    uint32_t seq_base = 1;           // number of the first exchange of the next solve (the same on every rank)
+    // of the current ghost plan: per send peer the first row of my block in ITS velocity table
+    std::vector<size_t> dst_first_row;
+  } hipc;
   // work buffers of the distributed solve
   DeviceBuffer send_rows, triples;
   std::vector<hipEvent_t> events;
@@ -179,6 +195,220 @@ __global__ void __launch_bounds__(64) k_mailbox_exchange(MailboxArgs m, const do
   mailbox_exchange_wave(m, local);
 }
 constexpr unsigned long long kMailboxTimeoutTicks = 2000000000ull;  // 20 s of the 100 MHz wall clock (ranks enter a solve at different times: the narrow phase of a mixed system is uneven)
+
+// ---- velocity halo through IPC-mapped inboxes -----------------------------------------------------------------------
+constexpr int kHaloWords = 12;      // a row of 6 doubles as 12 (data, exchange number) words
+constexpr int kHaloMaxPeers = 16;   // ranks of one node
+struct HaloPushArgs {
+  int npeers = 0;
+  unsigned long long* base[kHaloMaxPeers];  // peer k's inbox
+  unsigned first[kHaloMaxPeers + 1];        // send rows [first[k], first[k + 1]) go to peer k ...
+  unsigned dst_row[kHaloMaxPeers];          // ... into its rows dst_row[k] + (r - first[k])
+};
+// exchange number of this launch: seq_base + (init ? 0 : flips + 1); flips only changes in the finalize launches
+__device__ inline unsigned halo_seq(unsigned seq_base, int init, const unsigned* flips) {
+  return seq_base + (init ? 0u : *flips + 1u);
+}
+// one lane per (send row, word): consecutive lanes write consecutive words of a peer's inbox
+__global__ void __launch_bounds__(kBlock)
+    k_halo_push(HaloPushArgs a, size_t total_rows, const int32_t* __restrict__ send_index,
+                const double* __restrict__ vel, unsigned seq_base, int init, const unsigned* __restrict__ flips,
+                const int* __restrict__ done) {
+  if (!init && *done) return;
+  const unsigned seq = halo_seq(seq_base, init, flips);
+  const size_t nw = total_rows * kHaloWords;
+  for (size_t t = blockIdx.x * (size_t)kBlock + threadIdx.x; t < nw; t += (size_t)gridDim.x * kBlock) {
+    const unsigned r = static_cast<unsigned>(t / kHaloWords);
+    const int w = static_cast<int>(t % kHaloWords);
+    int k = 0;
+    while (k + 1 < a.npeers && r >= a.first[k + 1]) ++k;
+    const unsigned long long bits =
+        static_cast<unsigned long long>(__double_as_longlong(vel[6 * static_cast<size_t>(send_index[r]) + (w >> 1)]));
+    const unsigned half = static_cast<unsigned>((w & 1) ? (bits >> 32) : (bits & 0xffffffffull));
+    unsigned long long* dst = a.base[k] + (static_cast<size_t>(a.dst_row[k]) + (r - a.first[k])) * kHaloWords + w;
+    __hip_atomic_store(dst, (static_cast<unsigned long long>(seq) << 32) | half, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// one lane per (ghost row, word): polls its word until it carries this exchange's number (bounded), the even lane of a
+// pair writes the double into the velocity table.  Ghost rows = the local rows outside the owned block.
+__global__ void __launch_bounds__(kBlock)
+    k_halo_collect(const unsigned long long* __restrict__ inbox, size_t n_lo, size_t n_owned, size_t n_ghost,
+                   double* __restrict__ vel, unsigned seq_base, int init, const unsigned* __restrict__ flips,
+                   const int* __restrict__ done, unsigned long long* __restrict__ status,
+                   unsigned long long timeout) {
+  if (!init && *done) return;
+  const unsigned seq = halo_seq(seq_base, init, flips);
+  const size_t nw = n_ghost * kHaloWords;
+  for (size_t t0 = blockIdx.x * (size_t)kBlock; t0 < nw; t0 += (size_t)gridDim.x * kBlock) {
+    const size_t t = t0 + threadIdx.x;   // (t0 and kHaloWords are even: lanes (2m, 2m + 1) of a wave hold the two halves
+    const bool live = t < nw;            //  of one double, and both are live or both are not)
+    unsigned long long word = 0;
+    bool ok = true;
+    size_t row = 0;
+    int w = 0;
+    if (live) {
+      const size_t o = t / kHaloWords;
+      w = static_cast<int>(t % kHaloWords);
+      row = (o < n_lo) ? o : o + n_owned;
+      const unsigned long long* src = inbox + row * kHaloWords + w;
+      const unsigned long long start = wall_clock64();
+      for (;;) {
+        word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (static_cast<unsigned>(word >> 32) == seq) break;
+        if (__hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
+            wall_clock64() - start > timeout) {
+          ok = false;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!ok) __hip_atomic_store(&status[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // t even <-> w even (kHaloWords is even): lane pairs (2m, 2m + 1) hold the two halves of one double
+    const unsigned long long other = __shfl_xor(word, 1, 64);
+    const int ok_other = __shfl_xor(ok ? 1 : 0, 1, 64);
+    if (live && !(w & 1)) {
+      const unsigned long long bits = (other << 32) | (word & 0xffffffffull);
+      vel[6 * row + (w >> 1)] = (ok && ok_other) ? __longlong_as_double(static_cast<long long>(bits)) : __builtin_nan("");
+    }
+  }
+}
+void halo_ipc_close(mhip_comm* c) {
+  auto& h = c->hipc;
+  for (void* p : h.mapped)
+    if (p) (void)hipIpcCloseMemHandle(p);
+  if (h.own) (void)hipFree(h.own);
+  h.mapped.clear();
+  h.base.clear();
+  h.own = nullptr;
+  h.capacity = 0;
+  h.open = false;
+  h.plan_ok = false;
+}
+static int host_all_gather(mhip_comm* c, const double* in, size_t count, std::vector<double>& out, hipStream_t s);
+// (Re)opens the inboxes with room for `rows` rows on every rank.  Collective; every rank takes the same decisions.
+int halo_ipc_open(mhip_comm* c, size_t rows, hipStream_t s) {
+  auto& h = c->hipc;
+  halo_ipc_close(c);
+  const int world = c->world;
+  const size_t bytes = (rows * kHaloWords + (size_t)world) * sizeof(unsigned long long);  // + one probe word per rank
+  constexpr size_t kHandleDoubles = (sizeof(hipIpcMemHandle_t) + 7) / 8;
+  double mine_ok = 0.0;
+  hipIpcMemHandle_t handle;
+  memset(&handle, 0, sizeof(handle));
+  void* own = nullptr;
+  if (hipExtMallocWithFlags(&own, bytes, hipDeviceMallocFinegrained) == hipSuccess && own != nullptr) {
+    if (hipMemsetAsync(own, 0, bytes, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess &&
+        (world == 1 || hipIpcGetMemHandle(&handle, own) == hipSuccess)) {
+      mine_ok = 1.0;
+    } else {
+      (void)hipFree(own);
+      own = nullptr;
+    }
+  }
+  (void)hipGetLastError();
+  h.own = own;
+  std::vector<double> hsend(kHandleDoubles + 1, 0.0), hrecv;
+  memcpy(hsend.data(), &handle, sizeof(handle));
+  hsend[kHandleDoubles] = mine_ok;
+  if (int e = host_all_gather(c, hsend.data(), kHandleDoubles + 1, hrecv, s)) return e;
+  bool all = true;
+  for (int r = 0; r < world; ++r) all = all && hrecv[(kHandleDoubles + 1) * (size_t)r + kHandleDoubles] == 1.0;
+  double map_ok = all ? 1.0 : 0.0;
+  h.mapped.assign(world, nullptr);
+  h.base.assign(world, nullptr);
+  if (all) {
+    for (int r = 0; r < world; ++r) {
+      if (r == c->rank) {
+        h.base[r] = static_cast<unsigned long long*>(own);
+        continue;
+      }
+      hipIpcMemHandle_t hd;
+      memcpy(&hd, &hrecv[(kHandleDoubles + 1) * (size_t)r], sizeof(hd));
+      void* p = nullptr;
+      if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) == hipSuccess && p != nullptr) {
+        h.mapped[r] = p;
+        h.base[r] = static_cast<unsigned long long*>(p);
+        // a first write through the copy path of the runtime: an unreachable mapping is an error code HERE, not a fault
+        // of the kernel that stores into it
+        const unsigned long long probe = 0x68616c6full + static_cast<unsigned long long>(c->rank);
+        unsigned long long back = 0;
+        char* word = static_cast<char*>(p) + (rows * kHaloWords + (size_t)c->rank) * sizeof(unsigned long long);
+        if (hipMemcpy(word, &probe, sizeof(probe), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(&back, word, sizeof(back), hipMemcpyDeviceToHost) != hipSuccess || back != probe) {
+          (void)hipGetLastError();
+          map_ok = 0.0;
+        }
+      } else {
+        (void)hipGetLastError();
+        map_ok = 0.0;
+      }
+    }
+  }
+  std::vector<double> oks;
+  if (int e = host_all_gather(c, &map_ok, 1, oks, s)) return e;
+  for (double v : oks) all = all && v == 1.0;
+  if (!all) {
+    halo_ipc_close(c);
+    return MHIP_SUCCESS;
+  }
+  h.capacity = rows;
+  h.open = true;
+  return MHIP_SUCCESS;
+}
+// After a ghost plan: room for everybody's rows, and where my rows go in each peer's table.  Collective.
+int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*/, const std::vector<size_t>& owned,
+                  hipStream_t s) {
+  auto& h = c->hipc;
+  auto& gp = c->ghost;
+  h.plan_ok = false;
+  if (!h.wanted || c->world > kHaloMaxPeers) return MHIP_SUCCESS;
+  const size_t W = (size_t)c->world;
+  if (!c->mbox.status.ptr) {
+    if (int e = c->mbox.status.reserve(64)) return e;
+    MHIP_HIP(hipMemsetAsync(c->mbox.status.ptr, 0, 64, s));
+  }
+  // rows of every rank's table (the counts matrix and the owned counts are the same on every rank)
+  size_t need = 0;
+  std::vector<size_t> n_lo(W, 0), n_local(W, 0);
+  for (size_t d = 0; d < W; ++d) {
+    size_t lo = 0, hi = 0;
+    for (size_t p = 0; p < W; ++p)
+      if (p != d) (p < d ? lo : hi) += counts[p * W + d];
+    n_lo[d] = lo;
+    n_local[d] = lo + owned[d] + hi;
+    need = std::max(need, n_local[d]);
+  }
+  if (!h.open || h.capacity < need) {
+    if (int e = halo_ipc_open(c, need + need / 2 + 1024, s)) return e;   // (every rank sees the same `need`)
+    if (!h.open) return MHIP_SUCCESS;
+  } else if (h.own) {
+    // stale words of an earlier plan must never carry a number that comes round again: start from zeros (the
+    // collectives of the plan that follow order this before any peer's next push)
+    MHIP_HIP(hipMemsetAsync(h.own, 0, h.capacity * kHaloWords * sizeof(unsigned long long), s));
+    MHIP_HIP(hipStreamSynchronize(s));
+  }
+  std::vector<double> token(1, 1.0), tokens;   // nobody pushes before everybody has cleared
+  if (int e = host_all_gather(c, token.data(), 1, tokens, s)) return e;
+  // where the block of rank R starts in the table of rank d: ghosts of lower ranks in rank order, the owned block,
+  // ghosts of higher ranks in rank order (mhip_ghost_layout_from_counts)
+  const size_t R = (size_t)c->rank;
+  h.dst_first_row.assign(gp.send_peer.size(), 0);
+  for (size_t k = 0; k < gp.send_peer.size(); ++k) {
+    const size_t d = (size_t)gp.send_peer[k];
+    size_t row = 0;
+    if (R < d) {
+      for (size_t p = 0; p < R; ++p) row += counts[p * W + d];
+    } else {
+      row = n_lo[d] + owned[d];
+      for (size_t p = d + 1; p < R; ++p) row += counts[p * W + d];
+    }
+    h.dst_first_row[k] = row;
+  }
+  h.plan_ok = true;
+  return MHIP_SUCCESS;
+}
 
 MailboxArgs mailbox_next(mhip_comm* c, int width, double* gathered) {
   MailboxArgs m;
@@ -337,6 +567,18 @@ int mhip_comm_mailbox_close(mhip_comm_t c) {
   return MHIP_SUCCESS;
 }
 
+int mhip_comm_halo_ipc_enable(mhip_comm_t c, int on) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  c->hipc.wanted = on != 0;
+  if (!on) halo_ipc_close(c);
+  return MHIP_SUCCESS;
+}
+int mhip_comm_halo_ipc_active(mhip_comm_t c, int* active) {
+  MHIP_REQUIRE(c != nullptr && active != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  *active = (c->hipc.open && c->hipc.plan_ok) ? 1 : 0;
+  return MHIP_SUCCESS;
+}
+
 int mhip_comm_unique_id(unsigned char* id) {
   MHIP_REQUIRE(id != nullptr, MHIP_ERR_INVALID_ARGUMENT, "id is null");
   static_assert(sizeof(ncclUniqueId) == MHIP_COMM_ID_BYTES, "unique id size");
@@ -402,6 +644,7 @@ int mhip_comm_destroy(mhip_comm_t c) {
     b->release();
   mailbox_close(c);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  halo_ipc_close(c);
   if (c->nccl) (void)rccl().CommDestroy(c->nccl);
   if (c->ready) (void)hipEventDestroy(c->ready);
   if (c->done) (void)hipEventDestroy(c->done);
@@ -566,7 +809,8 @@ int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, 
   if (int e = mhip_comm_all_gather(c, mine, region, all, stream)) return e;
   // per peer: the owned bodies whose grown box meets any of the peer's boxes
   if (int e = gp.send_index.reserve(((size_t)(W > 1 ? W - 1 : 1) * n + 2) * sizeof(int32_t))) return e;
-  std::vector<double> send_cnt((size_t)W, 0.0);
+  std::vector<double> send_cnt((size_t)W + 1, 0.0);   // [W] = the bodies this rank owns
+  send_cnt[(size_t)W] = (double)n;
   size_t off = 0;
   for (int p = 0; p < W; ++p) {
     if (p == R || n == 0) continue;
@@ -578,12 +822,15 @@ int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, 
     off += cnt;
   }
   gp.total_send = off;
-  std::vector<double> counts;  // counts[s][d] = bodies rank s sends to rank d
-  if (int e = host_all_gather(c, send_cnt.data(), (size_t)W, counts, s)) return e;
+  std::vector<double> gathered_counts;  // per rank: its W send counts, then its owned count
+  if (int e = host_all_gather(c, send_cnt.data(), (size_t)W + 1, gathered_counts, s)) return e;
+  std::vector<size_t> cm((size_t)W * W), owned((size_t)W);  // cm[s][d] = bodies rank s sends to rank d
+  for (size_t r = 0; r < (size_t)W; ++r) {
+    for (size_t d = 0; d < (size_t)W; ++d) cm[r * W + d] = (size_t)gathered_counts[r * (W + 1) + d];
+    owned[r] = (size_t)gathered_counts[r * (W + 1) + W];
+  }
   gp.n = n;
   {
-    std::vector<size_t> cm(counts.size());
-    for (size_t k = 0; k < counts.size(); ++k) cm[k] = (size_t)counts[k];
     gp.send_peer.assign((size_t)W, 0); gp.send_rows.assign((size_t)W, 0);
     gp.recv_peer.assign((size_t)W, 0); gp.recv_first_row.assign((size_t)W, 0); gp.recv_rows.assign((size_t)W, 0);
     int ns = 0, nr = 0;
@@ -602,6 +849,7 @@ int mhip_ghost_plan(mhip_comm_t c, size_t n, const double* aabb, double buffer, 
     MHIP_LAUNCH_CHECK();
   }
   gp.valid = true;
+  if (int e = halo_ipc_plan(c, cm, owned, s)) return e;
   layout->num_ghost_lo = gp.n_lo;
   layout->num_owned = n;
   layout->num_ghost_hi = gp.n_hi;
@@ -896,8 +1144,30 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     rcount[k] = 6 * halo->recv_rows[k];
   }
   const bool has_halo = c->world > 1 && (halo->num_send_peers > 0 || halo->num_recv_peers > 0);
+  // the halo of the current ghost plan can go through the inboxes (same lists, same row numbering)
+  auto& hi = c->hipc;
+  const bool ipc = has_halo && hi.open && hi.plan_ok && c->ghost.valid && halo->velocity != nullptr &&
+                   halo->send_index == c->ghost.send_index_local.as<int32_t>() &&
+                   halo->num_send_peers == (int)c->ghost.send_peer.size() && halo->num_send_peers <= kHaloMaxPeers;
+  HaloPushArgs push{};
+  const unsigned* st_flips = nullptr;
+  const int* st_done = nullptr;
+  const size_t n_ghost = c->ghost.n_lo + c->ghost.n_hi;
+  if (ipc) {
+    push.npeers = halo->num_send_peers;
+    size_t off = 0;
+    for (int k = 0; k < halo->num_send_peers; ++k) {
+      push.base[k] = hi.base[(size_t)halo->send_peer[k]];
+      push.first[k] = (unsigned)off;
+      push.dst_row[k] = (unsigned)hi.dst_first_row[(size_t)k];
+      off += halo->send_rows[k];
+    }
+    push.first[halo->num_send_peers] = (unsigned)off;
+  }
+  const uint32_t seq_base = hi.seq_base;
 
   if (int e = mhip_bbpgd_stage_begin(op, q, space, config, x, g, x_tmp, g_tmp, stream)) return e;
+  stage_state_words(op, &st_flips, &st_done);
   size_t C = 0;
   if (int e = mhip_contact_op_sizes(op, &C, nullptr)) return e;
   MHIP_REQUIRE(interior_contacts <= C, MHIP_ERR_INVALID_ARGUMENT, "interior_contacts %zu exceeds the %zu constraints",
@@ -918,7 +1188,13 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     if (ev) MHIP_HIP(hipEventRecord(ev[0], s));
     if (int e = mhip_bbpgd_stage_body(op, init, stream)) return e;
     if (ev) MHIP_HIP(hipEventRecord(ev[1], s));
-    if (has_halo) {
+    if (ipc) {
+      if (send_total) {   // owned boundary rows straight into the tables' inboxes of the ranks that hold them as ghosts
+        k_halo_push<<<grid_for(send_total * kHaloWords), kBlock, 0, s>>>(push, send_total, halo->send_index,
+                                                                        halo->velocity, seq_base, init, st_flips, st_done);
+        MHIP_LAUNCH_CHECK();
+      }
+    } else if (has_halo) {
       if (send_total)
         if (int e = mhip_gather_rows(send_total, 6, halo->send_index, halo->velocity, c->send_rows.as<double>(), stream))
           return e;
@@ -930,8 +1206,16 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     // interior contacts need only this rank's own rows: swept while the ghost rows are in flight
     if (int e = mhip_bbpgd_stage_constraint_range(op, init, 0, interior_contacts, stream)) return e;
     if (ev) MHIP_HIP(hipEventRecord(ev[3], s));
-    if (has_halo)
+    if (ipc) {
+      if (n_ghost) {   // my ghost rows, as they arrive in my inbox, into the velocity table
+        k_halo_collect<<<grid_for(n_ghost * kHaloWords), kBlock, 0, s>>>(
+            hi.base[(size_t)c->rank], c->ghost.n_lo, c->ghost.n, n_ghost, halo->velocity, seq_base, init, st_flips,
+            st_done, c->mbox.status.as<unsigned long long>(), kMailboxTimeoutTicks);
+        MHIP_LAUNCH_CHECK();
+      }
+    } else if (has_halo) {
       if (int e = mhip_comm_exchange_finish(c, stream)) return e;
+    }
     if (ev) MHIP_HIP(hipEventRecord(ev[4], s));
     if (int e = mhip_bbpgd_stage_constraint_range(op, init, interior_contacts, C - interior_contacts, stream)) return e;
     if (c->mbox.open) {  // the record is posted, and everybody's collected, by the kernel that forms it
@@ -950,7 +1234,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
   int done = 0;
   for (;;) {
     if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
-    if (c->mbox.open)
+    if (c->mbox.open || ipc)
       if (int e = mailbox_check(c, s)) return e;
     if (prof && last_todo) {
       unsigned eff = result->num_iters - iter_before + ((result->converged && result->num_iters < config->max_iters) ? 1u : 0u);
@@ -986,6 +1270,8 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     enqueued += todo;
     last_todo = todo;
   }
+  // numbers of this solve's exchanges: seq_base (init) .. seq_base + iterations + 1; every rank ran the same count
+  hi.seq_base += result->num_iters + 2u;
   return mhip_bbpgd_stage_end(op, result, stream);
 }
 

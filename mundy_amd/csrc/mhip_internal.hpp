@@ -294,6 +294,9 @@ struct MailboxArgs {
 };
 // convex.hip: mhip_bbpgd_stage_reduce with the exchange inside the launch that forms the record
 int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const MailboxArgs& mb, hipStream_t s);
+// convex.hip: where the staged solve keeps its `flips` (completed non-terminal iterations) and `done` words on the
+// device -- the per-iteration halo (dist.hip) numbers its exchanges with the first and skips them on the second
+void stage_state_words(mhip_contact_op_t op, const unsigned** flips, const int** done);
 // Called by the first wave of a workgroup (threads 0 .. 63); `mine` = this rank's record, readable by every lane of the
 // wave (shared or global memory).  Two slot sets alternate: a rank can post exchange k + 2 only after it has read
 // everybody's k + 1, which the others posted after reading everybody's k -- nobody still reads the slots of k when they

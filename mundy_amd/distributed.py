@@ -149,7 +149,7 @@ class Comm:
     tests, where several ranks share one GPU and RCCL refuses duplicate devices), it is the message layer behind the
     library's host-callback transport.  All halo traffic and reductions of the step go through the library."""
 
-    def __init__(self, group=None, mailbox=True):
+    def __init__(self, group=None, mailbox=True, halo_ipc=True):
         lib = capi.load()
         self.group = group
         self.mailbox = False
@@ -191,12 +191,23 @@ class Comm:
             self._callbacks = (capi.EXCHANGE_FN(self._exchange_cb), capi.ALL_GATHER_FN(self._all_gather_cb))
             capi.check(lib.mhip_comm_create_host(C.byref(self._h), self.rank, self.world, self._callbacks[0],
                                                  self._callbacks[1], None))
-        if mailbox and torch.cuda.is_available():
+        self.halo_ipc = False
+        one_node = (mailbox or halo_ipc) and torch.cuda.is_available() and self._ranks_share_a_node()
+        if mailbox and one_node:
             self.mailbox = self._open_mailbox()
+        if halo_ipc and one_node and self.world > 1:
+            # the velocity halo of the iteration through IPC-mapped inboxes instead of send / recv; the inboxes are
+            # opened by the next ghost plan (collective), and anything short of success on every rank keeps send / recv
+            capi.check(lib.mhip_comm_halo_ipc_enable(self._h, 1))
+            self.halo_ipc = True
 
-    def _open_mailbox(self):
-        """The per-iteration reduction record through slots in the ranks' device memory instead of a collective launch
-        (mhip_comm_mailbox_open): ranks of one node only."""
+    def halo_ipc_active(self):
+        """True when the current ghost plan's velocity halo travels through the inboxes (known after a ghost plan)"""
+        a = C.c_int(0)
+        capi.check(capi.load().mhip_comm_halo_ipc_active(self._h, C.byref(a)))
+        return bool(a.value)
+
+    def _ranks_share_a_node(self):
         import socket
         import zlib
         if self.enabled and self.world > 1:
@@ -204,8 +215,12 @@ class Comm:
             host = torch.tensor([zlib.crc32(socket.gethostname().encode())], dtype=torch.int64, device=dev)
             hosts = [torch.zeros_like(host) for _ in range(self.world)]
             dist.all_gather(hosts, host, group=self.group)
-            if any(int(h) != int(host) for h in hosts):
-                return False      # ranks on several nodes: the transport's all-gather stays
+            return all(int(h) == int(host) for h in hosts)
+        return True
+
+    def _open_mailbox(self):
+        """The per-iteration reduction record through slots in the ranks' device memory instead of a collective launch
+        (mhip_comm_mailbox_open): ranks of one node only."""
         opened = C.c_int(0)
         capi.check(capi.load().mhip_comm_mailbox_open(self._h, C.byref(opened), _stream()))
         return bool(opened.value)

@@ -33,8 +33,10 @@ def main():
     D.Comm().self_check()
 
     def make_comm():   # DIST_NO_MAILBOX: the reduction records through the transport's all-gather, as on several nodes
-        comm = D.Comm(mailbox=not os.environ.get("DIST_NO_MAILBOX"))
+        # DIST_NO_HALO_IPC: the velocity halo of the iteration through the transport's send / recv instead of the inboxes
+        comm = D.Comm(mailbox=not os.environ.get("DIST_NO_MAILBOX"), halo_ipc=not os.environ.get("DIST_NO_HALO_IPC"))
         assert not (comm.mailbox and os.environ.get("DIST_NO_MAILBOX"))
+        assert not (comm.halo_ipc and os.environ.get("DIST_NO_HALO_IPC"))
         # (a box that refuses fine-grained IPC memory leaves everybody on the all-gather: the solve must not care;
         # test_mailbox_opens_between_the_ranks_of_the_test_box is the one that insists)
         print("MAILBOX rank %d opened %d" % (rank, int(comm.mailbox)), flush=True)
@@ -53,6 +55,7 @@ def main():
     if os.environ.get("DIST_TIER"):
         st.tiering = int(os.environ["DIST_TIER"])
     stats = st.step(integrate=False)
+    print("HALO_IPC rank %d active %d" % (rank, int(st.comm.halo_ipc_active())), flush=True)
     tier_stats = st.op.tier_stats() if st.op is not None else {}
     gid = st.local["gid"].cpu().numpy().astype(np.int64)
     pairs = st.pairs.cpu().numpy()

@@ -51,6 +51,20 @@ def test_mailbox_opens_between_the_ranks_of_the_test_box():
     assert out.count("MAILBOX rank") == 3 and "opened 0" not in out
 
 
+def test_velocity_halo_through_the_inboxes_of_the_test_box():
+    # three processes sharing the GPU: owned boundary rows written straight into the peers' IPC-mapped inboxes after
+    # the body sweep, ghost rows collected from the own inbox before the boundary sweep -- no send / recv launch inside
+    # the iteration.  Bit for bit the single-rank solve (the worker's checks), over a trajectory with rebuilds (every
+    # ghost plan re-plans the inboxes) and list reuse (the old plan's halo again)
+    out = _run(3, None, {"DIST_STEPS": "6", "DIST_BODIES": "9000"})
+    assert out.count("HALO_IPC rank") == 3 and "active 0" not in out
+
+
+def test_velocity_halo_through_the_transport_instead_of_the_inboxes():
+    out = _run(3, None, {"DIST_NO_HALO_IPC": "1", "DIST_STEPS": "3", "DIST_BODIES": "9000"})
+    assert out.count("HALO_IPC rank") == 3 and "active 1" not in out
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_equals_single_rank(world):
     _run(world, 29610 + world)
