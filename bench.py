@@ -140,6 +140,9 @@ def parse():
                    help="take the partitioned path even with one rank (under torch.distributed.run): one rank over RCCL")
     p.add_argument("--no-mailbox", action="store_true",
                    help="N > 1: the per-iteration reduction records through ncclAllGather instead of the node's mailbox")
+    p.add_argument("--no-halo-ipc", action="store_true",
+                   help="N > 1: the per-iteration velocity halo through grouped ncclSend / ncclRecv instead of the "
+                        "node's IPC-mapped inboxes")
     p.add_argument("--allow-host-transport", action="store_true",
                    help="print a line even when the halo is staged through host memory (gloo) instead of RCCL; "
                         "without it such a run exits with code 3")
@@ -521,7 +524,7 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     del centers
     b = synth.spherocylinders(len(mine), seed=1234, n_total=n_total, indices=mine)
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
-    comm = D.Comm(mailbox=not args.no_mailbox)
+    comm = D.Comm(mailbox=not args.no_mailbox, halo_ipc=not args.no_halo_ipc)
     if comm.transport != "rccl" and not args.allow_host_transport:
         # every rank takes this branch together (the transport is negotiated): a halo staged through host memory is not
         # a measurement of the xGMI path, so no line is printed
@@ -606,7 +609,8 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                                       % (world, "mailbox: IPC-mapped device slots" if comm.mailbox else "ncclAllGather"),
                        "transport": comm.transport,
                        # the per-iteration 5-double record: slots in the ranks' device memory, or the transport's all-gather
-                       "reduction_records": "mailbox" if comm.mailbox else "all-gather"},
+                       "reduction_records": "mailbox" if comm.mailbox else "all-gather",
+                       "velocity_halo": "IPC-mapped inboxes" if comm.halo_ipc_active() else "grouped send / recv"},
             "contact_pairs_per_sec": round(contacts_global * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
             # contacts x iterations per second over all ranks: separates the growth of the BBPGD iteration count with

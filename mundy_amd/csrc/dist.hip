@@ -380,9 +380,11 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
     n_local[d] = lo + owned[d] + hi;
     need = std::max(need, n_local[d]);
   }
+  bool fresh = false;
   if (!h.open || h.capacity < need) {
     if (int e = halo_ipc_open(c, need + need / 2 + 1024, s)) return e;   // (every rank sees the same `need`)
     if (!h.open) return MHIP_SUCCESS;
+    fresh = true;
   } else if (h.own) {
     // stale words of an earlier plan must never carry a number that comes round again: start from zeros (the
     // collectives of the plan that follow order this before any peer's next push)
@@ -405,6 +407,68 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
       for (size_t p = d + 1; p < R; ++p) row += counts[p * W + d];
     }
     h.dst_first_row[k] = row;
+  }
+  if (fresh) {
+    // newly mapped inboxes: the thing itself once, over the wire the solve will use, before a solve depends on it --
+    // every rank pushes rows that name it, collects its ghost rows and checks who they came from; anything short of
+    // success on every rank leaves everybody on send / recv
+    const size_t nl = gp.n_lo + gp.n + gp.n_hi, ng = gp.n_lo + gp.n_hi;
+    double trial_ok = 1.0;
+    DeviceBuffer tv;
+    if (tv.reserve((6 * nl + 8) * sizeof(double)) != MHIP_SUCCESS) trial_ok = 0.0;
+    std::vector<double> hv(6 * nl, -1.0);
+    for (size_t r = gp.n_lo; r < gp.n_lo + gp.n; ++r)
+      for (int k = 0; k < 6; ++k) hv[6 * r + k] = 1000.0 * (double)(c->rank + 1) + 0.125 * k;
+    unsigned long long* stw = c->mbox.status.as<unsigned long long>();
+    if (trial_ok == 1.0) {
+      if (nl) MHIP_HIP(hipMemcpyAsync(tv.ptr, hv.data(), 6 * nl * sizeof(double), hipMemcpyHostToDevice, s));
+      MHIP_HIP(hipMemsetAsync(stw + 3, 0, 2 * sizeof(unsigned long long), s));   // words 3, 4: a zero `done`, a zero `flips`
+      HaloPushArgs push{};
+      push.npeers = (int)gp.send_peer.size();
+      size_t off = 0;
+      for (size_t k = 0; k < gp.send_peer.size(); ++k) {
+        push.base[k] = h.base[(size_t)gp.send_peer[k]];
+        push.first[k] = (unsigned)off;
+        push.dst_row[k] = (unsigned)h.dst_first_row[k];
+        off += gp.send_rows[k];
+      }
+      push.first[gp.send_peer.size()] = (unsigned)off;
+      const unsigned* zflips = reinterpret_cast<const unsigned*>(stw + 4);
+      const int* zdone = reinterpret_cast<const int*>(stw + 3);
+      if (gp.total_send) {
+        k_halo_push<<<grid_for(gp.total_send * kHaloWords), kBlock, 0, s>>>(
+            push, gp.total_send, gp.send_index_local.as<int32_t>(), tv.as<double>(), h.seq_base, 1, zflips, zdone);
+        MHIP_LAUNCH_CHECK();
+      }
+      if (ng) {
+        k_halo_collect<<<grid_for(ng * kHaloWords), kBlock, 0, s>>>(h.base[(size_t)c->rank], gp.n_lo, gp.n, ng,
+                                                                   tv.as<double>(), h.seq_base, 1, zflips, zdone, stw,
+                                                                   kMailboxTimeoutTicks / 4);
+        MHIP_LAUNCH_CHECK();
+      }
+      if (nl) MHIP_HIP(hipMemcpyAsync(hv.data(), tv.ptr, 6 * nl * sizeof(double), hipMemcpyDeviceToHost, s));
+      unsigned long long bad = 0;
+      MHIP_HIP(hipMemcpyAsync(&bad, stw, sizeof(bad), hipMemcpyDeviceToHost, s));
+      MHIP_HIP(hipStreamSynchronize(s));
+      if (bad) {
+        trial_ok = 0.0;
+        MHIP_HIP(hipMemsetAsync(stw, 0, sizeof(unsigned long long), s));   // (the sticky timeout flag of this trial)
+      }
+      for (size_t k = 0; k < gp.recv_peer.size() && trial_ok == 1.0; ++k)
+        for (size_t r = gp.recv_first_row[k]; r < gp.recv_first_row[k] + gp.recv_rows[k]; ++r)
+          for (int q = 0; q < 6; ++q)
+            if (hv[6 * r + q] != 1000.0 * (double)(gp.recv_peer[k] + 1) + 0.125 * q) trial_ok = 0.0;
+    }
+    h.seq_base += 2u;
+    std::vector<double> oks;
+    if (int e = host_all_gather(c, &trial_ok, 1, oks, s)) return e;
+    bool all = true;
+    for (double v : oks) all = all && v == 1.0;
+    if (!all) {
+      halo_ipc_close(c);
+      h.wanted = false;   // (not tried again on this communicator)
+      return MHIP_SUCCESS;
+    }
   }
   h.plan_ok = true;
   return MHIP_SUCCESS;
