@@ -1179,6 +1179,10 @@ __global__ void __launch_bounds__(kBlock) k_fold_partials(int nparts, size_t str
 // tiered: the solve keeps contacts in a cold tier whose iterates are only known to be "x = 0, g > 0"; a step outside
 // [0, finite] would need their exact gradients, so the solve is paused (done = 2) for the host to leave the tiers first.
 template <int MODE>
+__device__ inline void finalize_state(SolverState* __restrict__ st, double rmax, DD numdd, DD dendd, int resid_kind,
+                                      double tol, unsigned max_iters, int tiered,
+                                      unsigned long long* __restrict__ tier_counters);
+template <int MODE>
 __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const double* __restrict__ partials, size_t si,
                                                          size_t sk, SolverState* __restrict__ st, int resid_kind,
                                                          double tol, unsigned max_iters, int tiered = 0,
@@ -1189,6 +1193,12 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
   DD numdd, dendd;
   reduce_records(nparts, partials, si, sk, scratch, rmax, numdd, dendd);
   if (threadIdx.x != 0) return;
+  finalize_state<MODE>(st, rmax, numdd, dendd, resid_kind, tol, max_iters, tiered, tier_counters);
+}
+template <int MODE>
+__device__ inline void finalize_state(SolverState* __restrict__ st, double rmax, DD numdd, DD dendd, int resid_kind,
+                                      double tol, unsigned max_iters, int tiered,
+                                      unsigned long long* __restrict__ tier_counters) {
   if (tier_counters) {
     tier_counters[1] = 0;                 // the fired bodies of this iteration have been dealt with
     tier_counters[2] = tier_counters[0];  // the contacts awake when the next iteration begins
@@ -1221,6 +1231,59 @@ __global__ void __launch_bounds__(kFinalBlock) k_finalize(int nparts, const doub
     if (st->iter >= max_iters) st->done = 1;
     else if (tiered == 2 || (tiered && !(st->step >= 0.0 && st->step <= 1.7976931348623157e308))) st->done = 2;
   }
+}
+
+// Fold and finalize in ONE launch (the fused solve): workgroup b folds slice b of the block partials as k_fold_partials
+// does, publishes its record with write-through stores, takes a ticket, and the workgroup whose ticket is the last
+// finalizes from all the records.  No fence that writes back or invalidates an L2 anywhere (MI355X_MICROARCH.md,
+// hand-offs with sc1 stores / loads): the records are stored with agent-scope relaxed atomics (global_store ... sc1: they
+// leave the XCD's L2 as they are written), the storing lane drains them (s_waitcnt vmcnt(0)) before its agent-scope
+// ticket add, and the last arriver reads them with agent-scope relaxed atomic loads (sc1: served past its L1) only
+// after its add has returned.  Round 1 had tried the ticket with a release / acquire fence pair (3.4 us, as long as the
+// launch it saved); as two launches fold + finalize took 4.8 + 4.8 us of every iteration.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+    k_fold_finalize(int nparts, size_t stride, const double* __restrict__ partials, double* __restrict__ folded,
+                    unsigned* __restrict__ ticket, SolverState* __restrict__ st, int resid_kind, double tol,
+                    unsigned max_iters, int tiered, unsigned long long* __restrict__ tier_counters) {
+  __shared__ double scratch[2 * kBlock / 64];
+  __shared__ int is_last;
+  const int groups = static_cast<int>(gridDim.x);
+  const int per = (nparts + groups - 1) / groups;
+  const int lo = blockIdx.x * per, hi = (lo + per < nparts) ? lo + per : nparts;
+  double rmax;
+  DD num, den;
+  reduce_records(hi > lo ? hi - lo : 0, partials + lo, 1, stride, scratch, rmax, num, den);
+  if (MODE == X_SOLVE && st->done) return;  // (after the loads above: one round trip, not two)
+  if (threadIdx.x == 0) {
+    const double rec[kRed] = {rmax, num.hi, num.lo, den.hi, den.lo};
+#pragma unroll
+    for (int k = 0; k < kRed; ++k)
+      __hip_atomic_store(folded + (size_t)k * groups + blockIdx.x, rec[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == static_cast<unsigned>(groups) - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (threadIdx.x >= 64) return;
+  // the last arriver's first wave: record i by lane i (groups <= 64), the wave's reduction, one lane finalizes
+  double m = kLowest;
+  DD a{0.0, 0.0}, b{0.0, 0.0};
+  const int i = threadIdx.x;
+  if (i < groups) {
+    m = __hip_atomic_load(folded + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.hi = __hip_atomic_load(folded + (size_t)groups + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.lo = __hip_atomic_load(folded + 2 * (size_t)groups + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.hi = __hip_atomic_load(folded + 3 * (size_t)groups + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b.lo = __hip_atomic_load(folded + 4 * (size_t)groups + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  m = wave_max(m);
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+  finalize_state<MODE>(st, m, a, b, resid_kind, tol, max_iters, tiered, tier_counters);
 }
 
 // block partials -> one (max, num, den) record of kRed doubles (this rank's contribution to the all-gather of SURVEY
@@ -1892,6 +1955,12 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
 #ifndef MHIP_FOLD_ABOVE
 #define MHIP_FOLD_ABOVE 4096
 #endif
+#ifndef MHIP_FOLD_FINALIZE
+#define MHIP_FOLD_FINALIZE 1
+#endif
+#ifndef MHIP_FOLD_BLOCK
+#define MHIP_FOLD_BLOCK 256
+#endif
 inline void fold_partials(unsigned& nparts, size_t& stride, double*& parts, const SolverState* st, int check_done,
                           hipStream_t s) {
   if (nparts <= MHIP_FOLD_ABOVE) return;  // one workgroup reads a few thousand triples as fast as a second launch would
@@ -2288,6 +2357,8 @@ int tier_update(mhip_contact_op* op, TierPairs& cur, unsigned iters_done, unsign
   MHIP_HIP(hipStreamSynchronize(s));
   const size_t H = static_cast<size_t>(H32);
 #ifdef MHIP_TIER_DEBUG
+  fprintf(stderr, "compact active entries at the last snapshot but one: %d of %zu half edges\n",
+          *reinterpret_cast<const int32_t*>(op->host_state + 1), 2 * C);
   fprintf(stderr, "tier_update: iter %u last_period %u next %u scale %.2f  H %zu of I %zu (%.3f)  active %d awake %llu\n",
           iters_done, last_period, next_period, scale, H, I, (double)H / (double)I, (int)t.active, awake);
 #endif
@@ -3076,10 +3147,19 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       }
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k + 2], s));
       double* pp = parts;
-      fold_partials(np, ps, pp, st, 1, s);
-      k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters,
-                                                        tier.active ? op->tiering : 0,
-                                                        tier.active ? op->view.tier_counters : nullptr);
+      if (MHIP_FOLD_FINALIZE && np > MHIP_FOLD_ABOVE) {
+        // (folded records behind the kRed planes of partials, as fold_partials places them; the ticket word lives in
+        // the spare words behind the solver state and is left at zero by every launch that finalizes)
+        k_fold_finalize<X_SOLVE><<<kFoldGroups, MHIP_FOLD_BLOCK, 0, s>>>(
+            (int)np, ps, pp, pp + kRed * ps, reinterpret_cast<unsigned*>(op->state.as<char>() + sizeof(SolverState) + 16),
+            st, rk, config->tol, config->max_iters, tier.active ? op->tiering : 0,
+            tier.active ? op->view.tier_counters : nullptr);
+      } else {
+        fold_partials(np, ps, pp, st, 1, s);
+        k_finalize<X_SOLVE><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, rk, config->tol, config->max_iters,
+                                                          tier.active ? op->tiering : 0,
+                                                          tier.active ? op->view.tier_counters : nullptr);
+      }
       MHIP_LAUNCH_CHECK();
     }
     enqueued += todo;

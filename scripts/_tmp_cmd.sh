@@ -1,7 +1,4 @@
-python3 scripts/stream_ceiling.py > /dev/null 2>&1
-for flags in "" "-DMHIP_STREAM_GRID=1048576" "-DMHIP_STREAM_GRID=1048576 -DMHIP_STREAM_UNROLL=2" "-DMHIP_STREAM_GRID=1048576 -DMHIP_STREAM_UNROLL=8" "-DMHIP_STREAM_GRID=2048" ""; do
-  export MHIP_EXTRA_HIPCC_FLAGS="$flags"
-  python3 -m mundy_amd.build > /dev/null 2>&1
-  echo "[$flags]"; python3 scripts/stream_ceiling.py 2>/dev/null | head -5
-done
+export MHIP_EXTRA_HIPCC_FLAGS="-DMHIP_TIER_DEBUG"
+python3 -m mundy_amd.build > /dev/null 2>&1
+python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --relaxed-steps 0 2>&1 | grep -E "tier_update|compact active" | head -40
 unset MHIP_EXTRA_HIPCC_FLAGS; python3 -m mundy_amd.build > /dev/null 2>&1
