@@ -165,6 +165,8 @@ def parse():
                    help="--mixed: LABELLED build option -- the ellipsoid minimisation classes from the build with "
                         "floating-point contraction on (results at the reference's 1e-4 tolerance instead of bit parity "
                         "with the oracle).  Never the default; the line says which arithmetic ran.")
+    p.add_argument("--friction-method", choices=("bbpgd", "apgd"), default="bbpgd",
+                   help="--friction: the reference's BBPGD iteration with a cone projection, or APGD (Mazhar et al. 2015)")
     p.add_argument("--friction", type=float, default=None,
                    help="BUILD EXTENSION, parity unpinned: Coulomb coefficient of the cone-complementarity solver "
                         "(the reference has no frictional solver; default = its frictionless LCP).  N = 1 only.")
@@ -252,7 +254,7 @@ def main():
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
     stepper = pipeline.ContactStepper("spherocylinder", center, radius, quat, length, dt=5e-3, viscosity=1e-3,
                                       search_buffer=args.buffer, search_kind=ops.SEARCH_AABB, cfg=cfg,
-                                      friction=args.friction)
+                                      friction=args.friction, friction_method=args.friction_method)
     if args.xcd_tile >= 0 or args.lanes_per_body > 0:
         stepper.work_mapping = (args.xcd_tile, args.lanes_per_body)
     if args.no_cold_tier:
@@ -393,7 +395,7 @@ def main():
             out["metric"] = "timesteps/sec, 10^6 spherocylinders per GPU, FRICTIONAL cone-complementarity contact (build extension)"
             out["config"]["workload"] = out["config"]["workload"].replace(
                 "frictionless LCP", "EXTENSION (parity unpinned): Coulomb friction mu = %g as a cone complementarity "
-                "problem," % args.friction)
+                "problem (%s)," % (args.friction, args.friction_method.upper()))
         out.update(extra)
         print(json.dumps(out))
     if dist is not None:

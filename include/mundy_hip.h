@@ -403,6 +403,14 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
 int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, double mu,
                                       const mhip_pgd_config* config /*[host]*/, double* p, double* g,
                                       mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
+/* The same problem, arguments, result and stopping rule by APGD -- Nesterov-accelerated projected gradient descent with
+ * adaptive restart and a backtracked curvature estimate (Mazhar, Heyn, Negrut, Tasora 2015: the algorithm BASELINE's
+ * north star names, and the paper mundy_math/convex.hpp:476 cites), arranged so that a sweep is ONE operator application
+ * (the gradient at the extrapolated point is the same extrapolation of the two stored gradients).  num_iters counts
+ * every sweep, refused steps included.  BUILD EXTENSION like the BBPGD form: the reference has no frictional solver. */
+int mhip_apgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, double mu,
+                                      const mhip_pgd_config* config /*[host]*/, double* p, double* g,
+                                      mhip_solve_result* result /*[host]*/, mhip_stream_t stream);
 /* Staged form of the same fused iteration for domain-decomposed runs: the host interleaves the halo
  * exchange and the cross-rank reduction between the stages, all asynchronously on `stream`:
  *     begin;  body(init) -> [ghost velocity halo] -> constraint(init, local) -> [all-gather local] -> finalize(init)

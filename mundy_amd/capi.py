@@ -139,6 +139,7 @@ SIGNATURES = {
     "mhip_bbpgd_solve_contact": [_vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
                                  C.POINTER(SolveResult), _vp],
     "mhip_bbpgd_solve_contact_friction": [_vp, _vp, _d, C.POINTER(PgdConfig), _vp, _vp, C.POINTER(SolveResult), _vp],
+    "mhip_apgd_solve_contact_friction": [_vp, _vp, _d, C.POINTER(PgdConfig), _vp, _vp, C.POINTER(SolveResult), _vp],
     "mhip_solve_small_cqpp_batch": [_sz, _i, _vp, _vp, C.POINTER(Space), C.POINTER(PgdConfig), _vp, _vp, _vp, _vp,
                                     _vp, _vp],
     "mhip_scrap_bbpgd_solve_contact": [_vp, _vp, _d, C.c_uint, _vp, _vp, _vp, _vp, C.POINTER(SolveResult),

@@ -1861,6 +1861,206 @@ __global__ void __launch_bounds__(kBlock) k_finish_friction(size_t C, const Solv
   }
 }
 
+
+// ---- APGD for the same cone complementarity problem (BUILD EXTENSION, parity unpinned like the rest of this block) ----------
+// Accelerated projected gradient descent with adaptive restart (Mazhar, Heyn, Negrut, Tasora 2015 -- the paper
+// mundy_math/convex.hpp:476 cites for the residual), arranged so that an iteration is ONE operator application:
+//   y   = p_k + beta (p_k - p_{k-1}),  g_y = g_k + beta (g_k - g_{k-1})      (g = N p + q is affine: no second sweep)
+//   p+  = Proj_K(y - g_y / L),  g+ = N p+ + q                                (body sweep + constraint sweep, as BBPGD)
+//   accept iff  (p+ - y) . (g+ - g_y) <= L |p+ - y|^2   -- the sufficient-decrease test f(p+) <= f(y) + g_y.(p+ - y) +
+//               L/2 |p+ - y|^2 with f(p+) - f(y) written out (d . N d against L d . d: no cancellation of large f's);
+//               otherwise L <- 2 L and the iteration is repeated from the same (p_k, p_{k-1}, beta)
+//   accepted:   converged iff the Linf projected-difference residual of (p+, g+) <= tol;
+//               theta+ = (-theta^2 + theta sqrt(theta^2 + 4)) / 2,  beta+ = theta (1 - theta) / (theta^2 + theta+);
+//               restart (beta+ = 0, theta+ = 1) iff g_y . (p+ - p_k) > 0;  L <- 0.9 L
+// Three packed (p, g) buffers rotate (current, previous, new): a rejected iterate is simply overwritten.  L starts at
+// the initial residual (the reciprocal of BBPGD's first step).  Every sweep -- accepted or rejected -- counts as an iteration.
+struct ApgdState {
+  double L, theta, beta;
+  int cur, prev, nxt;     // which of the three buffers holds p_k, p_{k-1}, and receives p+
+  unsigned rejected;      // sweeps whose step was refused
+};
+constexpr int kApgdRed = 7;  // max residual term; (p+ - y).(g+ - g_y), |p+ - y|^2, g_y.(p+ - p_k) as double-double pairs
+struct ApgdBufs {
+  double* P[3];
+};
+// the iterate a contact carries in an APGD sweep (bitwise the same wherever it is evaluated)
+__device__ inline V3 apgd_iterate(const ApgdBufs& B, const ApgdState& a, size_t c, V3 n, double mu, V3* y_out,
+                                  V3* gy_out, V3* pk_out) {
+  const PG k = load_pg(B.P[a.cur], c), m = load_pg(B.P[a.prev], c);
+  const V3 y{k.p.x + a.beta * (k.p.x - m.p.x), k.p.y + a.beta * (k.p.y - m.p.y), k.p.z + a.beta * (k.p.z - m.p.z)};
+  const V3 gy{k.g.x + a.beta * (k.g.x - m.g.x), k.g.y + a.beta * (k.g.y - m.g.y), k.g.z + a.beta * (k.g.z - m.g.z)};
+  if (y_out) *y_out = y;
+  if (gy_out) *gy_out = gy;
+  if (pk_out) *pk_out = k.p;
+  const double t = 1.0 / a.L;
+  return project_cone(V3{y.x + (-t) * gy.x, y.y + (-t) * gy.y, y.z + (-t) * gy.z}, n, mu);
+}
+template <int G, int U>
+__global__ void __launch_bounds__(kBlock)
+    k_body_friction_apgd(OpView op, const SolverState* __restrict__ st, const ApgdState* __restrict__ as, ApgdBufs B,
+                         double mu) {
+  if (st->done) return;
+  const ApgdState a = *as;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const int sub = static_cast<int>(t % G);
+  if (t / G >= op.body_count) return;
+  const size_t b = op.body_first + t / G;
+  DD3 Fdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, Tdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+  const int32_t beg = op.inc_ptr[b], end = op.inc_ptr[b + 1];
+  for (int32_t k0 = beg + sub; k0 < end; k0 += G * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int32_t k = k0 + u * G;
+      if (k >= end) continue;
+      const int32_t e = op.inc[k];
+      const double2* H2 = reinterpret_cast<const double2*>(op.half + (size_t)k * 6);
+      const double2 h0 = H2[0], h1 = H2[1], h2 = H2[2];
+      const V3 n{h0.x, h0.y, h1.x}, r{h1.y, h2.x, h2.y};
+      const V3 p = apgd_iterate(B, a, static_cast<size_t>(e >> 1), n, mu, nullptr, nullptr, nullptr);
+      const V3 f = (e & 1) ? p : V3{-p.x, -p.y, -p.z};
+      dd_add(Fdd, f);
+      dd_add(Tdd, cross(r, f));
+    }
+  }
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) {
+    dd_add(Fdd.x, dd_shfl_xor(Fdd.x, off)); dd_add(Fdd.y, dd_shfl_xor(Fdd.y, off)); dd_add(Fdd.z, dd_shfl_xor(Fdd.z, off));
+    dd_add(Tdd.x, dd_shfl_xor(Tdd.x, off)); dd_add(Tdd.y, dd_shfl_xor(Tdd.y, off)); dd_add(Tdd.z, dd_shfl_xor(Tdd.z, off));
+  }
+  if (sub != 0) return;
+  const V3 F = dd_value(Fdd), T = dd_value(Tdd);
+  const double mt = op.mt[b], mr = op.mr[b];
+  double2* v = reinterpret_cast<double2*>(op.vel + 6 * b);
+  v[0] = make_double2(mt * F.x, mt * F.y);
+  v[1] = make_double2(mt * F.z, mr * T.x);
+  v[2] = make_double2(mr * T.y, mr * T.z);
+}
+__global__ void __launch_bounds__(kBlock)
+    k_constraint_friction_apgd(OpView op, const SolverState* __restrict__ st, const ApgdState* __restrict__ as,
+                               ApgdBufs B, const double* __restrict__ sep, double mu, double* __restrict__ partials) {
+  __shared__ double scratch[2 * kBlock / 64];
+  if (st->done) return;
+  const ApgdState a = *as;
+  double* Pn = B.P[a.nxt];
+  double rmax = kLowest;
+  DD sa{0.0, 0.0}, sb{0.0, 0.0}, sr{0.0, 0.0};
+  const size_t ntiles = (op.C + kBlock - 1) / kBlock;
+  for (size_t lin = blockIdx.x; lin < ntiles; lin += gridDim.x) {
+    const size_t c = lin * kBlock + threadIdx.x;
+    if (c >= op.C) continue;
+    const int2 ij = op.pairs[c];
+    const V3 n = load3(op.normal, c);
+    V3 y, gy, pk;
+    const V3 p = apgd_iterate(B, a, c, n, mu, &y, &gy, &pk);
+    const double2* vi2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.x);
+    const double2* vj2 = reinterpret_cast<const double2*>(op.vel + 6 * (size_t)ij.y);
+    const double2 a0 = vi2[0], a1 = vi2[1], a2 = vi2[2], b0 = vj2[0], b1 = vj2[1], b2 = vj2[2];
+    const V3 vi = V3{a0.x, a0.y, a1.x} + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
+    const V3 vj = V3{b0.x, b0.y, b1.x} + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+    const double q = sep[c];
+    const V3 g{op.dt * (vj.x - vi.x) + q * n.x, op.dt * (vj.y - vi.y) + q * n.y, op.dt * (vj.z - vi.z) + q * n.z};
+    store_pg(Pn, c, p, g);
+    if (op.counted == nullptr || op.counted[c]) {
+      const V3 w = project_cone(V3{p.x - kSmallStep * g.x, p.y - kSmallStep * g.y, p.z - kSmallStep * g.z}, n, mu);
+      const double r = fmax(fabs(p.x - w.x), fmax(fabs(p.y - w.y), fabs(p.z - w.z)));
+      if (r > rmax) rmax = r;
+      const V3 d = p - y;
+      dd_add(sa, dot(d, g - gy));
+      dd_add(sb, dot(d, d));
+      dd_add(sr, dot(gy, p - pk));
+    }
+  }
+  const double m = block_max(rmax, scratch);
+  const DD s1 = block_sum(sa, scratch);
+  const DD s2 = block_sum(sb, scratch);
+  const DD s3 = block_sum(sr, scratch);
+  if (threadIdx.x == 0) {
+    const size_t stride = gridDim.x, slot = blockIdx.x;
+    partials[slot] = m;
+    partials[stride + slot] = s1.hi;
+    partials[2 * stride + slot] = s1.lo;
+    partials[3 * stride + slot] = s2.hi;
+    partials[4 * stride + slot] = s2.lo;
+    partials[5 * stride + slot] = s3.hi;
+    partials[6 * stride + slot] = s3.lo;
+  }
+}
+// after the INIT sweeps (k_finalize<X_INIT> has set residual / converged): the APGD state of a new solve
+__global__ void k_apgd_begin(const SolverState* __restrict__ st, ApgdState* __restrict__ as) {
+  as->L = st->residual;   // 1 / L = BBPGD's first step (convex.hpp:626-627)
+  if (!(as->L > 0.0)) as->L = 1.0;
+  as->theta = 1.0;
+  as->beta = 0.0;
+  as->cur = 0;            // the INIT sweep wrote (p_0, g_0) into buffer 0; p_{-1} = p_0
+  as->prev = 0;
+  as->nxt = 1;
+  as->rejected = 0;
+}
+__global__ void __launch_bounds__(kFinalBlock)
+    k_apgd_finalize(int nparts, const double* __restrict__ partials, SolverState* __restrict__ st,
+                    ApgdState* __restrict__ as, double tol, unsigned max_iters) {
+  __shared__ double scratch[2 * kFinalBlock / 64];
+  if (st->done) return;
+  double rmax = kLowest;
+  DD sa{0.0, 0.0}, sb{0.0, 0.0}, sr{0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+    if (partials[i] > rmax) rmax = partials[i];
+    dd_add(sa, DD{partials[(size_t)nparts + i], partials[2 * (size_t)nparts + i]});
+    dd_add(sb, DD{partials[3 * (size_t)nparts + i], partials[4 * (size_t)nparts + i]});
+    dd_add(sr, DD{partials[5 * (size_t)nparts + i], partials[6 * (size_t)nparts + i]});
+  }
+  rmax = block_max(rmax, scratch);
+  sa = block_sum(sa, scratch);
+  sb = block_sum(sb, scratch);
+  sr = block_sum(sr, scratch);
+  if (threadIdx.x != 0) return;
+  const double A = dd_value(sa), Bq = dd_value(sb), R = dd_value(sr);
+  st->iter += 1;  // every sweep counts
+  if (A > as->L * Bq) {  // not enough decrease for this L: twice the curvature, same (p_k, p_{k-1}, beta) again
+    as->L *= 2.0;
+    as->rejected += 1;
+    if (st->iter >= max_iters) st->done = 1;
+    return;
+  }
+  const double res = rmax / kSmallStep;
+  st->residual = res;
+  st->step = 1.0 / as->L;
+  const int accepted = as->nxt;
+  if (res <= tol) {
+    st->converged = 1;
+    st->done = 1;
+    as->cur = accepted;  // (k_finish_friction_apgd reads the solution from here)
+    return;
+  }
+  const double th = as->theta;
+  double th1 = (-(th * th) + th * sqrt(th * th + 4.0)) / 2.0;
+  double beta = th * (1.0 - th) / (th * th + th1);
+  if (R > 0.0) {  // the momentum points uphill: restart (O'Donoghue & Candes' gradient scheme, as APGD uses it)
+    beta = 0.0;
+    th1 = 1.0;
+  }
+  as->theta = th1;
+  as->beta = beta;
+  as->L *= 0.9;
+  const int old_cur = as->cur;
+  as->prev = old_cur;
+  as->cur = accepted;
+  as->nxt = 3 - old_cur - accepted;  // the buffer that is neither the new current nor the new previous
+  st->flips += 1;
+  if (st->iter >= max_iters) st->done = 1;
+}
+__global__ void __launch_bounds__(kBlock)
+    k_finish_friction_apgd(size_t C, const SolverState* __restrict__ st, const ApgdState* __restrict__ as, ApgdBufs B,
+                           double* __restrict__ p, double* __restrict__ g) {
+  const double* cur = st->converged_at_init ? B.P[0] : B.P[as->cur];
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const PG s = load_pg(cur, c);
+    store3(p, c, s.p);
+    store3(g, c, s.g);
+  }
+}
+
 }  // namespace mhip
 
 using namespace mhip;
@@ -3327,6 +3527,81 @@ int mhip_bbpgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, d
     if (chunk < 64) chunk *= 2;
   }
   k_finish_friction<<<grid_for(C), kBlock, 0, s>>>(C, st, P0, P1, p, g);
+  MHIP_LAUNCH_CHECK();
+  MHIP_HIP(hipStreamSynchronize(s));
+  result->num_iters = op->host_state->iter;
+  result->residual = op->host_state->residual;
+  result->converged = op->host_state->converged;
+  return MHIP_SUCCESS;
+}
+
+/* BUILD EXTENSION (parity unpinned): the same cone complementarity problem by APGD -- Nesterov-accelerated projected
+ * gradient descent with adaptive restart and a backtracked curvature estimate (Mazhar et al. 2015), one operator
+ * application per iteration (see k_constraint_friction_apgd).  Same arguments, result and stopping rule as
+ * mhip_bbpgd_solve_contact_friction; num_iters counts every sweep, refused steps included. */
+int mhip_apgd_solve_contact_friction(mhip_contact_op_t op, const double* sep, double mu, const mhip_pgd_config* config,
+                                     double* p, double* g, mhip_solve_result* result, mhip_stream_t stream) {
+  TraceRange trace_range("solve_friction_contact, APGD (extension)");
+  MHIP_REQUIRE(op != nullptr && result != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null handle / result");
+  if (int e = check_config(config)) return e;
+  MHIP_REQUIRE(config->residual_kind == MHIP_RESIDUAL_PROJECTED_DIFF, MHIP_ERR_INVALID_ARGUMENT,
+               "the friction extension supports the projected-difference residual only");
+  MHIP_REQUIRE(mu >= 0.0 && mu == mu, MHIP_ERR_INVALID_ARGUMENT, "friction coefficient must be >= 0, got %g", mu);
+  MHIP_REQUIRE(op->kin == KIN_RIGID, MHIP_ERR_INVALID_ARGUMENT,
+               "friction needs the vector-arm operator (mhip_contact_op_create with ra, rb, mob_rot)");
+  const size_t C = op->view.C;
+  hipStream_t s = as_stream(stream);
+  if (C == 0) {
+    result->num_iters = 0;
+    result->residual = kLowest / kSmallStep;
+    result->converged = 1;
+    return MHIP_SUCCESS;
+  }
+  MHIP_REQUIRE(sep && p && g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not be null");
+  MHIP_REQUIRE(p != g, MHIP_ERR_INVALID_ARGUMENT, "solver vectors must not alias");
+  MHIP_REQUIRE((reinterpret_cast<uintptr_t>(op->view.half) & 15) == 0, MHIP_ERR_RUNTIME, "misaligned records");
+  if (int e = op->iterate.reserve((3 * (6 * C + 2) + 16) * sizeof(double))) return e;
+  ApgdBufs B;
+  B.P[0] = op->iterate.as<double>();
+  B.P[1] = B.P[0] + 6 * C + 2;
+  B.P[2] = B.P[1] + 6 * C + 2;
+  ApgdState* as = reinterpret_cast<ApgdState*>(B.P[2] + 6 * C + 2);
+  SolverState* st = op->state.as<SolverState>();
+  double* parts = op->partials.as<double>();
+  const unsigned cgrid = constraint_grid(C);
+  static_assert(kApgdRed * kMaxConstraintGrid <= kRed * (int)kStageStride, "partials buffer holds the APGD records");
+  const int G = 8;
+  const unsigned bgrid = grid_exact(op->view.body_count * (size_t)G);
+  op->last_stream = s;
+  // p_0, g_0 = N p_0 + q and the initial residual: the INIT sweeps of the BBPGD extension (buffer 0 receives them)
+  if (op->view.body_count > 0) k_body_friction<true, 8, 2><<<bgrid, kBlock, 0, s>>>(op->view, st, B.P[0], B.P[1], p, mu);
+  k_constraint_friction<true><<<cgrid, kBlock, 0, s>>>(op->view, st, B.P[0], B.P[1], p, sep, mu, parts);
+  {
+    unsigned np = cgrid;
+    size_t ps = cgrid;
+    double* pp = parts;
+    fold_partials(np, ps, pp, st, 0, s);
+    k_finalize<X_INIT><<<1, final_block(np), 0, s>>>((int)np, pp, 1, ps, st, config->residual_kind, config->tol,
+                                                     config->max_iters);
+  }
+  k_apgd_begin<<<1, 1, 0, s>>>(st, as);
+  MHIP_LAUNCH_CHECK();
+  unsigned enqueued = 0, chunk = 8;
+  for (;;) {
+    MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+    if (op->host_state->done || enqueued >= config->max_iters) break;
+    const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
+    for (unsigned k = 0; k < todo; ++k) {
+      if (op->view.body_count > 0) k_body_friction_apgd<8, 2><<<bgrid, kBlock, 0, s>>>(op->view, st, as, B, mu);
+      k_constraint_friction_apgd<<<cgrid, kBlock, 0, s>>>(op->view, st, as, B, sep, mu, parts);
+      k_apgd_finalize<<<1, kFinalBlock, 0, s>>>((int)cgrid, parts, st, as, config->tol, config->max_iters);
+    }
+    MHIP_LAUNCH_CHECK();
+    enqueued += todo;
+    if (chunk < 64) chunk *= 2;
+  }
+  k_finish_friction_apgd<<<grid_for(C), kBlock, 0, s>>>(C, st, as, B, p, g);
   MHIP_LAUNCH_CHECK();
   MHIP_HIP(hipStreamSynchronize(s));
   result->num_iters = op->host_state->iter;

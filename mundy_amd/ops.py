@@ -643,7 +643,7 @@ def solve_cqpp(A, q, space, x0, cfg=None, state=None, fused=True):
     return x, g, SolveResult(int(res.num_iters), float(res.residual), bool(res.converged))
 
 
-def solve_friction_contact(A, sep, mu, p0=None, cfg=None):
+def solve_friction_contact(A, sep, mu, p0=None, cfg=None, method="bbpgd"):
     """BUILD EXTENSION, parity unpinned (the reference has no frictional solver): Coulomb friction as a
     cone complementarity problem on the vector-arm ContactOperator A (lever arms to the contact points ON THE
     SURFACES), solved by the fused BBPGD iteration with a per-contact cone projection.  Returns (p [C,3] world-frame
@@ -653,8 +653,10 @@ def solve_friction_contact(A, sep, mu, p0=None, cfg=None):
     p = torch.zeros((c, 3), dtype=torch.float64, device=sep.device) if p0 is None else p0.clone()
     g = torch.empty_like(p)
     res, pc = capi.SolveResult(), _cfg(cfg)
-    capi.check(capi.load().mhip_bbpgd_solve_contact_friction(A._h, _ptr(sep), float(mu), C.byref(pc), _ptr(p, cols=3),
-                                                             _ptr(g, cols=3), C.byref(res), _stream()))
+    if method not in ("bbpgd", "apgd"):   # "apgd": Mazhar et al. 2015, one operator application per sweep
+        raise ValueError("method must be 'bbpgd' or 'apgd'")
+    fn = capi.load().mhip_bbpgd_solve_contact_friction if method == "bbpgd" else capi.load().mhip_apgd_solve_contact_friction
+    capi.check(fn(A._h, _ptr(sep), float(mu), C.byref(pc), _ptr(p, cols=3), _ptr(g, cols=3), C.byref(res), _stream()))
     return p, g, SolveResult(int(res.num_iters), float(res.residual), bool(res.converged))
 
 

@@ -33,7 +33,7 @@ class ContactStepper:
     def __init__(self, kind, center, radius, quat=None, length=None, *, dt=5e-3, viscosity=1e-3, search_buffer=0.25,
                  search_kind=ops.SEARCH_AABB, periodic_box=None, cfg=None, warm_start=False, mob_trans=None,
                  mob_rot=None, rod_kinematics=True, kinds=None, shape=None, friction=None, contact_cutoff=None,
-                 conservative_ellipsoid_box=False):
+                 conservative_ellipsoid_box=False, friction_method="bbpgd"):
         """kind = "sphere" | "spherocylinder" | "mixed".  Mixed systems (BASELINE configs[4]) pass kinds [n] int32
         (0 sphere, 1 spherocylinder, 2 ellipsoid) and shape [n, 3] = (r,-,-) / (r,L,-) / (r1,r2,r3) instead of
         radius / length."""
@@ -52,6 +52,7 @@ class ContactStepper:
         # BUILD EXTENSION (parity unpinned: the reference has no frictional solver): Coulomb coefficient, None = the
         # reference's frictionless LCP
         self.friction = None if friction is None else float(friction)
+        self.friction_method = friction_method   # "bbpgd" or "apgd" (ops.solve_friction_contact)
         self.center, self.radius, self.quat, self.length = center, radius, quat, length
         self.kinds, self.shape = kinds, shape
         self.dt, self.viscosity = float(dt), float(viscosity)
@@ -222,7 +223,8 @@ class ContactStepper:
             ra, rb = ops.surface_lever_arms(pairs, c["normal"], c["ra"], c["rb"], self.radius)
             self.op = ops.ContactOperator(pairs, c["normal"], self.mob_trans, self.dt, ra=ra, rb=rb,
                                           mob_rot=self.mob_rot)
-            p, g, res = ops.solve_friction_contact(self.op, c["sep"], self.friction, cfg=self.cfg)
+            p, g, res = ops.solve_friction_contact(self.op, c["sep"], self.friction, cfg=self.cfg,
+                                                   method=self.friction_method)
             self.impulse, self.lam = p, (p * c["normal"]).sum(dim=1)
             return res
         if self.kind == "spherocylinder" and self.rod_kinematics:

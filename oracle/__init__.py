@@ -450,18 +450,23 @@ def solve_cqpp_contact(pairs, normal, ra, rb, mt, mr, dt, q, x0, space=(LOWER_BO
     return x, g, _result(it, res, conv)
 
 
-def solve_friction_contact(pairs, normal, ra, rb, mt, mr, dt, sep, mu, p0=None, max_iters=10000, tol=1e-5):
-    """BUILD EXTENSION, parity unpinned (the reference has no frictional solver): BBPGD on the cone complementarity
-    problem with world-frame impulses p [C, 3]; returns (p, g, result)."""
+def solve_friction_contact(pairs, normal, ra, rb, mt, mr, dt, sep, mu, p0=None, max_iters=10000, tol=1e-5,
+                           method="bbpgd"):
+    """BUILD EXTENSION, parity unpinned (the reference has no frictional solver): BBPGD (or, method="apgd", the
+    accelerated projected gradient descent of Mazhar et al. 2015) on the cone complementarity problem with world-frame
+    impulses p [C, 3]; returns (p, g, result)."""
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     normal, ra, rb, mt, mr, sep = _f(normal), _f(ra), _f(rb), _f(mt), _f(mr), _f(sep)
     c = len(pairs)
     p = np.zeros((c, 3)) if p0 is None else _f(p0).copy()
     g = np.zeros((c, 3))
     it, res, conv = C.c_uint(), C.c_double(), C.c_int()
-    lib().o_solve_friction_contact(C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(normal), _p(ra), _p(rb), _p(mt),
-                                   _p(mr), C.c_double(dt), _p(sep), C.c_double(mu), C.c_uint(max_iters),
-                                   C.c_double(tol), _p(p), _p(g), C.byref(it), C.byref(res), C.byref(conv))
+    if method not in ("bbpgd", "apgd"):
+        raise ValueError("method must be 'bbpgd' or 'apgd'")
+    fn = lib().o_solve_friction_contact if method == "bbpgd" else lib().o_solve_friction_contact_apgd
+    fn(C.c_size_t(c), C.c_size_t(len(mt)), _p(pairs), _p(normal), _p(ra), _p(rb), _p(mt),
+       _p(mr), C.c_double(dt), _p(sep), C.c_double(mu), C.c_uint(max_iters),
+       C.c_double(tol), _p(p), _p(g), C.byref(it), C.byref(res), C.byref(conv))
     return p, g, _result(it, res, conv)
 
 

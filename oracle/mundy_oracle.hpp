@@ -1441,6 +1441,102 @@ inline SolveResult solve_friction_contact(const FrictionOp& op, double mu, unsig
   return out;
 }
 
+// BUILD EXTENSION (parity unpinned): the same cone complementarity problem by APGD (Mazhar, Heyn, Negrut, Tasora 2015),
+// as the device runs it (csrc/convex.hip, k_constraint_friction_apgd): one operator application per sweep,
+//   y = p_k + beta (p_k - p_{k-1}),  g_y = g_k + beta (g_k - g_{k-1}),  p+ = Proj_K(y - g_y / L),  g+ = N p+ + q,
+//   accepted iff (p+ - y).(g+ - g_y) <= L |p+ - y|^2 (else L <- 2 L and again), converged iff the projected-difference
+//   residual of (p+, g+) <= tol, theta / beta by Nesterov's recursion, restart iff g_y.(p+ - p_k) > 0, L <- 0.9 L,
+//   L_0 = the initial residual.  num_iters counts every sweep.
+inline SolveResult solve_friction_contact_apgd(const FrictionOp& op, double mu, unsigned max_iters, double tol, double* p,
+                                               double* g) {
+  const size_t C = op.C;
+  auto nrm = [&](size_t c) { return V3{op.normal[3 * c], op.normal[3 * c + 1], op.normal[3 * c + 2]}; };
+  auto residual = [&](const double* x, const double* gr) {
+    double r = -1.7976931348623157e308;
+    for (size_t c = 0; c < C; ++c) {
+      const V3 pc{x[3 * c], x[3 * c + 1], x[3 * c + 2]}, gc{gr[3 * c], gr[3 * c + 1], gr[3 * c + 2]};
+      const V3 w = project_cone(pc - gc * 1e-6, nrm(c), mu);
+      for (int k = 0; k < 3; ++k) r = std::max(r, std::fabs(pc[k] - w[k]));
+    }
+    return r / 1e-6;
+  };
+  std::vector<double> P[3], G[3];
+  for (int b = 0; b < 3; ++b) {
+    P[b].assign(3 * C, 0.0);
+    G[b].assign(3 * C, 0.0);
+  }
+  std::copy(p, p + 3 * C, P[0].begin());
+  op.gradient(P[0].data(), G[0].data());
+  SolveResult out{0, residual(P[0].data(), G[0].data()), false};
+  auto finish = [&](int b) {
+    std::copy(P[b].begin(), P[b].end(), p);
+    std::copy(G[b].begin(), G[b].end(), g);
+  };
+  if (out.residual <= tol || max_iters == 0) {
+    out.converged = out.residual <= tol;
+    finish(0);
+    return out;
+  }
+  double L = out.residual, theta = 1.0, beta = 0.0;
+  if (!(L > 0.0)) L = 1.0;
+  int cur = 0, prev = 0, nxt = 1;
+  std::vector<double> y(3 * C), gy(3 * C);
+  while (out.num_iters < max_iters) {
+    const double t = 1.0 / L;
+    for (size_t c = 0; c < C; ++c) {
+      V3 v;
+      for (int k = 0; k < 3; ++k) {
+        const size_t q = 3 * c + k;
+        y[q] = P[cur][q] + beta * (P[cur][q] - P[prev][q]);
+        gy[q] = G[cur][q] + beta * (G[cur][q] - G[prev][q]);
+        v[k] = y[q] + (-t) * gy[q];
+      }
+      const V3 w = project_cone(v, nrm(c), mu);
+      for (int k = 0; k < 3; ++k) P[nxt][3 * c + k] = w[k];
+    }
+    op.gradient(P[nxt].data(), G[nxt].data());
+    ++out.num_iters;
+    Acc sa, sb, sr;
+    for (size_t c = 0; c < C; ++c) {
+      V3 d, dg, gyc, dk;
+      for (int k = 0; k < 3; ++k) {
+        const size_t q = 3 * c + k;
+        d[k] = P[nxt][q] - y[q];
+        dg[k] = G[nxt][q] - gy[q];
+        gyc[k] = gy[q];
+        dk[k] = P[nxt][q] - P[cur][q];
+      }
+      sa.add(dot(d, dg));
+      sb.add(dot(d, d));
+      sr.add(dot(gyc, dk));
+    }
+    if (sa.value() > L * sb.value()) {
+      L *= 2.0;
+      continue;
+    }
+    out.residual = residual(P[nxt].data(), G[nxt].data());
+    if (out.residual <= tol) {
+      out.converged = true;
+      finish(nxt);
+      return out;
+    }
+    double th1 = (-(theta * theta) + theta * std::sqrt(theta * theta + 4.0)) / 2.0;
+    beta = theta * (1.0 - theta) / (theta * theta + th1);
+    if (sr.value() > 0.0) {
+      beta = 0.0;
+      th1 = 1.0;
+    }
+    theta = th1;
+    L *= 0.9;
+    const int old_cur = cur;
+    prev = old_cur;
+    cur = nxt;
+    nxt = 3 - old_cur - cur;
+  }
+  finish(cur);
+  return out;
+}
+
 // The scrap app's own matrix-free BBPGD (scrap/lcp_spheres/NgpLcp.cpp:558-759, DRY mobility), serial order.
 // Differs from convex.hpp's PGDStrategy: Dai-Fletcher residual with a 1e-12 active-set test (:376-405), strict `<`
 // convergence test, BB1/BB2 alternating by the parity of ite_count with `|b| < 1e-12 -> b += 1e-12` (:716-731),

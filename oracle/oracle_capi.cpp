@@ -432,6 +432,16 @@ void o_solve_friction_contact(size_t C, size_t N, const int32_t* pairs, const do
   *res = r.residual;
   *converged = r.converged;
 }
+void o_solve_friction_contact_apgd(size_t C, size_t N, const int32_t* pairs, const double* normal, const double* ra,
+                                   const double* rb, const double* mt, const double* mr, double dt, const double* sep,
+                                   double mu, unsigned max_iters, double tol, double* p, double* g, unsigned* num_iters,
+                                   double* res, int* converged) {
+  FrictionOp op{pairs, normal, ra, rb, mt, mr, sep, dt, C, N, {}, {}, {}, {}};
+  const SolveResult r = solve_friction_contact_apgd(op, mu, max_iters, tol, p, g);
+  *num_iters = r.num_iters;
+  *res = r.residual;
+  *converged = r.converged;
+}
 void o_project_cone(size_t n, const double* v, const double* nrm, double mu, double* out) {
   for (size_t i = 0; i < n; ++i) st3(out, i, project_cone(ld3(v, i), ld3(nrm, i), mu));
 }

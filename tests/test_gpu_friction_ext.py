@@ -129,3 +129,40 @@ def test_friction_at_full_size_on_the_relaxed_packing(ops, oracle):
     pt = (p - pn[:, None] * c["normal"]).norm(dim=1)
     assert int((pt > 1e-6).sum()) > 10_000          # friction is at work
     st.op.close()
+
+
+@pytest.mark.parametrize("mu", [0.0, 0.3, 1.0])
+def test_apgd_matches_its_oracle_and_the_cone_conditions(ops, oracle, mu):
+    # BUILD EXTENSION: APGD (Mazhar et al. 2015) on the GPU against the serial statement of the same algorithm in
+    # oracle/ (double-double sums on both sides: the same accept / restart decisions, hence the same sweep count),
+    # the cone complementarity conditions, and BBPGD's gradient
+    from gpu_util import dev, host
+    from test_oracle_friction_ext import _rod_system, cone_checks
+    P = _rod_system(oracle, 2500, seed=13)
+    tol = 1e-6
+    op = _op(ops, P)
+    cfg = ops.PGDConfig(max_iters=50000, tol=tol)
+    p, g, r = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=cfg, method="apgd")
+    with oracle.compensated_sums():
+        po, go, ro = oracle.solve_friction_contact(P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"], 5e-3,
+                                                   P["sep"], mu, max_iters=50000, tol=tol, method="apgd")
+    assert r.converged and ro["converged"] and r.residual <= tol
+    print("friction mu=%g, APGD: sweeps gpu %d oracle %d" % (mu, r.num_iters, ro["num_iters"]))
+    assert abs(r.num_iters - ro["num_iters"]) <= 2
+    cone_checks(host(p), host(g), P["normal"], mu, tol)
+    np.testing.assert_allclose(host(g), go, atol=40 * tol)
+    pb, gb, rb = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=cfg)
+    assert rb.converged
+    np.testing.assert_allclose(host(g), host(gb), atol=40 * tol)
+    if mu > 0:
+        assert r.num_iters < rb.num_iters
+    # deterministic; an iteration cap returns the last accepted iterate
+    p2, g2, r2 = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=cfg, method="apgd")
+    assert r2.num_iters == r.num_iters and np.array_equal(host(p2), host(p))
+    p3, g3, r3 = ops.solve_friction_contact(op, dev(P["sep"]), mu, cfg=ops.PGDConfig(max_iters=9, tol=tol), method="apgd")
+    assert not r3.converged and r3.num_iters == 9
+    with oracle.compensated_sums():
+        p3o, g3o, r3o = oracle.solve_friction_contact(P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"], 5e-3,
+                                                      P["sep"], mu, max_iters=9, tol=tol, method="apgd")
+    np.testing.assert_allclose(host(p3), p3o, rtol=1e-9, atol=1e-12)
+    op.close()

@@ -84,3 +84,27 @@ def test_friction_solution_satisfies_the_cone_complementarity_conditions(oracle,
     pt = np.linalg.norm(p - pn[:, None] * P["normal"], axis=1)
     assert (pt > 1e-6).sum() > 10          # friction is really engaged somewhere
     assert pn.max() > 0
+
+
+@pytest.mark.parametrize("mu", [0.0, 0.3, 1.0])
+def test_apgd_reaches_the_same_solution_in_fewer_sweeps(oracle, mu):
+    # BUILD EXTENSION: APGD (Mazhar, Heyn, Negrut, Tasora 2015) on the same cone complementarity problem and with the
+    # same stopping rule as the BBPGD form: the cone conditions hold, the gradient (the unique part of the solution)
+    # agrees with BBPGD's, and with friction it gets there in fewer operator applications
+    P = _rod_system(oracle, 2500, seed=13)
+    tol = 1e-6
+    args = (P["pairs"], P["normal"], P["ras"], P["rbs"], P["mt"], P["mr"], 5e-3, P["sep"], mu)
+    pb, gb, rb = oracle.solve_friction_contact(*args, max_iters=50000, tol=tol)
+    pa, ga, ra = oracle.solve_friction_contact(*args, max_iters=50000, tol=tol, method="apgd")
+    assert rb["converged"] and ra["converged"] and ra["residual"] <= tol
+    cone_checks(pa, ga, P["normal"], mu, tol)
+    np.testing.assert_allclose(ga, gb, atol=40 * tol)
+    print("mu=%g: sweeps apgd %d, bbpgd %d" % (mu, ra["num_iters"], rb["num_iters"]))
+    if mu > 0:
+        assert ra["num_iters"] < rb["num_iters"]
+    # an iteration cap ends it unconverged with the last accepted iterate (still in the cone)
+    pc, gc, rc = oracle.solve_friction_contact(*args, max_iters=7, tol=tol, method="apgd")
+    assert not rc["converged"] and rc["num_iters"] == 7
+    pn = (pc * P["normal"]).sum(1)
+    pt = np.linalg.norm(pc - pn[:, None] * P["normal"], axis=1)
+    assert np.all(pt <= mu * pn + 1e-12 * (1 + np.abs(pn)))
