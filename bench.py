@@ -165,7 +165,7 @@ def parse():
                    help="--mixed: LABELLED build option -- the ellipsoid minimisation classes from the build with "
                         "floating-point contraction on (results at the reference's 1e-4 tolerance instead of bit parity "
                         "with the oracle).  Never the default; the line says which arithmetic ran.")
-    p.add_argument("--friction-method", choices=("bbpgd", "apgd"), default="bbpgd",
+    p.add_argument("--friction-method", choices=("bbpgd", "apgd"), default="apgd",
                    help="--friction: the reference's BBPGD iteration with a cone projection, or APGD (Mazhar et al. 2015)")
     p.add_argument("--friction", type=float, default=None,
                    help="BUILD EXTENSION, parity unpinned: Coulomb coefficient of the cone-complementarity solver "
