@@ -1086,8 +1086,8 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
     if (KIN == KIN_RIGID) {
       const double2 a2 = vi2[2], b2 = vj2[2];
-      vi = vi + cross(V3{a1.y, a2.x, a2.y}, load3(op.ra, c));
-      vj = vj + cross(V3{b1.y, b2.x, b2.y}, load3(op.rb, c));
+      vi = vi + cross(V3{a1.y, a2.x, a2.y}, ld_s3<NTC>(op.ra, c));
+      vj = vj + cross(V3{b1.y, b2.x, b2.y}, ld_s3<NTC>(op.rb, c));
     }
     if (KIN == KIN_ROD) {
       const double2 a2 = vi2[2], b2 = vj2[2];
@@ -1578,38 +1578,8 @@ __global__ void __launch_bounds__(kBlock)
     cnt[t] = __popcll(m);
   }
 }
-// G lanes per body copy its flagged entries and records (HW doubles each) in slot order
-template <int HW>
-__global__ void __launch_bounds__(kBlock)
-    k_active_fill(size_t first, size_t count, const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ inc,
-                  const double* __restrict__ half, const unsigned long long* __restrict__ body_mask,
-                  const int32_t* __restrict__ aptr_local, int32_t* __restrict__ aptr, int32_t* __restrict__ aent,
-                  double* __restrict__ arec, unsigned long long* __restrict__ snap_mask, size_t n_all) {
-  for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < count; t += (size_t)gridDim.x * blockDim.x) {
-    const size_t b = first + t;
-    const int32_t beg = inc_ptr[b], deg = inc_ptr[b + 1] - beg;
-    unsigned long long m = body_mask[b];
-    if (deg < 64) m &= (1ull << deg) - 1ull;
-    snap_mask[b] = m;
-    int32_t out = aptr_local[t];
-    aptr[b] = out;
-    if (t + 1 == count) aptr[b + 1] = aptr_local[count];
-    while (m) {
-      const int bit = __ffsll(static_cast<long long>(m)) - 1;
-      m &= m - 1ull;
-      const size_t k = static_cast<size_t>(beg + bit);
-      aent[out] = inc[k];
-      const double* src = half + k * HW;
-      double* dst = arec + static_cast<size_t>(out) * HW;
-#pragma unroll
-      for (int w = 0; w < HW; ++w) dst[w] = src[w];
-      ++out;
-    }
-  }
-  (void)n_all;
-}
-
-// The same copy with the OUTPUT slots dealt to the lanes (one lane per body walked its flagged entries one after the
+// The flagged entries and their records (HW doubles each), body by body in slot order, with the OUTPUT slots dealt to
+// the lanes (one lane per body walked its flagged entries one after the
 // other, 8 bytes at a time: 1.4 TB/s): a workgroup takes 256 bodies, keeps their masks, list starts and output offsets
 // in LDS, and every lane then fills output slots o, o + 256, ... of the tile -- it finds the body by bisection of the
 // offsets and the entry as the (o - offset)-th set bit of its mask.  Stores are contiguous, loads come from the tile's
