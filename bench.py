@@ -676,7 +676,7 @@ def cpu_baseline(b, stepper, args, gpu_iters):
     per_iter = t["solve_sample"] / (k + 1)  # k iterations + the initial operator apply
     step_s = t["aabb"] + t["search"] + t["narrow"] + per_iter * (gpu_iters + 1)
     return {"value": round(1.0 / step_s, 6), "unit": "timesteps/s", "cores": threads, "kind": "port",
-            "sample": "full-size AABB (%.2fs, OpenMP), cell-list search (%.2fs, 1 thread), narrow phase (%.2fs, "
+            "sample": "full-size AABB (%.2fs, OpenMP), cell-list search (%.2fs, OpenMP), narrow phase (%.2fs, "
                       "OpenMP) once + %d BBPGD iterations on %d OpenMP threads (%.3fs/iter), solve extrapolated to the "
                       "GPU's %d iterations; contacts %d" % (t["aabb"], t["search"], t["narrow"], k, threads, per_iter,
                                                            gpu_iters, len(pairs))}
@@ -719,7 +719,7 @@ def cpu_baseline_mixed(b, st, pristine, args, gpu_iters):
     per_iter = t["solve_sample"] / (k + 1)
     step_s = t["aabb"] + t["search"] + narrow + per_iter * (gpu_iters + 1)
     return {"value": round(1.0 / step_s, 6), "unit": "timesteps/s", "cores": threads, "kind": "port",
-            "sample": "full-size AABB (%.2fs, OpenMP) and cell-list search (%.2fs, 1 thread) once; narrow phase on every "
+            "sample": "full-size AABB (%.2fs, OpenMP) and cell-list search (%.2fs, OpenMP) once; narrow phase on every "
                       "%dth pair (%d pairs, %.2fs on %d OpenMP threads; x%d = %.1fs); %d BBPGD iterations of the full LCP "
                       "(%.3fs/iter) extrapolated to the GPU's %d; contacts %d (pair list equal to the GPU's: %s)"
                       % (t["aabb"], t["search"], stride, len(sample), t["narrow_sample"], threads, stride, narrow, k,

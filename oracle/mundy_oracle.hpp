@@ -1752,8 +1752,16 @@ inline void search_celllist(int kind, size_t n, const double* lo, const double* 
     std::vector<int32_t> cur(head.begin(), head.end() - 1);
     for (size_t i = 0; i < n; ++i) order[cur[cellid[i]]++] = static_cast<int32_t>(i);
   }
+  // rows of consecutive bodies in chunks, the chunks on the OpenMP threads (the CPU baseline runs this on all host
+  // cores); every chunk keeps its own pair list and the lists are joined in chunk order: the same list as a serial walk
+  constexpr size_t kChunk = 2048;
+  const size_t nchunks = (n + kChunk - 1) / kChunk;
+  std::vector<std::vector<int32_t>> chunk_pairs(nchunks);
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t ch = 0; ch < nchunks; ++ch) {
   std::vector<int32_t> row;
-  for (size_t i = 0; i < n; ++i) {
+  std::vector<int32_t>& pairs = chunk_pairs[ch];  // (shadows the output list inside the chunk)
+  for (size_t i = ch * kChunk; i < std::min(n, (ch + 1) * kChunk); ++i) {
     row.clear();
     const int cx = cellid[i] % nc[0], cy = (cellid[i] / nc[0]) % nc[1], cz = cellid[i] / (nc[0] * nc[1]);
     int seen[27];
@@ -1787,6 +1795,11 @@ inline void search_celllist(int kind, size_t n, const double* lo, const double* 
       pairs.push_back(j);
     }
   }
+  }
+  size_t total = 0;
+  for (const auto& cp : chunk_pairs) total += cp.size();
+  pairs.reserve(total);
+  for (const auto& cp : chunk_pairs) pairs.insert(pairs.end(), cp.begin(), cp.end());
 }
 
 // ---------------------------------------------------------------------------------------------------------------
