@@ -2280,7 +2280,7 @@ constexpr double kTierMinGap = 1e-9;        // a contact goes cold only with g a
 // 34.2 ms, 3.8M 94 / 108 ms, 7.6M 150 / 190 ms; scripts/tier_crossover.py)
 constexpr size_t kTierMinContacts = 1500000;
 #ifndef MHIP_TIER_RETIER_PERCENT
-#define MHIP_TIER_RETIER_PERCENT 6  // (10: 149.1 ms per step at 10^6 rods, 6: 147.3 -- a third renumbering at iteration 248)
+#define MHIP_TIER_RETIER_PERCENT 4  // (round 2: 10 -> 149.1 ms per step at 10^6 rods, 6 -> 147.3; round 3, tiers from iteration 56: 10 -> 133.6, 4 -> 133.2 with a fourth renumbering)
 #endif
 constexpr unsigned kTierHorizon = 64;  // iterations a sleeper's slack is sized for, at least
 // share of a sleeper's gradient g0 each of its two bodies may drift by: g stays above (1 - 2 share) g0 > 0.  Round 2
