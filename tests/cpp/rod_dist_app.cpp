@@ -97,6 +97,8 @@ int main(int argc, char** argv) {
     int opened = 0;
     check(mhip_comm_mailbox_open(comm, &opened, nullptr));
     std::printf("MAILBOX rank %d opened %d\n", rank, opened);
+    // ... and the per-iteration velocity halo through the inboxes (opened by the first ghost plan; send / recv otherwise)
+    check(mhip_comm_halo_ipc_enable(comm, world > 1 ? 1 : 0));
   }
 
   const size_t base = n / world, rem = n % world;
