@@ -134,3 +134,20 @@ def test_partitioned_line_is_configs3_and_refuses_a_host_staged_halo():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["scaling"] == "weak" and "PER GPU" in d["metric"]
+
+
+def test_gpus_2_without_a_launcher_prints_a_two_rank_line():
+    # `python bench.py --gpus 2` with no launcher around it starts its own (a child torch.distributed.run) and relays
+    # rank 0's line: n_gpus == --gpus.  Two ranks share the test box's one GPU here (gloo; the halo of the partitioned
+    # path goes through the inboxes, the records through the mailbox), which is why the host transport is allowed.
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bodies", "40000", "--steps", "1",
+                        "--warmup", "1", "--allow-host-transport"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(env, MUNDY_BENCH_BACKEND="gloo"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_total"] == 40000
+    assert d["config"]["velocity_halo"] in ("IPC-mapped inboxes", "grouped send / recv")
+    assert all(d["config"]["converged"])
