@@ -598,10 +598,20 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   // (a template parameter: carried as a run-time flag the bookkeeping cost the untracked sweep 6 % in registers)
   constexpr bool track = TRACK && MODE == X_SOLVE && PACKED;
   V3 dF{0.0, 0.0, 0.0}, dS{0.0, 0.0, 0.0};
+  // With 3 x 256 entries per chunk the workgroup's 36 KB of LDS allow four workgroups per CU, i.e. 128 VGPRs per lane:
+  // there the words the END of the sweep needs (drift, firing threshold) are fetched now, beside the others, instead of
+  // costing one more memory round trip in the life of every workgroup; with 2 x 256 entries (five workgroups per CU at
+  // <= 96 VGPRs) the extra registers would cost a wave per SIMD (measured: + 9 %), so they stay where they are used.
+  constexpr bool kEarlyTail = FLAT && FLATP >= 3 && track;
+  double drift_old = 0.0, fire_thr = 0.0;
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
     if (KIN == KIN_ROD) axis = load3(op.axis, b);
+    if (kEarlyTail) {
+      drift_old = op.drift[b];
+      if (op.fire_at != nullptr) fire_thr = op.fire_at[b];
+    }
   }
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
@@ -851,9 +861,9 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     }
     // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|, dW = mr dT
     if (KIN == KIN_RIGID) d += op.arm_max[b] * mr * (fabs(dS.x) + fabs(dS.y) + fabs(dS.z));
-    const double D = op.drift[b] + op.dt * d;
+    const double D = (kEarlyTail ? drift_old : op.drift[b]) + op.dt * d;
     op.drift[b] = D;
-    if (op.fire_at != nullptr && !(D < op.fire_at[b]))  // one of its sleeping contacts has used up its share of slack
+    if (op.fire_at != nullptr && !(D < (kEarlyTail ? fire_thr : op.fire_at[b])))  // one of its sleeping contacts has used up its share of slack
       op.fired[atomicAdd(&op.tier_counters[1], 1ull)] = static_cast<int32_t>(b);
   }
 }
