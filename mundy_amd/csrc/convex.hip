@@ -603,7 +603,10 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   // costing one more memory round trip in the life of every workgroup; with 2 x 256 entries (five workgroups per CU at
   // <= 96 VGPRs) the extra registers would cost a wave per SIMD (measured: + 9 %), so they stay where they are used.
   constexpr bool kEarlyTail = FLAT && FLATP >= 3 && track;
+  constexpr bool kEarlySnap = FLAT && FLATP >= 3;
   double drift_old = 0.0, fire_thr = 0.0;
+  unsigned long long snap_early = 0ull;
+  if (kEarlySnap && op.aptr != nullptr && op.body_mask != nullptr) snap_early = op.snap_mask[b];
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
@@ -785,7 +788,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     const int32_t head = (end - beg < 64) ? end - beg : 64;
     unsigned long long mm = op.body_mask[b];
     if (head < 64) mm &= (1ull << head) - 1ull;
-    if (op.aptr != nullptr) mm &= ~op.snap_mask[b];
+    if (op.aptr != nullptr) mm &= ~(kEarlySnap ? snap_early : op.snap_mask[b]);
     if (FLAT && !has_body) mm = 0ull;
     int32_t kk[U];
 #pragma unroll
