@@ -1089,22 +1089,40 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     const size_t c = op.c_first + xcd_tile(lin, ntiles, op.xcd_aware) * kBlock + threadIdx.x;
     if (c >= op.c_end) continue;
     constexpr bool NTC = (MHIP_NT & 2) != 0 && MODE == X_SOLVE && PACKED;
+    // every load that depends on nothing but c first (the ISA of the round-2 form fetched the second arclength and q
+    // each behind a wait of its own: two more memory round trips in the life of every workgroup), then the gathers of
+    // the two body rows, which depend on the pair
     const int2 ij = ld_s<NTC>(op.pairs + c);
-    double x_old = 0.0, g_old = 0.0;
-    const double xc = iterate_x<MODE, PACKED, NTC>(c, xt, gt, step, step_is_zero, sp, &x_old, &g_old);
+    const double2 pold = iterate_load<MODE, PACKED, NTC>(c, xt, gt);
     const V3 n = ld_s3<NTC>(op.normal, c);
+    double arc_i = 0.0, arc_j = 0.0;
+    V3 arm_i{0.0, 0.0, 0.0}, arm_j{0.0, 0.0, 0.0};
+    if (KIN == KIN_ROD) {
+      arc_i = ld_s<NTC>(op.arc_s + c);
+      arc_j = ld_s<NTC>(op.arc_t + c);
+    }
+    if (KIN == KIN_RIGID) {
+      arm_i = ld_s3<NTC>(op.ra, c);
+      arm_j = ld_s3<NTC>(op.rb, c);
+    }
+    const double qc = (MODE != X_APPLY) ? ld_s<NTC>(q + c) : 0.0;
     const double2* vi2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.x);
     const double2* vj2 = reinterpret_cast<const double2*>(vel + 6 * (size_t)ij.y);
     const double2 a0 = vi2[0], a1 = vi2[1], b0 = vj2[0], b1 = vj2[1];
+    double2 a2 = make_double2(0.0, 0.0), b2 = make_double2(0.0, 0.0);
+    if (KIN != KIN_TRANS) {
+      a2 = vi2[2];
+      b2 = vj2[2];
+    }
+    const double x_old = (MODE == X_SOLVE) ? pold.x : 0.0, g_old = (MODE == X_SOLVE) ? pold.y : 0.0;
+    const double xc = iterate_value<MODE>(pold, step, step_is_zero, sp);
     V3 vi{a0.x, a0.y, a1.x}, vj{b0.x, b0.y, b1.x};
     if (KIN == KIN_RIGID) {
-      const double2 a2 = vi2[2], b2 = vj2[2];
-      vi = vi + cross(V3{a1.y, a2.x, a2.y}, ld_s3<NTC>(op.ra, c));
-      vj = vj + cross(V3{b1.y, b2.x, b2.y}, ld_s3<NTC>(op.rb, c));
+      vi = vi + cross(V3{a1.y, a2.x, a2.y}, arm_i);
+      vj = vj + cross(V3{b1.y, b2.x, b2.y}, arm_j);
     }
     if (KIN == KIN_ROD) {
-      const double2 a2 = vi2[2], b2 = vj2[2];
-      const double ci = rod_arm_coef(ld_s<NTC>(op.arc_s + c)), cj = rod_arm_coef(ld_s<NTC>(op.arc_t + c));
+      const double ci = rod_arm_coef(arc_i), cj = rod_arm_coef(arc_j);
       vi = vi + ci * V3{a1.y, a2.x, a2.y};
       vj = vj + cj * V3{b1.y, b2.x, b2.y};
     }
@@ -1114,7 +1132,7 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
     if (MODE == X_APPLY) {
       gn[c] = y;
     } else {
-      const double g = 1.0 * ld_s<NTC>(q + c) + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
+      const double g = 1.0 * qc + 1.0 * y;  // axpby(1, q, 1, grad)  (convex.hpp:623, :651)
       if (PACKED) {
         reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
         if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
