@@ -606,7 +606,15 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   constexpr bool kEarlySnap = FLAT && FLATP >= 3;
   double drift_old = 0.0, fire_thr = 0.0;
   unsigned long long snap_early = 0ull;
-  if (kEarlySnap && op.aptr != nullptr && op.body_mask != nullptr) snap_early = op.snap_mask[b];
+  if (kEarlySnap) {
+    // (an UNCONDITIONAL load from a pointer chosen on the scalar side: inside a branch the compiler complemented the
+    // word on the spot, i.e. waited for it -- a full memory round trip in front of everything else.  Without a
+    // snapshot the word read is never used; the body rows are always there to be read.)
+    const unsigned long long* src = (op.aptr != nullptr && op.body_mask != nullptr)
+                                        ? op.snap_mask
+                                        : reinterpret_cast<const unsigned long long*>(op.vel);
+    snap_early = src[b];
+  }
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
