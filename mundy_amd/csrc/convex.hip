@@ -615,6 +615,12 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
                                         : reinterpret_cast<const unsigned long long*>(op.vel);
     snap_early = src[b];
   }
+  unsigned long long mask_early = 0ull;  // (the body's activity mask: used after the flat stream, asked for now)
+  if (kEarlySnap) {
+    const unsigned long long* src = (op.body_mask != nullptr) ? op.body_mask
+                                                              : reinterpret_cast<const unsigned long long*>(op.vel);
+    mask_early = src[b];
+  }
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
@@ -716,24 +722,35 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
           // phase A: FLATP entries per lane, all their loads in flight together
           int32_t fe[FLATP];
           double2 r0[FLATP], r1[FLATP], r2[FLATP];
+          // (the entries of all passes first: the gathers wait for them alone while the records are still on their way;
+          // a slot past the end of the range reads the range's last entry and is dropped -- unconditional loads keep the
+          // code straight-line, so the wait counts are exact)
+          bool live[FLATP];
 #pragma unroll
           for (int p = 0; p < FLATP; ++p) {
             const int32_t k = base + p * kBlock + static_cast<int32_t>(threadIdx.x);
-            fe[p] = (k < E1) ? ld_s<NTS>(op.aent + k) : -1;
-            r0[p] = r1[p] = r2[p] = make_double2(0.0, 0.0);
-            if (k < E1) {
-              if (KIN == KIN_TRANS) {
-                const double* H = op.arec + static_cast<size_t>(k) * HW;
-                r0[p] = make_double2(ld_s<NTS>(H), ld_s<NTS>(H + 1));
-                r1[p] = make_double2(ld_s<NTS>(H + 2), 0.0);
-              } else {
-                const double2* H2 = reinterpret_cast<const double2*>(op.arec + static_cast<size_t>(k) * HW);
-                r0[p] = ld_s<NTS>(H2);
-                r1[p] = ld_s<NTS>(H2 + 1);
-                if (KIN == KIN_RIGID) r2[p] = ld_s<NTS>(H2 + 2);
-              }
+            live[p] = k < E1;
+            fe[p] = ld_s<NTS>(op.aent + (live[p] ? k : E1 - 1));
+          }
+#pragma unroll
+          for (int p = 0; p < FLATP; ++p) {
+            const int32_t k0 = base + p * kBlock + static_cast<int32_t>(threadIdx.x);
+            const size_t k = static_cast<size_t>(live[p] ? k0 : E1 - 1);
+            r2[p] = make_double2(0.0, 0.0);
+            if (KIN == KIN_TRANS) {
+              const double* H = op.arec + k * HW;
+              r0[p] = make_double2(ld_s<NTS>(H), ld_s<NTS>(H + 1));
+              r1[p] = make_double2(ld_s<NTS>(H + 2), 0.0);
+            } else {
+              const double2* H2 = reinterpret_cast<const double2*>(op.arec + k * HW);
+              r0[p] = ld_s<NTS>(H2);
+              r1[p] = ld_s<NTS>(H2 + 1);
+              if (KIN == KIN_RIGID) r2[p] = ld_s<NTS>(H2 + 2);
             }
           }
+#pragma unroll
+          for (int p = 0; p < FLATP; ++p)
+            if (!live[p]) fe[p] = -1;
           double2 pit[FLATP];
 #pragma unroll
           for (int p = 0; p < FLATP; ++p)
@@ -794,7 +811,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
       }
     }
     const int32_t head = (end - beg < 64) ? end - beg : 64;
-    unsigned long long mm = op.body_mask[b];
+    unsigned long long mm = kEarlySnap ? mask_early : op.body_mask[b];
     if (head < 64) mm &= (1ull << head) - 1ull;
     if (op.aptr != nullptr) mm &= ~(kEarlySnap ? snap_early : op.snap_mask[b]);
     if (FLAT && !has_body) mm = 0ull;
