@@ -1301,7 +1301,8 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock)
     k_fold_finalize(int nparts, size_t stride, const double* __restrict__ partials, double* __restrict__ folded,
                     unsigned* __restrict__ ticket, SolverState* __restrict__ st, int resid_kind, double tol,
-                    unsigned max_iters, int tiered, unsigned long long* __restrict__ tier_counters) {
+                    unsigned max_iters, int tiered, unsigned long long* __restrict__ tier_counters,
+                    MailboxArgs mb = MailboxArgs{}) {
   __shared__ double scratch[2 * kBlock / 64];
   __shared__ int is_last;
   const int groups = static_cast<int>(gridDim.x);
@@ -1337,6 +1338,31 @@ __global__ void __launch_bounds__(kBlock)
   m = wave_max(m);
   a = wave_sum(a);
   b = wave_sum(b);
+  if (mb.peers != nullptr) {
+    // ranks of one node (the staged solve): what has been added up so far is THIS RANK's record; it goes to
+    // everybody's mailbox, everybody's records come back into shared memory, and their sum -- formed as k_finalize
+    // forms it from the all-gathered records: record r by lane r, the wave's reduction -- is what is finalized
+    __shared__ double record[kRed];
+    __shared__ double world_records[kMailboxMaxWorld * kRed];
+    if (threadIdx.x == 0) store_partial(record, 1, 0, m, a, b);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    mailbox_exchange_wave(mb, record, world_records);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    m = kLowest;
+    a = DD{0.0, 0.0};
+    b = DD{0.0, 0.0};
+    if (i < mb.world) {
+      const double* r = world_records + (size_t)i * kRed;
+      if (r[0] > m) m = r[0];
+      dd_add(a, DD{r[1], r[2]});
+      dd_add(b, DD{r[3], r[4]});
+    }
+    m = wave_max(m);
+    a = wave_sum(a);
+    b = wave_sum(b);
+  }
   if (threadIdx.x != 0) return;
   __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
   finalize_state<MODE>(st, m, a, b, resid_kind, tol, max_iters, tiered, tier_counters);
@@ -2896,6 +2922,30 @@ void stage_state_words(mhip_contact_op_t op, const unsigned** flips, const int**
   const SolverState* st = op->state.as<SolverState>();
   *flips = &st->flips;
   *done = &st->done;
+}
+int stage_reduce_exchange_finalize(mhip_contact_op_t op, int init, const MailboxArgs& mb, hipStream_t s) {
+  MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");
+  MHIP_REQUIRE(mb.peers != nullptr && mb.width == kRed && mb.world >= 1 && mb.world <= kMailboxMaxWorld,
+               MHIP_ERR_INVALID_ARGUMENT, "mailbox of %d ranks, record width %d", mb.world, mb.width);
+  const unsigned np = op->stage.part_used;
+  const size_t ps = kStageStride;
+  double* pp = op->partials.as<double>();
+  const auto& cfg = op->stage.cfg;
+  SolverState* st = op->state.as<SolverState>();
+  // (folded records behind the kRed planes of partials, ticket word behind the solver state: as in the fused solve)
+  unsigned* ticket = reinterpret_cast<unsigned*>(op->state.as<char>() + sizeof(SolverState) + 16);
+  if (init)
+    k_fold_finalize<X_INIT><<<kFoldGroups, MHIP_FOLD_BLOCK, 0, s>>>((int)np, ps, pp, pp + kRed * ps, ticket, st,
+                                                                     cfg.residual_kind, cfg.tol, cfg.max_iters, 0,
+                                                                     nullptr, mb);
+  else
+    k_fold_finalize<X_SOLVE><<<kFoldGroups, MHIP_FOLD_BLOCK, 0, s>>>(
+        (int)np, ps, pp, pp + kRed * ps, ticket, st, cfg.residual_kind, cfg.tol, cfg.max_iters,
+        op->stage.pause_on_bad_step ? ((op->tiering == 2 && op->stage.polls >= 10) ? 2 : 1) : 0,
+        op->tier.active ? op->view.tier_counters : nullptr, mb);
+  MHIP_LAUNCH_CHECK();
+  op->stage.part_used = 0;
+  return MHIP_SUCCESS;
 }
 int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const MailboxArgs& mb, hipStream_t s) {
   MHIP_REQUIRE(op != nullptr && op->stage.active, MHIP_ERR_RUNTIME, "mhip_bbpgd_stage_begin has not been called");

@@ -1282,6 +1282,12 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     }
     if (ev) MHIP_HIP(hipEventRecord(ev[4], s));
     if (int e = mhip_bbpgd_stage_constraint_range(op, init, interior_contacts, C - interior_contacts, stream)) return e;
+    if (c->mbox.open && c->world <= kMailboxMaxWorld) {
+      // the record is formed, posted, everybody's collected and the iteration finalized in one launch
+      if (int e = stage_reduce_exchange_finalize(op, init, mailbox_next(c, kRed, gathered), s)) return e;
+      if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
+      return MHIP_SUCCESS;
+    }
     if (c->mbox.open) {  // the record is posted, and everybody's collected, by the kernel that forms it
       if (int e = stage_reduce_exchange(op, init, local3, mailbox_next(c, kRed, gathered), s)) return e;
       if (ev) MHIP_HIP(hipEventRecord(ev[5], s));

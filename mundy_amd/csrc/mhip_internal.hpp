@@ -294,6 +294,9 @@ struct MailboxArgs {
 };
 // convex.hip: mhip_bbpgd_stage_reduce with the exchange inside the launch that forms the record
 int stage_reduce_exchange(mhip_contact_op_t op, int init, double* local, const MailboxArgs& mb, hipStream_t s);
+// convex.hip: the same and mhip_bbpgd_stage_finalize in ONE launch (fold, record, exchange, finalize)
+int stage_reduce_exchange_finalize(mhip_contact_op_t op, int init, const MailboxArgs& mb, hipStream_t s);
+constexpr int kMailboxMaxWorld = 64;  // ranks whose records one wave collects and adds up
 // convex.hip: where the staged solve keeps its `flips` (completed non-terminal iterations) and `done` words on the
 // device -- the per-iteration halo (dist.hip) numbers its exchanges with the first and skips them on the second
 void stage_state_words(mhip_contact_op_t op, const unsigned** flips, const int** done);
@@ -307,7 +310,9 @@ void stage_state_words(mhip_contact_op_t op, const unsigned** flips, const int**
 // All accesses are relaxed system-scope atomics on fine-grained memory (uncached: nothing to write
 // back or invalidate -- a release / acquire pair at system scope would flush the whole L2 every iteration).  The wait
 // is bounded: a rank that never posts ends in an error on the host (status[0]), not in waves that never finish.
-__device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double* mine) {
+// `into` (optional, shared memory): the collected records go there instead of m.gathered -- for a caller that goes on
+// to use them in the same launch.
+__device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double* mine, double* into = nullptr) {
   if (threadIdx.x >= 64) return;
   const int nw = 2 * m.width;
   // exchanges on one rank are launches on one stream, one wave each: nothing else touches status[1] meanwhile
@@ -343,7 +348,8 @@ __device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double*
     }
     if (!ok) __hip_atomic_store(&m.status[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long bits = (hi << 32) | (lo & 0xffffffffull);
-    m.gathered[(size_t)r * m.width + k] = ok ? __longlong_as_double(static_cast<long long>(bits)) : __builtin_nan("");
+    (into ? into : m.gathered)[(size_t)r * m.width + k] =
+        ok ? __longlong_as_double(static_cast<long long>(bits)) : __builtin_nan("");
   }
   // (every lane has read status[1] above: the wave runs in lockstep and the barrier keeps the store below the loops)
   __builtin_amdgcn_wave_barrier();
