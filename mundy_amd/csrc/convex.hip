@@ -3430,6 +3430,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       op->tier.active = false;
     }
   } tier_guard{op};
+  PollPlan plan;
   for (;;) {
     MHIP_HIP(hipMemcpyAsync(op->host_state, st, sizeof(SolverState), hipMemcpyDeviceToHost, s));
     MHIP_HIP(hipStreamSynchronize(s));
@@ -3464,14 +3465,26 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
     if (op->host_state->done || enqueued >= config->max_iters) break;
     // cold tier: the drift bookkeeping starts with the first iteration, the first classification comes with the first
     // snapshot (short solves -- a relaxed packing needs ~100 iterations -- get their tiers early)
-    if (!tier.disabled && (enqueued >= kSnapshotAfter || !tier.tracking)) {
-      const unsigned left = config->max_iters - enqueued;
-      if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, C, /*pingpong=*/true, s)) return e;
+    const bool light = plan.light_poll();
+    if (!light) {
+      const size_t retiers_before = tier.retiers;
+      if (!tier.disabled && (enqueued >= kSnapshotAfter || !tier.tracking)) {
+        const unsigned left = config->max_iters - enqueued;
+        if (int e = tier_update(op, cur, op->host_state->iter, left < chunk ? left : chunk, C, /*pingpong=*/true, s)) return e;
+      }
+      if (enqueued >= kSnapshotAfter)
+        if (int e = op_snapshot_active(op, s)) return e;
+      plan.full_poll_done(enqueued, *reinterpret_cast<const int32_t*>(op->host_state + 1),
+                          tier.retiers != retiers_before, !tier.disabled && !tier.active);
     }
-    if (enqueued >= kSnapshotAfter)
-      if (int e = op_snapshot_active(op, s)) return e;
     iter_before = op->host_state->iter;
-    const unsigned todo = (config->max_iters - enqueued < chunk) ? config->max_iters - enqueued : chunk;
+    const unsigned stretch = plan.stretch(chunk, op->host_state->iter, op->host_state->residual, config->tol);
+    const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
+#ifdef MHIP_TIER_DEBUG
+    fprintf(stderr, "poll: iter %u residual %.3e light %d quiet %u stretch %u (regular %u) snapshot entries %d\n",
+            op->host_state->iter, op->host_state->residual, (int)light, plan.quiet, stretch, chunk,
+            *reinterpret_cast<const int32_t*>(op->host_state + 1));
+#endif
     for (unsigned k = 0; k < todo; ++k) {
       const bool pk = prof && (k % kProfileStride == 0);
       if (pk) MHIP_HIP(hipEventRecord(op->events[3 * k], s));

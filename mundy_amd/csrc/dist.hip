@@ -1302,6 +1302,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
   if (int e = iteration(1, nullptr)) return e;
   unsigned enqueued = 0, last_todo = 0, iter_before = 0, chunk = 8;
   int done = 0;
+  PollPlan plan;  // (only its rule for the last stretches: the residual is the same on every rank, so is the decision)
   for (;;) {
     if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
     if (c->mbox.open || ipc)
@@ -1325,12 +1326,12 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     // (after a pause -- mhip_bbpgd_stage_poll has handled it -- the rest of the chunk did nothing: count what ran)
     if (!done && result->num_iters < enqueued) enqueued = result->num_iters;
     if (done || enqueued >= config->max_iters) break;
-    if (enqueued >= 8)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
+    if (enqueued >= 8 && !plan.shortened)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
       if (int e = mhip_bbpgd_stage_snapshot_active(op, stream)) return e;
     iter_before = result->num_iters;
     // (stretches of 8, 16, 32, ... iterations up to poll_every, as in the fused driver: an easy solve is found converged
     // early, a long one is polled as rarely as the caller allows)
-    const unsigned stretch = chunk < poll_every ? chunk : poll_every;
+    const unsigned stretch = plan.stretch(chunk < poll_every ? chunk : poll_every, result->num_iters, result->residual, config->tol);
     if (chunk < poll_every) chunk *= 2;
     const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
     for (unsigned k = 0; k < todo; ++k) {

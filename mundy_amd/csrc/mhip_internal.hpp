@@ -356,6 +356,46 @@ __device__ inline void mailbox_exchange_wave(const MailboxArgs& m, const double*
   if (threadIdx.x == 0) __hip_atomic_store(&m.status[1], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// What a convergence poll of the fused / staged drivers does besides reading the solver state, and how many iterations
+// are enqueued until the next one.
+//   * A full poll reclassifies the tiers and rebuilds the compact active lists: ~0.35 ms at 10^6 rods (0.25 ms of
+//     kernels, the rest bubbles around the host's reads), 14 of them in a 770-iteration solve.  Both are optimisations
+//     -- the wake-up mechanism keeps a tiered sweep exact whatever the age of the classification, and an entry that
+//     became active after the snapshot takes the per-body path -- so once two full polls in a row have found nothing to
+//     do (no renumbering, the compact lists within 0.1 % of their length), the next kQuietPolls polls only read the
+//     state.
+//   * Near the tolerance the stretches are short: the launches enqueued behind the converging iteration return at
+//     once, but three launches of 10^4 workgroups that return at once still cost time (54 of them behind iteration 770
+//     of the 10^6-rod solve).  The residual of a BB iteration is far too bursty to extrapolate (at the polls of that
+//     solve: 4.3, 5.3, 2.7e-2, 8.0e-2, 2.9e-3, 8.2e-3, 5.0e-2, 2.0e-3, 4.2e-4, 4.9e-4, 5.7e-5, converged ten
+//     iterations later), so the rule is only: within a factor kNearTol of the tolerance, kShortStretch iterations at
+//     a time, polled lightly.
+struct PollPlan {
+  static constexpr unsigned kQuietPolls = 3, kShortStretch = 16;
+  static constexpr double kNearTol = 32.0;
+  unsigned light_left = 0, quiet = 0;
+  int32_t snap_prev = -1;
+  bool shortened = false;  // the stretch that has just run was a short one
+  bool light_poll() {
+    if (shortened) return true;  // (the early poll of a shortened stretch never does the full work)
+    if (light_left == 0) return false;
+    --light_left;
+    return true;
+  }
+  void full_poll_done(unsigned enqueued, int32_t snapshot_entries, bool renumbered, bool tier_pending) {
+    const bool still = enqueued >= 64 && !renumbered && !tier_pending && snap_prev > 0 &&
+                       (snapshot_entries > snap_prev ? snapshot_entries - snap_prev : snap_prev - snapshot_entries) <=
+                           snap_prev / 1024;
+    snap_prev = snapshot_entries;
+    quiet = still ? quiet + 1 : 0;
+    if (quiet >= 2) light_left = kQuietPolls;
+  }
+  unsigned stretch(unsigned regular, unsigned iter, double residual, double tol) {
+    shortened = iter >= 64 && regular > kShortStretch && residual > tol && residual < kNearTol * tol;
+    return shortened ? kShortStretch : regular;
+  }
+};
+
 // sort.hip: stable LSD radix sort of (u64 key, u32 value) records over the key bits [0, 8 * passes), passes even (the
 // result is back in keys / vals); segment sorts (ascending, unsigned) -- see sort.hip
 constexpr int kShortSegment = 32;  // segments up to this length are sorted by one thread
