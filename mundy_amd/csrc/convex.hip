@@ -3478,7 +3478,7 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
                           tier.retiers != retiers_before, !tier.disabled && !tier.active);
     }
     iter_before = op->host_state->iter;
-    const unsigned stretch = plan.stretch(chunk, op->host_state->iter, op->host_state->residual, config->tol);
+    const unsigned stretch = plan.stretch(chunk, op->host_state->iter, op->host_state->residual, config->tol, C);
     const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
 #ifdef MHIP_TIER_DEBUG
     fprintf(stderr, "poll: iter %u residual %.3e light %d quiet %u stretch %u (regular %u) snapshot entries %d\n",

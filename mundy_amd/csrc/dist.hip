@@ -1331,7 +1331,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     iter_before = result->num_iters;
     // (stretches of 8, 16, 32, ... iterations up to poll_every, as in the fused driver: an easy solve is found converged
     // early, a long one is polled as rarely as the caller allows)
-    const unsigned stretch = plan.stretch(chunk < poll_every ? chunk : poll_every, result->num_iters, result->residual, config->tol);
+    const unsigned stretch = plan.stretch(chunk < poll_every ? chunk : poll_every, result->num_iters, result->residual, config->tol, C);
     if (chunk < poll_every) chunk *= 2;
     const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
     for (unsigned k = 0; k < todo; ++k) {
