@@ -134,6 +134,17 @@ def test_segseg_known_distance_property(ops):
     np.testing.assert_allclose(t[ok], v[ok], atol=1e-6, rtol=0)
 
 
+def test_segseg_intersecting_and_colinear_generators_at_the_reference_sample_count(ops):
+    # the other two generators of UnitTestSegmentSegment.cpp (:74-103 intersecting, :129-140 colinear) at its 10^6
+    # samples, through the C ABI; tolerances as in the reference (1e-6) / the oracle's own test
+    from gpu_util import dev, host
+    from test_oracle_geom_kat import check_colinear, check_intersecting, colinear_segments, intersecting_segments
+    segseg = lambda *a: [host(x) for x in ops.distance_segment_segment(*[dev(v) for v in a])]
+    pointseg = lambda *a: [host(x) for x in ops.distance_point_segment(*[dev(v) for v in a])]
+    check_intersecting(segseg, *intersecting_segments(np.random.default_rng(12), 1_000_000))
+    check_colinear(segseg, pointseg, *colinear_segments(np.random.default_rng(4), 1_000_000))
+
+
 @pytest.mark.parametrize("periodic", [False, True])
 def test_contact_spheres_bit_exact(ops, oracle, periodic):
     from gpu_util import assert_bits_equal, dev, host

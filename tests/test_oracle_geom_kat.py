@@ -161,36 +161,49 @@ def test_point_segment_known_distance(oracle):
     np.testing.assert_allclose(cp, a12, atol=TOL_SEG, rtol=0)
 
 
-def test_segseg_intersecting(oracle):
-    # generate_intersecting_line_segments (UnitTestSegmentSegment.cpp:74-103): distance 0 at parameters u, v
-    rng = np.random.default_rng(11)
-    n = 50_000
+def intersecting_segments(rng, n):
+    """generate_intersecting_line_segments (UnitTestSegmentSegment.cpp:74-103), vectorised: distance 0 at (u, v)."""
     inter, a1, b1 = rng.random((n, 3)), rng.random((n, 3)), rng.random((n, 3))
     a2 = a1 + (inter - a1) * (1.0 + rng.random(n))[:, None]
     b2 = b1 + (inter - b1) * (1.0 + rng.random(n))[:, None]
     u = np.linalg.norm(a1 - inter, axis=1) / np.linalg.norm(a2 - a1, axis=1)
     v = np.linalg.norm(b1 - inter, axis=1) / np.linalg.norm(b2 - b1, axis=1)
-    dist, cp1, cp2, s, t, sep = oracle.distance_segment_segment(a1, a2, b1, b2)
+    return a1, a2, b1, b2, u, v
+
+
+def colinear_segments(rng, n):
+    """generate_colinear_line_segments (UnitTestSegmentSegment.cpp:129-140): B = A translated."""
+    a1, a2 = rng.random((n, 3)), rng.random((n, 3))
+    tmp = rng.random((n, 3))
+    return a1, a2, a1 + tmp, a2 + tmp
+
+
+def check_intersecting(segseg, a1, a2, b1, b2, u, v):
+    dist, cp1, cp2, s, t, sep = segseg(a1, a2, b1, b2)
     ok = np.linalg.norm(np.cross(a2 - a1, b2 - b1), axis=1) ** 2 > 1e-4  # well away from the colinear branch
+    assert ok.mean() > 0.9
     np.testing.assert_allclose(dist[ok], 0.0, atol=TOL_SEG)
     np.testing.assert_allclose(s[ok], u[ok], atol=1e-5)
     np.testing.assert_allclose(t[ok], v[ok], atol=1e-5)
 
 
-def test_segseg_colinear_symmetric(oracle):
-    # generate_colinear_line_segments (UnitTestSegmentSegment.cpp:129-140): parallel segments, distance symmetric and
-    # equal to the brute-force minimum over endpoint-to-segment distances
-    rng = np.random.default_rng(3)
-    n = 20_000
-    a1, a2 = rng.random((n, 3)), rng.random((n, 3))
-    tmp = rng.random((n, 3))
-    b1, b2 = a1 + tmp, a2 + tmp
-    d_ab = oracle.distance_segment_segment(a1, a2, b1, b2)[0]
-    d_ba = oracle.distance_segment_segment(b1, b2, a1, a2)[0]
+def check_colinear(segseg, pointseg, a1, a2, b1, b2):
+    # distance symmetric and equal to the brute-force minimum over endpoint-to-segment distances
+    d_ab = segseg(a1, a2, b1, b2)[0]
+    d_ba = segseg(b1, b2, a1, a2)[0]
     np.testing.assert_allclose(d_ab, d_ba, atol=TOL_SEG)
-    e = np.minimum(np.minimum(oracle.distance_point_segment(a1, b1, b2)[0], oracle.distance_point_segment(a2, b1, b2)[0]),
-                   np.minimum(oracle.distance_point_segment(b1, a1, a2)[0], oracle.distance_point_segment(b2, a1, a2)[0]))
+    e = np.minimum(np.minimum(pointseg(a1, b1, b2)[0], pointseg(a2, b1, b2)[0]),
+                   np.minimum(pointseg(b1, a1, a2)[0], pointseg(b2, a1, a2)[0]))
     np.testing.assert_allclose(d_ab, e, atol=TOL_SEG)
+
+
+def test_segseg_intersecting(oracle):
+    check_intersecting(oracle.distance_segment_segment, *intersecting_segments(np.random.default_rng(11), 50_000))
+
+
+def test_segseg_colinear_symmetric(oracle):
+    check_colinear(oracle.distance_segment_segment, oracle.distance_point_segment,
+                   *colinear_segments(np.random.default_rng(3), 20_000))
 
 
 # ---- sphere-sphere (no reference test exists: analytic) -----------------------------------------------------------------
