@@ -134,8 +134,9 @@ int mhip_contact_spherocylinders_periodic(size_t c, const int32_t* pairs, const 
  * (r,L,-) / (r1,r2,r3); quat is ignored for spheres.  compute_aabb dispatches on kind (compute_aabb.hpp:72-127) and
  * also returns the bounding radii (compute_bounding_radius.hpp:61-93).  contact_mixed bins the pairs by shape class and
  * runs one distance routine per class: S-S, S-R (scrap/.../SphereSpherocylinderLinker.cpp:210-239), R-R, E-E as above;
- * S-E = distance(Point, Ellipsoid) - r and R-E = shared-normal minimisation with the rod's support map are build
- * extensions (the reference's SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp are empty stubs): parity unpinned.
+ * S-E = distance(Point, Ellipsoid) - r and R-E = closest approach of the rod's centreline to the ellipsoid (exact
+ * signed point - ellipsoid distance minimised along the centreline, closed form: csrc/segment_ellipsoid.hpp) - r are
+ * build extensions (the reference's SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp are empty stubs): parity unpinned.
  * class_counts [host, 6] (optional) = pairs per class in the order SS, SR, SE, RR, RE, EE (synchronises if given). */
 int mhip_compute_aabb_mixed(size_t n, const int32_t* kind, const double* center, const double* quat,
                             const double* shape, double* aabb, double* bounding_radius, mhip_stream_t stream);
@@ -150,13 +151,13 @@ int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, cons
                        const double* shape, double* sep, double* normal, double* cp1, double* cp2, double* ra,
                        double* rb, size_t* class_counts /*[host]*/, mhip_stream_t stream);
 /* BUILD OPTION, labelled wherever it is exposed: on = 1 makes the following mhip_contact_mixed* calls (any thread) run
- * the S-E, R-E and E-E minimisation classes from a build with floating-point contraction ON (fused multiply-adds):
+ * the S-E and E-E minimisation classes from a build with floating-point contraction ON (fused multiply-adds):
  * their results then agree with the default build -- which is bit-identical to the CPU oracle -- only to the
  * reference's own tolerance for ellipsoid distances, 1e-4 (UnitTestEllipsoidEllipsoid.cpp:53), on >= 99.5 % of pairs
- * (tests/test_gpu_mixed.py).  The closed-form classes (S-S, S-R, R-R) are not affected.  Default 0. */
+ * (tests/test_gpu_mixed.py).  The closed-form classes (S-S, S-R, R-R, R-E) are not affected.  Default 0. */
 int mhip_contact_mixed_set_contraction(int on);
-/* objective evaluations the L-BFGS classes (S-E, R-E, E-E) needed in the last mhip_contact_mixed* call of this host
- * thread, and in the last mhip_distance_ellipsoid_* / mhip_contact_ellipsoids call: these kernels are fp64-vector bound
+/* objective evaluations the L-BFGS classes (S-E, E-E; the middle word was R-E's, closed-form since round 3: 0)
+ * needed in the last mhip_contact_mixed* call of this host thread, and in the last mhip_distance_ellipsoid_* / mhip_contact_ellipsoids call: these kernels are fp64-vector bound
  * (about 2.3 * 10^3 fp64 instructions per evaluation), so evaluations x that / time is their roofline figure */
 int mhip_contact_mixed_last_evaluations(unsigned long long evaluations[3] /*[host]*/, mhip_stream_t stream);
 int mhip_ellipsoid_last_evaluations(unsigned long long* evaluations /*[host]*/, mhip_stream_t stream);

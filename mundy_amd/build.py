@@ -10,7 +10,7 @@ LIB = os.path.join(HERE, "lib", "libmundy_hip.so")
 SOURCES = ["runtime.hip", "sort.hip", "geometry.hip", "broadphase.hip", "convex.hip", "reorder.hip", "halo.hip", "ellipsoid.hip", "mixed.hip", "mixed_fma.hip", "dist.hip"]
 # per-source flag substitutions: the contracted build of the ellipsoid minimisation classes (see mixed_fma.hip)
 FLAG_OVERRIDES = {"mixed_fma.hip": {"-ffp-contract=off": "-ffp-contract=fast"}}
-HEADERS = ["mhip_internal.hpp", "geom_device.hpp", "ellipsoid_device.hpp", "ellipsoid_lockstep.hpp", os.path.join("..", "..", "include", "mundy_hip.h")]
+HEADERS = ["mhip_internal.hpp", "geom_device.hpp", "ellipsoid_device.hpp", "ellipsoid_lockstep.hpp", "segment_ellipsoid.hpp", os.path.join("..", "..", "include", "mundy_hip.h")]
 # -ffp-contract=off: a*b+c stays two roundings so per-element results are bit-identical to the scalar reference order
 FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

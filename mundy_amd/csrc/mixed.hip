@@ -6,12 +6,14 @@
 //   2. 6 x (flag, scan, scatter)   stable counting sort of pair indices by class (device-resident class offsets)
 //   3. one kernel per class over its index range, results scattered back to the pairs' own slots
 // S-E and R-E have no reference implementation (empty stubs SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp): build
-// extensions, parity unpinned (see the oracle): the point - ellipsoid minimisation with the sphere's centre, resp. the
-// closest point of the rod's centreline, as the point, minus the radius.  kind: 0 sphere, 1 spherocylinder, 2 ellipsoid; shape [n][3] =
-// (r,-,-) / (r,L,-) / (r1,r2,r3).
+// extensions, parity unpinned (see the oracle).  S-E = the reference's point - ellipsoid minimisation with the sphere's
+// centre as the point, minus the radius (SURVEY 8f.4's routing); R-E = the closest approach of the rod's centreline to
+// the ellipsoid in closed form (segment_ellipsoid.hpp), minus the radius.  kind: 0 sphere, 1 spherocylinder,
+// 2 ellipsoid; shape [n][3] = (r,-,-) / (r,L,-) / (r1,r2,r3).
 #include <atomic>
 
 #include "ellipsoid_lockstep.hpp"
+#include "segment_ellipsoid.hpp"
 
 // This file is compiled twice.  mixed.hip itself: everything, under the library's -ffp-contract=off (every a*b+c two
 // roundings: results bit-identical to the scalar reference order).  mixed_fma.hip (which only includes this file with
@@ -120,7 +122,7 @@ __device__ inline void store_contact(const MixedOut& o, size_t k, bool swapped, 
 }
 
 #ifndef MHIP_MIXED_FMA_TU
-// the closed-form classes: sphere - sphere, sphere - rod, rod - rod
+// the closed-form classes: sphere - sphere, sphere - rod, rod - rod, rod - ellipsoid
 template <int CLS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
     k_contact_class(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
@@ -155,13 +157,17 @@ __global__ void __launch_bounds__(BLOCK)
       const double radius_sum = A.s.x + B.s.x;
       const double inv = 1.0 / r.dist;
       store_contact(out, k, swapped, r.dist - radius_sum, (r.cp2 - r.cp1) * inv, r.cp1, r.cp2, bi.c, bj.c);
+    } else if (CLS == 4) {  // rod - ellipsoid (segment_ellipsoid.hpp)
+      const V3 hd = rod_half_axis(A.q, A.s.y);
+      const segell::SegmentResult r = segell::segment_ellipsoid(A.c - hd, A.c + hd, EllipsoidD{B.c, B.q, B.s});
+      store_contact(out, k, swapped, r.sdist - A.s.x, V3{-r.n.x, -r.n.y, -r.n.z}, r.p, r.x, bi.c, bj.c);
     }
   }
 }
 
 #endif  // !MHIP_MIXED_FMA_TU
 
-// The three minimisation classes (S-E, R-E, E-E) in lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one
+// The two minimisation classes (S-E, E-E) in lockstep form (ellipsoid_lockstep.hpp): persistent wavefronts, one
 // lane per pair of the class, objective evaluations converged, lanes refilled from a per-class counter.  Same
 // arithmetic per lane as the nested-loop form the tests build as their checker (tests/cpp/ellipsoid_nested_ref.hip).
 // Two waves per SIMD: 20 KB of LDS history per wave (ellipsoid_lockstep.hpp).
@@ -171,7 +177,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
                              const int2* __restrict__ pairs, const int32_t* __restrict__ kind,
                              const double* __restrict__ center, const double* __restrict__ quat,
                              const double* __restrict__ shape, MixedOut out, unsigned long long* __restrict__ counter) {
-  static_assert(CLS == 2 || CLS == 4 || CLS == 5, "lockstep kernels exist for the minimisation classes only");
+  static_assert(CLS == 2 || CLS == 5, "lockstep kernels exist for the minimisation classes only");
   const int32_t beg = class_start[CLS], end = class_start[CLS + 1];
   const size_t n = static_cast<size_t>(end - beg);
   const int lane = threadIdx.x & 63;
@@ -181,7 +187,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
   m.phase = lockstep::PH_IDLE;
   BodyD A{}, B{};
   lockstep::Frame frA{}, frB{};  // per-pair constants of the objective (see ellipsoid_lockstep.hpp)
-  V3 rod_p0{0, 0, 0}, rod_p1{0, 0, 0};  // the rod's centreline segment (R-E)
   bool swapped = false;
   size_t k = 0;
   bool active = false, need = true;
@@ -207,11 +212,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
           B = swapped ? bi : bj;
           frB = lockstep::make_frame(B.q);
           if (CLS == 5) frA = lockstep::make_frame(A.q);
-          if (CLS == 4) {
-            const V3 hd = rod_half_axis(A.q, A.s.y);
-            rod_p0 = A.c - hd;
-            rod_p1 = A.c + hd;
-          }
           lockstep::begin_pair(m);
         }
       }
@@ -231,10 +231,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
       if (CLS == 2) {         // point - ellipsoid: n1 is the ellipsoid's outward normal, f1 its foot point
         f1 = lockstep::normal_to_foot_point_framed(n1, elB, frB);
         fv = dist_point_point(f1, A.c, sv);
-      } else if (CLS == 4) {  // segment - ellipsoid: the foot point against the closest point f2 of the rod's centreline
-        double tt;
-        f1 = lockstep::normal_to_foot_point_framed(n1, elB, frB);
-        fv = dist_point_segment(f1, rod_p0, rod_p1, f2, tt, sv);
       } else {                // ellipsoid - ellipsoid
         f1 = lockstep::normal_to_foot_point_framed(n1, EllipsoidD{A.c, A.q, A.s}, frA);
         f2 = lockstep::normal_to_foot_point_framed(V3{-n1.x, -n1.y, -n1.z}, elB, frB);
@@ -246,9 +242,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
       if (CLS == 2) {
         const double d = dot(A.c - f1, n1);
         store_contact(out, k, swapped, d - A.s.x, V3{-n1.x, -n1.y, -n1.z}, A.c, f1, ci, cj);
-      } else if (CLS == 4) {
-        const double d = dot(f2 - f1, n1);
-        store_contact(out, k, swapped, d - A.s.x, V3{-n1.x, -n1.y, -n1.z}, f2, f1, ci, cj);
       } else {
         store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, ci, cj);
       }
@@ -260,12 +253,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
   }
 }
 
-// the three launches (S-E, R-E, E-E); cnt[k] = next pair of class k, cnt[4 + k] = its objective evaluations
+// the two launches (S-E, E-E); cnt[k] = next pair of class k, cnt[4 + k] = its objective evaluations (k = 1 was R-E,
+// which runs in closed form since round 3: its words stay zero)
 int MHIP_LOCKSTEP_LAUNCH(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
                          const int32_t* kind, const double* center, const double* quat, const double* shape,
                          const MixedOut& out, unsigned long long* cnt, hipStream_t s) {
   MHIP_LOCKSTEP_KERNEL<2><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 0);
-  MHIP_LOCKSTEP_KERNEL<4><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 1);
   MHIP_LOCKSTEP_KERNEL<5><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 2);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -380,6 +373,7 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
   CLASS(0, kBlock, gs);
   CLASS(1, kBlock, gs);
   CLASS(3, kBlock, gs);
+  CLASS(4, kBlock, gs);
   {
     if (int e = ms.counters.reserve(64)) return e;
     unsigned long long* cnt = ms.counters.as<unsigned long long>();  // [k]: next pair of class k; [4 + k]: its evaluations
@@ -408,7 +402,7 @@ int mhip_contact_mixed_set_contraction(int on) {
 }
 
 /* objective evaluations of the S-E, R-E and E-E classes in the last mhip_contact_mixed* call on this host thread
- * (synchronises the stream) */
+ * (synchronises the stream); R-E is evaluated in closed form and reports 0 */
 int mhip_contact_mixed_last_evaluations(unsigned long long evaluations[3], mhip_stream_t stream) {
   MHIP_REQUIRE(evaluations != nullptr, MHIP_ERR_INVALID_ARGUMENT, "evaluations is null");
   MixedScratch& ms = mixed_scratch();

@@ -197,13 +197,13 @@ def contact_mixed(pairs, kind, center, quat, shape, want_counts=False, box=None)
 
 
 def contact_mixed_set_contraction(on):
-    """BUILD OPTION (labelled): the S-E / R-E / E-E minimisation classes of contact_mixed from the build with fused
+    """BUILD OPTION (labelled): the S-E / E-E minimisation classes of contact_mixed from the build with fused
     multiply-adds -- results at the reference's 1e-4 instead of bit parity with the oracle.  Default off."""
     capi.check(capi.load().mhip_contact_mixed_set_contraction(1 if on else 0))
 
 
 def contact_mixed_last_evaluations():
-    """objective evaluations of the (S-E, R-E, E-E) classes in the last contact_mixed call"""
+    """objective evaluations of the (S-E, R-E, E-E) classes in the last contact_mixed call (R-E is closed-form: 0)"""
     ev = (C.c_ulonglong * 3)()
     capi.check(capi.load().mhip_contact_mixed_last_evaluations(ev, _stream()))
     return dict(SE=int(ev[0]), RE=int(ev[1]), EE=int(ev[2]))

@@ -830,6 +830,184 @@ inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3&
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Rod - ellipsoid (R-E): NO reference function exists (LineSegmentEllipsoid.hpp:21-33 is an empty stub).  BUILD
+// EXTENSION, PARITY UNPINNED.  Round 3 definition (see mundy_amd/csrc/segment_ellipsoid.hpp for the derivation): the
+// closest approach of the rod's centreline to the ellipsoid, from
+//   (a) the exact signed distance of a point to an ellipsoid -- closest point x_i = e_i^2 y_i / (tau + e_i^2), tau the
+//       root of the Lagrange condition (Eberly's first-octant / sorted-axes case analysis; Newton on the
+//       secular-equation form of the condition), and
+//   (b) bisection on the sign of the derivative n(t) . (p1 - p0) of that (convex) distance along the centreline.
+// This CPU restatement keeps the product's arithmetic (the same IEEE operations on the same values in the same order,
+// so that the GPU can be compared bit for bit) but not its code: the axes are sorted through an index permutation
+// here, by conditional exchanges of registers there.  What pins the DEFINITION is independent of both: the scan of the
+// reference-pinned point - ellipsoid distance along the centreline (tests/test_oracle_ellipsoid_kat.py).
+// ---------------------------------------------------------------------------------------------------------------
+namespace segell {
+constexpr int kNewtonMax = 64, kBisections = 48;
+constexpr double kTiny = 1e-290;
+// root in u > 0 of sum_k (r[k] z[k] / (u + m[k]))^2 = 1 with m[k] = r[k] - 1, r[N - 1] = 1 (u = Eberly's s + 1: the
+// distance from the pole, which can be as small as z[N - 1]): Newton on 1 - 1 / sqrt(sum) from u = z[N - 1]
+template <int N>
+inline double secular_root(const double (&r)[N], const double (&m)[N], const double (&z)[N]) {
+  double u = z[N - 1];
+  for (int it = 0; it < kNewtonMax; ++it) {
+    double Q = 0.0, dg = 0.0;
+    for (int k = 0; k < N; ++k) {
+      const double d = (k == N - 1) ? u : u + m[k];
+      const double q = (k == N - 1) ? z[k] / d : r[k] * z[k] / d;
+      Q = (k == 0) ? q * q : Q + q * q;
+      dg = (k == 0) ? q * q / d : dg + q * q / d;
+    }
+    if (!(Q > 1.0)) break;
+    const double un = u + Q * (std::sqrt(Q) - 1.0) / dg;
+    if (!(un > u)) break;
+    u = un;
+  }
+  return u;
+}
+// closest point of the ellipse with semi-axes e0 >= e1 to (y0, y1) >= 0
+inline double closest_on_ellipse(double e0, double e1, double y0, double y1, double& x0, double& x1) {
+  if (y1 > 0.0) {
+    if (y0 > 0.0) {
+      const double z[2] = {y0 / e0, y1 / e1};
+      const double g = z[0] * z[0] + z[1] * z[1] - 1.0;
+      if (g == 0.0) {
+        x0 = y0; x1 = y1;
+        return 0.0;
+      }
+      const double ratio = e0 / e1;
+      const double r[2] = {ratio * ratio, 1.0}, m[2] = {(ratio - 1.0) * (ratio + 1.0), 0.0};
+      const double u = secular_root<2>(r, m, z);
+      x0 = r[0] * y0 / (u + m[0]);
+      x1 = y1 / u;
+      const double a = x0 - y0, b = x1 - y1;
+      return std::sqrt(a * a + b * b);
+    }
+    x0 = 0.0; x1 = e1;
+    return std::fabs(y1 - e1);
+  }
+  const double numer0 = e0 * y0, denom0 = e0 * e0 - e1 * e1;
+  if (numer0 < denom0) {
+    const double xde0 = numer0 / denom0;
+    x0 = e0 * xde0;
+    x1 = e1 * std::sqrt(1.0 - xde0 * xde0);
+    const double a = x0 - y0;
+    return std::sqrt(a * a + x1 * x1);
+  }
+  x0 = e0; x1 = 0.0;
+  return std::fabs(y0 - e0);
+}
+// closest point of the ellipsoid with semi-axes e[0] >= e[1] >= e[2] to y >= 0
+inline double closest_on_ellipsoid(const double (&e)[3], const double (&y)[3], double (&x)[3]) {
+  if (y[2] > 0.0) {
+    if (y[1] > 0.0) {
+      if (y[0] > 0.0) {
+        const double z[3] = {y[0] / e[0], y[1] / e[1], y[2] / e[2]};
+        const double g = z[0] * z[0] + z[1] * z[1] + z[2] * z[2] - 1.0;
+        if (g == 0.0) {
+          x[0] = y[0]; x[1] = y[1]; x[2] = y[2];
+          return 0.0;
+        }
+        const double ratio0 = e[0] / e[2], ratio1 = e[1] / e[2];
+        const double r[3] = {ratio0 * ratio0, ratio1 * ratio1, 1.0};
+        const double m[3] = {(ratio0 - 1.0) * (ratio0 + 1.0), (ratio1 - 1.0) * (ratio1 + 1.0), 0.0};
+        const double u = secular_root<3>(r, m, z);
+        x[0] = r[0] * y[0] / (u + m[0]);
+        x[1] = r[1] * y[1] / (u + m[1]);
+        x[2] = y[2] / u;
+        const double a = x[0] - y[0], b = x[1] - y[1], c = x[2] - y[2];
+        return std::sqrt(a * a + b * b + c * c);
+      }
+      x[0] = 0.0;
+      return closest_on_ellipse(e[1], e[2], y[1], y[2], x[1], x[2]);
+    }
+    if (y[0] > 0.0) {
+      x[1] = 0.0;
+      return closest_on_ellipse(e[0], e[2], y[0], y[2], x[0], x[2]);
+    }
+    x[0] = 0.0; x[1] = 0.0; x[2] = e[2];
+    return std::fabs(y[2] - e[2]);
+  }
+  const double denom0 = e[0] * e[0] - e[2] * e[2], denom1 = e[1] * e[1] - e[2] * e[2];
+  const double numer0 = e[0] * y[0], numer1 = e[1] * y[1];
+  if (numer0 < denom0 && numer1 < denom1) {
+    const double xde0 = numer0 / denom0, xde1 = numer1 / denom1;
+    const double discr = 1.0 - xde0 * xde0 - xde1 * xde1;
+    if (discr > 0.0) {
+      x[0] = e[0] * xde0;
+      x[1] = e[1] * xde1;
+      x[2] = e[2] * std::sqrt(discr);
+      const double a = x[0] - y[0], b = x[1] - y[1];
+      return std::sqrt(a * a + b * b + x[2] * x[2]);
+    }
+  }
+  x[2] = 0.0;
+  return closest_on_ellipse(e[0], e[1], y[0], y[1], x[0], x[1]);
+}
+struct PointResult {
+  double sdist;
+  V3 x, n;
+};
+// signed distance (negative inside), closest surface point and outward unit normal, all in the ellipsoid's body frame
+inline PointResult point_ellipsoid_body(const V3& yv, const V3& radii) {
+  const double yy[3] = {yv.x, yv.y, yv.z}, rr[3] = {radii.x, radii.y, radii.z};
+  double sgn[3];
+  for (int k = 0; k < 3; ++k) sgn[k] = yy[k] < 0.0 ? -1.0 : 1.0;
+  // places 0, 1, 2 of the sorted order hold the axes perm[0..2]: the exchange network (0,1), (1,2), (0,1) on strict <
+  int perm[3] = {0, 1, 2};
+  if (rr[perm[0]] < rr[perm[1]]) std::swap(perm[0], perm[1]);
+  if (rr[perm[1]] < rr[perm[2]]) std::swap(perm[1], perm[2]);
+  if (rr[perm[0]] < rr[perm[1]]) std::swap(perm[0], perm[1]);
+  double e[3], y[3], x[3];
+  for (int k = 0; k < 3; ++k) {
+    e[k] = rr[perm[k]];
+    y[k] = sgn[perm[k]] * yy[perm[k]];
+    if (y[k] < kTiny) y[k] = 0.0;  // (a coordinate a division by a semi-axis could flush to zero IS zero below)
+  }
+  const double dist = closest_on_ellipsoid(e, y, x);
+  const double w0 = y[0] / e[0], w1 = y[1] / e[1], w2 = y[2] / e[2];
+  const bool inside = w0 * w0 + w1 * w1 + w2 * w2 < 1.0;
+  double m[3];
+  for (int k = 0; k < 3; ++k) m[k] = x[k] / (e[k] * e[k]);
+  const double inv = 1.0 / std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+  double xo[3], no[3];
+  for (int k = 0; k < 3; ++k) {
+    xo[perm[k]] = sgn[perm[k]] * x[k];
+    no[perm[k]] = sgn[perm[k]] * (m[k] * inv);
+  }
+  return {inside ? -dist : dist, {xo[0], xo[1], xo[2]}, {no[0], no[1], no[2]}};
+}
+struct SegmentResult {
+  double sdist, t;
+  V3 p, x, n;  // centreline point, closest surface point, outward unit normal there (lab frame)
+};
+inline SegmentResult segment_ellipsoid(const V3& p0, const V3& p1, const Ellipsoid& el) {
+  const Quat qc = conjugate(el.q);
+  const V3 y0 = qrot(qc, p0 - el.center), y1 = qrot(qc, p1 - el.center);
+  const V3 dy = y1 - y0;
+  double t = 0.0;
+  PointResult best = point_ellipsoid_body(y0, el.radii);
+  if (dot(best.n, dy) < 0.0) {
+    const PointResult end = point_ellipsoid_body(y1, el.radii);
+    if (!(dot(end.n, dy) > 0.0)) {
+      best = end;
+      t = 1.0;
+    } else {
+      double lo = 0.0, hi = 1.0;
+      for (int it = 0; it < kBisections; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        const double h = dot(point_ellipsoid_body(y0 + mid * dy, el.radii).n, dy);
+        if (h < 0.0) lo = mid; else hi = mid;
+      }
+      t = 0.5 * (lo + hi);
+      best = point_ellipsoid_body(y0 + t * dy, el.radii);
+    }
+  }
+  return {best.sdist, t, p0 + t * (p1 - p0), qrot(el.q, best.x) + el.center, qrot(el.q, best.n)};
+}
+}  // namespace segell
+
+// ---------------------------------------------------------------------------------------------------------------
 // Mixed-shape contact generation (BASELINE configs[4]).  Body kinds: 0 sphere, 1 spherocylinder, 2 ellipsoid;
 // shape = (r, -, -) / (r, L, -) / (r1, r2, r3).  Per pair class:
 //   S-S  contact_spheres                               (SphereSphere.hpp:54-59, NgpLcp.cpp:360-372)
@@ -840,13 +1018,12 @@ inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3&
 //   S-E  distance(Point, Ellipsoid) - r_s (the reference's SphereEllipsoid.hpp:21-33 is an empty stub, so
 //        this routing is a build-side definition: PARITY UNPINNED), normal = -ellipsoid normal
 //   R-E  NO reference function exists (LineSegmentEllipsoid.hpp:21-33 is an empty stub).  Build extension, PARITY
-//        UNPINNED: distance(Point, Ellipsoid)'s minimisation with the point replaced by the rod's centreline segment --
-//        minimise, over the ellipsoid's outward normal n, the distance from its foot point f(n) to the closest point
-//        p of the segment (LineSegmentPoint's point-segment distance, a C^1 objective) -- then subtract the rod radius,
-//        as the sphere classes do.  A rod of zero length gives S-E.  (A spherocylinder's own support map
-//        c + sign(n.a)(L/2)a + r n jumps between the end caps where n is normal to the axis -- the very orientation
-//        of a side-on contact -- so a shared-normal minimisation over it can neither reach a contact point on the
-//        cylinder nor converge there; that was this class's first definition.)
+//        UNPINNED: segell::segment_ellipsoid above -- the closest approach of the rod's centreline to the ellipsoid
+//        (exact signed point - ellipsoid distance, minimised along the centreline), minus the rod radius, as the
+//        sphere classes do; contact points = the centreline point and the closest surface point, normal = rod ->
+//        ellipsoid.  A rod of zero length gives the exact S-E.  (Rounds 1-2 ran distance(Point, Ellipsoid)'s
+//        nine-start L-BFGS with the centreline's closest point as the point: the same quantity for a centreline
+//        outside the ellipsoid, to that minimiser's 1e-4, at 1 280 objective evaluations per pair.)
 // The pair is evaluated in canonical class order (lower kind first) and flipped back if the list order is the reverse.
 // ---------------------------------------------------------------------------------------------------------------
 enum BodyKind : int { kSphere = 0, kRod = 1, kEllipsoid = 2 };
@@ -892,37 +1069,12 @@ inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody&
     o.cp1 = A.c;
     o.cp2 = closest;
   } else {  // rod - ellipsoid (extension)
-    const Ellipsoid el{B.c, B.q, B.shape};
     const V3 hd = spherocylinder_half_axis(A.q, A.shape.y);
-    const V3 p0 = A.c - hd, p1 = A.c + hd;
-    V3 ne, foot, closest, sepv;
-    double t;
-    auto objective = [&](const minimize::Vec<2>& tp) {
-      double st, ct, sp, cp;
-      sincos_mode(tp[0], st, ct);
-      sincos_mode(tp[1], sp, cp);
-      ne = {st * cp, st * sp, ct};
-      foot = map_surface_normal_to_foot_point(ne, el);
-      return distance_point_segment(foot, p0, p1, closest, t, sepv);
-    };
-    constexpr double pi = 3.141592653589793;
-    const double tg[3] = {0.0, 0.5 * pi, pi}, pg[3] = {pi / 3.0, pi, 5.0 * (pi / 3.0)};
-    double best = std::numeric_limits<double>::infinity();
-    minimize::Vec<2> btp{{0.0, 0.0}};
-    for (int t3 = 0; t3 < 3; ++t3)
-      for (int p3 = 0; p3 < 3; ++p3) {
-        minimize::Vec<2> tp{{tg[t3], pg[p3]}};
-        const double d = minimize::find_min<10, 2>(objective, tp, kRelaxedZeroTol);
-        if (d < best) {
-          best = d;
-          btp = tp;
-        }
-      }
-    objective(btp);
-    o.sep = dot(closest - foot, ne) - A.shape.x;
-    o.normal = {-ne.x, -ne.y, -ne.z};
-    o.cp1 = closest;
-    o.cp2 = foot;
+    const segell::SegmentResult r = segell::segment_ellipsoid(A.c - hd, A.c + hd, Ellipsoid{B.c, B.q, B.shape});
+    o.sep = r.sdist - A.shape.x;
+    o.normal = {-r.n.x, -r.n.y, -r.n.z};
+    o.cp1 = r.p;
+    o.cp2 = r.x;
   }
   return o;
 }

@@ -129,3 +129,116 @@ def test_rod_ellipsoid_extension_against_a_scan_of_the_centreline(oracle):
         np.testing.assert_allclose(np.linalg.norm(gap) - r[i], out["sep"][i], atol=2e-4)
         checked += 1
     assert checked >= 25
+
+
+# ---- R-E in closed form (round 3): optimality conditions certify the global optimum of a convex problem ---------------
+def _rod_ellipsoid_case(rng, n, degenerate=False):
+    ec = rng.uniform(-0.5, 0.5, (n, 3))
+    er = rng.uniform(0.3, 1.5, (n, 3))
+    if degenerate:
+        # axis-aligned frames, equal semi-axes, rods through the centre / in the symmetry planes / along the axes:
+        # every special branch of the closest-point case analysis
+        eq = np.tile([1.0, 0.0, 0.0, 0.0], (n, 1))
+        rq = np.tile([1.0, 0.0, 0.0, 0.0], (n, 1))       # rod axis = z
+        er[: n // 4] = er[: n // 4, :1]                   # spheres
+        er[n // 4: n // 2, 1] = er[n // 4: n // 2, 0]     # two equal axes
+        rc = ec + rng.integers(-2, 3, (n, 3)).astype(float) * rng.choice([0.0, 0.25, 0.5, 1.0, 2.0], (n, 1))
+        L = rng.choice([0.0, 0.5, 1.0, 4.0], n)
+    else:
+        eq = rng.normal(size=(n, 4)); eq /= np.linalg.norm(eq, axis=1, keepdims=True)
+        rq = rng.normal(size=(n, 4)); rq /= np.linalg.norm(rq, axis=1, keepdims=True)
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rc = ec + d * rng.uniform(0.0, 3.0, (n, 1))       # from deep inside to well outside
+        L = rng.uniform(0.0, 3.0, n)
+    r = rng.uniform(0.1, 0.4, n)
+    kind = np.concatenate([np.full(n, 1), np.full(n, 2)]).astype(np.int32)
+    center, quat = np.concatenate([rc, ec]), np.concatenate([rq, eq])
+    shape = np.concatenate([np.stack([r, L, np.zeros(n)], axis=1), er])
+    pairs = np.stack([np.arange(n), np.arange(n) + n], axis=1).astype(np.int32)
+    return dict(pairs=pairs, kind=kind, center=center, quat=quat, shape=shape, n=n, ec=ec, eq=eq, er=er, rc=rc, rq=rq,
+                r=r, L=L)
+
+
+def check_rod_ellipsoid_optimality(oracle, case, out, tol=1e-9):
+    """KKT of min_t s(p(t)) with s the signed distance to the ellipsoid (convex): cp2 on the surface, `normal` = minus
+    the surface normal there, cp1 - cp2 = s * n_E, and the slope n_E . (p1 - p0) zero inside (0, 1), >= 0 at t = 0,
+    <= 0 at t = 1."""
+    n, ec, eq, er, r = case["n"], case["ec"], case["eq"], case["er"], case["r"]
+    seg = oracle.spherocylinder_segments(case["rc"], case["rq"], r, case["L"])
+    p0, p1 = seg[:, 0:3], seg[:, 3:6]
+    conj = eq * np.array([1.0, -1.0, -1.0, -1.0])
+    xb = oracle.quat_rotate(conj, out["cp2"] - ec)                      # closest point in the body frame
+    np.testing.assert_allclose(np.sum((xb / er) ** 2, axis=1), 1.0, atol=1e-12)
+    grad = oracle.quat_rotate(eq, xb / er ** 2)
+    n_e = grad / np.linalg.norm(grad, axis=1, keepdims=True)
+    np.testing.assert_allclose(out["normal"], -n_e, atol=1e-12)
+    s = out["sep"] + r
+    np.testing.assert_allclose(out["cp1"] - out["cp2"], s[:, None] * n_e, atol=1e-9)
+    d = p1 - p0
+    len2 = np.maximum(np.sum(d * d, axis=1), 1e-300)
+    t = np.sum((out["cp1"] - p0) * d, axis=1) / len2
+    slope = np.sum(n_e * d, axis=1)
+    point_like = np.sum(d * d, axis=1) < 1e-24
+    assert np.all((t > -1e-12) & (t < 1 + 1e-12))
+    inner = (t > 1e-9) & (t < 1 - 1e-9) & ~point_like
+    # (inside the ellipsoid the signed distance has kinks -- the medial surface, where the closest point jumps -- and the
+    #  deepest point of a centreline usually sits on one: the slope condition is for the smooth, exterior part)
+    smooth = inner & (s > 0)
+    assert np.all(np.abs(slope[smooth]) < tol * np.sqrt(len2[smooth]) + 1e-9), np.abs(slope[smooth]).max()
+    at0 = (t <= 1e-9) & ~point_like
+    at1 = (t >= 1 - 1e-9) & ~point_like
+    assert np.all(slope[at0] > -1e-9) and np.all(slope[at1] < 1e-9)
+    # the minimisation over the centreline against brute force, kinks or not: the exact point - ellipsoid distance
+    # (a rod of zero length) at 65 stations is nowhere below what was found
+    stations = np.linspace(0.0, 1.0, 65)
+    lowest = np.full(n, np.inf)
+    shape0 = case["shape"].copy()
+    shape0[:n, 1] = 0.0
+    for u in stations:
+        c = case["center"].copy()
+        c[:n] = p0 + u * d
+        o = oracle.contact_mixed(case["pairs"], case["kind"], c, case["quat"], shape0)
+        lowest = np.minimum(lowest, o["sep"])
+    assert np.all(out["sep"] <= lowest + 1e-12), float((out["sep"] - lowest).max())
+    assert np.all(out["sep"] >= lowest - 0.05 * np.sqrt(len2) - 1e-12)   # (|slope| <= |d|, stations 1/64 apart)
+    return dict(inner=int(inner.sum()), at0=int(at0.sum()), at1=int(at1.sum()), inside=int((s < 0).sum()))
+
+
+def test_rod_ellipsoid_closed_form_satisfies_the_optimality_conditions(oracle):
+    case = _rod_ellipsoid_case(np.random.default_rng(23), 4000)
+    out = oracle.contact_mixed(case["pairs"], case["kind"], case["center"], case["quat"], case["shape"])
+    stats = check_rod_ellipsoid_optimality(oracle, case, out)
+    assert stats["inner"] > 500 and stats["at0"] > 200 and stats["at1"] > 200 and stats["inside"] > 200, stats
+
+
+def test_rod_ellipsoid_closed_form_on_degenerate_configurations(oracle):
+    # exact zeros in the body frame (symmetry planes, axes, the centre), equal semi-axes, zero-length rods
+    case = _rod_ellipsoid_case(np.random.default_rng(29), 4000, degenerate=True)
+    out = oracle.contact_mixed(case["pairs"], case["kind"], case["center"], case["quat"], case["shape"])
+    assert np.all(np.isfinite(out["sep"])) and np.all(np.isfinite(out["normal"])) and np.all(np.isfinite(out["cp2"]))
+    # (a rod through the exact centre of an ellipsoid has no unique closest point: the conditions that do not depend
+    # on uniqueness still hold)
+    stats = check_rod_ellipsoid_optimality(oracle, case, out)
+    assert stats["inside"] > 100 and stats["inner"] + stats["at0"] + stats["at1"] > 2000, stats
+    # spheres: the closed form of a segment against a sphere
+    k = case["n"] // 4
+    seg = oracle.spherocylinder_segments(case["rc"][:k], case["rq"][:k], case["r"][:k], case["L"][:k])
+    dist = oracle.distance_point_segment(case["ec"][:k], seg[:, 0:3], seg[:, 3:6])[0]
+    np.testing.assert_allclose(out["sep"][:k], dist - case["er"][:k, 0] - case["r"][:k], atol=1e-12)
+
+
+def test_zero_length_rod_is_the_exact_sphere_ellipsoid_distance(oracle):
+    # R-E of a rod of zero length = exact signed point - ellipsoid distance minus r; S-E = the reference's L-BFGS
+    # point - ellipsoid distance minus r, good to its own 1e-4 (UnitTestEllipsoidEllipsoid.cpp:52-53) -- outside AND
+    # inside the ellipsoid (negative distances)
+    rng = np.random.default_rng(31)
+    case = _rod_ellipsoid_case(rng, 600)
+    case["shape"][: case["n"], 1] = 0.0
+    out_re = oracle.contact_mixed(case["pairs"], case["kind"], case["center"], case["quat"], case["shape"])
+    kind_s = case["kind"].copy()
+    kind_s[: case["n"]] = 0
+    out_se = oracle.contact_mixed(case["pairs"], kind_s, case["center"], case["quat"], case["shape"])
+    assert (out_re["sep"] + case["r"] < -0.05).sum() > 30
+    np.testing.assert_allclose(out_re["sep"], out_se["sep"], atol=1e-4)
+    far = np.abs(out_re["sep"] + case["r"]) > 0.05   # (the normal of a point on the surface is that point's own)
+    np.testing.assert_allclose(out_re["normal"][far], out_se["normal"][far], atol=5e-3)
