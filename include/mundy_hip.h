@@ -134,7 +134,7 @@ int mhip_contact_spherocylinders_periodic(size_t c, const int32_t* pairs, const 
  * (r,L,-) / (r1,r2,r3); quat is ignored for spheres.  compute_aabb dispatches on kind (compute_aabb.hpp:72-127) and
  * also returns the bounding radii (compute_bounding_radius.hpp:61-93).  contact_mixed bins the pairs by shape class and
  * runs one distance routine per class: S-S, S-R (scrap/.../SphereSpherocylinderLinker.cpp:210-239), R-R, E-E as above;
- * S-E = distance(Point, Ellipsoid) - r and R-E = closest approach of the rod's centreline to the ellipsoid (exact
+ * S-E = distance(Point, Ellipsoid) - r (exact by default, see mhip_contact_mixed_set_sphere_ellipsoid_route) and R-E = closest approach of the rod's centreline to the ellipsoid (exact
  * signed point - ellipsoid distance minimised along the centreline, closed form: csrc/segment_ellipsoid.hpp) - r are
  * build extensions (the reference's SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp are empty stubs): parity unpinned.
  * class_counts [host, 6] (optional) = pairs per class in the order SS, SR, SE, RR, RE, EE (synchronises if given). */
@@ -156,6 +156,12 @@ int mhip_contact_mixed(size_t c, const int32_t* pairs, const int32_t* kind, cons
  * reference's own tolerance for ellipsoid distances, 1e-4 (UnitTestEllipsoidEllipsoid.cpp:53), on >= 99.5 % of pairs
  * (tests/test_gpu_mixed.py).  The closed-form classes (S-S, S-R, R-R, R-E) are not affected.  Default 0. */
 int mhip_contact_mixed_set_contraction(int on);
+/* S-E (a build extension: the reference's SphereEllipsoid.hpp is an empty stub) = signed distance of the sphere's centre
+ * to the ellipsoid, minus the radius.  route 0 (default): the exact distance in closed form (csrc/segment_ellipsoid.hpp);
+ * route 1: distance(Point, Ellipsoid) as the reference computes it (PointEllipsoid.hpp:94-135, nine-start L-BFGS over
+ * the surface normal; SURVEY 8f.4's routing), which route 0 matches to that routine's own 1e-4.  Applies to the
+ * following mhip_contact_mixed* calls of any thread. */
+int mhip_contact_mixed_set_sphere_ellipsoid_route(int route);
 /* objective evaluations the L-BFGS classes (S-E, E-E; the middle word was R-E's, closed-form since round 3: 0)
  * needed in the last mhip_contact_mixed* call of this host thread, and in the last mhip_distance_ellipsoid_* / mhip_contact_ellipsoids call: these kernels are fp64-vector bound
  * (about 2.3 * 10^3 fp64 instructions per evaluation), so evaluations x that / time is their roofline figure */

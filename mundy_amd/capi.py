@@ -90,6 +90,7 @@ SIGNATURES = {
     "mhip_compute_aabb_mixed_conservative": [_sz] + [_vp] * 7,
     "mhip_contact_mixed": [_sz] + [_vp] * 11 + [C.POINTER(_sz), _vp],
     "mhip_contact_mixed_set_contraction": [_i],
+    "mhip_contact_mixed_set_sphere_ellipsoid_route": [_i],
     "mhip_contact_mixed_last_evaluations": [C.POINTER(C.c_ulonglong), _vp],
     "mhip_ellipsoid_last_evaluations": [C.POINTER(C.c_ulonglong), _vp],
     "mhip_contact_mixed_periodic": [_sz] + [_vp] * 5 + [C.POINTER(_d)] + [_vp] * 6 + [C.POINTER(_sz), _vp],

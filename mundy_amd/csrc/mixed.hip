@@ -6,9 +6,11 @@
 //   2. 6 x (flag, scan, scatter)   stable counting sort of pair indices by class (device-resident class offsets)
 //   3. one kernel per class over its index range, results scattered back to the pairs' own slots
 // S-E and R-E have no reference implementation (empty stubs SphereEllipsoid.hpp / LineSegmentEllipsoid.hpp): build
-// extensions, parity unpinned (see the oracle).  S-E = the reference's point - ellipsoid minimisation with the sphere's
-// centre as the point, minus the radius (SURVEY 8f.4's routing); R-E = the closest approach of the rod's centreline to
-// the ellipsoid in closed form (segment_ellipsoid.hpp), minus the radius.  kind: 0 sphere, 1 spherocylinder,
+// extensions, parity unpinned (see the oracle).  S-E = the signed distance of the sphere's centre to the ellipsoid minus
+// the radius: by default the exact distance in closed form (segment_ellipsoid.hpp; a rod of zero length), on request
+// (mhip_contact_mixed_set_sphere_ellipsoid_route(1)) the reference's own point - ellipsoid routine, the nine-start
+// L-BFGS of PointEllipsoid.hpp:94-135 (SURVEY 8f.4's routing), which the closed form matches to that routine's 1e-4;
+// R-E = the closest approach of the rod's centreline to the ellipsoid in closed form, minus the radius.  kind: 0 sphere, 1 spherocylinder,
 // 2 ellipsoid; shape [n][3] = (r,-,-) / (r,L,-) / (r1,r2,r3).
 #include <atomic>
 
@@ -122,7 +124,7 @@ __device__ inline void store_contact(const MixedOut& o, size_t k, bool swapped, 
 }
 
 #ifndef MHIP_MIXED_FMA_TU
-// the closed-form classes: sphere - sphere, sphere - rod, rod - rod, rod - ellipsoid
+// the closed-form classes: sphere - sphere, sphere - rod, rod - rod, rod - ellipsoid, sphere - ellipsoid (default route)
 template <int CLS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
     k_contact_class(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
@@ -157,6 +159,9 @@ __global__ void __launch_bounds__(BLOCK)
       const double radius_sum = A.s.x + B.s.x;
       const double inv = 1.0 / r.dist;
       store_contact(out, k, swapped, r.dist - radius_sum, (r.cp2 - r.cp1) * inv, r.cp1, r.cp2, bi.c, bj.c);
+    } else if (CLS == 2) {  // sphere - ellipsoid, exact (segment_ellipsoid.hpp): what a rod of zero length gets
+      const segell::SegmentResult r = segell::segment_ellipsoid(A.c, A.c, EllipsoidD{B.c, B.q, B.s});
+      store_contact(out, k, swapped, r.sdist - A.s.x, V3{-r.n.x, -r.n.y, -r.n.z}, r.p, r.x, bi.c, bj.c);
     } else if (CLS == 4) {  // rod - ellipsoid (segment_ellipsoid.hpp)
       const V3 hd = rod_half_axis(A.q, A.s.y);
       const segell::SegmentResult r = segell::segment_ellipsoid(A.c - hd, A.c + hd, EllipsoidD{B.c, B.q, B.s});
@@ -257,8 +262,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 // which runs in closed form since round 3: its words stay zero)
 int MHIP_LOCKSTEP_LAUNCH(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
                          const int32_t* kind, const double* center, const double* quat, const double* shape,
-                         const MixedOut& out, unsigned long long* cnt, hipStream_t s) {
-  MHIP_LOCKSTEP_KERNEL<2><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 0);
+                         const MixedOut& out, unsigned long long* cnt, bool sphere_ellipsoid, hipStream_t s) {
+  if (sphere_ellipsoid)
+    MHIP_LOCKSTEP_KERNEL<2><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 0);
   MHIP_LOCKSTEP_KERNEL<5><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 2);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -269,8 +275,9 @@ int MHIP_LOCKSTEP_LAUNCH(unsigned grid, const int32_t* start, const int32_t* ord
 int launch_contact_classes_lockstep_fma(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
                                         const int32_t* kind, const double* center, const double* quat,
                                         const double* shape, const MixedOut& out, unsigned long long* cnt,
-                                        hipStream_t s);
+                                        bool sphere_ellipsoid, hipStream_t s);
 std::atomic<int> g_mixed_contraction{0};
+std::atomic<int> g_mixed_se_route{0};  // 0: S-E in closed form; 1: through the reference's point - ellipsoid minimiser
 
 struct MixedScratch {
   DeviceBuffer cls, flags, pos, order, start, scanws, counters;
@@ -374,15 +381,17 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
   CLASS(1, kBlock, gs);
   CLASS(3, kBlock, gs);
   CLASS(4, kBlock, gs);
+  const bool se_minimiser = g_mixed_se_route.load() != 0;
+  if (!se_minimiser) CLASS(2, kBlock, gs);
   {
     if (int e = ms.counters.reserve(64)) return e;
     unsigned long long* cnt = ms.counters.as<unsigned long long>();  // [k]: next pair of class k; [4 + k]: its evaluations
     MHIP_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), s));
     const unsigned gl = static_cast<unsigned>(c / 64 + 1 > 2048 ? 2048 : c / 64 + 1);  // persistent waves
     if (g_mixed_contraction.load() != 0) {
-      if (int e = launch_contact_classes_lockstep_fma(gl, start, order, p2, kind, center, quat, shape, out, cnt, s)) return e;
+      if (int e = launch_contact_classes_lockstep_fma(gl, start, order, p2, kind, center, quat, shape, out, cnt, se_minimiser, s)) return e;
     } else {
-      if (int e = launch_contact_classes_lockstep(gl, start, order, p2, kind, center, quat, shape, out, cnt, s)) return e;
+      if (int e = launch_contact_classes_lockstep(gl, start, order, p2, kind, center, quat, shape, out, cnt, se_minimiser, s)) return e;
     }
   }
 #undef CLASS
@@ -392,6 +401,12 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
     MHIP_HIP(hipStreamSynchronize(s));
     for (int k = 0; k < 6; ++k) class_counts[k] = static_cast<size_t>(ms.host[k + 1] - ms.host[k]);
   }
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_mixed_set_sphere_ellipsoid_route(int route) {
+  MHIP_REQUIRE(route == 0 || route == 1, MHIP_ERR_INVALID_ARGUMENT, "route must be 0 (closed form) or 1 (the reference's minimiser), got %d", route);
+  g_mixed_se_route.store(route);
   return MHIP_SUCCESS;
 }
 

@@ -196,6 +196,12 @@ def contact_mixed(pairs, kind, center, quat, shape, want_counts=False, box=None)
     return out
 
 
+def contact_mixed_set_sphere_ellipsoid_route(reference_minimiser):
+    """S-E of contact_mixed: False (default) = the exact point - ellipsoid distance in closed form, True = the reference's
+    own point - ellipsoid routine (nine-start L-BFGS, PointEllipsoid.hpp:94-135), which the closed form matches to 1e-4"""
+    capi.check(capi.load().mhip_contact_mixed_set_sphere_ellipsoid_route(1 if reference_minimiser else 0))
+
+
 def contact_mixed_set_contraction(on):
     """BUILD OPTION (labelled): the S-E / E-E minimisation classes of contact_mixed from the build with fused
     multiply-adds -- results at the reference's 1e-4 instead of bit parity with the oracle.  Default off."""

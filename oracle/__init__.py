@@ -368,6 +368,21 @@ class shared_trig:
         return False
 
 
+class sphere_ellipsoid_minimiser_route:
+    """`with oracle.sphere_ellipsoid_minimiser_route():` -- S-E of contact_mixed through distance(Point, Ellipsoid), the
+    reference's own L-BFGS routine, instead of the exact closed form (the default), for the enclosed calls"""
+
+    def __enter__(self):
+        for fast in (False, True):
+            lib(fast).o_set_sphere_ellipsoid_route(C.c_int(1))
+        return self
+
+    def __exit__(self, *exc):
+        for fast in (False, True):
+            lib(fast).o_set_sphere_ellipsoid_route(C.c_int(0))
+        return False
+
+
 def shared_sincos(x):
     x = _f(x)
     s, c = np.empty_like(x), np.empty_like(x)

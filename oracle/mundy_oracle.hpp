@@ -1015,8 +1015,10 @@ inline SegmentResult segment_ellipsoid(const V3& p0, const V3& p1, const Ellipso
 //   E-E  distance_ellipsoid_ellipsoid                  (EllipsoidEllipsoid.hpp:106-151)
 //   S-R  point-segment distance minus (r_s + r_rod), normal = (closest - centre)/dist, contact points = sphere centre
 //        and centreline point (scrap/.../SphereSpherocylinderLinker.cpp:210-239; LineSegmentSphere.hpp:56-61)
-//   S-E  distance(Point, Ellipsoid) - r_s (the reference's SphereEllipsoid.hpp:21-33 is an empty stub, so
-//        this routing is a build-side definition: PARITY UNPINNED), normal = -ellipsoid normal
+//   S-E  signed distance of the sphere's centre to the ellipsoid - r_s, normal = -ellipsoid normal (the reference's
+//        SphereEllipsoid.hpp:21-33 is an empty stub: a build-side definition, PARITY UNPINNED).  Route 0 (default): the
+//        exact distance (segell, as a rod of zero length); route 1: distance(Point, Ellipsoid), the reference's own
+//        nine-start L-BFGS (SURVEY 8f.4's routing) -- the two agree to that routine's 1e-4
 //   R-E  NO reference function exists (LineSegmentEllipsoid.hpp:21-33 is an empty stub).  Build extension, PARITY
 //        UNPINNED: segell::segment_ellipsoid above -- the closest approach of the rod's centreline to the ellipsoid
 //        (exact signed point - ellipsoid distance, minimised along the centreline), minus the rod radius, as the
@@ -1027,6 +1029,11 @@ inline SegmentResult segment_ellipsoid(const V3& p0, const V3& p1, const Ellipso
 // The pair is evaluated in canonical class order (lower kind first) and flipped back if the list order is the reverse.
 // ---------------------------------------------------------------------------------------------------------------
 enum BodyKind : int { kSphere = 0, kRod = 1, kEllipsoid = 2 };
+// S-E route: 0 = exact (segell, a rod of zero length), 1 = distance_point_ellipsoid (the reference's minimiser)
+inline int& sphere_ellipsoid_route() {
+  static int route = 0;
+  return route;
+}
 struct MixedBody {
   int kind;
   V3 c;
@@ -1061,6 +1068,12 @@ inline MixedContact contact_mixed_canonical(const MixedBody& A, const MixedBody&
     o.normal = (closest - A.c) * inv;
     o.cp1 = A.c;
     o.cp2 = closest;
+  } else if (A.kind == kSphere && B.kind == kEllipsoid && sphere_ellipsoid_route() == 0) {
+    const segell::SegmentResult r = segell::segment_ellipsoid(A.c, A.c, Ellipsoid{B.c, B.q, B.shape});
+    o.sep = r.sdist - A.shape.x;
+    o.normal = {-r.n.x, -r.n.y, -r.n.z};
+    o.cp1 = r.p;
+    o.cp2 = r.x;
   } else if (A.kind == kSphere && B.kind == kEllipsoid) {
     V3 closest, ne;
     const double d = distance_point_ellipsoid(A.c, {B.c, B.q, B.shape}, closest, ne);

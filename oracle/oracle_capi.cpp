@@ -374,6 +374,7 @@ void o_solve_cqpp_contact(size_t C, size_t N, const int32_t* pairs, const double
 }
 
 // sin / cos used by the ellipsoid objective and rotate_quaternion (mundy_oracle.hpp, TrigMode)
+void o_set_sphere_ellipsoid_route(int route) { sphere_ellipsoid_route() = route ? 1 : 0; }
 void o_set_trig_mode(int mode) { trig_mode() = (mode == kTrigShared) ? kTrigShared : kTrigLibm; }
 void o_shared_sincos(size_t n, const double* x, double* s, double* c) {
   for (size_t i = 0; i < n; ++i) shared_sincos(x[i], s[i], c[i]);

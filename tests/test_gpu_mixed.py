@@ -98,9 +98,16 @@ def test_mixed_lockstep_classes_are_bitwise_the_nested_minimisers(ops, oracle):
     aabb, brad = ops.compute_aabb_mixed(dk, dc, dq, ds)
     links = ops.GenNeighborLinks().set_search_kind(ops.SEARCH_AABB).set_search_buffer(0.1).concretize()
     links.generate(aabb, dc, brad)
-    lock = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True)
-    assert min(lock["class_counts"][k] for k in ("SE", "RE", "EE")) > 300
+    default = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True)   # S-E in closed form
     ev = ops.contact_mixed_last_evaluations()
+    assert ev["SE"] == 0 and ev["RE"] == 0 and ev["EE"] > 300 * default["class_counts"]["EE"], ev
+    try:   # S-E through the reference's point - ellipsoid minimiser (the route the nested checker restates)
+        ops.contact_mixed_set_sphere_ellipsoid_route(True)
+        lock = ops.contact_mixed(links.pairs, dk, dc, dq, ds, want_counts=True)
+        ev = ops.contact_mixed_last_evaluations()
+    finally:
+        ops.contact_mixed_set_sphere_ellipsoid_route(False)
+    assert min(lock["class_counts"][k] for k in ("SE", "RE", "EE")) > 300
     assert all(ev[k] > 300 * lock["class_counts"][k] for k in ("SE", "EE")) and ev["RE"] == 0, ev
     pi, pj = links.pairs[:, 0].long(), links.pairs[:, 1].long()
     ki, kj = dk[pi], dk[pj]
@@ -127,6 +134,15 @@ def test_mixed_lockstep_classes_are_bitwise_the_nested_minimisers(ops, oracle):
     se = (ka == 0) & (kb == 2)   # sphere - ellipsoid: distance(Point, Ellipsoid) - r, normal = -ellipsoid normal
     dist, cp, nrm = nested.distance_point_ellipsoid(g(dc, ia[se]), g(dc, ib[se]), g(dq, ib[se]), g(ds, ib[se]))
     check(se, dist - ds[ia[se], 0], -nrm, g(dc, ia[se]), cp)
+    # the default route (closed form) against that minimiser: the reference's own 1e-4 (UnitTestEllipsoidEllipsoid.cpp:53)
+    # on >= 99.5 % of the pairs (the minimiser has its local minima), every other class untouched by the switch
+    agree = (default["sep"][se] - lock["sep"][se]).abs() <= 1e-4
+    assert float(agree.double().mean()) >= 0.995, float(agree.double().mean())
+    assert torch.equal(default["sep"][~se], lock["sep"][~se]) and torch.equal(default["normal"][~se], lock["normal"][~se])
+    from gpu_util import assert_bits_equal, host
+    exp_se = oracle.contact_mixed(np.ascontiguousarray(host(links.pairs[se])), b["kind"], b["center"], b["quat"], b["shape"])
+    for key in ("sep", "normal", "cp1", "cp2", "ra", "rb"):
+        assert_bits_equal(host(default[key][se]), exp_se[key], "S-E (closed form) " + key)
     re = (ka == 1) & (kb == 2)
     sep, nrm, cp1, cp2 = nested.contact_rod_ellipsoid(g(dc, ia[re]), g(dq, ia[re]), g(ds, ia[re]), g(dc, ib[re]),
                                                       g(dq, ib[re]), g(ds, ib[re]))
@@ -134,7 +150,6 @@ def test_mixed_lockstep_classes_are_bitwise_the_nested_minimisers(ops, oracle):
     assert int(outside.sum()) > 200
     close = (lock["sep"][re][outside] - sep[outside]).abs() <= 1e-4
     assert float(close.double().mean()) >= 0.995, float(close.double().mean())
-    from gpu_util import assert_bits_equal, host
     sub = np.ascontiguousarray(host(links.pairs[re]))
     exp = oracle.contact_mixed(sub, b["kind"], b["center"], b["quat"], b["shape"])
     for key in ("sep", "normal", "cp1", "cp2", "ra", "rb"):
@@ -276,16 +291,20 @@ def test_contracted_build_of_the_minimisation_classes_meets_the_reference_tolera
     links = ops.GenNeighborLinks().set_search_kind(ops.SEARCH_AABB).set_search_buffer(0.05).concretize()
     links.generate(aabb, dc, brad)
     pairs = host(links.pairs)
-    with oracle.shared_trig():
+    # (S-E through the reference's minimiser here, so that the option has two classes to act on; by default S-E is
+    #  closed-form and only E-E is a minimisation class)
+    with oracle.shared_trig(), oracle.sphere_ellipsoid_minimiser_route():
         exp = oracle.contact_mixed(pairs, kind, c, q, shape)
-    exact_build = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
-    for k in ("sep", "normal", "ra", "rb"):
-        assert_bits_equal(host(exact_build[k]), exp[k], "default build " + k)
     try:
+        ops.contact_mixed_set_sphere_ellipsoid_route(True)
+        exact_build = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
+        for k in ("sep", "normal", "ra", "rb"):
+            assert_bits_equal(host(exact_build[k]), exp[k], "default build " + k)
         ops.contact_mixed_set_contraction(True)
         fma = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
     finally:
         ops.contact_mixed_set_contraction(False)
+        ops.contact_mixed_set_sphere_ellipsoid_route(False)
     ka, kb = kind[pairs[:, 0]], kind[pairs[:, 1]]
     cls = np.minimum(ka, kb) * 3 + np.maximum(ka, kb)
     closed = np.isin(cls, (0, 1, 4, 5))
@@ -299,6 +318,8 @@ def test_contracted_build_of_the_minimisation_classes_meets_the_reference_tolera
         assert (d > 0).any(), name      # it IS another arithmetic
         nrm = host(fma["normal"])[sel]
         np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-9)
+    with oracle.shared_trig():
+        exp_default = oracle.contact_mixed(pairs, kind, c, q, shape)
     again = ops.contact_mixed(links.pairs, dk, dc, dq, ds)
-    assert_bits_equal(host(again["sep"]), exp["sep"], "default restored")
+    assert_bits_equal(host(again["sep"]), exp_default["sep"], "defaults restored")
     links.close()

@@ -237,7 +237,11 @@ def test_zero_length_rod_is_the_exact_sphere_ellipsoid_distance(oracle):
     out_re = oracle.contact_mixed(case["pairs"], case["kind"], case["center"], case["quat"], case["shape"])
     kind_s = case["kind"].copy()
     kind_s[: case["n"]] = 0
-    out_se = oracle.contact_mixed(case["pairs"], kind_s, case["center"], case["quat"], case["shape"])
+    exact_se = oracle.contact_mixed(case["pairs"], kind_s, case["center"], case["quat"], case["shape"])
+    for key in ("sep", "normal", "cp1", "cp2"):   # S-E's default route IS the rod of zero length
+        assert np.array_equal(exact_se[key], out_re[key]), key
+    with oracle.sphere_ellipsoid_minimiser_route():
+        out_se = oracle.contact_mixed(case["pairs"], kind_s, case["center"], case["quat"], case["shape"])
     assert (out_re["sep"] + case["r"] < -0.05).sum() > 30
     np.testing.assert_allclose(out_re["sep"], out_se["sep"], atol=1e-4)
     far = np.abs(out_re["sep"] + case["r"]) > 0.05   # (the normal of a point on the surface is that point's own)
