@@ -29,18 +29,21 @@ struct EEOutput {
 // POINT = false: ellipsoid-ellipsoid (EllipsoidEllipsoid.hpp:106-151); true: point-ellipsoid (PointEllipsoid.hpp:94-135)
 template <bool POINT>
 __global__ void __launch_bounds__(kEllBlock) ELL_OCC
-    k_ellipsoid_pairs_lockstep(size_t n, EEInput in, EEOutput out, unsigned long long* __restrict__ counter) {
+    k_ellipsoid_pairs_lockstep(size_t n, EEInput in, EEOutput out, unsigned long long* __restrict__ counter,
+                               lockstep::StartBoard board) {
   const int lane = threadIdx.x & 63;
   __shared__ double history_tile[lockstep::kHistorySlots][64];  // one column per lane (workgroup = one wave)
   const lockstep::History hist{&history_tile[0][threadIdx.x & 63]};
   lockstep::Machine m;
   m.phase = lockstep::PH_IDLE;
+  m.evals = 0;
+  const int spu = lockstep::starts_per_unit(n), units = 9 / spu;
   EllipsoidD e1{}, e2{};
   lockstep::Frame fr1{}, fr2{};  // per-pair constants of the foot-point maps
   size_t k = 0;
   bool active = false, need = true;
   for (unsigned round = 0;; ++round) {
-    // lanes without a pair take the next ones from the global counter (one atomic per wave)
+    // lanes without work take the next units -- (pair, third of its starts) -- from the global counter (one atomic per wave)
     const unsigned long long want = __ballot(need);
     if (want) {
       const int leader = __ffsll(static_cast<long long>(want)) - 1;
@@ -48,7 +51,8 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
       if (lane == leader) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(want)));
       base = __shfl(base, leader, 64);
       if (need) {
-        k = base + __popcll(want & ((1ull << lane) - 1ull));
+        const size_t unit = base + __popcll(want & ((1ull << lane) - 1ull));
+        k = unit / units;
         need = false;
         active = k < n;
         if (active) {
@@ -65,7 +69,7 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
           }
           fr1 = lockstep::make_frame(e1.q);
           if (!POINT) fr2 = lockstep::make_frame(e2.q);
-          lockstep::begin_pair(m);
+          lockstep::begin_item(m, static_cast<int>(unit % units), spu);
         }
       }
     }
@@ -94,16 +98,21 @@ __global__ void __launch_bounds__(kEllBlock) ELL_OCC
       if (out.cp2) store3(out.cp2, k, f2);
       if (out.ra) store3(out.ra, k, f1 - e1.c);
       if (out.rb) store3(out.rb, k, f2 - e2.c);
-      atomicAdd(counter + 1, static_cast<unsigned long long>(m.evals));  // objective evaluations, for the fp64 roofline
       active = false;
       need = true;
     }
     lockstep::scheduled_transitions(m, hist, active, round);
+    // a start has returned: on the pair's board with it; the ninth arrival goes on to the final evaluation
+    if (active && m.phase == lockstep::PH_START_DONE && !lockstep::post_start(m, board, k)) {
+      active = false;
+      need = true;
+    }
   }
+  if (m.evals) atomicAdd(counter + 1, static_cast<unsigned long long>(m.evals));  // objective evaluations, for the fp64 roofline
 }
 
 struct EllipsoidScratch {
-  DeviceBuffer counter;
+  DeviceBuffer counter, board;
 };
 EllipsoidScratch& ellipsoid_scratch() {
   thread_local EllipsoidScratch s;
@@ -114,12 +123,17 @@ int launch_ellipsoid_lockstep(size_t n, const EEInput& in, const EEOutput& out, 
   EllipsoidScratch& es = ellipsoid_scratch();
   if (int e = es.counter.reserve(64)) return e;
   MHIP_HIP(hipMemsetAsync(es.counter.ptr, 0, 2 * sizeof(unsigned long long), s));
-  const size_t waves = (n + 63) / 64;
+  // the start board: the records of every pair, then the arrival counters (zeroed)
+  const size_t rec_doubles = lockstep::board_doubles(n);
+  if (int e = es.board.reserve(rec_doubles * sizeof(double) + n * sizeof(unsigned) + 64)) return e;
+  const lockstep::StartBoard board{es.board.as<double>(), reinterpret_cast<unsigned*>(es.board.as<double>() + rec_doubles)};
+  MHIP_HIP(hipMemsetAsync(board.arrived, 0, n * sizeof(unsigned), s));
+  const size_t waves = ((9 / lockstep::starts_per_unit(n)) * n + 63) / 64;
   const unsigned grid = static_cast<unsigned>(waves < 2048 ? waves : 2048);  // 256 CUs x 4 SIMDs x 2 waves: all resident
   if (in.point)
-    k_ellipsoid_pairs_lockstep<true><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
+    k_ellipsoid_pairs_lockstep<true><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>(), board);
   else
-    k_ellipsoid_pairs_lockstep<false><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>());
+    k_ellipsoid_pairs_lockstep<false><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>(), board);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

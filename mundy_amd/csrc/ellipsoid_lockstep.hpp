@@ -8,8 +8,17 @@
 // so the expensive part (two sincos, four quaternion rotations, two foot-point maps: ~850 instructions) runs with all
 // lanes converged whatever line-search branch, L-BFGS iteration, start point or pair each lane is in; only the
 // minimiser logic diverges, and the wave runs its heavy pieces on a schedule rather than whenever a lane gets there
-// ("Scheduling" below).  A lane that finishes a pair takes the next one from a global counter, so no lane waits for
-// the slowest pair of its wave either.  (One thread per pair with the minimiser called
+// ("Scheduling" below).  The unit of work a lane takes from the global counter is a THIRD of a pair -- three of its
+// nine starts (round 3; it was the whole pair): the nine minimisations of a pair are independent until the best of
+// them is chosen, and a launch rarely has more than a few pairs per lane of the machine (10^6 mixed bodies:
+// 2.5 * 10^5 E-E pairs on 1.3 * 10^5 lanes) -- with whole pairs the launch lasted as long as its unluckiest lane's two
+// or three pairs, and an eighth of the system (one rank of eight) would have lasted exactly as long as the whole.
+// Each unit leaves its best (cost, point) on a per-pair board; the lane whose unit is the last to finish picks the
+// best in the reference's order (first of equals) and runs the final evaluation ("Start board" below).  Single
+// starts as units are finer still, but the hand-over -- stores, drain, ticket -- then sits in every second round of a
+// wave: they pay only where the launch has less than a pair per two lanes.  E-E pairs, ms per launch, units of 9 / 3 / 1
+// starts (profiles/r03_lockstep_units.txt): 3 * 10^4 pairs 7.6 / 3.8 / 2.7; 10^5 10.2 / 6.1 / 6.9; 2.5 * 10^5
+// 15.9 / 11.4 / 16.0; 10^6 42.1 / 38.9 / 60.9 -- so the unit is one start up to kSingleStartBelow pairs, three beyond.  (One thread per pair with the minimiser called
 // as ordinary nested loops spends most of its time with lanes masked off: pairs need 577...1640 objective
 // evaluations, and lanes are in different loops at any moment.)
 //
@@ -36,6 +45,7 @@ enum Phase : int {
   // over that piece of minimiser logic (see "Scheduling" below)
   PH_WAIT_LS1, PH_WAIT_LS2,  // the tests at the bottom of the bracketing / sectioning loop
   PH_WAIT_HEAD,              // head of find_min's loop: stop tests, L-BFGS direction, line-search set-up
+  PH_START_DONE,             // this start's find_min has returned (cost, x): to be posted on the pair's board
   PH_IDLE
 };
 
@@ -74,7 +84,7 @@ struct Machine {
   double ls_first, ls_last, val, fp, fm;
   int itr;
   // multistart (EllipsoidEllipsoid.hpp:106-151)
-  int start;
+  int start, starts_per_unit;
   double best;
   V2 best_tp;
   int phase;
@@ -144,9 +154,19 @@ __device__ inline void begin_start(Machine& m) {
   m.prev_val = 0;
   m.phase = PH_COST_INIT;
 }
-__device__ inline void begin_pair(Machine& m) {
-  m.evals = 0;
-  m.start = 0;
+// a lane's next unit of work: starts [unit * spu, (unit + 1) * spu) of some pair, spu = 1, 3 or 9 starts per unit
+// (m.evals keeps counting over the lane's units)
+#ifndef MHIP_LOCKSTEP_STARTS_PER_UNIT
+#define MHIP_LOCKSTEP_STARTS_PER_UNIT 0  // 0: by the size of the launch (starts_per_unit below); 1 / 3 / 9 force it (A/B)
+#endif
+constexpr size_t kSingleStartBelow = 60000;
+__host__ __device__ inline int starts_per_unit(size_t pairs) {
+  if (MHIP_LOCKSTEP_STARTS_PER_UNIT) return MHIP_LOCKSTEP_STARTS_PER_UNIT;
+  return pairs <= kSingleStartBelow ? 1 : 3;
+}
+__device__ inline void begin_item(Machine& m, int unit, int spu) {
+  m.starts_per_unit = spu;
+  m.start = unit * spu;
   m.best = __builtin_huge_val();
   m.best_tp = V2{0.0, 0.0};
   begin_start(m);
@@ -180,17 +200,67 @@ __device__ inline void line_search_done(Machine& m, double alpha) {
   m.phase = PH_G0P;
 }
 
-// one start is finished: keep it if it is the best so far, go to the next start or to the final evaluation
+// one start is finished (find_min's return value is m.cost, its point m.x): kept if it is the best of the unit so far
+// -- `if (d < global_dist)`, EllipsoidEllipsoid.hpp:141-145 -- then the unit's next start, or the board (post_start)
 __device__ inline void finish_start(Machine& m) {
   if (m.cost < m.best) {
     m.best = m.cost;
     m.best_tp = m.x;
   }
   ++m.start;
-  if (m.start < 9)
+  if (m.start % m.starts_per_unit != 0)
     begin_start(m);
   else
-    m.phase = PH_FINAL;
+    m.phase = PH_START_DONE;
+}
+
+// Start board.  Per pair of a launch: one (cost, theta, phi) record per unit and an arrival counter (zeroed by the host
+// before the launch).  A lane posts its unit's best with write-through stores, drains them, takes a ticket; the last
+// arrival reads the records past its L1 and chooses as the reference's loop over the starts does -- `if (d <
+// global_dist)` in start order, within a unit and between units: the first of equal costs
+// (EllipsoidEllipsoid.hpp:131-147).  Same hand-off as k_fold_finalize
+// (convex.hip): agent-scope relaxed atomics, no fence that writes back or invalidates an L2.
+struct StartBoard {
+  double* records;   // [pairs][9 / starts per unit][3]
+  unsigned* arrived; // [pairs]
+};
+// doubles of the records of a launch of up to `pairs` pairs whatever unit the kernel picks for the pairs it finds
+__host__ __device__ inline size_t board_doubles(size_t pairs) {
+  if (MHIP_LOCKSTEP_STARTS_PER_UNIT) return pairs * 3 * (9 / MHIP_LOCKSTEP_STARTS_PER_UNIT);
+  const size_t small = pairs < kSingleStartBelow ? pairs : kSingleStartBelow;
+  return small * 27 > pairs * 9 ? small * 27 : pairs * 9;
+}
+// returns true when this lane's unit was the last of its pair: the machine then holds the best point and wants the
+// final evaluation (PH_FINAL); false: the lane is free for its next unit
+__device__ inline bool post_start(Machine& m, const StartBoard& board, size_t pair) {
+  const int units = 9 / m.starts_per_unit;
+  const int unit = m.start / m.starts_per_unit - 1;  // (m.start has moved past the unit's last start)
+  double* rec = board.records + (pair * units + static_cast<size_t>(unit)) * 3;
+  __hip_atomic_store(rec + 0, m.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(rec + 1, m.best_tp.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(rec + 2, m.best_tp.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned ticket = __hip_atomic_fetch_add(board.arrived + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (ticket != static_cast<unsigned>(units - 1)) {
+    m.phase = PH_IDLE;
+    return false;
+  }
+  const double* all = board.records + pair * units * 3;
+  double best = __builtin_huge_val();
+  V2 best_tp{0.0, 0.0};
+  for (int s = 0; s < units; ++s) {
+    const double d = __hip_atomic_load(all + 3 * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double a = __hip_atomic_load(all + 3 * s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double b = __hip_atomic_load(all + 3 * s + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d < best) {
+      best = d;
+      best_tp = V2{a, b};
+    }
+  }
+  m.best = best;
+  m.best_tp = best_tp;
+  m.phase = PH_FINAL;
+  return true;
 }
 
 // head of find_min's loop: stop tests, L-BFGS direction, line-search set-up (no objective evaluation in here).

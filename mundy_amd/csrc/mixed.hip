@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
     MHIP_LOCKSTEP_KERNEL(const int32_t* __restrict__ class_start, const int32_t* __restrict__ order,
                              const int2* __restrict__ pairs, const int32_t* __restrict__ kind,
                              const double* __restrict__ center, const double* __restrict__ quat,
-                             const double* __restrict__ shape, MixedOut out, unsigned long long* __restrict__ counter) {
+                             const double* __restrict__ shape, MixedOut out, unsigned long long* __restrict__ counter,
+                             lockstep::StartBoard board) {
   static_assert(CLS == 2 || CLS == 5, "lockstep kernels exist for the minimisation classes only");
   const int32_t beg = class_start[CLS], end = class_start[CLS + 1];
   const size_t n = static_cast<size_t>(end - beg);
@@ -190,10 +191,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
   const lockstep::History hist{&history_tile[0][threadIdx.x & 63]};
   lockstep::Machine m;
   m.phase = lockstep::PH_IDLE;
+  m.evals = 0;
+  const int spu = lockstep::starts_per_unit(n), units = 9 / spu;  // (by the size of the CLASS, known here only)
   BodyD A{}, B{};
   lockstep::Frame frA{}, frB{};  // per-pair constants of the objective (see ellipsoid_lockstep.hpp)
   bool swapped = false;
-  size_t k = 0;
+  size_t k = 0, slot = 0;  // the pair's place in the caller's list, and in this class (its row of the start board)
   bool active = false, need = true;
   for (unsigned round = 0;; ++round) {
     const unsigned long long want = __ballot(need);
@@ -203,11 +206,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
       if (lane == leader) base = atomicAdd(counter, static_cast<unsigned long long>(__popcll(want)));
       base = __shfl(base, leader, 64);
       if (need) {
-        const size_t idx = base + __popcll(want & ((1ull << lane) - 1ull));
+        const size_t unit = base + __popcll(want & ((1ull << lane) - 1ull));  // (pair of the class, third of its starts)
+        slot = unit / units;
         need = false;
-        active = idx < n;
+        active = slot < n;
         if (active) {
-          k = static_cast<size_t>(order[beg + idx]);
+          k = static_cast<size_t>(order[beg + slot]);
           const int2 ij = pairs[k];
           const BodyD bi = load_body(kind, center, quat, shape, ij.x);
           BodyD bj = load_body(kind, center, quat, shape, ij.y);
@@ -217,7 +221,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
           B = swapped ? bi : bj;
           frB = lockstep::make_frame(B.q);
           if (CLS == 5) frA = lockstep::make_frame(A.q);
-          lockstep::begin_pair(m);
+          lockstep::begin_item(m, static_cast<int>(unit % units), spu);
         }
       }
     }
@@ -250,22 +254,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
       } else {
         store_contact(out, k, swapped, dot(f2 - f1, n1), n1, f1, f2, ci, cj);
       }
-      atomicAdd(counter + 4, static_cast<unsigned long long>(m.evals));  // objective evaluations of the class
       active = false;
       need = true;
     }
     lockstep::scheduled_transitions(m, hist, active, round);
+    if (active && m.phase == lockstep::PH_START_DONE && !lockstep::post_start(m, board, slot)) {
+      active = false;
+      need = true;
+    }
   }
+  if (m.evals) atomicAdd(counter + 4, static_cast<unsigned long long>(m.evals));  // objective evaluations of the class
 }
 
 // the two launches (S-E, E-E); cnt[k] = next pair of class k, cnt[4 + k] = its objective evaluations (k = 1 was R-E,
 // which runs in closed form since round 3: its words stay zero)
 int MHIP_LOCKSTEP_LAUNCH(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
                          const int32_t* kind, const double* center, const double* quat, const double* shape,
-                         const MixedOut& out, unsigned long long* cnt, bool sphere_ellipsoid, hipStream_t s) {
+                         const MixedOut& out, unsigned long long* cnt, bool sphere_ellipsoid,
+                         const lockstep::StartBoard& board_se, const lockstep::StartBoard& board_ee, hipStream_t s) {
   if (sphere_ellipsoid)
-    MHIP_LOCKSTEP_KERNEL<2><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 0);
-  MHIP_LOCKSTEP_KERNEL<5><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 2);
+    MHIP_LOCKSTEP_KERNEL<2><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 0, board_se);
+  MHIP_LOCKSTEP_KERNEL<5><<<grid, 64, 0, s>>>(start, order, pairs, kind, center, quat, shape, out, cnt + 2, board_ee);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }
@@ -275,12 +284,13 @@ int MHIP_LOCKSTEP_LAUNCH(unsigned grid, const int32_t* start, const int32_t* ord
 int launch_contact_classes_lockstep_fma(unsigned grid, const int32_t* start, const int32_t* order, const int2* pairs,
                                         const int32_t* kind, const double* center, const double* quat,
                                         const double* shape, const MixedOut& out, unsigned long long* cnt,
-                                        bool sphere_ellipsoid, hipStream_t s);
+                                        bool sphere_ellipsoid, const lockstep::StartBoard& board_se,
+                                        const lockstep::StartBoard& board_ee, hipStream_t s);
 std::atomic<int> g_mixed_contraction{0};
 std::atomic<int> g_mixed_se_route{0};  // 0: S-E in closed form; 1: through the reference's point - ellipsoid minimiser
 
 struct MixedScratch {
-  DeviceBuffer cls, flags, pos, order, start, scanws, counters;
+  DeviceBuffer cls, flags, pos, order, start, scanws, counters, board;
   int32_t* host = nullptr;
 };
 MixedScratch& mixed_scratch() {
@@ -387,11 +397,22 @@ static int contact_mixed_impl(size_t c, const int32_t* pairs, const int32_t* kin
     if (int e = ms.counters.reserve(64)) return e;
     unsigned long long* cnt = ms.counters.as<unsigned long long>();  // [k]: next pair of class k; [4 + k]: its evaluations
     MHIP_HIP(hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), s));
-    const unsigned gl = static_cast<unsigned>(c / 64 + 1 > 2048 ? 2048 : c / 64 + 1);  // persistent waves
+    const unsigned gl = static_cast<unsigned>(9 * c / 64 + 1 > 2048 ? 2048 : 9 * c / 64 + 1);  // persistent waves (up to nine units per pair)
+    // start boards of the minimisation classes (ellipsoid_lockstep.hpp), one row per pair of the class.  The class
+    // sizes stay on the device, so each board is sized for every pair of the list (the S-E one only when that class
+    // is routed through the minimiser)
+    const size_t boards = se_minimiser ? 2 : 1;
+    const size_t rec_doubles = lockstep::board_doubles(c);
+    if (int e = ms.board.reserve(boards * (rec_doubles * sizeof(double) + c * sizeof(unsigned) + 64))) return e;
+    double* rec = ms.board.as<double>();
+    unsigned* arr = reinterpret_cast<unsigned*>(rec + boards * rec_doubles);
+    MHIP_HIP(hipMemsetAsync(arr, 0, boards * c * sizeof(unsigned), s));
+    const lockstep::StartBoard board_ee{rec, arr};
+    const lockstep::StartBoard board_se{rec + (boards - 1) * rec_doubles, arr + (boards - 1) * c};
     if (g_mixed_contraction.load() != 0) {
-      if (int e = launch_contact_classes_lockstep_fma(gl, start, order, p2, kind, center, quat, shape, out, cnt, se_minimiser, s)) return e;
+      if (int e = launch_contact_classes_lockstep_fma(gl, start, order, p2, kind, center, quat, shape, out, cnt, se_minimiser, board_se, board_ee, s)) return e;
     } else {
-      if (int e = launch_contact_classes_lockstep(gl, start, order, p2, kind, center, quat, shape, out, cnt, se_minimiser, s)) return e;
+      if (int e = launch_contact_classes_lockstep(gl, start, order, p2, kind, center, quat, shape, out, cnt, se_minimiser, board_se, board_ee, s)) return e;
     }
   }
 #undef CLASS

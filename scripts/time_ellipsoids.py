@@ -14,4 +14,4 @@ for _ in range(5):
     t = time.perf_counter(); ops.distance_ellipsoid_ellipsoid(*a, *b); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
 dt = float(np.median(ts))
 ev = ops.ellipsoid_last_evaluations()
-print("ellipsoid pairs %d: %.3f s  -> %.3f us/pair, %.3g pairs/s; %.0f objective evaluations per pair" % (n, dt, 1e6 * dt / n, n / dt, ev / n))
+print("ellipsoid pairs %d: %.4f s  -> %.3f us/pair, %.3g pairs/s; %.0f objective evaluations per pair" % (n, dt, 1e6 * dt / n, n / dt, ev / n))
