@@ -412,6 +412,8 @@ def main_mixed(args, ops, pipeline, synth, dev):
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
     st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=args.buffer, cfg=cfg,
                                  kinds=dev(b["kind"]), shape=dev(b["shape"]))
+    if args.xcd_tile >= 0 or args.lanes_per_body > 0:
+        st.work_mapping = (args.xcd_tile, args.lanes_per_body)
     pristine = st.snapshot()
     prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
 
