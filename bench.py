@@ -543,7 +543,7 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
         sys.exit(3)
     comm.self_check()  # pairwise messages + all-gather with known contents, before anything is timed
     st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
-                                     comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=32,
+                                     comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=64,
                                      domain=(0.0, float(box)), curve_level=6)
     # set-up, untimed: one solve on the equal-COUNT cut to measure the work per body, then the curve is re-cut at equal
     # WORK (1 + contacts per body) and the bodies move to their new owners (the reference rebalances with

@@ -743,7 +743,7 @@ typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that
  *   begin;  per iteration: body sweep of the owned bodies -> pack + start the velocity halo -> constraint sweep of the
  *   interior contacts [0, interior_contacts) while the halo is in flight -> finish halo -> sweep of the boundary
  *   contacts -> local (max, sum dx^2, sum dx dg) record -> all-gather -> every rank reduces the records in rank order
- *   (bit-identical steps) ;  convergence polled after stretches of 8, 16, 32, ... iterations, at most poll_every (0: 32) ;  end.
+ *   (bit-identical steps) ;  convergence polled after stretches of 8, 16, 32, ... iterations, at most poll_every (0: 64) ;  end.
  * Same iterates as the mhip_bbpgd_stage_* sequence driven by hand.  op must carry mhip_contact_op_set_partition; the
  * four solver vectors are caller owned as in mhip_bbpgd_solve_contact.  profile may be NULL. */
 int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t comm, const mhip_velocity_halo* halo,

@@ -359,7 +359,7 @@ class DistributedSpherocylinderStepper {
     const mhip_pgd_config pc{cfg_.max_iters, cfg_.tol, MHIP_RESIDUAL_PROJECTED_DIFF};
     mhip_solve_result res{};
     check(mhip_bbpgd_solve_contact_distributed(op.handle(), comm_, &lay_.halo, n_int_, sep, &lcp, &pc, x, g, x_tmp,
-                                               g_tmp, /*poll_every=*/32, &res, nullptr, nullptr));
+                                               g_tmp, /*poll_every=*/64, &res, nullptr, nullptr));
     st.num_iters = res.num_iters;
     st.residual = res.residual;
     st.converged = res.converged != 0;

@@ -358,7 +358,7 @@ class DistributedContactStepper:
     RECORD = 15
 
     def __init__(self, center, quat, radius, length, gid_first, *, comm=None, dt=5e-3, viscosity=1e-3,
-                 search_buffer=0.1, cfg=None, poll_every=16, kind=None, shape=None, entity_id=None, domain=None,
+                 search_buffer=0.1, cfg=None, poll_every=64, kind=None, shape=None, entity_id=None, domain=None,
                  curve_level=5, recut_every=4):
         """entity_id [n] (float64 or int64): ids that stay with a body when it changes owner (default: the initial
         global ids).  domain = (lo, hi): the fixed box whose (2^curve_level)^3 Hilbert lattice decides ownership when

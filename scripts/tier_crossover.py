@@ -7,7 +7,8 @@ from mundy_amd import distributed as D, ops, pipeline, synth
 sizes = [int(a) for a in sys.argv[1:]] or [30000, 60000, 125000, 250000, 500000]
 dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29735", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-cfg = ops.PGDConfig(max_iters=10000, tol=1e-5)
+import os
+cfg = ops.PGDConfig(max_iters=10000, tol=float(os.environ.get("TOL", "1e-5")))
 comm = D.Comm()
 def med(fn):
     fn(); torch.cuda.synchronize(); ts = []
