@@ -159,7 +159,8 @@ def parse():
                    help="BASELINE configs[4] instead of the headline workload: --bodies bodies, one third each spheres "
                         "(r 0.5), spherocylinders (r 0.5, L 2) and ellipsoids (0.8, 0.5, 0.4), random orientations, "
                         "--mixed-phi volume fraction; shape classes binned, L-BFGS ellipsoid distances, vector-arm "
-                        "operator.  N = 1 only; never the default line.")
+                        "operator.  With --gpus N > 1 the one system is Hilbert-partitioned over the ranks like the rods "
+                        "(configs[4] as BASELINE states it).  Never the default line.")
     p.add_argument("--mixed-phi", type=float, default=0.30)
     p.add_argument("--ellipsoid-fma", action="store_true",
                    help="--mixed: LABELLED build option -- the ellipsoid minimisation classes from the build with "
@@ -243,8 +244,6 @@ def main():
     n = args.bodies
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     if world > 1 or args.distributed:
-        if args.mixed:
-            raise SystemExit("--mixed is a single-GPU line (the mixed distributed path is covered by the tests)")
         return main_distributed(args, rank, world, dist, ops, synth, dev)
     if args.mixed:
         return main_mixed(args, ops, pipeline, synth, dev)
@@ -522,13 +521,21 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     n = args.bodies // world if strong else args.bodies
     n_total = n * world
     # every rank derives the same global order from the counter-based generator (no set-up communication)
-    centers, box = synth.spherocylinder_centers(np.arange(n_total), n_total, seed=1234)
+    if args.mixed:   # BASELINE configs[4]: the mixed system over the ranks (every rank generates it, keeps its slice)
+        whole = synth.mixed_bodies(n_total, volume_fraction=args.mixed_phi, seed=1234)
+        centers, box = whole["center"], whole["box"]
+    else:
+        centers, box = synth.spherocylinder_centers(np.arange(n_total), n_total, seed=1234)
     order = D.hilbert_order(centers, 0.0, box, level=7)
     starts = D.partition_ranges(n_total, world)
     a, e = int(starts[rank]), int(starts[rank + 1])
     mine = order[a:e]
     del centers
-    b = synth.spherocylinders(len(mine), seed=1234, n_total=n_total, indices=mine)
+    if args.mixed:
+        b = {k: np.ascontiguousarray(whole[k][mine]) for k in ("center", "quat", "kind", "shape")}
+        del whole
+    else:
+        b = synth.spherocylinders(len(mine), seed=1234, n_total=n_total, indices=mine)
     cfg = ops.PGDConfig(max_iters=args.max_iters, tol=args.tol)
     comm = D.Comm(mailbox=not args.no_mailbox, halo_ipc=not args.no_halo_ipc)
     if comm.transport != "rccl" and not args.allow_host_transport:
@@ -542,9 +549,14 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
         dist.destroy_process_group()
         sys.exit(3)
     comm.self_check()  # pairwise messages + all-gather with known contents, before anything is timed
-    st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
-                                     comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=64,
-                                     domain=(0.0, float(box)), curve_level=6)
+    if args.mixed:
+        st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), None, None, a, comm=comm,
+                                         search_buffer=args.buffer, cfg=cfg, poll_every=64, kind=dev(b["kind"]),
+                                         shape=dev(b["shape"]), domain=(0.0, float(box)), curve_level=6)
+    else:
+        st = D.DistributedContactStepper(dev(b["center"]), dev(b["quat"]), dev(b["radius"]), dev(b["length"]), a,
+                                         comm=comm, search_buffer=args.buffer, cfg=cfg, poll_every=64,
+                                         domain=(0.0, float(box)), curve_level=6)
     # set-up, untimed: one solve on the equal-COUNT cut to measure the work per body, then the curve is re-cut at equal
     # WORK (1 + contacts per body) and the bodies move to their new owners (the reference rebalances with
     # stk::balance, NGPSpheresLCP.cpp:956)
@@ -590,19 +602,25 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
     roof, extra = None, {}
     if st.prof["iters"] > 0:
         roof, extra, _, _ = roofline_entries(stats[-1]["local_contacts"], n, st.prof["con_ms"] / st.prof["iters"],
-                                             st.prof["body_ms"] / st.prof["iters"], st.prof["iters"], ", rank 0")
+                                             st.prof["body_ms"] / st.prof["iters"], st.prof["iters"], ", rank 0",
+                                             kin="rigid" if args.mixed else "rod")
     if rank == 0:
         out = {
-            "metric": METRIC if strong else
-            "timesteps/sec, 10^6 spherocylinders PER GPU (one system of N x 10^6), frictionless LCP contact (BBPGD)",
+            "metric": ("timesteps/sec, 10^6 mixed sphere / spherocylinder / ellipsoid bodies, frictionless LCP contact (BBPGD)"
+                       if args.mixed else METRIC) if strong else
+            "timesteps/sec, 10^6 bodies PER GPU (one system of N x 10^6), frictionless LCP contact (BBPGD)",
             # strong: timesteps per second of the one fixed-size system; weak: world x (10^6-rod workloads per second)
             "value": round((1 if strong else world) * args.steps / elapsed, 4), "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[3]: %.3gM spherocylinders r=0.5 L=2 at 40%% volume fraction, one system "
+            "config": {"workload": ("configs[4]: %.3gM mixed bodies (one third each spheres r=0.5, spherocylinders r=0.5 "
+                                    "L=2, ellipsoids (0.8, 0.5, 0.4)) at %.0f%% volume fraction, one system "
+                                    % (n_total / 1e6, 100 * args.mixed_phi) if args.mixed else
+                                    "configs[3]: %.3gM spherocylinders r=0.5 L=2 at 40%% volume fraction, one system "
+                                    % (n_total / 1e6)) +
                                    "Hilbert-partitioned over %d GPUs, AABB+%.2g neighbour list, frictionless LCP tol %.0e"
-                                   % (n_total / 1e6, world, args.buffer, args.tol),
+                                   % (world, args.buffer, args.tol),
                        "bodies_per_gpu": n, "bodies_total": n_total, "contacts_total": contacts_global,
                        "ghost_bodies_total": ghosts_global, "bbpgd_iters_per_step": iters,
                        "owned_contacts_per_rank": per_rank_contacts,
