@@ -106,14 +106,14 @@ def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", acti
     return ent[dominant], {other: ent[other]}, dominant, other
 
 
-def attach_traffic(roof, extra, dom, oth, n, buffer):
+def attach_traffic(roof, extra, dom, oth, n, buffer, name="traffic.json"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (scripts/profile_bench.sh:
     separate FETCH_SIZE / WRITE_SIZE runs, 2 x FETCH_SIZE + WRITE_SIZE as the gfx950 guide prescribes).  They are NOT
     measured in this run -- the source is named next to the number."""
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    tpath = os.path.join(ROOT, "profiles", name)
     if os.path.exists(tpath) and n == 1_000_000 and buffer == 0.1:
         tj = json.load(open(tpath))
-        src = "profiles/traffic.json (%s)" % tj.get("_source", "rocprofv3 --pmc passes of `python bench.py`, committed")
+        src = "profiles/%s (%s)" % (name, tj.get("_source", "rocprofv3 --pmc passes of `python bench.py`, committed"))
         for ent, k in ((roof, dom), (extra[oth], oth)):
             ent["traffic"] = tj.get(k, {}).get("hbm_bytes_per_launch")
             ent["traffic_source"] = src if ent["traffic"] is not None else None
@@ -488,9 +488,11 @@ def main_mixed(args, ops, pipeline, synth, dev):
     if prof["iters"] > 0:
         # the same accounting as the headline line (kernel_bytes: what the launch REQUIRES, with the activity masks and
         # the cold tier as measured in this run), for explicit lever arms
-        roof, extra, _, _ = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"], prof["body_ms"] / prof["iters"],
-                                             prof["iters"], active_contacts=active, tier=prof.get("tier"),
-                                             iterations=prof.get("solve_iters"), kin="rigid")
+        roof, extra, dom, oth = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"], prof["body_ms"] / prof["iters"],
+                                                 prof["iters"], active_contacts=active, tier=prof.get("tier"),
+                                                 iterations=prof.get("solve_iters"), kin="rigid")
+        if args.mixed_phi == 0.30:
+            attach_traffic(roof, extra, dom, oth, n, args.buffer, name="traffic_mixed.json")
     out = {
         "metric": "timesteps/sec, 10^6 mixed sphere / spherocylinder / ellipsoid bodies, frictionless LCP contact (BBPGD)",
         "value": round(args.steps / elapsed, 4), "unit": "timesteps/s", "n_gpus": 1, "steps": args.steps,

@@ -24,7 +24,8 @@ def find(sub, pat):
     return r[0] if r else None
 
 
-print("# rocprofv3 summary of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (kernel trace + stats)")
+EXTRA = " ".join(sys.argv[2:])
+print("# rocprofv3 summary of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline%s` (kernel trace + stats)" % ((" " + EXTRA) if EXTRA else ""))
 try:
     line = open(os.path.join(out, "bench_trace.json")).read().strip().splitlines()[-1]
     print("bench line (profiled run):", line)
@@ -83,8 +84,9 @@ if traffic:
         if k in eff:
             traffic[k]["trace_avg_effective_us"] = eff[k] / 1e3
     traffic["_source"] = ("scripts/profile_bench.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py "
-                          "--steps 1 --warmup 0` (the whole solve: untiered first iterations and tiered rest, as in the timed run), 2 x FETCH_SIZE + WRITE_SIZE per effective launch"
-                          % os.path.basename(out.rstrip("/")).replace("prof_", ""))
+                          "--steps 1 --warmup 0%s` (the whole solve: untiered first iterations and tiered rest, as in the timed "
+                          "run), 2 x FETCH_SIZE + WRITE_SIZE per effective launch"
+                          % (os.path.basename(out.rstrip("/")).replace("prof_", ""), (" " + EXTRA) if EXTRA else ""))
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print("\n## HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
     for k, v in traffic.items():
