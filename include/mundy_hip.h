@@ -94,6 +94,15 @@ int mhip_distance_sphere_sphere(size_t n, const double* c1, const double* r1, co
                                 double* dist, double* sep, mhip_stream_t stream);
 int mhip_distance_point_segment(size_t n, const double* p, const double* a0, const double* a1, double* dist,
                                 double* cp, double* t, double* sep, mhip_stream_t stream);
+/* Replaces: distance(SharedNormalSigned, Point, Sphere[, sep])       .../distance/PointSphere.hpp:46-80
+ *           distance(SharedNormalSigned, LineSegment, Sphere[, cp, arch_length, sep])
+ *                                                                    .../distance/LineSegmentSphere.hpp:47-100
+ * (the centre's distance to the point / to the segment, minus the radius; sep rescaled to the sphere's surface:
+ * point -> surface, and for the segment the separation PointLineSegment hands back, centre -> closest point). */
+int mhip_distance_point_sphere(size_t n, const double* p, const double* c, const double* r, double* dist, double* sep,
+                               mhip_stream_t stream);
+int mhip_distance_segment_sphere(size_t n, const double* a0, const double* a1, const double* c, const double* r,
+                                 double* dist, double* cp, double* t, double* sep, mhip_stream_t stream);
 int mhip_distance_segment_segment(size_t n, const double* a0, const double* a1, const double* b0, const double* b1,
                                   double* dist, double* cp1, double* cp2, double* s, double* t, double* sep,
                                   mhip_stream_t stream);

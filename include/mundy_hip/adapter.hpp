@@ -258,6 +258,53 @@ inline std::vector<double> distance(SharedNormalSigned, const std::vector<Sphere
   return dist.download();
 }
 
+// distance(SharedNormalSigned, Point, Sphere[, sep]) (PointSphere.hpp:57-79), element-wise over two equal-length lists
+inline std::vector<double> distance(SharedNormalSigned, const std::vector<Point<double>>& p,
+                                    const std::vector<Sphere<double>>& s, std::vector<Point<double>>* sep = nullptr) {
+  if (p.size() != s.size()) throw std::invalid_argument("distance: list sizes differ");
+  const size_t n = p.size();
+  std::vector<double> pp, c, r;
+  for (size_t i = 0; i < n; ++i) {
+    detail::push3(pp, p[i]); detail::push3(c, s[i].center()); r.push_back(s[i].radius());
+  }
+  DeviceVector dp(pp), dc(c), dr(r), dist(n), dsep(3 * n);
+  check(mhip_distance_point_sphere(n, dp.data(), dc.data(), dr.data(), dist.data(), dsep.data(), nullptr));
+  if (sep) {
+    const auto h = dsep.download();
+    sep->resize(n);
+    for (size_t i = 0; i < n; ++i) (*sep)[i] = Point<double>(h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+  }
+  return dist.download();
+}
+
+struct SegmentSphereResult {
+  std::vector<double> distance, arch_length;
+  std::vector<Point<double>> closest_point, sep;
+};
+// distance(SharedNormalSigned, LineSegment, Sphere, closest_point, arch_length, sep) (LineSegmentSphere.hpp:88-100)
+inline SegmentSphereResult distance(SharedNormalSigned, const std::vector<LineSegment<double>>& a,
+                                    const std::vector<Sphere<double>>& s) {
+  if (a.size() != s.size()) throw std::invalid_argument("distance: list sizes differ");
+  const size_t n = a.size();
+  std::vector<double> a0, a1, c, r;
+  for (size_t i = 0; i < n; ++i) {
+    detail::push3(a0, a[i].start()); detail::push3(a1, a[i].end());
+    detail::push3(c, s[i].center()); r.push_back(s[i].radius());
+  }
+  DeviceVector da0(a0), da1(a1), dc(c), dr(r), dist(n), cp(3 * n), t(n), dsep(3 * n);
+  check(mhip_distance_segment_sphere(n, da0.data(), da1.data(), dc.data(), dr.data(), dist.data(), cp.data(), t.data(),
+                                     dsep.data(), nullptr));
+  SegmentSphereResult out;
+  out.distance = dist.download(); out.arch_length = t.download();
+  auto to_pts = [n](const std::vector<double>& h) {
+    std::vector<Point<double>> q(n);
+    for (size_t i = 0; i < n; ++i) q[i] = Point<double>(h[3 * i], h[3 * i + 1], h[3 * i + 2]);
+    return q;
+  };
+  out.closest_point = to_pts(cp.download()); out.sep = to_pts(dsep.download());
+  return out;
+}
+
 struct EllipsoidEllipsoidResult {
   std::vector<double> distance;
   std::vector<Point<double>> closest_point1, closest_point2, shared_normal1, shared_normal2;
@@ -370,6 +417,39 @@ inline double distance(SharedNormalSigned t, const Sphere<double>& sphere1, cons
 }
 inline double distance(const Sphere<double>& sphere1, const Sphere<double>& sphere2, Point<double>& sep) {
   return distance(SharedNormalSigned{}, sphere1, sphere2, sep);  // SphereSphere.hpp:66-76
+}
+inline double distance(SharedNormalSigned t, const Point<double>& point, const Sphere<double>& sphere) {
+  return distance(t, std::vector<Point<double>>{point}, std::vector<Sphere<double>>{sphere})[0];
+}
+inline double distance(const Point<double>& point, const Sphere<double>& sphere) {  // PointSphere.hpp:46-50
+  return distance(SharedNormalSigned{}, point, sphere);
+}
+inline double distance(const Point<double>& point, const Sphere<double>& sphere, Point<double>& sep) {
+  std::vector<Point<double>> s;   // PointSphere.hpp:69-79
+  const double d = distance(SharedNormalSigned{}, std::vector<Point<double>>{point}, std::vector<Sphere<double>>{sphere}, &s)[0];
+  sep = s[0];
+  return d;
+}
+inline double distance(SharedNormalSigned t, const LineSegment<double>& line_segment, const Sphere<double>& sphere,
+                       Point<double>& closest_point, double& arch_length, Point<double>& sep) {
+  const SegmentSphereResult r = distance(t, std::vector<LineSegment<double>>{line_segment},
+                                         std::vector<Sphere<double>>{sphere});   // LineSegmentSphere.hpp:88-100
+  closest_point = r.closest_point[0];
+  arch_length = r.arch_length[0];
+  sep = r.sep[0];
+  return r.distance[0];
+}
+inline double distance(const LineSegment<double>& line_segment, const Sphere<double>& sphere,
+                       Point<double>& closest_point, double& arch_length, Point<double>& sep) {
+  return distance(SharedNormalSigned{}, line_segment, sphere, closest_point, arch_length, sep);  // :71-78
+}
+inline double distance(SharedNormalSigned t, const LineSegment<double>& line_segment, const Sphere<double>& sphere) {
+  Point<double> cp, sep;   // LineSegmentSphere.hpp:58-62
+  double al;
+  return distance(t, line_segment, sphere, cp, al, sep);
+}
+inline double distance(const LineSegment<double>& line_segment, const Sphere<double>& sphere) {
+  return distance(SharedNormalSigned{}, line_segment, sphere);   // LineSegmentSphere.hpp:47-51
 }
 inline double distance(SharedNormalSigned t, const LineSegment<double>& line_segment1,
                        const LineSegment<double>& line_segment2, Point<double>& closest_point1,

@@ -82,6 +82,8 @@ SIGNATURES = {
     "mhip_spherocylinder_segments": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_distance_sphere_sphere": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_distance_point_segment": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_distance_point_sphere": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mhip_distance_segment_sphere": [_sz] + [_vp] * 9,
     "mhip_distance_segment_segment": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mhip_distance_ellipsoid_ellipsoid": [_sz] + [_vp] * 12,
     "mhip_distance_point_ellipsoid": [_sz] + [_vp] * 8,

@@ -107,6 +107,38 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 __global__ void __launch_bounds__(kBlock)
+    k_dist_point_sphere(size_t n, const double* __restrict__ p, const double* __restrict__ c,
+                        const double* __restrict__ r, double* __restrict__ dist, double* __restrict__ sep) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // distance(Point, Sphere, sep): PointSphere.hpp:69-79 (sep from the point to the surface; NaN when the point is
+    // the centre, as in the reference: 0 * (d / 0))
+    V3 s;
+    const double cc = dist_point_point(load3(p, i), load3(c, i), s);
+    const double d = cc - r[i];
+    if (dist) dist[i] = d;
+    if (sep) store3(sep, i, s * (d / cc));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    k_dist_segment_sphere(size_t n, const double* __restrict__ a0, const double* __restrict__ a1,
+                          const double* __restrict__ c, const double* __restrict__ r, double* __restrict__ dist,
+                          double* __restrict__ cp, double* __restrict__ t, double* __restrict__ sep) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // distance(LineSegment, Sphere, cp, t, sep): LineSegmentSphere.hpp:88-100 -- distance(sphere.center(), segment,
+    // ...) rescaled to the surface; the separation is the one that routine hands back (centre -> closest point)
+    V3 cl, s;
+    double tt;
+    const double lc = dist_point_segment(load3(c, i), load3(a0, i), load3(a1, i), cl, tt, s);
+    const double d = lc - r[i];
+    if (dist) dist[i] = d;
+    if (cp) store3(cp, i, cl);
+    if (t) t[i] = tt;
+    if (sep) store3(sep, i, s * (d / lc));
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
     k_dist_point_segment(size_t n, const double* __restrict__ p, const double* __restrict__ a0,
                          const double* __restrict__ a1, double* __restrict__ dist, double* __restrict__ cp,
                          double* __restrict__ t, double* __restrict__ sep) {
@@ -280,6 +312,24 @@ int mhip_distance_sphere_sphere(size_t n, const double* c1, const double* r1, co
   REQ_PTR(c1); REQ_PTR(r1); REQ_PTR(c2); REQ_PTR(r2);
   if (n == 0) return MHIP_SUCCESS;
   k_dist_sphere_sphere<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, c1, r1, c2, r2, dist, sep);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_distance_point_sphere(size_t n, const double* p, const double* c, const double* r, double* dist, double* sep,
+                               mhip_stream_t stream) {
+  REQ_PTR(p); REQ_PTR(c); REQ_PTR(r);
+  if (n == 0) return MHIP_SUCCESS;
+  k_dist_point_sphere<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, p, c, r, dist, sep);
+  MHIP_LAUNCH_CHECK();
+  return MHIP_SUCCESS;
+}
+
+int mhip_distance_segment_sphere(size_t n, const double* a0, const double* a1, const double* c, const double* r,
+                                 double* dist, double* cp, double* t, double* sep, mhip_stream_t stream) {
+  REQ_PTR(a0); REQ_PTR(a1); REQ_PTR(c); REQ_PTR(r);
+  if (n == 0) return MHIP_SUCCESS;
+  k_dist_segment_sphere<<<grid_for(n), kBlock, 0, as_stream(stream)>>>(n, a0, a1, c, r, dist, cp, t, sep);
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
 }

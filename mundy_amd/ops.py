@@ -123,6 +123,24 @@ def distance_point_segment(p, a0, a1):
     return dist, cp, t, sep
 
 
+def distance_point_sphere(p, c, r):
+    """distance(Point, Sphere, sep) (PointSphere.hpp:69-79)."""
+    n = p.shape[0]
+    dist, sep = _new(p, n), _new(p, n, 3)
+    capi.check(capi.load().mhip_distance_point_sphere(n, _ptr(p, cols=3), _ptr(c, cols=3), _ptr(r), _ptr(dist),
+                                                      _ptr(sep), _stream()))
+    return dist, sep
+
+
+def distance_segment_sphere(a0, a1, c, r):
+    """distance(LineSegment, Sphere, closest_point, arch_length, sep) (LineSegmentSphere.hpp:88-100)."""
+    n = a0.shape[0]
+    dist, cp, t, sep = _new(a0, n), _new(a0, n, 3), _new(a0, n), _new(a0, n, 3)
+    capi.check(capi.load().mhip_distance_segment_sphere(n, _ptr(a0, cols=3), _ptr(a1, cols=3), _ptr(c, cols=3), _ptr(r),
+                                                        _ptr(dist), _ptr(cp), _ptr(t), _ptr(sep), _stream()))
+    return dist, cp, t, sep
+
+
 def distance_segment_segment(a0, a1, b0, b1):
     n = a0.shape[0]
     dist, cp1, cp2 = _new(a0, n), _new(a0, n, 3), _new(a0, n, 3)

@@ -164,6 +164,22 @@ def distance_sphere_sphere(c1, r1, c2, r2):
     return dist, sep
 
 
+def distance_point_sphere(p, c, r):
+    p, c, r = _f(p), _f(c), _f(r)
+    n = len(r)
+    dist, sep = np.empty(n), np.empty((n, 3))
+    lib().o_distance_point_sphere(C.c_size_t(n), _p(p), _p(c), _p(r), _p(dist), _p(sep))
+    return dist, sep
+
+
+def distance_segment_sphere(a0, a1, c, r):
+    a0, a1, c, r = _f(a0), _f(a1), _f(c), _f(r)
+    n = len(r)
+    dist, cp, t, sep = np.empty(n), np.empty((n, 3)), np.empty(n), np.empty((n, 3))
+    lib().o_distance_segment_sphere(C.c_size_t(n), _p(a0), _p(a1), _p(c), _p(r), _p(dist), _p(cp), _p(t), _p(sep))
+    return dist, cp, t, sep
+
+
 def contact_spheres(pairs, center, radius, box=None, fast=False):
     pairs = np.ascontiguousarray(pairs, dtype=np.int32)
     center, radius = _f(center), _f(radius)

@@ -391,6 +391,24 @@ inline double distance_point_segment(const V3& point, const V3& p1, const V3& p2
   return distance_point_point(point, closest, &sep);
 }
 
+// mundy/geom/src/mundy_geom/distance/PointSphere.hpp:57-62 (no sep) and :69-79 (sep rescaled to the surface; NaN when
+// the point is the centre).
+inline double distance_point_sphere(const V3& point, const V3& c, double r) { return distance_point_point(point, c) - r; }
+inline double distance_point_sphere(const V3& point, const V3& c, double r, V3& sep) {
+  const double center_point_distance = distance_point_point(point, c, &sep);
+  const double surface_distance = center_point_distance - r;
+  sep = sep * (surface_distance / center_point_distance);
+  return surface_distance;
+}
+// mundy/geom/src/mundy_geom/distance/LineSegmentSphere.hpp:88-100: distance(sphere.center(), line_segment, cp, t, sep)
+// minus the radius, sep rescaled (it is the separation PointLineSegment returns: centre -> closest point).
+inline double distance_segment_sphere(const V3& p1, const V3& p2, const V3& c, double r, V3& closest, double& t, V3& sep) {
+  const double line_center_distance = distance_point_segment(c, p1, p2, closest, t, sep);
+  const double surface_distance = line_center_distance - r;
+  sep = sep * (surface_distance / line_center_distance);
+  return surface_distance;
+}
+
 // mundy/geom/src/mundy_geom/distance/LineSegmentLineSegment.hpp:189-318.
 inline double distance_segment_segment(const V3& l0, const V3& l1, const V3& m0, const V3& m1, V3& cp1, V3& cp2,
                                        double& s, double& t, V3& sep) {

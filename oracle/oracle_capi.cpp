@@ -120,6 +120,22 @@ void o_distance_sphere_sphere(size_t n, const double* c1, const double* r1, cons
     st3(sep, i, s);
   }
 }
+void o_distance_point_sphere(size_t n, const double* p, const double* c, const double* r, double* dist, double* sep) {
+  for (size_t i = 0; i < n; ++i) {
+    V3 s;
+    dist[i] = distance_point_sphere(ld3(p, i), ld3(c, i), r[i], s);
+    st3(sep, i, s);
+  }
+}
+void o_distance_segment_sphere(size_t n, const double* a0, const double* a1, const double* c, const double* r,
+                               double* dist, double* cp, double* t, double* sep) {
+  for (size_t i = 0; i < n; ++i) {
+    V3 cl, s;
+    dist[i] = distance_segment_sphere(ld3(a0, i), ld3(a1, i), ld3(c, i), r[i], cl, t[i], s);
+    st3(cp, i, cl);
+    st3(sep, i, s);
+  }
+}
 void o_contact_spheres(size_t C, const int32_t* pairs, const double* center, const double* radius,
                        const double* box, double* sep, double* normal) {
   const PeriodicScaledMetric pm(box ? V3{box[0], box[1], box[2]} : V3{1, 1, 1});

@@ -252,6 +252,26 @@ static void test_single_object_overloads() {
   const LineSegment<double> l(Point<double>(0, 0, -1), Point<double>(0, 0, 1)), m(Point<double>(0.8, 0, 1.5), Point<double>(0.8, 0, 3.5));
   distance(SharedNormalSigned{}, l, m, cp1, cp2, t1, t2, sep);
   EXPECT_TRUE(t1 == 1.0 && t2 == -0.25 && cp2[2] == 1.5);
+  // distance(Point, Sphere[, sep]) (PointSphere.hpp:46-80) and distance(LineSegment, Sphere[, cp, arch_length, sep])
+  // (LineSegmentSphere.hpp:47-100): the reference has no test of its own for either; hand-computed answers
+  const Sphere<double> ball(Point<double>(0, 0, 0), 1.0);
+  EXPECT_NEAR(distance(Point<double>(0, 0, 5), ball), 4.0, 1e-15);
+  EXPECT_NEAR(distance(SharedNormalSigned{}, Point<double>(0, 3, 4), ball), 4.0, 1e-15);
+  EXPECT_NEAR(distance(Point<double>(0, 0, 0.25), ball), -0.75, 1e-15);              // inside: negative
+  EXPECT_NEAR(distance(Point<double>(0, 0, 5), ball, sep), 4.0, 1e-15);
+  EXPECT_TRUE(sep[0] == 0.0 && sep[1] == 0.0);
+  EXPECT_NEAR(sep[2], -4.0, 1e-15);                                                 // from the point to the surface
+  const LineSegment<double> rail(Point<double>(-1, 0, 0), Point<double>(1, 0, 0));
+  const Sphere<double> bead(Point<double>(0.5, 3, 0), 1.0);
+  EXPECT_NEAR(distance(rail, bead), 2.0, 1e-15);
+  EXPECT_NEAR(distance(SharedNormalSigned{}, rail, bead), 2.0, 1e-15);
+  EXPECT_NEAR(distance(rail, bead, cp1, t1, sep), 2.0, 1e-15);
+  EXPECT_NEAR(t1, 0.75, 1e-15);
+  EXPECT_NEAR(cp1[0], 0.5, 1e-15);
+  EXPECT_NEAR(sep[1], -2.0, 1e-15);                  // PointLineSegment's separation (centre -> closest point), rescaled
+  // beyond the end: closest point clamped, arch length left unclamped (PointLineSegment.hpp:156-166)
+  EXPECT_NEAR(distance(rail, Sphere<double>(Point<double>(4, 0, 0), 0.5), cp1, t1, sep), 2.5, 1e-15);
+  EXPECT_TRUE(t1 == 2.5 && cp1[0] == 1.0);
   // two spheres as ellipsoids (UnitTestEllipsoidEllipsoid.cpp:65-145), tolerance 1e-4
   const Ellipsoid<double> e1(Point<double>(0, 0, 0), id, Point<double>(1, 1, 1)), e2(Point<double>(4, 0, 0), x90, Point<double>(2, 2, 2));
   Point<double> n1, n2;

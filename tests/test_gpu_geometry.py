@@ -116,6 +116,16 @@ def test_distance_batches_bit_exact(ops, oracle):
     exp = oracle.distance_sphere_sphere(a0, r1, b0, r2)
     assert_bits_equal(got[0], exp[0], "sphere-sphere dist")
     assert_bits_equal(got[1], exp[1], "sphere-sphere sep")
+    # distance(Point, Sphere, sep) / distance(LineSegment, Sphere, cp, t, sep): PointSphere.hpp:69-79,
+    # LineSegmentSphere.hpp:88-100 (the segment cases above include degenerate and far-away segments)
+    got = [host(x) for x in ops.distance_point_sphere(dev(p), dev(b0), dev(r1))]
+    exp = oracle.distance_point_sphere(p, b0, r1)
+    for g, e, name in zip(got, exp, ("dist", "sep")):
+        assert_bits_equal(g, e, "point-sphere " + name)
+    got = [host(x) for x in ops.distance_segment_sphere(dev(a0), dev(a1), dev(p), dev(r2))]
+    exp = oracle.distance_segment_sphere(a0, a1, p, r2)
+    for g, e, name in zip(got, exp, ("dist", "cp", "t", "sep")):
+        assert_bits_equal(g, e, "segment-sphere " + name)
 
 
 def test_segseg_known_distance_property(ops):

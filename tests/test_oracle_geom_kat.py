@@ -216,6 +216,35 @@ def test_sphere_sphere(oracle):
     np.testing.assert_allclose(n[0], [0, 0.8, 0.6], atol=1e-15)
 
 
+def test_point_sphere_and_segment_sphere(oracle):
+    # distance(Point, Sphere[, sep]) (PointSphere.hpp:46-80), distance(LineSegment, Sphere, cp, arch_length, sep)
+    # (LineSegmentSphere.hpp:47-100): no reference test exists -- analytic cases, and the definitions themselves on a
+    # random batch (centre distance minus radius; sep rescaled to the surface)
+    d, sep = oracle.distance_point_sphere([[0, 0, 5.0], [0, 0, 0.25]], [[0, 0, 0], [0, 0, 0]], [1.0, 1.0])
+    assert d[0] == 4.0 and d[1] == -0.75
+    np.testing.assert_allclose(sep[0], [0, 0, -4.0], atol=1e-15)      # from the point to the surface
+    np.testing.assert_allclose(sep[1], [0, 0, 0.75], atol=1e-15)      # inside: the shortest way out
+    d, cp, t, sep = oracle.distance_segment_sphere([[-1, 0, 0], [-1, 0, 0]], [[1, 0, 0], [1, 0, 0]],
+                                                   [[0.5, 3, 0], [4, 0, 0]], [1.0, 0.5])
+    assert d[0] == 2.0 and t[0] == 0.75
+    np.testing.assert_allclose(cp[0], [0.5, 0, 0], atol=1e-15)
+    np.testing.assert_allclose(sep[0], [0, -2.0, 0], atol=1e-15)      # PointLineSegment's sep (centre -> closest point)
+    assert d[1] == 2.5 and t[1] == 2.5 and cp[1][0] == 1.0            # clamped point, unclamped parameter
+    rng = np.random.default_rng(8)
+    n = 5000
+    p, c, a0, a1 = (rng.uniform(-2, 2, (n, 3)) for _ in range(4))
+    r = rng.uniform(0.1, 1.5, n)
+    d, sep = oracle.distance_point_sphere(p, c, r)
+    cc = np.linalg.norm(c - p, axis=1)
+    np.testing.assert_allclose(d, cc - r, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(sep, (c - p) * ((cc - r) / cc)[:, None], rtol=0, atol=1e-14)
+    d, cp, t, sep = oracle.distance_segment_sphere(a0, a1, c, r)
+    d0, cp0, t0, sep0 = oracle.distance_point_segment(c, a0, a1)
+    assert np.array_equal(cp, cp0) and np.array_equal(t, t0)
+    np.testing.assert_allclose(d, d0 - r, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(np.linalg.norm(sep, axis=1), np.abs(d), rtol=0, atol=1e-13)
+
+
 def test_rod_contact_assembly(oracle):
     # two perpendicular rods, centrelines 1 apart along z: sep = 1 - (0.25 + 0.5), n = +z
     c = np.array([[0, 0, 0], [0, 0, 1.0]])
