@@ -168,8 +168,13 @@ int mhip_contact_mixed_set_contraction(int on);
 /* S-E (a build extension: the reference's SphereEllipsoid.hpp is an empty stub) = signed distance of the sphere's centre
  * to the ellipsoid, minus the radius.  route 0 (default): the exact distance in closed form (csrc/segment_ellipsoid.hpp);
  * route 1: distance(Point, Ellipsoid) as the reference computes it (PointEllipsoid.hpp:94-135, nine-start L-BFGS over
- * the surface normal; SURVEY 8f.4's routing), which route 0 matches to that routine's own 1e-4.  Applies to the
- * following mhip_contact_mixed* calls of any thread. */
+ * the surface normal).  ROUTE 1 IS THE REFERENCE-ROUTINE ROUTE, the one SURVEY 8f.4 prescribes for S-E; route 0 solves
+ * the same problem (closest surface point in the Euclidean sense, signed by inside / outside) exactly and matches
+ * route 1 to that routine's own 1e-4 wherever its minimiser reaches the global minimum.  Where the two differ by more
+ * than 1e-4 (the nine starts stall in a local minimum: needles, flakes, points near a long axis; < 0.5 % of the pairs
+ * of the mixed packing) the tests certify PAIR BY PAIR that route 0's foot point is the closer one and satisfies the
+ * optimality conditions (tests/test_gpu_mixed.py, tests/test_oracle_ellipsoid_kat.py:
+ * certify_sphere_ellipsoid_disagreements).  Applies to the following mhip_contact_mixed* calls of any thread. */
 int mhip_contact_mixed_set_sphere_ellipsoid_route(int route);
 /* objective evaluations the L-BFGS classes (S-E, E-E; the middle word was R-E's, closed-form since round 3: 0)
  * needed in the last mhip_contact_mixed* call of this host thread, and in the last mhip_distance_ellipsoid_* / mhip_contact_ellipsoids call: these kernels are fp64-vector bound

@@ -28,6 +28,7 @@ namespace segell {
 constexpr int kNewtonMax = 64;    // (3-6 in practice; the loop ends when the iterate stops moving)
 constexpr int kBisections = 48;   // interval 2^-48 of the centreline
 constexpr double kTiny = 1e-290;
+constexpr double kRelTiny = 1e-100;  // a coordinate this far below the point's largest one is zero for the case analysis
 
 // root of Q(u) = (r0 z0 / (u + r0 - 1))^2 + (r1 z1 / (u + r1 - 1))^2 + (z2 / u)^2 = 1 on u > 0 (Eberly's s = u - 1:
 // the unknown is kept as the distance from the pole at s = -1, which a point next to the plane of the two long axes
@@ -169,9 +170,15 @@ __device__ inline PointResult point_ellipsoid_body(V3 y, V3 e) {
   double e0 = e.x, e1 = e.y, e2 = e.z;
   double a0 = sx * y.x, a1 = sy * y.y, a2 = sz * y.z;
   // (a coordinate that a division by a semi-axis could flush to zero IS zero for the case analysis below)
-  a0 = a0 < kTiny ? 0.0 : a0;
-  a1 = a1 < kTiny ? 0.0 : a1;
-  a2 = a2 < kTiny ? 0.0 : a2;
+  // ... and so is one more than 100 decades below the point's largest coordinate: with equal semi-axes (m = 0, the
+  // pole term d = u) Newton starts at u = z2 and Q = (r z / u)^2 would overflow; the symmetry-plane branches are exact
+  // for such a point to 1e-100 relative
+  double amax = a0 < a1 ? a1 : a0;
+  amax = amax < a2 ? a2 : amax;
+  const double floor_ = kRelTiny * amax < kTiny ? kTiny : kRelTiny * amax;
+  a0 = a0 < floor_ ? 0.0 : a0;
+  a1 = a1 < floor_ ? 0.0 : a1;
+  a2 = a2 < floor_ ? 0.0 : a2;
   double i0 = 0.0, i1 = 1.0, i2 = 2.0;  // which lab axis sits in which sorted place
   {
     const bool c = e0 < e1;

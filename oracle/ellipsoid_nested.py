@@ -1,5 +1,6 @@
-"""Test infrastructure: builds and wraps tests/cpp/ellipsoid_nested_ref.hip, the ellipsoid distances with the reference's
-minimiser written as plain nested loops (one thread per pair).  The production kernels run the same arithmetic as a
+"""Test infrastructure (part of the oracle: restated reference code lives under oracle/ only): builds and wraps
+oracle/ellipsoid_nested_ref.hip, the ellipsoid distances with the reference's minimiser written as plain nested loops
+(one thread per pair; minimize_impl.hpp:151-605).  The production kernels run the same arithmetic as a
 per-lane state machine; the GPU tests require the two to agree bit for bit.  Not imported by mundy_amd/."""
 import ctypes as C
 import os
@@ -7,8 +8,8 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "cpp", "ellipsoid_nested_ref.hip")
-LIB = os.path.join(HERE, "cpp", "libellipsoid_nested_ref.so")
+SRC = os.path.join(HERE, "ellipsoid_nested_ref.hip")
+LIB = os.path.join(HERE, "libellipsoid_nested_ref.so")
 DEPS = [SRC] + [os.path.join(HERE, "..", "mundy_amd", "csrc", f)
                 for f in ("ellipsoid_device.hpp", "geom_device.hpp", "mhip_internal.hpp")]
 _lib = None

@@ -4,10 +4,10 @@
 // mundy_geom/distance/EllipsoidEllipsoid.hpp:106-151 and PointEllipsoid.hpp:94-135 do.  It is a close restatement of
 // that algorithm (like oracle/, and for the same reason: to be a checker) and exists for ONE purpose: the production
 // kernels run the same arithmetic as a per-lane state machine (mundy_amd/csrc/ellipsoid_lockstep.hpp), and the tests
-// require every output of the two forms to agree bit for bit.  Built by tests/ellipsoid_nested.py into
-// tests/cpp/libellipsoid_nested_ref.so; shares only the per-evaluation device functions with the product
+// require every output of the two forms to agree bit for bit.  Built by oracle/ellipsoid_nested.py into
+// oracle/libellipsoid_nested_ref.so; shares only the per-evaluation device functions with the product
 // (foot-point maps, det_sincos, poly_min_extrap).
-#include "../../mundy_amd/csrc/ellipsoid_device.hpp"
+#include "../mundy_amd/csrc/ellipsoid_device.hpp"
 
 namespace mhip {
 namespace lbfgs {

@@ -863,6 +863,7 @@ inline double distance_point_ellipsoid(const V3& point, const Ellipsoid& el, V3&
 namespace segell {
 constexpr int kNewtonMax = 64, kBisections = 48;
 constexpr double kTiny = 1e-290;
+constexpr double kRelTiny = 1e-100;  // a coordinate this far below the point's largest one is zero for the case analysis
 // root in u > 0 of sum_k (r[k] z[k] / (u + m[k]))^2 = 1 with m[k] = r[k] - 1, r[N - 1] = 1 (u = Eberly's s + 1: the
 // distance from the pole, which can be as small as z[N - 1]): Newton on 1 - 1 / sqrt(sum) from u = z[N - 1]
 template <int N>
@@ -977,10 +978,15 @@ inline PointResult point_ellipsoid_body(const V3& yv, const V3& radii) {
   if (rr[perm[1]] < rr[perm[2]]) std::swap(perm[1], perm[2]);
   if (rr[perm[0]] < rr[perm[1]]) std::swap(perm[0], perm[1]);
   double e[3], y[3], x[3];
+  // (a coordinate a division by a semi-axis could flush to zero IS zero below, and so is one more than 100 decades
+  // below the point's largest: with equal semi-axes the Newton start u = z2 would overflow Q -- the device's rule)
+  double amax = sgn[0] * yy[0] < sgn[1] * yy[1] ? sgn[1] * yy[1] : sgn[0] * yy[0];
+  amax = amax < sgn[2] * yy[2] ? sgn[2] * yy[2] : amax;
+  const double floor_ = kRelTiny * amax < kTiny ? kTiny : kRelTiny * amax;
   for (int k = 0; k < 3; ++k) {
     e[k] = rr[perm[k]];
     y[k] = sgn[perm[k]] * yy[perm[k]];
-    if (y[k] < kTiny) y[k] = 0.0;  // (a coordinate a division by a semi-axis could flush to zero IS zero below)
+    if (y[k] < floor_) y[k] = 0.0;
   }
   const double dist = closest_on_ellipsoid(e, y, x);
   const double w0 = y[0] / e[0], w1 = y[1] / e[1], w2 = y[2] / e[2];

@@ -12,4 +12,5 @@ export LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=lib
 export ASAN_OPTIONS=detect_leaks=0 MUNDY_ORACLE_PATH="$W"
 cd "$ROOT"
 python -m pytest tests/test_oracle_geom_kat.py tests/test_oracle_convex_kat.py tests/test_oracle_zmorton_hilbert_kat.py \
-  tests/test_oracle_search.py tests/test_oracle_ellipsoid_kat.py tests/test_oracle_friction_ext.py -x -q -p no:cacheprovider
+  tests/test_oracle_search.py tests/test_oracle_ellipsoid_kat.py tests/test_oracle_friction_ext.py \
+  tests/test_oracle_aligned_rods.py tests/test_oracle_sums.py -x -q -p no:cacheprovider

@@ -44,7 +44,9 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_or_fails_loudly():
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert "starting" in p.stderr and "--nproc-per-node 2" in p.stderr
-    assert p.stderr.count("bench.py needs a GPU") >= 2, p.stderr[-3000:]
+    # (the elastic agent ends the other rank as soon as one exits non-zero, so only ONE of them is sure to get its
+    # message out)
+    assert p.stderr.count("bench.py needs a GPU") >= 1, p.stderr[-3000:]
     # a launcher that started ONE rank for --gpus 2: refused by name
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=600, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))

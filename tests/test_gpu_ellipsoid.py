@@ -87,10 +87,10 @@ def test_random_ellipsoids_vs_oracle(ops, oracle):
 def test_lockstep_kernel_is_bitwise_the_nested_loop_minimiser(ops):
     # the production kernel runs the multistart L-BFGS as a per-lane state machine with converged objective evaluations
     # and lane refill (ellipsoid_lockstep.hpp); the plain nested-loop form of the same algorithm is the tests' own
-    # checker (tests/cpp/ellipsoid_nested_ref.hip, NOT in libmundy_hip.so): every output must agree bit for bit,
+    # checker (oracle/ellipsoid_nested_ref.hip, NOT in libmundy_hip.so): every output must agree bit for bit,
     # including for pair counts that do not fill a wavefront and for the neighbour-list entry point
     import torch
-    import ellipsoid_nested as nested
+    from oracle import ellipsoid_nested as nested
     from gpu_util import dev
     rng = np.random.default_rng(11)
 

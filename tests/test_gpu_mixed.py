@@ -86,11 +86,11 @@ def test_extension_classes_on_sphere_like_bodies(ops):
 
 def test_mixed_lockstep_classes_are_bitwise_the_nested_minimisers(ops, oracle):
     # S-E and E-E contacts come from lockstep state-machine kernels; the nested-loop form of the same minimiser is
-    # the tests' own checker (tests/cpp/ellipsoid_nested_ref.hip): identical bits for every output of every pair.
+    # the tests' own checker (oracle/ellipsoid_nested_ref.hip): identical bits for every output of every pair.
     # R-E is closed-form since round 3: identical bits to the oracle, and within the minimiser's 1e-4 of its former
     # definition (that checker's nested L-BFGS over the surface normal) wherever the centreline is outside the ellipsoid
     import torch
-    import ellipsoid_nested as nested
+    from oracle import ellipsoid_nested as nested
     from gpu_util import dev
     from mundy_amd import synth
     b = synth.mixed_bodies(9000, volume_fraction=0.3, seed=5)
@@ -138,6 +138,17 @@ def test_mixed_lockstep_classes_are_bitwise_the_nested_minimisers(ops, oracle):
     # on >= 99.5 % of the pairs (the minimiser has its local minima), every other class untouched by the switch
     agree = (default["sep"][se] - lock["sep"][se]).abs() <= 1e-4
     assert float(agree.double().mean()) >= 0.995, float(agree.double().mean())
+    # ... and every pair of the other <= 0.5 % is certified: the closed form's foot point is the closer one and satisfies
+    # the optimality conditions, i.e. the disagreement is the reference minimiser's local minimum (round-3 review)
+    from gpu_util import host as _h
+    from test_oracle_ellipsoid_kat import certify_sphere_ellipsoid_disagreements
+    sw_se = swapped[se][:, None]
+    on_ell = lambda o: _h(torch.where(sw_se, o["cp1"][se], o["cp2"][se]))  # noqa: E731  the ellipsoid's contact point
+    k_bad = certify_sphere_ellipsoid_disagreements(
+        oracle, _h(dc[ia[se]]), _h(ds[ia[se], 0]), _h(dc[ib[se]]), _h(dq[ib[se]]), _h(ds[ib[se]]),
+        dict(sep=_h(default["sep"][se]), cp=on_ell(default)), dict(sep=_h(lock["sep"][se]), cp=on_ell(lock)))
+    print("S-E: %d of %d pairs of the mixed packing differ by more than 1e-4 between the default (closed form) and the "
+          "reference route; each certified as the minimiser's local minimum" % (k_bad, int(se.sum())))
     assert torch.equal(default["sep"][~se], lock["sep"][~se]) and torch.equal(default["normal"][~se], lock["normal"][~se])
     from gpu_util import assert_bits_equal, host
     exp_se = oracle.contact_mixed(np.ascontiguousarray(host(links.pairs[se])), b["kind"], b["center"], b["quat"], b["shape"])
@@ -178,6 +189,54 @@ def test_rod_ellipsoid_closed_form_is_the_oracle_bit_for_bit(ops, oracle, degene
     assert_bits_equal(host(flipped["sep"]), exp["sep"], "R-E sep, pair reversed")
     assert_bits_equal(host(flipped["normal"]), -exp["normal"], "R-E normal, pair reversed")
     assert_bits_equal(host(flipped["cp1"]), exp["cp2"], "R-E contact points, pair reversed")
+
+
+def test_sphere_ellipsoid_default_route_certified_against_the_reference_route(ops, oracle):
+    # S-E on needles and flakes (semi-axes 0.02 ... 4), points from deep inside to well outside: where the reference's
+    # nine-start L-BFGS (route 1 = SURVEY 8f.4's routing, PointEllipsoid.hpp:94-135 minus r) stalls in a local minimum
+    # the default (closed form) must be the better answer of the same problem -- pair by pair; both routes bit-identical
+    # to the oracle's statement of them
+    from gpu_util import assert_bits_equal, dev, host
+    from test_oracle_ellipsoid_kat import _rod_ellipsoid_case, certify_sphere_ellipsoid_disagreements
+    rng = np.random.default_rng(77)
+    n = 20_000
+    case = _rod_ellipsoid_case(rng, n)
+    case["er"][: n // 2] = rng.uniform(0.02, 4.0, (n // 2, 3))
+    case["shape"][n:] = case["er"]
+    case["shape"][:n, 1] = 0.0
+    kind = case["kind"].copy()
+    kind[:n] = 0
+    args = (dev(case["pairs"]), dev(kind), dev(case["center"]), dev(case["quat"]), dev(case["shape"]))
+    closed = {k: host(v) for k, v in ops.contact_mixed(*args).items() if k in ("sep", "normal", "cp1", "cp2")}
+    try:
+        ops.contact_mixed_set_sphere_ellipsoid_route(True)
+        mini = {k: host(v) for k, v in ops.contact_mixed(*args).items() if k in ("sep", "normal", "cp1", "cp2")}
+    finally:
+        ops.contact_mixed_set_sphere_ellipsoid_route(False)
+    exp = oracle.contact_mixed(case["pairs"], kind, case["center"], case["quat"], case["shape"])
+    with oracle.sphere_ellipsoid_minimiser_route(), oracle.shared_trig():
+        exp_min = oracle.contact_mixed(case["pairs"], kind, case["center"], case["quat"], case["shape"])
+    for key in ("sep", "normal", "cp1", "cp2"):
+        assert_bits_equal(closed[key], exp[key], "S-E closed form " + key)
+        assert_bits_equal(mini[key], exp_min[key], "S-E reference route " + key)
+    agree = np.abs(closed["sep"] - mini["sep"]) <= 1e-4
+    assert agree.mean() >= 0.99 and (~agree).sum() >= 5, (agree.mean(), (~agree).sum())
+    k = certify_sphere_ellipsoid_disagreements(oracle, case["rc"], case["r"], case["ec"], case["eq"], case["er"],
+                                               dict(sep=closed["sep"], cp=closed["cp2"]), dict(sep=mini["sep"], cp=mini["cp2"]))
+    print("S-E: %d of %d needle / flake pairs differ by more than 1e-4; each certified" % (k, n))
+
+
+def test_closed_form_with_a_coordinate_far_below_the_others_is_the_oracle(ops, oracle):
+    # the overflow case of the round-3 review (Q = (r z / u)^2 with equal semi-axes and a coordinate ~1e-200): finite,
+    # and the oracle's bits
+    from gpu_util import assert_bits_equal, dev, host
+    from test_oracle_ellipsoid_kat import tiny_coordinate_case
+    c = tiny_coordinate_case()
+    got = ops.contact_mixed(dev(c["pairs"]), dev(c["kind"]), dev(c["center"]), dev(c["quat"]), dev(c["shape"]))
+    exp = oracle.contact_mixed(c["pairs"], c["kind"], c["center"], c["quat"], c["shape"])
+    for key in ("sep", "normal", "cp1", "cp2"):
+        assert np.all(np.isfinite(host(got[key]))), key
+        assert_bits_equal(host(got[key]), exp[key], "tiny coordinate " + key)
 
 
 def test_conservative_ellipsoid_box_finds_every_overlapping_pair(ops, oracle):
