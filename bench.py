@@ -143,6 +143,8 @@ def parse():
     p.add_argument("--no-halo-ipc", action="store_true",
                    help="N > 1: the per-iteration velocity halo through grouped ncclSend / ncclRecv instead of the "
                         "node's IPC-mapped inboxes")
+    p.add_argument("--no-transport-ab", action="store_true",
+                   help="N > 1: skip the untimed A/B of the transport mechanisms after the timed steps (`transport_ab`)")
     p.add_argument("--allow-host-transport", action="store_true",
                    help="print a line even when the halo is staged through host memory (gloo) instead of RCCL; "
                         "without it such a run exits with code 3")
@@ -516,6 +518,54 @@ def main_mixed(args, ops, pipeline, synth, dev):
     print(json.dumps(out))
 
 
+def transport_ab(st, comm, dist, one_step, rank, world, steps=2):
+    """UNTIMED, after the timed steps of a partitioned run: the same step with each combination of the two per-iteration
+    transport mechanisms -- velocity halo through the IPC-mapped inboxes or through grouped ncclSend / ncclRecv, reduction
+    records through the mailbox or through ncclAllGather -- so that the first run on a real multi-GPU node explains
+    itself: microseconds per BBPGD iteration, where they go (HIP events of sampled iterations on every rank), and which
+    mechanism was ACTUALLY active on every rank (reported by the library, not by the flags)."""
+    import torch
+    out = {"what": "untimed A/B after the timed steps: %d steps per variant (after one warm step that re-plans the "
+                   "ghosts); us_per_iteration = max over ranks of the solve phase's wall time / iterations; per_rank = "
+                   "HIP-event means over the sampled iterations of that rank (body sweep, halo post, interior + boundary "
+                   "constraint sweeps, wait for the halo, record = reduction + exchange + finalize incl. the wait for "
+                   "the slowest rank)" % steps, "variants": []}
+    want_ipc, want_mbox = comm.halo_ipc, comm.mailbox
+    for name, ipc, mbox in (("inboxes + mailbox", True, True), ("send/recv + mailbox", False, True),
+                            ("inboxes + all-gather", True, False), ("send/recv + all-gather", False, False)):
+        comm.set_halo_ipc(ipc)
+        comm.set_mailbox(mbox)
+        one_step(False)                    # (every step of this bench rebuilds: the ghost plan makes the switch effective)
+        st.prof = dict(body_ms=0.0, con_ms=0.0, iters=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        solve_ms, iters = 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s = one_step(True)
+            solve_ms += st.phase_ms.get("solve", 0.0)
+            iters += s["num_iters"]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        k = max(1, st.prof["iters"])
+        mine = {"rank": rank, "halo": st.prof.get("halo_path", "?"), "records": st.prof.get("record_path", "?"),
+                "solve_us_per_iteration": round(1e3 * solve_ms / max(1, iters), 2),
+                "body_us": round(1e3 * st.prof["body_ms"] / k, 2), "constraint_us": round(1e3 * st.prof["con_ms"] / k, 2),
+                "halo_post_us": round(1e3 * st.prof.get("halo_post_ms", 0.0) / k, 2),
+                "halo_wait_us": round(1e3 * st.prof.get("halo_wait_ms", 0.0) / k, 2),
+                "record_us": round(1e3 * st.prof.get("record_ms", 0.0) / k, 2), "step_ms": round(1e3 * el / steps, 3)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        out["variants"].append({"requested": name, "iterations_per_step": iters // steps,
+                                "ms_per_step": max(e["step_ms"] for e in every),
+                                "us_per_iteration": max(e["solve_us_per_iteration"] for e in every),
+                                "halo_active": sorted({e["halo"] for e in every}),
+                                "records_active": sorted({e["records"] for e in every}), "per_rank": every})
+    comm.set_halo_ipc(want_ipc)
+    comm.set_mailbox(want_mbox)
+    return out
+
+
 def main_distributed(args, rank, world, dist, ops, synth, dev):
     """N > 1: one Hilbert-partitioned system of world x bodies rods, RCCL halo (see module docstring)."""
     from mundy_amd import distributed as D
@@ -606,6 +656,17 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
         roof, extra, _, _ = roofline_entries(stats[-1]["local_contacts"], n, st.prof["con_ms"] / st.prof["iters"],
                                              st.prof["body_ms"] / st.prof["iters"], st.prof["iters"], ", rank 0",
                                              kin="rigid" if args.mixed else "rod")
+    timed_prof = dict(st.prof)
+    timed_phase_ms = dict(st.phase_ms)
+    paths = [None] * world   # what every rank's solve actually used during the timed steps
+    dist.all_gather_object(paths, (timed_prof.get("halo_path", "?"), timed_prof.get("record_path", "?")))
+
+    def finish(ab):
+        if rank == 0:
+            out["transport_ab"] = ab
+            print(json.dumps(out), flush=True)
+
+    out = None
     if rank == 0:
         out = {
             "metric": ("timesteps/sec, 10^6 mixed sphere / spherocylinder / ellipsoid bodies, frictionless LCP contact (BBPGD)"
@@ -636,19 +697,43 @@ def main_distributed(args, rank, world, dist, ops, synth, dev):
                        "transport": comm.transport,
                        # the per-iteration 5-double record: slots in the ranks' device memory, or the transport's all-gather
                        "reduction_records": "mailbox" if comm.mailbox else "all-gather",
-                       "velocity_halo": "IPC-mapped inboxes" if comm.halo_ipc_active() else "grouped send / recv"},
+                       "velocity_halo": "IPC-mapped inboxes" if comm.halo_ipc_active() else "grouped send / recv",
+                       # ... and what the library reports every rank's solves USED in the timed steps
+                       "paths_active_per_rank": [{"halo": h, "records": r} for h, r in paths]},
             "contact_pairs_per_sec": round(contacts_global * args.steps / elapsed, 1),
             "bbpgd_iterations_per_sec": round(sum(iters) / elapsed, 1),
             # contacts x iterations per second over all ranks: separates the growth of the BBPGD iteration count with
             # the system size (algorithmic) from what the halo and the all-gather cost per iteration
             "constraint_updates_per_sec": round(contacts_global * sum(iters) / elapsed, 1),
-            "halo_wait_ms_per_iteration": round(st.prof.get("halo_wait_ms", 0.0) / max(1, st.prof["iters"]), 4),
+            "halo_wait_ms_per_iteration": round(timed_prof.get("halo_wait_ms", 0.0) / max(1, timed_prof["iters"]), 4),
+            "record_ms_per_iteration": round(timed_prof.get("record_ms", 0.0) / max(1, timed_prof["iters"]), 4),
             # host wall time per phase of the last step on rank 0 (each phase ends with a device sync)
-            "stage_ms": {k: round(v, 3) for k, v in st.phase_ms.items() if k != "start"},
+            "stage_ms": {k: round(v, 3) for k, v in timed_phase_ms.items() if k != "start"},
             "roofline": roof, "cpu_baseline": None,
         }
         out.update(extra)
-        print(json.dumps(out), flush=True)
+    # ---- untimed: the transport mechanisms side by side.  The line must come out whatever happens in here (this is the
+    # first code that ever runs these mechanisms between real GPUs): an exception is recorded in its place, and a
+    # watchdog prints the line without it if a rank gets stuck in a collective
+    if world > 1 and not args.no_transport_ab:
+        import threading
+
+        def give_up():
+            finish({"error": "the A/B did not finish within 300 s on rank %d: skipped" % rank})
+            sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(300.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            ab = transport_ab(st, comm, dist, one_step, rank, world)
+        except Exception as e:  # noqa: BLE001
+            ab = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        dog.cancel()
+        finish(ab)
+    else:
+        finish(None)
     st.op.close()
     comm.close()   # the library's RCCL communicator goes before the launcher's process group
     dist.barrier()

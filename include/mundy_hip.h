@@ -658,6 +658,15 @@ int mhip_comm_mailbox_close(mhip_comm_t comm);
  * Replaces: communicate_field_data (scrap/.../SpherocylinderSpherocylinderLinker.cpp:154-155) inside the iteration,
  * the ghost refresh the reference leaves as a TODO (NGPSpheresLCP.cpp:1057). */
 int mhip_comm_halo_ipc_enable(mhip_comm_t comm, int on);
+/* Bound of every wait on a peer's words (mailbox records, inbox rows) in seconds; default 20.  A wait that exceeds it
+ * ends the solve with MHIP_ERR_RUNTIME on that rank -- no wave waits forever.  After ANY failed distributed solve the
+ * ranks may disagree on the exchange numbers: the next mhip_ghost_plan (collective) re-agrees them (the maximum over the
+ * ranks) and clears the sticky error flag, so the recovery is "rebuild, then solve again". */
+int mhip_comm_set_exchange_timeout(mhip_comm_t comm, double seconds);
+/* TEST HOOK: the next mhip_bbpgd_solve_contact_distributed on this communicator returns MHIP_ERR_RUNTIME at its
+ * at_poll-th convergence poll (1 = the first), after the iterations enqueued until then; 0 = off.  One shot.  Exists so
+ * that the tests can show a failed solve leaves the communicator usable (exchange numbers retired on every exit). */
+int mhip_comm_inject_fault(mhip_comm_t comm, unsigned at_poll);
 /* *active [host] = 1 when the current ghost plan's halo will travel through the inboxes */
 int mhip_comm_halo_ipc_active(mhip_comm_t comm, int* active /*[host]*/);
 /* recv[r][0..count) = rank r's send[0..count); later work on `stream` sees recv */
@@ -749,9 +758,18 @@ int mhip_migrate_plan(mhip_comm_t comm, size_t n, const uint32_t* keys, const in
                       mhip_stream_t stream);
 int mhip_migrate_exchange(mhip_comm_t comm, size_t width, const double* records /*[n][width]*/,
                           double* out /*[n_new][width]*/, mhip_stream_t stream);
-typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that did work, summed */
-  double body_ms, constraint_ms, halo_wait_ms;
+typedef struct mhip_dist_profile { /* HIP-event times of sampled iterations that did work, summed over them */
+  double body_ms;        /* body sweep */
+  double constraint_ms;  /* interior + boundary constraint sweeps (the wait for the halo excluded) */
+  double halo_wait_ms;   /* between the interior and the boundary sweep: collect from the inbox / finish of send-recv */
   size_t timed_iterations;
+  double halo_post_ms;   /* after the body sweep: the push into the peers' inboxes / gather + start of send-recv */
+  double record_ms;      /* after the boundary sweep: this rank's record, its exchange (the wait for the slowest rank
+                            included) and the finalize */
+  int halo_path;         /* what this solve ACTUALLY used: 0 no halo (one rank / no ghosts), 1 IPC-mapped inboxes,
+                            2 grouped send / recv of the transport */
+  int record_path;       /* 1 mailbox inside the fold-finalize launch, 2 mailbox in the record's launch (world > the
+                            fused limit), 3 all-gather of the transport */
 } mhip_dist_profile;
 /* The domain-decomposed BBPGD solve, whole loop on the host side of this library (no interpreter between the stages):
  *   begin;  per iteration: body sweep of the owned bodies -> pack + start the velocity halo -> constraint sweep of the

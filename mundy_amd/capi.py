@@ -51,7 +51,8 @@ class GhostLayout(C.Structure):
 
 class DistProfile(C.Structure):
     _fields_ = [("body_ms", C.c_double), ("constraint_ms", C.c_double), ("halo_wait_ms", C.c_double),
-                ("timed_iterations", C.c_size_t)]
+                ("timed_iterations", C.c_size_t), ("halo_post_ms", C.c_double), ("record_ms", C.c_double),
+                ("halo_path", C.c_int), ("record_path", C.c_int)]
 
 
 # host-callback transport (mhip_comm_create_host): device pointers arrive as integers
@@ -186,6 +187,8 @@ SIGNATURES = {
     "mhip_comm_mailbox_open": [_vp, C.POINTER(_i), _vp],
     "mhip_comm_mailbox_close": [_vp],
     "mhip_comm_halo_ipc_enable": [_vp, _i],
+    "mhip_comm_set_exchange_timeout": [_vp, C.c_double],
+    "mhip_comm_inject_fault": [_vp, C.c_uint],
     "mhip_comm_halo_ipc_active": [_vp, C.POINTER(_i)],
     "mhip_comm_all_gather": [_vp, _vp, _sz, _vp, _vp],
     "mhip_comm_exchange_start": [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i),

@@ -1311,8 +1311,12 @@ __global__ void __launch_bounds__(kBlock)
   double rmax;
   DD num, den;
   reduce_records(hi > lo ? hi - lo : 0, partials + lo, 1, stride, scratch, rmax, num, den);
-  if (MODE == X_SOLVE && st->done) return;  // (after the loads above: one round trip, not two)
-  if (threadIdx.x == 0) {
+  // (after the loads above: one round trip, not two.)  ONE lane's reading decides for the workgroup, through LDS: the
+  // last arriver of THIS launch may set `done` while a late wave of another workgroup has yet to look at it, and a
+  // wave that returned on its own reading would leave its workgroup's barrier short of a wave
+  const unsigned done_seen = (MODE == X_SOLVE) ? st->done : 0u;
+  if (threadIdx.x == 0) is_last = 0;
+  if (threadIdx.x == 0 && !done_seen) {
     const double rec[kRed] = {rmax, num.hi, num.lo, den.hi, den.lo};
 #pragma unroll
     for (int k = 0; k < kRed; ++k)

@@ -116,10 +116,18 @@ struct mhip_comm {
     size_t capacity = 0;             // rows it holds
     std::vector<void*> mapped;       // the other ranks' inboxes as mapped here
     std::vector<unsigned long long*> base;  // [world] inbox pointers as seen from this rank
-    uint32_t seq_base = 1;           // number of the first exchange of the next solve (the same on every rank)
+    uint32_t seq_base = 1;           // number of the first exchange of the next solve (the same on every rank:
+                                     // advanced at ONE place per solve whatever its outcome, re-agreed -- the
+                                     // maximum over the ranks -- by every ghost plan; never 0, the cleared inbox's tag)
     // of the current ghost plan: per send peer the first row of my block in ITS velocity table
     std::vector<size_t> dst_first_row;
   } hipc;
+  // bound of every wait on a peer's words (mailbox, inboxes), in ticks of the 100 MHz wall clock
+  unsigned long long timeout_ticks = 2000000000ull;
+  // TEST HOOK (mhip_comm_inject_fault): the next distributed solve fails at this convergence poll (0 = off)
+  unsigned fault_at_poll = 0;
+  // what the last distributed solve used (mhip_dist_profile reports it)
+  int last_halo_path = 0, last_record_path = 0;
   // work buffers of the distributed solve
   DeviceBuffer send_rows, triples;
   std::vector<hipEvent_t> events;
@@ -194,7 +202,8 @@ static int host_all_gather(mhip_comm* c, const double* in, size_t count, std::ve
 __global__ void __launch_bounds__(64) k_mailbox_exchange(MailboxArgs m, const double* __restrict__ local) {
   mailbox_exchange_wave(m, local);
 }
-constexpr unsigned long long kMailboxTimeoutTicks = 2000000000ull;  // 20 s of the 100 MHz wall clock (ranks enter a solve at different times: the narrow phase of a mixed system is uneven)
+// (default of mhip_comm::timeout_ticks: 20 s of the 100 MHz wall clock -- ranks enter a solve at different times: the
+//  narrow phase of a mixed system is uneven; mhip_comm_set_exchange_timeout changes it)
 
 // ---- velocity halo through IPC-mapped inboxes -----------------------------------------------------------------------
 constexpr int kHaloWords = 12;      // a row of 6 doubles as 12 (data, exchange number) words
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(kBlock)
     const size_t t = t0 + threadIdx.x;   // (t0 and kHaloWords are even: lanes (2m, 2m + 1) of a wave hold the two halves
     const bool live = t < nw;            //  of one double, and both are live or both are not)
     unsigned long long word = 0;
-    bool ok = true;
+    bool ok = true, overrun = false;
     size_t row = 0;
     int w = 0;
     if (live) {
@@ -255,7 +264,17 @@ __global__ void __launch_bounds__(kBlock)
       const unsigned long long start = wall_clock64();
       for (;;) {
         word = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (static_cast<unsigned>(word >> 32) == seq) break;
+        const unsigned tag = static_cast<unsigned>(word >> 32);
+        if (tag == seq) break;
+        // One slot per ghost row: a peer's push of exchange k + 1 must not land before this rank has collected exchange
+        // k.  The iteration's own dependencies give that order (a peer pushes k + 1 after ITS finalize of k, which
+        // needs this rank's record of k, formed after this collect): a word that is AHEAD of the exchange being
+        // collected means the order was broken -- reported, never consumed.
+        if (tag != 0u && tag - seq - 1u < 0x3fffffffu) {
+          overrun = true;
+          ok = false;
+          break;
+        }
         if (__hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
             wall_clock64() - start > timeout) {
           ok = false;
@@ -263,7 +282,7 @@ __global__ void __launch_bounds__(kBlock)
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      if (!ok) __hip_atomic_store(&status[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!ok) __hip_atomic_store(&status[0], overrun ? 2ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // t even <-> w even (kHaloWords is even): lane pairs (2m, 2m + 1) hold the two halves of one double
     const unsigned long long other = __shfl_xor(word, 1, 64);
@@ -357,13 +376,52 @@ int halo_ipc_open(mhip_comm* c, size_t rows, hipStream_t s) {
   h.open = true;
   return MHIP_SUCCESS;
 }
+// Exchange numbers of the inbox halo: a solve uses seq_base .. seq_base + iterations + 1.  The tag is 32 bits and 0 is
+// the tag of a cleared inbox, so the numbers wrap to 1, never through 0 (a re-plan zero-fills the inboxes: after ~4e9
+// exchanges -- days at 770 iterations a step -- a number that came round to 0 would have matched them).
+static uint32_t next_seq_base(uint32_t base, unsigned used) {
+  const unsigned long long next = (unsigned long long)base + used + 2ull;
+  return next > 0xf0000000ull ? 1u : (uint32_t)next;   // (a solve never has 2^28 iterations: required where it starts)
+}
+// Re-agreement of the exchange numbers of the mailbox and the inboxes.  Collective; part of every ghost plan.  A solve
+// that ended in an error on some rank (a peer's words that never came, a launch error) may have left the ranks with
+// different counts; all of them take the maximum -- ahead of every number any rank has posted or waited for -- and the
+// sticky error flag is cleared.  Costs one small all-gather per neighbour-list rebuild.
+static int comm_resync(mhip_comm* c, hipStream_t s) {
+  unsigned long long st[2] = {0, 0};   // [0] sticky error flag, [1] mailbox exchanges made (device-counted)
+  if (c->mbox.status.ptr) {
+    MHIP_HIP(hipMemcpyAsync(st, c->mbox.status.ptr, sizeof(st), hipMemcpyDeviceToHost, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+  }
+  const double mine[3] = {(double)c->hipc.seq_base, (double)st[1], (double)st[0]};
+  std::vector<double> all;
+  if (int e = host_all_gather(c, mine, 3, all, s)) return e;
+  double seq = 0.0, count = 0.0, flagged = 0.0;
+  bool same = true;
+  for (int r = 0; r < c->world; ++r) {
+    same = same && all[3 * (size_t)r] == mine[0] && all[3 * (size_t)r + 1] == mine[1];
+    seq = std::max(seq, all[3 * (size_t)r]);
+    count = std::max(count, all[3 * (size_t)r + 1]);
+    flagged = std::max(flagged, all[3 * (size_t)r + 2]);
+  }
+  if (same && flagged == 0.0) return MHIP_SUCCESS;   // (every rebuild of a healthy run)
+  c->hipc.seq_base = (uint32_t)seq;
+  if (c->mbox.status.ptr) {
+    // two beyond the largest count: a rank that posted exchange N + 1 and never finished it has left words tagged
+    // N + 1 in its peers' boxes
+    const unsigned long long fresh[2] = {0ull, same ? st[1] : (unsigned long long)count + 2ull};
+    MHIP_HIP(hipMemcpyAsync(c->mbox.status.ptr, fresh, sizeof(fresh), hipMemcpyHostToDevice, s));
+    MHIP_HIP(hipStreamSynchronize(s));
+  }
+  return MHIP_SUCCESS;
+}
 // After a ghost plan: room for everybody's rows, and where my rows go in each peer's table.  Collective.
 int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*/, const std::vector<size_t>& owned,
                   hipStream_t s) {
   auto& h = c->hipc;
   auto& gp = c->ghost;
   h.plan_ok = false;
-  if (!h.wanted || c->world > kHaloMaxPeers) return MHIP_SUCCESS;
+  if (!h.wanted || c->world > kHaloMaxPeers) return comm_resync(c, s);
   const size_t W = (size_t)c->world;
   if (!c->mbox.status.ptr) {
     if (int e = c->mbox.status.reserve(64)) return e;
@@ -383,7 +441,7 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
   bool fresh = false;
   if (!h.open || h.capacity < need) {
     if (int e = halo_ipc_open(c, need + need / 2 + 1024, s)) return e;   // (every rank sees the same `need`)
-    if (!h.open) return MHIP_SUCCESS;
+    if (!h.open) return comm_resync(c, s);
     fresh = true;
   } else if (h.own) {
     // stale words of an earlier plan must never carry a number that comes round again: start from zeros (the
@@ -391,8 +449,8 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
     MHIP_HIP(hipMemsetAsync(h.own, 0, h.capacity * kHaloWords * sizeof(unsigned long long), s));
     MHIP_HIP(hipStreamSynchronize(s));
   }
-  std::vector<double> token(1, 1.0), tokens;   // nobody pushes before everybody has cleared
-  if (int e = host_all_gather(c, token.data(), 1, tokens, s)) return e;
+  // nobody pushes before everybody has cleared -- and everybody leaves with the same exchange numbers (comm_resync)
+  if (int e = comm_resync(c, s)) return e;
   // where the block of rank R starts in the table of rank d: ghosts of lower ranks in rank order, the owned block,
   // ghosts of higher ranks in rank order (mhip_ghost_layout_from_counts)
   const size_t R = (size_t)c->rank;
@@ -413,14 +471,15 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
     // every rank pushes rows that name it, collects its ghost rows and checks who they came from; anything short of
     // success on every rank leaves everybody on send / recv
     const size_t nl = gp.n_lo + gp.n + gp.n_hi, ng = gp.n_lo + gp.n_hi;
-    double trial_ok = 1.0;
+    // (whatever fails on this rank -- an allocation, a copy, a launch -- is a failed trial, never an early return: the
+    //  peers are on their way into the all-gather of the outcomes below and must find this rank there)
     DeviceBuffer tv;
-    if (tv.reserve((6 * nl + 8) * sizeof(double)) != MHIP_SUCCESS) trial_ok = 0.0;
     std::vector<double> hv(6 * nl, -1.0);
     for (size_t r = gp.n_lo; r < gp.n_lo + gp.n; ++r)
       for (int k = 0; k < 6; ++k) hv[6 * r + k] = 1000.0 * (double)(c->rank + 1) + 0.125 * k;
     unsigned long long* stw = c->mbox.status.as<unsigned long long>();
-    if (trial_ok == 1.0) {
+    auto trial = [&]() -> int {
+      if (int e = tv.reserve((6 * nl + 8) * sizeof(double))) return e;
       if (nl) MHIP_HIP(hipMemcpyAsync(tv.ptr, hv.data(), 6 * nl * sizeof(double), hipMemcpyHostToDevice, s));
       MHIP_HIP(hipMemsetAsync(stw + 3, 0, 2 * sizeof(unsigned long long), s));   // words 3, 4: a zero `done`, a zero `flips`
       HaloPushArgs push{};
@@ -443,7 +502,7 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
       if (ng) {
         k_halo_collect<<<grid_for(ng * kHaloWords), kBlock, 0, s>>>(h.base[(size_t)c->rank], gp.n_lo, gp.n, ng,
                                                                    tv.as<double>(), h.seq_base, 1, zflips, zdone, stw,
-                                                                   kMailboxTimeoutTicks / 4);
+                                                                   c->timeout_ticks / 4);
         MHIP_LAUNCH_CHECK();
       }
       if (nl) MHIP_HIP(hipMemcpyAsync(hv.data(), tv.ptr, 6 * nl * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -451,15 +510,23 @@ int halo_ipc_plan(mhip_comm* c, const std::vector<size_t>& counts /*[s * W + d]*
       MHIP_HIP(hipMemcpyAsync(&bad, stw, sizeof(bad), hipMemcpyDeviceToHost, s));
       MHIP_HIP(hipStreamSynchronize(s));
       if (bad) {
-        trial_ok = 0.0;
-        MHIP_HIP(hipMemsetAsync(stw, 0, sizeof(unsigned long long), s));   // (the sticky timeout flag of this trial)
+        (void)hipMemsetAsync(stw, 0, sizeof(unsigned long long), s);   // (the sticky flag of this trial)
+        return fail(MHIP_ERR_RUNTIME, "trial exchange through the inboxes: status %llu", bad);
       }
-      for (size_t k = 0; k < gp.recv_peer.size() && trial_ok == 1.0; ++k)
+      for (size_t k = 0; k < gp.recv_peer.size(); ++k)
         for (size_t r = gp.recv_first_row[k]; r < gp.recv_first_row[k] + gp.recv_rows[k]; ++r)
           for (int q = 0; q < 6; ++q)
-            if (hv[6 * r + q] != 1000.0 * (double)(gp.recv_peer[k] + 1) + 0.125 * q) trial_ok = 0.0;
+            if (hv[6 * r + q] != 1000.0 * (double)(gp.recv_peer[k] + 1) + 0.125 * q)
+              return fail(MHIP_ERR_RUNTIME, "trial exchange through the inboxes: row %zu did not come from rank %d", r,
+                          gp.recv_peer[k]);
+      return MHIP_SUCCESS;
+    };
+    double trial_ok = (trial() == MHIP_SUCCESS) ? 1.0 : 0.0;
+    if (trial_ok == 0.0) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(s);
     }
-    h.seq_base += 2u;
+    h.seq_base = next_seq_base(h.seq_base, 0u);
     std::vector<double> oks;
     if (int e = host_all_gather(c, &trial_ok, 1, oks, s)) return e;
     bool all = true;
@@ -482,7 +549,7 @@ MailboxArgs mailbox_next(mhip_comm* c, int width, double* gathered) {
   m.width = width;
   m.gathered = gathered;
   m.status = c->mbox.status.as<unsigned long long>();
-  m.timeout = kMailboxTimeoutTicks;
+  m.timeout = c->timeout_ticks;
   return m;
 }
 int mailbox_exchange(mhip_comm* c, int width, const double* local, double* gathered, hipStream_t s) {
@@ -495,9 +562,14 @@ int mailbox_check(mhip_comm* c, hipStream_t s) {
   unsigned long long st[2] = {0, 0};
   MHIP_HIP(hipMemcpyAsync(st, c->mbox.status.ptr, sizeof(st), hipMemcpyDeviceToHost, s));
   MHIP_HIP(hipStreamSynchronize(s));
+  MHIP_REQUIRE(st[0] != 2, MHIP_ERR_RUNTIME,
+               "rank %d: a ghost row of a LATER exchange was found in the inbox before this one had been collected -- the "
+               "ranks disagree on the exchange numbers (an earlier solve failed on some rank?): run mhip_ghost_plan, "
+               "which re-agrees them, before the next solve", c->rank);
   MHIP_REQUIRE(st[0] == 0, MHIP_ERR_RUNTIME,
-               "rank %d: a peer's reduction record did not arrive in the mailbox within 20 s (exchange %llu)", c->rank,
-               st[1] + 1);
+               "rank %d: a peer's words (reduction record or ghost rows) did not arrive within %.0f s (mailbox exchange "
+               "%llu); mhip_ghost_plan re-agrees the exchange numbers before the next solve", c->rank,
+               (double)c->timeout_ticks * 1e-8, st[1] + 1);
   return MHIP_SUCCESS;
 }
 void mailbox_close(mhip_comm* c) {
@@ -1229,16 +1301,33 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     push.first[halo->num_send_peers] = (unsigned)off;
   }
   const uint32_t seq_base = hi.seq_base;
-
-  if (int e = mhip_bbpgd_stage_begin(op, q, space, config, x, g, x_tmp, g_tmp, stream)) return e;
-  stage_state_words(op, &st_flips, &st_done);
+  MHIP_REQUIRE(!ipc || config->max_iters < (1u << 28), MHIP_ERR_INVALID_ARGUMENT,
+               "max_iters %u: the exchange numbers of the inbox halo allow 2^28 iterations per solve", config->max_iters);
   size_t C = 0;
   if (int e = mhip_contact_op_sizes(op, &C, nullptr)) return e;
   MHIP_REQUIRE(interior_contacts <= C, MHIP_ERR_INVALID_ARGUMENT, "interior_contacts %zu exceeds the %zu constraints",
                interior_contacts, C);
+  // The length of the stretches between polls must be the SAME decision on every rank (a rank that polls out of phase
+  // stalls the others in the record exchange): it is taken from the global constraint count, not from this rank's
+  size_t C_global = C;
+  if (c->world > 1) {
+    const double mine = (double)C;
+    std::vector<double> every;
+    if (int e = host_all_gather(c, &mine, 1, every, s)) return e;
+    double sum = 0.0;
+    for (double v : every) sum += v;
+    C_global = (size_t)sum;
+  }
+  c->last_halo_path = !has_halo ? 0 : (ipc ? 1 : 2);
+  c->last_record_path = c->mbox.open ? (c->world <= kMailboxMaxWorld ? 1 : 2) : 3;
+  const unsigned fault_at_poll = c->fault_at_poll;
+  c->fault_at_poll = 0;
+
+  if (int e = mhip_bbpgd_stage_begin(op, q, space, config, x, g, x_tmp, g_tmp, stream)) return e;
+  stage_state_words(op, &st_flips, &st_done);
 
   // sampled timing: every kStride-th iteration of a chunk is bracketed by events
-  constexpr unsigned kStride = 8, kEv = 6;
+  constexpr unsigned kStride = 8, kEv = 7;
   const bool prof = profile != nullptr;
   const unsigned slots = (poll_every + kStride - 1) / kStride;
   if (prof && c->events.size() < (size_t)kEv * slots) {
@@ -1246,7 +1335,11 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     c->events.resize((size_t)kEv * slots);
     for (size_t k = old; k < c->events.size(); ++k) MHIP_HIP(hipEventCreate(&c->events[k]));
   }
-  if (prof) *profile = mhip_dist_profile{0.0, 0.0, 0.0, 0};
+  if (prof) {
+    *profile = mhip_dist_profile{};
+    profile->halo_path = c->last_halo_path;
+    profile->record_path = c->last_record_path;
+  }
 
   auto iteration = [&](int init, hipEvent_t* ev) -> int {
     if (ev) MHIP_HIP(hipEventRecord(ev[0], s));
@@ -1274,7 +1367,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
       if (n_ghost) {   // my ghost rows, as they arrive in my inbox, into the velocity table
         k_halo_collect<<<grid_for(n_ghost * kHaloWords), kBlock, 0, s>>>(
             hi.base[(size_t)c->rank], c->ghost.n_lo, c->ghost.n, n_ghost, halo->velocity, seq_base, init, st_flips,
-            st_done, c->mbox.status.as<unsigned long long>(), kMailboxTimeoutTicks);
+            st_done, c->mbox.status.as<unsigned long long>(), c->timeout_ticks);
         MHIP_LAUNCH_CHECK();
       }
     } else if (has_halo) {
@@ -1282,68 +1375,114 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
     }
     if (ev) MHIP_HIP(hipEventRecord(ev[4], s));
     if (int e = mhip_bbpgd_stage_constraint_range(op, init, interior_contacts, C - interior_contacts, stream)) return e;
+    if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
+    // ev[5] .. ev[6]: the reduction of the iteration -- this rank's record, its exchange with every rank (the wait for
+    // the slowest of them included) and the finalize
     if (c->mbox.open && c->world <= kMailboxMaxWorld) {
       // the record is formed, posted, everybody's collected and the iteration finalized in one launch
       if (int e = stage_reduce_exchange_finalize(op, init, mailbox_next(c, kRed, gathered), s)) return e;
-      if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
+      if (ev) MHIP_HIP(hipEventRecord(ev[6], s));
       return MHIP_SUCCESS;
     }
     if (c->mbox.open) {  // the record is posted, and everybody's collected, by the kernel that forms it
       if (int e = stage_reduce_exchange(op, init, local3, mailbox_next(c, kRed, gathered), s)) return e;
-      if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
     } else {
       if (int e = mhip_bbpgd_stage_reduce(op, init, local3, stream)) return e;
-      if (ev) MHIP_HIP(hipEventRecord(ev[5], s));
       if (int e = mhip_comm_all_gather(c, local3, kRed, gathered, stream)) return e;
     }
-    return mhip_bbpgd_stage_finalize(op, init, gathered, c->world, stream);
+    if (int e = mhip_bbpgd_stage_finalize(op, init, gathered, c->world, stream)) return e;
+    if (ev) MHIP_HIP(hipEventRecord(ev[6], s));
+    return MHIP_SUCCESS;
   };
 
-  if (int e = iteration(1, nullptr)) return e;
-  unsigned enqueued = 0, last_todo = 0, iter_before = 0, chunk = 8;
-  int done = 0;
-  PollPlan plan;  // (only its rule for the last stretches: the residual is the same on every rank, so is the decision)
-  for (;;) {
-    if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
-    if (c->mbox.open || ipc)
-      if (int e = mailbox_check(c, s)) return e;
-    if (prof && last_todo) {
-      unsigned eff = result->num_iters - iter_before + ((result->converged && result->num_iters < config->max_iters) ? 1u : 0u);
-      if (eff > last_todo) eff = last_todo;
-      for (unsigned k = 0; k < eff; k += kStride) {
-        hipEvent_t* ev = &c->events[(size_t)kEv * (k / kStride)];
-        float a = 0.f, b = 0.f, w = 0.f, d = 0.f;
-        MHIP_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
-        MHIP_HIP(hipEventElapsedTime(&b, ev[2], ev[3]));
-        MHIP_HIP(hipEventElapsedTime(&w, ev[3], ev[4]));
-        MHIP_HIP(hipEventElapsedTime(&d, ev[4], ev[5]));
-        profile->body_ms += a;
-        profile->constraint_ms += b + d;  // the wait for the halo is not part of the sweep's time
-        profile->halo_wait_ms += w;
-        profile->timed_iterations += 1;
+  // ONE exit: whatever happens between here and the end of the loop, the exchange numbers this solve may have used are
+  // retired below (a rank that left them behind would meet its own stale inbox words in the next solve)
+  unsigned enqueued = 0;
+  auto run = [&]() -> int {
+    if (int e = iteration(1, nullptr)) return e;
+    unsigned last_todo = 0, iter_before = 0, chunk = 8, polls = 0;
+    int done = 0;
+    PollPlan plan;  // (only its rule for the last stretches: the residual is the same on every rank, so is the decision)
+    for (;;) {
+      if (int e = mhip_bbpgd_stage_poll(op, result, &done, stream)) return e;
+      if (c->mbox.open || ipc)
+        if (int e = mailbox_check(c, s)) return e;
+      if (++polls == fault_at_poll)
+        return fail(MHIP_ERR_RUNTIME, "rank %d: injected fault at poll %u (mhip_comm_inject_fault)", c->rank, polls);
+      if (prof && last_todo) {
+        unsigned eff = result->num_iters - iter_before + ((result->converged && result->num_iters < config->max_iters) ? 1u : 0u);
+        if (eff > last_todo) eff = last_todo;
+        for (unsigned k = 0; k < eff; k += kStride) {
+          hipEvent_t* ev = &c->events[(size_t)kEv * (k / kStride)];
+          float a = 0.f, p = 0.f, b = 0.f, w = 0.f, d = 0.f, r = 0.f;
+          MHIP_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
+          MHIP_HIP(hipEventElapsedTime(&p, ev[1], ev[2]));
+          MHIP_HIP(hipEventElapsedTime(&b, ev[2], ev[3]));
+          MHIP_HIP(hipEventElapsedTime(&w, ev[3], ev[4]));
+          MHIP_HIP(hipEventElapsedTime(&d, ev[4], ev[5]));
+          MHIP_HIP(hipEventElapsedTime(&r, ev[5], ev[6]));
+          profile->body_ms += a;
+          profile->halo_post_ms += p;
+          profile->constraint_ms += b + d;  // the wait for the halo is not part of the sweep's time
+          profile->halo_wait_ms += w;
+          profile->record_ms += r;
+          profile->timed_iterations += 1;
+        }
       }
+      // (after a pause -- mhip_bbpgd_stage_poll has handled it -- the rest of the chunk did nothing: count what ran)
+      if (!done && result->num_iters < enqueued) enqueued = result->num_iters;
+      if (done || enqueued >= config->max_iters) break;
+      if (enqueued >= 8 && !plan.shortened)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
+        if (int e = mhip_bbpgd_stage_snapshot_active(op, stream)) return e;
+      iter_before = result->num_iters;
+      // (stretches of 8, 16, 32, ... iterations up to poll_every, as in the fused driver: an easy solve is found converged
+      // early, a long one is polled as rarely as the caller allows)
+      const unsigned stretch = plan.stretch(chunk < poll_every ? chunk : poll_every, result->num_iters, result->residual,
+                                            config->tol, C_global);
+      if (chunk < poll_every) chunk *= 2;
+      const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
+      for (unsigned k = 0; k < todo; ++k) {
+        hipEvent_t* ev = (prof && k % kStride == 0) ? &c->events[(size_t)kEv * (k / kStride)] : nullptr;
+        if (int e = iteration(0, ev)) {
+          enqueued += k + 1;
+          return e;
+        }
+      }
+      enqueued += todo;
+      last_todo = todo;
     }
-    // (after a pause -- mhip_bbpgd_stage_poll has handled it -- the rest of the chunk did nothing: count what ran)
-    if (!done && result->num_iters < enqueued) enqueued = result->num_iters;
-    if (done || enqueued >= config->max_iters) break;
-    if (enqueued >= 8 && !plan.shortened)  // the masks have settled: stream the active entries from a snapshot (convex.hip, OpView::aptr)
-      if (int e = mhip_bbpgd_stage_snapshot_active(op, stream)) return e;
-    iter_before = result->num_iters;
-    // (stretches of 8, 16, 32, ... iterations up to poll_every, as in the fused driver: an easy solve is found converged
-    // early, a long one is polled as rarely as the caller allows)
-    const unsigned stretch = plan.stretch(chunk < poll_every ? chunk : poll_every, result->num_iters, result->residual, config->tol, C);
-    if (chunk < poll_every) chunk *= 2;
-    const unsigned todo = (config->max_iters - enqueued < stretch) ? config->max_iters - enqueued : stretch;
-    for (unsigned k = 0; k < todo; ++k) {
-      hipEvent_t* ev = (prof && k % kStride == 0) ? &c->events[(size_t)kEv * (k / kStride)] : nullptr;
-      if (int e = iteration(0, ev)) return e;
-    }
-    enqueued += todo;
-    last_todo = todo;
+    return MHIP_SUCCESS;
+  };
+  const int rc = run();
+  // numbers of this solve's exchanges: seq_base (init) .. seq_base + iterations + 1.  A solve that ran to its end ran
+  // the same count on every rank; one that failed retires everything it had enqueued (its peers' counts may differ then:
+  // the next ghost plan re-agrees them)
+  const unsigned used = (rc == MHIP_SUCCESS) ? result->num_iters : (enqueued > result->num_iters ? enqueued : result->num_iters);
+  hi.seq_base = next_seq_base(seq_base, used);
+  if (rc != MHIP_SUCCESS) {
+    const std::string why = last_error_storage();   // (the clean-up below must not replace the message)
+    (void)hipStreamSynchronize(s);
+    if (c->in_flight) (void)mhip_comm_exchange_finish(c, stream);
+    mhip_solve_result dummy{};
+    (void)mhip_bbpgd_stage_end(op, &dummy, stream);
+    (void)hipGetLastError();
+    last_error_storage() = why;
+    return rc;
   }
-  // numbers of this solve's exchanges: seq_base (init) .. seq_base + iterations + 1; every rank ran the same count
-  hi.seq_base += result->num_iters + 2u;
   return mhip_bbpgd_stage_end(op, result, stream);
+}
+
+int mhip_comm_set_exchange_timeout(mhip_comm_t c, double seconds) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  MHIP_REQUIRE(seconds >= 0.01 && seconds <= 3600.0, MHIP_ERR_INVALID_ARGUMENT, "timeout must be within [0.01, 3600] s");
+  c->timeout_ticks = (unsigned long long)(seconds * 1e8);
+  return MHIP_SUCCESS;
+}
+
+int mhip_comm_inject_fault(mhip_comm_t c, unsigned at_poll) {
+  MHIP_REQUIRE(c != nullptr, MHIP_ERR_INVALID_ARGUMENT, "communicator is null");
+  c->fault_at_poll = at_poll;
+  return MHIP_SUCCESS;
 }
 
 }  // extern "C"

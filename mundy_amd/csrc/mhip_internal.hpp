@@ -10,6 +10,14 @@
 
 #include "../../include/mundy_hip.h"
 
+// The hand-offs between workgroups (k_fold_finalize, lockstep::post_start, the mailbox / inbox protocols) publish with
+// relaxed agent-scope atomic stores drained by s_waitcnt vmcnt(0) and read with relaxed agent-scope loads -- no release /
+// acquire pair.  That is sound on the CDNA3/4 memory system these kernels are written for (sc1 stores write through the
+// XCD's L2, stores are counted in vmcnt); on any other target it would silently read stale records.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "libmundy_hip's inter-workgroup hand-offs assume the gfx950 (gfx942) memory model: build with --offload-arch=gfx950"
+#endif
+
 namespace mhip {
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -201,6 +201,30 @@ class Comm:
             capi.check(lib.mhip_comm_halo_ipc_enable(self._h, 1))
             self.halo_ipc = True
 
+    def set_exchange_timeout(self, seconds):
+        """bound of every wait on a peer's words (mailbox records, inbox rows); default 20 s"""
+        capi.check(capi.load().mhip_comm_set_exchange_timeout(self._h, float(seconds)))
+
+    def inject_fault(self, at_poll):
+        """TEST HOOK: this rank's next distributed solve fails at its at_poll-th convergence poll (one shot)"""
+        capi.check(capi.load().mhip_comm_inject_fault(self._h, int(at_poll)))
+
+    def set_mailbox(self, on):
+        """Opens / closes the mailbox of the reduction records (collective: every rank makes the same call).  Returns
+        whether it is open afterwards."""
+        if on and not self.mailbox:
+            self.mailbox = self._open_mailbox()
+        elif not on and self.mailbox:
+            capi.check(capi.load().mhip_comm_mailbox_close(self._h))
+            self.mailbox = False
+        return self.mailbox
+
+    def set_halo_ipc(self, on):
+        """The velocity halo through the inboxes (on) or through the transport's send / recv (off), from the next
+        ghost plan on (collective: every rank makes the same call)."""
+        capi.check(capi.load().mhip_comm_halo_ipc_enable(self._h, 1 if on else 0))
+        self.halo_ipc = bool(on)
+
     def halo_ipc_active(self):
         """True when the current ghost plan's velocity halo travels through the inboxes (known after a ghost plan)"""
         a = C.c_int(0)
@@ -607,7 +631,12 @@ class DistributedContactStepper:
             self.prof["body_ms"] += dprof.body_ms
             self.prof["con_ms"] += dprof.constraint_ms
             self.prof["halo_wait_ms"] = self.prof.get("halo_wait_ms", 0.0) + dprof.halo_wait_ms
+            self.prof["halo_post_ms"] = self.prof.get("halo_post_ms", 0.0) + dprof.halo_post_ms
+            self.prof["record_ms"] = self.prof.get("record_ms", 0.0) + dprof.record_ms
             self.prof["iters"] += int(dprof.timed_iterations)
+            # what the solve ACTUALLY used (the library reports it, not the flags it was asked with)
+            self.prof["halo_path"] = ("none", "inboxes", "send/recv")[int(dprof.halo_path)]
+            self.prof["record_path"] = ("?", "mailbox (fused)", "mailbox", "all-gather")[int(dprof.record_path)]
         tick("solve")
         self.lam, self.grad, self.contacts, self.pairs, self.counted = x, g, con, pairs, counted
         self.lam_prev, self.grad_prev = x_tmp, g_tmp     # the iterate before (what a warm restart continues from)

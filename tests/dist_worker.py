@@ -22,9 +22,10 @@ def main():
 
     mixed = os.environ.get("DIST_MIXED", "0") == "1"   # BASELINE configs[4]: spheres + rods + ellipsoids
     phi, buf = float(os.environ.get("DIST_PHI", "0.4")), float(os.environ.get("DIST_BUFFER", "0.1"))
-    b = synth.mixed_bodies(n_total, volume_fraction=0.25, seed=7) if mixed else \
-        synth.spherocylinders(n_total, seed=7, volume_fraction=phi)
-    order = D.hilbert_order(b["center"], 0.0, b["box"], level=5)
+    seed = int(os.environ.get("DIST_SEED", "7"))     # 1234 at 10^6 bodies = the bench system (configs[3])
+    b = synth.mixed_bodies(n_total, volume_fraction=0.25, seed=seed) if mixed else \
+        synth.spherocylinders(n_total, seed=seed, volume_fraction=phi)
+    order = D.hilbert_order(b["center"], 0.0, b["box"], level=5 if n_total < 200_000 else 7)
     starts = D.partition_ranges(n_total, world)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     g_center, g_quat = b["center"][order], b["quat"][order]
@@ -49,12 +50,34 @@ def main():
     else:
         g_radius, g_length = b["radius"][order], b["length"][order]
         st = D.DistributedContactStepper(dev(g_center[a:e]), dev(g_quat[a:e]), dev(g_radius[a:e]), dev(g_length[a:e]),
-                                         a, comm=make_comm(), search_buffer=buf, cfg=cfg, poll_every=8,
+                                         a, comm=make_comm(), search_buffer=buf, cfg=cfg,
+                                         poll_every=int(os.environ.get("DIST_POLL", "8")),
                                          domain=(0.0, b["box"]), curve_level=4, recut_every=3)
     # DIST_TIER: cold tier mode of every rank's operator (3 = tier whatever the size, 2 = and leave the tiers mid-solve)
     if os.environ.get("DIST_TIER"):
         st.tiering = int(os.environ["DIST_TIER"])
-    stats = st.step(integrate=False)
+    # DIST_FAULT: the first solve ends in an injected error (mhip_comm_inject_fault), the checked one comes after it.
+    #   sym   every rank fails at its second poll (8 iterations enqueued everywhere); the next solve reuses the ghost plan
+    #         and the inboxes as they are: the exchange numbers of the failed solve were retired on every rank
+    #   asym  only the last rank fails; the others run on, time out waiting for its words (bound set to 3 s) and fail one
+    #         poll later with MORE iterations enqueued: the ranks now disagree on the numbers, and the next ghost plan
+    #         (a rebuild) re-agrees them
+    fault = os.environ.get("DIST_FAULT")
+    if fault:
+        st.comm.set_exchange_timeout(3.0)
+        if fault == "sym" or rank == world - 1:
+            st.comm.inject_fault(2)
+        try:
+            st.step(integrate=False)
+            failed = False
+        except RuntimeError as e:
+            failed = True
+            print("FAULT rank %d: %s" % (rank, str(e)[:160]), flush=True)
+        assert failed, "the injected fault did not end the solve on rank %d" % rank
+        stats = st.step(integrate=False, force_rebuild=(fault != "sym"))
+        assert stats["rebuilt"] == (fault != "sym")
+    else:
+        stats = st.step(integrate=False)
     print("HALO_IPC rank %d active %d" % (rank, int(st.comm.halo_ipc_active())), flush=True)
     tier_stats = st.op.tier_stats() if st.op is not None else {}
     gid = st.local["gid"].cpu().numpy().astype(np.int64)
@@ -103,18 +126,25 @@ def main():
         dv = np.abs(vel - rvel).max() / max(1e-30, np.abs(rvel).max())
         checks["owned velocities vs single rank (rel %.3g)" % dv] = dv <= 1e-3
         # duplicated (cross-rank) contacts carry bit-identical (x, g) on both ranks
-        dup = {}
         n_dup = 0
-        for o in gathered:
-            for p, c, x, g in zip(o["gpairs"], o["counted"], o["x"], o["g"]):
-                k = (int(p[0]), int(p[1]))
-                if k in dup:
-                    n_dup += 1
-                    if dup[k] != (x.tobytes(), g.tobytes()):
-                        checks["duplicate contact %s bitwise equal" % (k,)] = False
-                elif world > 1:
-                    dup[k] = (x.tobytes(), g.tobytes())
+        if world > 1:
+            kk = np.concatenate([key(o["gpairs"]) for o in gathered])
+            xx = np.concatenate([o["x"] for o in gathered]).view(np.int64)
+            gg = np.concatenate([o["g"] for o in gathered]).view(np.int64)
+            o_ = np.argsort(kk, kind="stable")
+            kk, xx, gg = kk[o_], xx[o_], gg[o_]
+            same_key = kk[1:] == kk[:-1]
+            n_dup = int(same_key.sum())
+            differ = same_key & ((xx[1:] != xx[:-1]) | (gg[1:] != gg[:-1]))
+            if differ.any():
+                checks["%d duplicated contacts differ in (x, g)" % int(differ.sum())] = False
         checks["%d duplicated cross-rank contacts found" % n_dup] = (n_dup > 0) or world == 1 or dilute
+        if os.environ.get("DIST_EXACT") and checks["pair set == single-rank neighbour list"]:
+            # the partitioned solve IS the fused single-rank solve: same iteration count, same multipliers, bit for bit
+            checks["iteration count equals the fused solve's (%d vs %d)" % (iters[0], rs.num_iters)] = iters[0] == rs.num_iters
+            checks["multipliers bit-identical to the fused solve"] = np.array_equal(allx[srt], ref.lam.cpu().numpy())
+            if os.environ.get("DIST_EXPECT_ITERS"):
+                checks["iterations == %s" % os.environ["DIST_EXPECT_ITERS"]] = iters[0] == int(os.environ["DIST_EXPECT_ITERS"])
         # (a rank that owns nothing -- fewer bodies than ranks -- holds no ghosts either, but takes part in every collective)
         checks["ghosts exchanged"] = world == 1 or dilute or \
             all(o["stats"]["ghosts"] > 0 for o in gathered if len(o["vel"]) > 0)

@@ -151,6 +151,25 @@ def test_gpus_2_without_a_launcher_prints_a_two_rank_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["bodies_total"] == 40000
     assert d["config"]["velocity_halo"] in ("IPC-mapped inboxes", "grouped send / recv")
     assert all(d["config"]["converged"])
+    # what every rank's solves actually used in the timed steps (the library reports it) ...
+    assert len(d["config"]["paths_active_per_rank"]) == 2
+    assert all(p_["halo"] in ("inboxes", "send/recv") for p_ in d["config"]["paths_active_per_rank"])
+    # ... and the untimed A/B of the transport mechanisms that makes an N > 1 line explain itself: four variants, each
+    # with the mechanism ACTUALLY active on every rank and where an iteration's microseconds go
+    ab = d["transport_ab"]
+    assert "error" not in ab, ab
+    assert [v["requested"] for v in ab["variants"]] == ["inboxes + mailbox", "send/recv + mailbox",
+                                                        "inboxes + all-gather", "send/recv + all-gather"]
+    for v in ab["variants"]:
+        assert len(v["per_rank"]) == 2 and v["us_per_iteration"] > 0 and v["iterations_per_step"] > 0
+        for e in v["per_rank"]:
+            assert e["body_us"] > 0 and e["constraint_us"] > 0 and e["record_us"] > 0
+    assert ab["variants"][1]["halo_active"] == ["send/recv"] and ab["variants"][3]["halo_active"] == ["send/recv"]
+    assert ab["variants"][2]["records_active"] == ["all-gather"] and ab["variants"][3]["records_active"] == ["all-gather"]
+    # (the test box grants IPC between processes: the first variant really runs inboxes + mailbox)
+    assert ab["variants"][0]["halo_active"] == ["inboxes"] and ab["variants"][0]["records_active"] == ["mailbox (fused)"]
+    its = {v["iterations_per_step"] for v in ab["variants"]}
+    assert len(its) == 1                      # the wire does not reach the iterates
 
 
 def test_mixed_system_over_two_ranks_prints_the_configs4_line():
