@@ -624,6 +624,9 @@ class DistributedContactStepper:
         halo.velocity = self.vel.data_ptr()
         res = capi.SolveResult()
         dprof = capi.DistProfile()
+        # (what a later step without a rebuild continues from is in place BEFORE the solve: a solve that ends in an
+        # error -- a peer's words that never came -- leaves a stepper that can step again)
+        self.contacts, self.pairs, self.counted = con, pairs, counted
         capi.check(lib.mhip_bbpgd_solve_contact_distributed(
             op._h, comm._h, C.byref(halo), nci, _p(con["sep"]), C.byref(sp), C.byref(pc), _p(x), _p(g), _p(x_tmp),
             _p(g_tmp), self.poll_every, C.byref(res), C.byref(dprof) if self.profile else None, _stream()))
