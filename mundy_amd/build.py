@@ -26,6 +26,20 @@ def _flag_string():
     return " ".join(FLAGS + os.environ.get("MHIP_EXTRA_HIPCC_FLAGS", "").split())
 
 
+def sweep_kernels_stamp():
+    """Identifies the code of the two BBPGD sweeps as built: hash of the sources they are compiled from + the flag
+    string.  profiles/traffic*.json (PMC traffic per launch, measured by scripts/profile_bench.sh) carry it, and
+    bench.py prints `traffic: null` when the running library's differs -- a figure measured on other kernels is not a
+    measurement of these."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("convex.hip", "mhip_internal.hpp"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(_flag_string().encode())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True

@@ -87,6 +87,9 @@ if traffic:
                           "--steps 1 --warmup 0%s` (the whole solve: untiered first iterations and tiered rest, as in the timed "
                           "run), 2 x FETCH_SIZE + WRITE_SIZE per effective launch"
                           % (os.path.basename(out.rstrip("/")).replace("prof_", ""), (" " + EXTRA) if EXTRA else ""))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mundy_amd import build as _hip_build
+    traffic["_kernel_stamp"] = _hip_build.sweep_kernels_stamp()   # bench.py drops the figure when the kernels changed
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     print("\n## HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)")
     for k, v in traffic.items():

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mundy_amd import ops, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300_000
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-b = synth.mixed_bodies(n, volume_fraction=0.3)
+b = synth.mixed_bodies(n, volume_fraction=0.4)
 dk, dc, dq, ds = dev(b["kind"]), dev(b["center"]), dev(b["quat"]), dev(b["shape"])
 aabb, brad = ops.compute_aabb_mixed(dk, dc, dq, ds)
 links = ops.GenNeighborLinks().set_search_kind(ops.SEARCH_AABB).set_search_buffer(0.1).concretize()

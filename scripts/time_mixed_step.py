@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mundy_amd import ops, pipeline, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-phi = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+phi = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 b = synth.mixed_bodies(n, volume_fraction=phi)
 st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=0.1,

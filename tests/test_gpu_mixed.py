@@ -282,7 +282,7 @@ def test_configs4_at_full_size(ops, oracle):
     from gpu_util import assert_bits_equal, dev, host
     from mundy_amd import pipeline, synth
     n, tol = 1_000_000, 1e-5
-    b = synth.mixed_bodies(n, volume_fraction=0.30, seed=1234)     # bench.py --mixed
+    b = synth.mixed_bodies(n, volume_fraction=0.40, seed=1234)     # bench.py --mixed (box "from phi" = 0.40)
     st = pipeline.ContactStepper("mixed", dev(b["center"]), None, dev(b["quat"]), search_buffer=0.1,
                                  cfg=ops.PGDConfig(max_iters=10000, tol=tol), kinds=dev(b["kind"]), shape=dev(b["shape"]))
     st.reorder_bodies(cell_size=3.0, lo=[0.0, 0.0, 0.0])
