@@ -559,23 +559,11 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
   constexpr bool FLAT = FLATP > 0 && MODE == X_SOLVE && PACKED;
-  constexpr int kFlatPlanes = (KIN == KIN_RIGID) ? 4 : 3;
+  // the image holds PRODUCTS: the entry's force f = +/-lambda n and, with it, what the torque sum takes -- the arclength
+  // coefficient (rods: S += coef f) or r x f itself (vector arms): 32 / 48 bytes per entry (round 3 stored (n, arm,
+  // +/-lambda, +/-dlambda): 48 / 64), i.e. 24 / 36 KB per workgroup at 3 x 256 entries
+  constexpr int kFlatPlanes = (KIN == KIN_RIGID) ? 3 : 2;
   __shared__ double2 flat_img[FLAT ? kFlatPlanes * FLATP * kBlock : 1];
-  const double* xt = X0;
-  const double* gt = G0;
-  double step = 0.0;
-  double* vel_new = op.vel;  // rows this sweep writes (tiered solves: the buffer of the new iterate's parity)
-  if (MODE == X_SOLVE) {
-    if (st->done) return;
-    const bool odd = st->flips & 1u;
-    if (odd) {
-      xt = X1;
-      gt = G1;
-    }
-    if (op.vel_alt) vel_new = odd ? op.vel : op.vel_alt;
-    step = st->step;
-  }
-  const bool step_is_zero = fabs(-step) < kZeroTol;
   // one tile = one workgroup's worth of bodies (see xcd_tile), the grid covers them once
   const size_t tile = xcd_tile(blockIdx.x, gridDim.x, op.xcd_aware);
   const size_t t = tile * (size_t)blockDim.x + threadIdx.x;
@@ -584,6 +572,35 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   if (!FLAT && !has_body) return;  // whole groups leave together (G divides the wave size)
   // (FLAT: lanes without a body still stream entries and meet the workgroup's barriers; b is clamped for them)
   const size_t b = op.body_first + (has_body ? t / G : op.body_count - 1);
+  // FLAT: the tile's share [E0, E1) of the compact arrays (uniform over the workgroup: two scalar loads) is asked for
+  // HERE, together with the solver state below -- round 3 read `done` first, alone, and everything else behind the
+  // branch on it: one full memory round trip at the head of every workgroup's chain of dependent accesses
+  int32_t E0 = 0, E1 = 0;
+  if constexpr (FLAT) {
+    if (op.aptr != nullptr) {
+      const size_t tb0r = tile * (size_t)(kBlock / G);
+      const size_t tb0 = (tb0r < op.body_count) ? tb0r : op.body_count;  // (the grid is rounded up to whole XCD rounds)
+      const size_t tb1 = (tb0 + kBlock / G < op.body_count) ? tb0 + kBlock / G : op.body_count;
+      E0 = op.aptr[op.body_first + tb0];
+      E1 = op.aptr[op.body_first + tb1];
+    }
+  }
+  const double* xt = X0;
+  const double* gt = G0;
+  double step = 0.0;
+  double* vel_new = op.vel;  // rows this sweep writes (tiered solves: the buffer of the new iterate's parity)
+  if (MODE == X_SOLVE) {
+    const int done = st->done;
+    const bool odd = st->flips & 1u;
+    step = st->step;
+    if (done) return;
+    if (odd) {
+      xt = X1;
+      gt = G1;
+    }
+    if (op.vel_alt) vel_new = odd ? op.vel : op.vel_alt;
+  }
+  const bool step_is_zero = fabs(-step) < kZeroTol;
   constexpr int HW = (KIN == KIN_RIGID) ? 6 : (KIN == KIN_ROD ? 4 : 3);
   // force and torque sums in double-double: their rounded values do not depend on the order of the list, on G or on U
   DD3 Fdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}}, Tdd{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
@@ -592,16 +609,17 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   // not one more dependent memory level at the end of the chain
   double mt = 0.0, mr = 0.0;
   V3 axis{0.0, 0.0, 0.0};
-  // drift bookkeeping of tiered solves: how far this body's row moves in this sweep, from the changes of its
-  // multipliers (F_new - F_old = sum +/- (lam - x_old) n over the entries walked: an entry that is not walked has
-  // lam = x_old = 0) -- no second pass over the rows
+  // drift bookkeeping of tiered solves: how far this body's row moves in this sweep.  Round 4: taken from the ROWS --
+  // the row of the previous iterate is still there when the new one is written (the other buffer of the ping-pong, or
+  // the row about to be overwritten), so |dU|_1, |dZ|_1 are differences of two rows; rounds 2-3 accumulated
+  // F_new - F_old = sum +/- (lam - x_old) n beside the sums, which cost the sweep 18 VGPRs, a fourth LDS plane and the
+  // cross products of phase B.  A bound only: its value never reaches an iterate.
   // (a template parameter: carried as a run-time flag the bookkeeping cost the untracked sweep 6 % in registers)
   constexpr bool track = TRACK && MODE == X_SOLVE && PACKED;
-  V3 dF{0.0, 0.0, 0.0}, dS{0.0, 0.0, 0.0};
-  // With 3 x 256 entries per chunk the workgroup's 36 KB of LDS allow four workgroups per CU, i.e. 128 VGPRs per lane:
-  // there the words the END of the sweep needs (drift, firing threshold) are fetched now, beside the others, instead of
-  // costing one more memory round trip in the life of every workgroup; with 2 x 256 entries (five workgroups per CU at
-  // <= 96 VGPRs) the extra registers would cost a wave per SIMD (measured: + 9 %), so they stay where they are used.
+  // With 3 x 256 entries per chunk the words the END of the sweep needs (drift, firing threshold) are fetched now, beside
+  // the others, instead of costing one more memory round trip in the life of every workgroup (round 3, when the 36 KB
+  // image capped the sweep at four workgroups per CU and 128 VGPRs were free; round 4: 24 KB image and 96 VGPRs -- five
+  // workgroups -- with these words still in); with 2 x 256 entries they stay where they are used.
   constexpr bool kEarlyTail = FLAT && FLATP >= 3 && track;
   constexpr bool kEarlySnap = FLAT && FLATP >= 3;
   double drift_old = 0.0, fire_thr = 0.0;
@@ -639,7 +657,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   auto process = [&](const int32_t* __restrict__ ent, const double* __restrict__ rec, const int32_t* kk,
                      const bool eager) {
     int32_t e[U];
-    double lam[U], xo[U];
+    double lam[U];
     double2 h0[U], h1[U], h2[U];
     auto fetch = [&](int u) {
       const size_t k = static_cast<size_t>(kk[u]);
@@ -667,30 +685,18 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     for (int u = 0; u < U; ++u)
       pit[u] = iterate_load<MODE, PACKED>(e[u] >= 0 ? static_cast<size_t>(e[u] >> 1) : 0, xt, gt);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      xo[u] = (e[u] >= 0 && MODE == X_SOLVE) ? pit[u].x : 0.0;
-      lam[u] = (e[u] >= 0) ? iterate_value<MODE>(pit[u], step, step_is_zero, sp) : 0.0;
-    }
+    for (int u = 0; u < U; ++u) lam[u] = (e[u] >= 0) ? iterate_value<MODE>(pit[u], step, step_is_zero, sp) : 0.0;
     // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so (when the
-    // records are not fetched eagerly) its record is never fetched (unless its multiplier just dropped to zero and the
-    // drift bookkeeping wants the change)
+    // records are not fetched eagerly) its record is never fetched
     if (!eager) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (lam[u] != 0.0 || (track && xo[u] != 0.0)) fetch(u);
+        if (lam[u] != 0.0) fetch(u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (lam[u] == 0.0 && !(track && xo[u] != 0.0)) continue;
-      const V3 n{h0[u].x, h0[u].y, h1[u].x};
-      if (track) {  // change of this body's force (and of S) against the previous iterate: plain sums, a bound only
-        const double dl = (e[u] & 1) ? lam[u] - xo[u] : xo[u] - lam[u];
-        const V3 df{dl * n.x, dl * n.y, dl * n.z};
-        dF = dF + df;
-        if (KIN == KIN_ROD) dS = dS + h1[u].y * df;
-        if (KIN == KIN_RIGID) dS = dS + cross(V3{h1[u].y, h2[u].x, h2[u].y}, df);  // change of the torque
-      }
       if (lam[u] == 0.0) continue;
+      const V3 n{h0[u].x, h0[u].y, h1[u].x};
       V3 f{lam[u] * n.x, lam[u] * n.y, lam[u] * n.z};
       if (!(e[u] & 1)) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
       dd_add(Fdd, f);
@@ -707,17 +713,11 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     if (op.aptr != nullptr) {  // the snapshot's active entries, streamed; what became active since stays in mm
       const int32_t ab = op.aptr[b], ae = op.aptr[b + 1];
       if constexpr (FLAT) {
-        // the tile's bodies and their share [E0, E1) of the compact arrays (uniform over the workgroup)
-        const size_t tb0r = tile * (size_t)(kBlock / G);
-        const size_t tb0 = (tb0r < op.body_count) ? tb0r : op.body_count;  // (the grid is rounded up to whole XCD rounds)
-        const size_t tb1 = (tb0 + kBlock / G < op.body_count) ? tb0 + kBlock / G : op.body_count;
-        const int32_t E0 = op.aptr[op.body_first + tb0], E1 = op.aptr[op.body_first + tb1];
         constexpr int kChunk = FLATP * kBlock;
         constexpr bool NTS = (MHIP_NT & 1) != 0;
-        double2* const pl0 = flat_img;
-        double2* const pl1 = flat_img + kChunk;
-        double2* const pl2 = flat_img + 2 * kChunk;
-        double2* const pl3 = flat_img + (kFlatPlanes - 1) * kChunk;  // (+/-lambda, +/-dlambda)
+        double2* const pl0 = flat_img;                               // (f.x, f.y)
+        double2* const pl1 = flat_img + kChunk;                      // (f.z, coef)  |  (f.z, (r x f).x)
+        double2* const pl2 = flat_img + (kFlatPlanes - 1) * kChunk;  // vector arms: ((r x f).y, (r x f).z)
         for (int32_t base = E0; base < E1; base += kChunk) {
           // phase A: FLATP entries per lane, all their loads in flight together
           int32_t fe[FLATP];
@@ -755,48 +755,48 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
 #pragma unroll
           for (int p = 0; p < FLATP; ++p)
             pit[p] = iterate_load<MODE, PACKED>(fe[p] >= 0 ? static_cast<size_t>(fe[p] >> 1) : 0, xt, gt);
-          double sl[FLATP], sdl[FLATP];
 #pragma unroll
           for (int p = 0; p < FLATP; ++p) {
-            const double xo = (fe[p] >= 0) ? pit[p].x : 0.0;
-            const double lam = (fe[p] >= 0) ? iterate_value<MODE>(pit[p], step, step_is_zero, sp) : 0.0;
-            // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472); the same sign on the multiplier's change
-            sl[p] = (fe[p] & 1) ? lam : -lam;
-            sdl[p] = (fe[p] & 1) ? lam - xo : xo - lam;
-          }
-#pragma unroll
-          for (int p = 0; p < FLATP; ++p) {
+            // (the iterate is USED unconditionally and the dead slot's value dropped by a select: with the use inside
+            // `fe >= 0` the compiler sinks the gather into that branch and waits for it there with vmcnt(0))
+            const double lam_live = iterate_value<MODE>(pit[p], step, step_is_zero, sp);
+            const double lam = (fe[p] >= 0) ? lam_live : 0.0;
+            // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472): the products the per-body chains form, formed
+            // here by the lane that holds the record (the same multiplications: the same bits)
+            const double sl = (fe[p] & 1) ? lam : -lam;
+            const V3 f{sl * r0[p].x, sl * r0[p].y, sl * r1[p].x};
             const int slot = p * kBlock + static_cast<int>(threadIdx.x);
-            pl0[slot] = r0[p];
-            pl1[slot] = r1[p];
-            if (KIN == KIN_RIGID) pl2[slot] = r2[p];
-            pl3[slot] = make_double2(sl[p], sdl[p]);
+            pl0[slot] = make_double2(f.x, f.y);
+            if (KIN == KIN_RIGID) {
+              const V3 tq = cross(V3{r1[p].y, r2[p].x, r2[p].y}, f);  // torque r x (+/- lam n)
+              pl1[slot] = make_double2(f.z, tq.x);
+              pl2[slot] = make_double2(tq.y, tq.z);
+            } else {
+              pl1[slot] = make_double2(f.z, r1[p].y);  // rods: the arclength coefficient (spheres: 0)
+            }
           }
           __syncthreads();
-          // phase B: a body's lanes add up its slice of the image
+          // phase B: a body's lanes add up its slice of the image (an entry whose multiplier is zero holds +/-0: adding
+          // it leaves every sum as it is, bit for bit)
           if (has_body) {
             const int32_t lo = (ab > base) ? ab : base;
             const int32_t hi = (ae < base + kChunk) ? ae : base + kChunk;
             for (int32_t k = lo + sub; k < hi; k += G) {
               const int slot = k - base;
-              const double2 a0 = pl0[slot], a1 = pl1[slot], a3 = pl3[slot];
-              const V3 n{a0.x, a0.y, a1.x};
-              V3 arm{0.0, 0.0, 0.0};
+              const double2 a0 = pl0[slot], a1 = pl1[slot];
+              const V3 f{a0.x, a0.y, a1.x};
+#ifdef MHIP_EXP_PLAIN_SUMS   // TIMING EXPERIMENT ONLY (what the double-double sums of phase B cost): plain sums
+              Fdd.x.hi += f.x; Fdd.y.hi += f.y; Fdd.z.hi += f.z;
+              if (KIN == KIN_ROD) { Tdd.x.hi += a1.y * f.x; Tdd.y.hi += a1.y * f.y; Tdd.z.hi += a1.y * f.z; }
+              if (KIN == KIN_RIGID) { const double2 a2 = pl2[slot]; Tdd.x.hi += a1.y; Tdd.y.hi += a2.x; Tdd.z.hi += a2.y; }
+#else
+              dd_add(Fdd, f);
               if (KIN == KIN_RIGID) {
                 const double2 a2 = pl2[slot];
-                arm = V3{a1.y, a2.x, a2.y};
+                dd_add(Tdd, V3{a1.y, a2.x, a2.y});
               }
-              if (track && a3.y != 0.0) {
-                const V3 df{a3.y * n.x, a3.y * n.y, a3.y * n.z};
-                dF = dF + df;
-                if (KIN == KIN_ROD) dS = dS + a1.y * df;
-                if (KIN == KIN_RIGID) dS = dS + cross(arm, df);
-              }
-              if (a3.x == 0.0) continue;
-              const V3 f{a3.x * n.x, a3.x * n.y, a3.x * n.z};
-              dd_add(Fdd, f);
-              if (KIN == KIN_RIGID) dd_add(Tdd, cross(arm, f));
-              if (KIN == KIN_ROD) dd_add(Tdd, a1.y * f);
+              if (KIN == KIN_ROD) dd_add(Tdd, a1.y * f);  // S = sum coef f
+#endif
             }
           }
           __syncthreads();
@@ -854,14 +854,16 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
       dd_add(Tdd.z, dd_shfl_xor(Tdd.z, off));
     }
   }
-  if (track) {
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-      dF = dF + V3{__shfl_xor(dF.x, off, 64), __shfl_xor(dF.y, off, 64), __shfl_xor(dF.z, off, 64)};
-      if (KIN != KIN_TRANS) dS = dS + V3{__shfl_xor(dS.x, off, 64), __shfl_xor(dS.y, off, 64), __shfl_xor(dS.z, off, 64)};
-    }
-  }
   if (sub != 0) return;
+  // tracked sweeps: the row of the previous iterate, asked for before the last arithmetic of the sweep
+  double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0;
+  if (track) {
+    const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
+    const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
+    o0 = vo[0];
+    o1 = vo[1];
+    o2 = vo[2];
+  }
   const V3 F = dd_value(Fdd), T = dd_value(Tdd);  // the one rounding of each sum
   double2* v = reinterpret_cast<double2*>(vel_new + 6 * b);
   V3 W{0.0, 0.0, 0.0};
@@ -880,15 +882,12 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   v[2] = make_double2(W.y, W.z);
   if (track) {
     // |change of n . (U + coef Z)| <= |dU|_1 + |coef| |dZ|_1 with |coef| <= 1/2 (rods; spheres carry no Z): what any
-    // contact of this body can have moved by, times dt as the gradient sees it.  dU = mt dF, dZ = (mr (u x dS)) x u.
-    double d = mt * (fabs(dF.x) + fabs(dF.y) + fabs(dF.z));
-    if (KIN == KIN_ROD) {
-      const V3 tq = cross(axis, dS);
-      const V3 dZ = cross(V3{mr * tq.x, mr * tq.y, mr * tq.z}, axis);
-      d += 0.5 * (fabs(dZ.x) + fabs(dZ.y) + fabs(dZ.z));
-    }
-    // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|, dW = mr dT
-    if (KIN == KIN_RIGID) d += op.arm_max[b] * mr * (fabs(dS.x) + fabs(dS.y) + fabs(dS.z));
+    // contact of this body can have moved by, times dt as the gradient sees it.  The row holds (U, Z) resp. (U, W).
+    double d = fabs(Ub.x - o0.x) + fabs(Ub.y - o0.y) + fabs(Ub.z - o1.x);
+    const double dw = fabs(W.x - o1.y) + fabs(W.y - o2.x) + fabs(W.z - o2.y);
+    if (KIN == KIN_ROD) d += 0.5 * dw;
+    // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|
+    if (KIN == KIN_RIGID) d += op.arm_max[b] * dw;
     const double D = (kEarlyTail ? drift_old : op.drift[b]) + op.dt * d;
     op.drift[b] = D;
     if (op.fire_at != nullptr && !(D < (kEarlyTail ? fire_thr : op.fire_at[b])))  // one of its sleeping contacts has used up its share of slack
