@@ -362,11 +362,24 @@ __global__ void __launch_bounds__(kBlock) k_emit_long_rows(const int32_t* __rest
   }
 }
 
+// The counting pass of every search structure parks the partners it finds in a slab, up to kSlab per body (entry-major:
+// slab[a * n + slot], so the lanes of a wave write neighbouring words); the filling pass then copies the rows that fit
+// and searches again only for the bodies with more partners than that -- on a monodisperse system none.  (Round 2 gave
+// this to the tree traversal; round 4 to the cell grid, whose second walk of the stencil was 0.65 of the 1.4 ms a
+// rebuild of the 10^6-rod list took.)
+constexpr int kSlab = kShortSegment;
+__device__ inline void row_from_slab(const RowSink& out, const int32_t* __restrict__ slab, size_t n, size_t slot, int i,
+                                     int32_t base, int have) {
+  for (int a = 0; a < have; ++a) out.col[base + a] = slab[static_cast<size_t>(a) * n + slot];
+  finish_row(out, i, base, have);
+}
+
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
     k_pairs(size_t n, BpArgs A, const GridParams* __restrict__ gpp, const SearchRec* __restrict__ recs,
             const int32_t* __restrict__ slot_cell, const int32_t* __restrict__ cell_ptr,
-            int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, RowSink out) {
+            int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, RowSink out,
+            int32_t* __restrict__ slab) {
   const GridParams gp = *gpp;
   const size_t s = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (s >= n) return;
@@ -377,6 +390,14 @@ __global__ void __launch_bounds__(kBlock)
     return;
   }
   int32_t* col = out.col;
+  if (FILL) {
+    const int32_t b0 = row_ptr[i];
+    const int have = row_ptr[i + 1] - b0;
+    if (have <= kSlab) {  // the counting pass kept the whole row
+      row_from_slab(out, slab, n, s, i, b0, have);
+      return;
+    }
+  }
   const int cid = slot_cell[s];
   const int cx = cid % gp.nc[0], cy = (cid / gp.nc[0]) % gp.nc[1], cz = cid / (gp.nc[0] * gp.nc[1]);
   int xs[3], ys[3], zs[3];
@@ -397,6 +418,7 @@ __global__ void __launch_bounds__(kBlock)
           const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
           if (hit) {
             if (FILL) col[base + cnt] = j;
+            else if (cnt < kSlab) slab[static_cast<size_t>(cnt) * n + s] = j;
             ++cnt;
           }
         }
@@ -422,7 +444,8 @@ template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
     k_pairs_lds(size_t n, BpArgs A, const GridParams* __restrict__ gpp, const SearchRec* __restrict__ recs,
                 const int32_t* __restrict__ slot_cell, const int32_t* __restrict__ cell_ptr,
-                int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, RowSink out) {
+                int32_t* __restrict__ counts, const int32_t* __restrict__ row_ptr, RowSink out,
+                int32_t* __restrict__ slab) {
   __shared__ __attribute__((aligned(16))) SearchRec tile[kPairTile];
   int32_t* col = out.col;
   const GridParams gp = *gpp;
@@ -434,6 +457,25 @@ __global__ void __launch_bounds__(kBlock)
   if (live) {
     me = recs[s];
     i = static_cast<int>(me.id);
+  }
+  bool searching = live && is_source(A, i);  // a body outside the source set stages tiles but owns no row
+  const int32_t base = (FILL && live) ? row_ptr[i] : 0;
+  if (FILL) {
+    // rows the counting pass parked in the slab are copied; the stencil is walked again only by a workgroup that has a
+    // longer row (its other bodies then only help staging the tiles)
+    bool walk = false;
+    if (searching) {
+      const int have = row_ptr[i + 1] - base;
+      if (have <= kSlab) {
+        row_from_slab(out, slab, n, s, i, base, have);
+        searching = false;
+      } else {
+        walk = true;
+      }
+    }
+    if (!__syncthreads_or(walk ? 1 : 0)) return;
+  }
+  if (live) {
     const int cid = slot_cell[s];
     cx = cid % gp.nc[0];
     cy = (cid / gp.nc[0]) % gp.nc[1];
@@ -441,9 +483,7 @@ __global__ void __launch_bounds__(kBlock)
   }
   const int c_first = slot_cell[s0];
   const int c_last = slot_cell[(s0 + kBlock <= n ? s0 + kBlock : n) - 1];
-  const bool searching = live && is_source(A, i);  // a body outside the source set stages tiles but owns no row
   int cnt = 0;
-  const int32_t base = (FILL && live) ? row_ptr[i] : 0;
   for (int dz = -1; dz <= 1; ++dz)
     for (int dy = -1; dy <= 1; ++dy) {
       const long long off = (static_cast<long long>(dz) * gp.nc[1] + dy) * gp.nc[0];
@@ -478,6 +518,7 @@ __global__ void __launch_bounds__(kBlock)
           const bool hit = (i <= j) ? volumes_overlap(A, me, o) : volumes_overlap(A, o, me);
           if (hit) {
             if (FILL) col[base + cnt] = j;
+            else if (cnt < kSlab) slab[static_cast<size_t>(cnt) * n + s] = j;
             ++cnt;
           }
         }
@@ -488,7 +529,7 @@ __global__ void __launch_bounds__(kBlock)
     counts[i] = cnt;
     return;
   }
-  finish_row(out, i, base, cnt);
+  if (searching) finish_row(out, i, base, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -727,7 +768,6 @@ __global__ void __launch_bounds__(kBlock)
 // The tree is walked ONCE for most bodies: the counting pass parks a body's first kSlab partners in a slab
 // (slab[slot * n + q]: lanes of a wave write neighbouring words), the filling pass copies them into the row and walks
 // the tree again only for the bodies with more partners than that.
-constexpr int kSlab = kShortSegment;
 template <bool FILL>
 __global__ void __launch_bounds__(kBlock)
     k_lbvh_pairs(int n, BpArgs A, const SearchRec* __restrict__ recs, const BvhNode* __restrict__ nodes,
@@ -1172,12 +1212,15 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
     k_cell_scatter<<<g, kBlock, 0, s>>>(n, A, aabb, center, bounding_radius, h->cell_of.as<int32_t>(),
                                        h->cursor.as<int32_t>(), h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>());
     MHIP_LAUNCH_CHECK();
+    if (int e = h->slab.reserve((static_cast<size_t>(kSlab) * n + 2) * sizeof(int32_t))) return e;
     if (lds)
       k_pairs_lds<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                              h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, none);
+                                              h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, none,
+                                              h->slab.as<int32_t>());
     else
       k_pairs<false><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                          h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, none);
+                                          h->cell_ptr.as<int32_t>(), h->counts.as<int32_t>(), nullptr, none,
+                                          h->slab.as<int32_t>());
     MHIP_LAUNCH_CHECK();
   } else {
     if (int e = h->keys.reserve(n * sizeof(unsigned long long))) return e;
@@ -1260,10 +1303,12 @@ int mhip_broadphase_build(mhip_broadphase_t h, const mhip_broadphase_config* con
   if (method == MHIP_SEARCH_METHOD_GRID) {
     if (lds)
       k_pairs_lds<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                             h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
+                                             h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink,
+                                             h->slab.as<int32_t>());
     else
       k_pairs<true><<<gb, kBlock, 0, s>>>(n, A, gp, h->recs.as<SearchRec>(), h->slot_cell.as<int32_t>(),
-                                         h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink);
+                                         h->cell_ptr.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink,
+                                         h->slab.as<int32_t>());
   } else {
     k_lbvh_pairs<true><<<gb, kBlock, 0, s>>>(nn, A, h->recs.as<SearchRec>(), h->nodes.as<BvhNode>(),
                                             h->leaf_rope.as<int32_t>(), nullptr, h->row_ptr.as<int32_t>(), sink,

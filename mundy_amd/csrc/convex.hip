@@ -1606,6 +1606,88 @@ __global__ void __launch_bounds__(kBlock) k_inc_fill(size_t C, const int2* __res
     inc[atomicAdd(&cursor[ij.y], 1)] = static_cast<int32_t>(e | 1u);
   }
 }
+// ---- incidence build, fast path: the pair list is a neighbour list as the broad phase emits it -- rows sorted by the
+// lower body, i < j in every row (GenNeighborLinks: unique pairs, sorted by (i, j)).  Then a body's SOURCE half (the
+// contacts it is the lower body of) is its row of the list as it stands, and every contact it is the TARGET of lies in
+// the row of a lower body, i.e. before its own row: only the transpose half needs counting with atomics, filling
+// through atomic cursors and sorting (round 3 did all of that for both halves: k_inc_count, k_inc_fill and the segment
+// sort over 2C entries were 1.6 of the 3.6 ms a rebuild step spent on list + operator; profiles/r03_kernel_stats.csv).
+// flags: [0] an index out of range / a self pair, [1] the list is not of that form (-> the general path), [2] (k_inc_deg)
+__global__ void __launch_bounds__(kBlock)
+    k_inc_count_sorted(size_t C, size_t N, const int2* __restrict__ pairs, int32_t* __restrict__ tdeg,
+                       int32_t* __restrict__ row_start, int* __restrict__ flags) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    if (ij.x < 0 || ij.y < 0 || (size_t)ij.x >= N || (size_t)ij.y >= N || ij.x == ij.y) {
+      flags[0] = 1;  // checked on the host before any gather runs: out-of-range indices never reach a kernel
+      continue;
+    }
+    int prev = -1;
+    if (c > 0) {
+      prev = pairs[c - 1].x;
+      if (prev < 0 || (size_t)prev >= N) prev = ij.x;  // (that row is reported by its own thread)
+    }
+    if (ij.x >= ij.y || prev > ij.x) flags[1] = 1;
+    atomicAdd(&tdeg[ij.y], 1);
+    for (int b = prev + 1; b <= ij.x; ++b) row_start[b] = static_cast<int32_t>(c);  // first row of every body up to this one
+    if (c + 1 == C)
+      for (size_t b = (size_t)ij.x + 1; b <= N; ++b) row_start[b] = static_cast<int32_t>(C);
+  }
+}
+__global__ void __launch_bounds__(kBlock) k_inc_deg(size_t N, const int32_t* __restrict__ tdeg,
+                                                   const int32_t* __restrict__ row_start, int32_t* __restrict__ deg) {
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x)
+    deg[b] = tdeg[b] + (row_start[b + 1] - row_start[b]);
+}
+// staged lists: [targets, in the order their atomics arrived][sources, ascending]; the class bit as in k_inc_fill
+__global__ void __launch_bounds__(kBlock)
+    k_inc_fill_sorted(size_t C, const int2* __restrict__ pairs, const int32_t* __restrict__ inc_ptr,
+                      const int32_t* __restrict__ tdeg, int32_t* __restrict__ tcursor,
+                      const int32_t* __restrict__ row_start, unsigned* __restrict__ stage,
+                      const double* __restrict__ priority) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < C; c += (size_t)gridDim.x * blockDim.x) {
+    const int2 ij = pairs[c];
+    const unsigned cls = (priority && !(priority[c] < 0.0)) ? 0x80000000u : 0u;
+    const unsigned e = static_cast<unsigned>(c << 1) | cls;
+    stage[inc_ptr[ij.x] + tdeg[ij.x] + (static_cast<int32_t>(c) - row_start[ij.x])] = e;
+    stage[inc_ptr[ij.y] + atomicAdd(&tcursor[ij.y], 1)] = e | 1u;
+  }
+}
+// One thread per body: its targets sorted (a handful), then the list in the order of the general path -- ascending
+// (class, constraint, side) = [targets of class 0][sources of class 0][targets of class 1][sources of class 1] (every
+// target constraint precedes every source constraint) -- with the class bit cleared, and the slot table beside it.
+__global__ void __launch_bounds__(kBlock)
+    k_inc_arrange(size_t N, const int32_t* __restrict__ inc_ptr, const int32_t* __restrict__ tdeg,
+                  unsigned* __restrict__ stage, int32_t* __restrict__ inc, unsigned char* __restrict__ pos) {
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x) {
+    const int32_t beg = inc_ptr[b], end = inc_ptr[b + 1], lt = tdeg[b];
+    unsigned* T = stage + beg;
+    for (int32_t a = 1; a < lt; ++a) {  // insertion sort by (class, constraint): the key as it stands
+      const unsigned key = T[a];
+      int32_t k = a - 1;
+      while (k >= 0 && T[k] > key) {
+        T[k + 1] = T[k];
+        --k;
+      }
+      T[k + 1] = key;
+    }
+    int32_t out = beg;
+    auto emit = [&](unsigned e) {
+      const unsigned v = e & 0x7fffffffu;
+      inc[out] = static_cast<int32_t>(v);
+      const int32_t slot = out - beg;
+      pos[2 * static_cast<size_t>(v >> 1) + (v & 1u)] = static_cast<unsigned char>(slot < 255 ? slot : 255);
+      ++out;
+    };
+    for (unsigned cls = 0; cls < 2u; ++cls) {
+      for (int32_t k = 0; k < lt; ++k)
+        if ((T[k] >> 31) == cls) emit(T[k]);
+      for (int32_t k = beg + lt; k < end; ++k)
+        if ((stage[k] >> 31) == cls) emit(stage[k]);
+    }
+  }
+}
+
 // Each body's list in a fixed order whatever order the atomics arrived in: ascending (constraint, side) -- or, given a
 // priority array, the contacts with priority < 0 first (ascending), then the others (ascending).  With priority = the
 // signed separation the contacts that overlap at the start of the step, i.e. nearly all that will carry an impulse,
@@ -2330,6 +2412,9 @@ int op_snapshot_active(mhip_contact_op* op, hipStream_t s) {
 }
 // from this many completed iterations on the masks have settled enough for a snapshot to pay
 constexpr unsigned kSnapshotAfter = 8;
+#ifndef MHIP_SNAPSHOT_AT_INIT
+#define MHIP_SNAPSHOT_AT_INIT 1
+#endif
 
 
 // ---- Cold tier ---------------------------------------------------------------------------------------------------------
@@ -3116,26 +3201,58 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
   if (he == hipSuccess) he = hipMemsetAsync(op->vel.ptr, 0, (6 * N + 2) * sizeof(double), s);
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
   const int2* p2 = reinterpret_cast<const int2*>(pairs);
+  if (int e = op->body_mask.reserve((N + 2) * sizeof(unsigned long long))) return bail(e);
+  if (int e = op->pos.reserve(2 * C + 16)) return bail(e);
+  bool pos_built = false;
+  bool sorted_rows = false;   // the list has the broad phase's form: rows sorted by the lower body, i < j
   if (C > 0) {
-    k_inc_count<<<grid_for(C), kBlock, 0, s>>>(C, N, p2, deg, bad);
-    int hbad = 0;
-    he = hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+    // first the fast path's count (it validates the indices as well); a list of another form takes the general path
+    if (int e = op->acnt.reserve((N + 2) * sizeof(int32_t))) return bail(e);
+    if (int e = op->aptr.reserve((N + 2) * sizeof(int32_t))) return bail(e);
+    int32_t* row_start = op->aptr.as<int32_t>();   // (both free until the first snapshot of the active lists)
+    k_inc_count_sorted<<<grid_for(C), kBlock, 0, s>>>(C, N, p2, deg, row_start, bad);
+    int hflags[2] = {0, 0};
+    he = hipMemcpyAsync(hflags, bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
     if (he == hipSuccess) he = hipStreamSynchronize(s);
     if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "pair validation failed: %s", hipGetErrorString(he)));
-    if (hbad)
+    if (hflags[0])
       return bail(fail(MHIP_ERR_INVALID_ARGUMENT, "pairs contain an index outside [0, %zu) or a self pair", N));
+    sorted_rows = hflags[1] == 0;
+    if (!sorted_rows) {
+      he = hipMemsetAsync(deg, 0, (N + 1) * sizeof(int32_t), s);
+      if (he == hipSuccess) he = hipMemsetAsync(bad, 0, 2 * sizeof(int), s);
+      if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
+      k_inc_count<<<grid_for(C), kBlock, 0, s>>>(C, N, p2, deg, bad);
+    }
   }
-  if (int e = exclusive_scan_i32(deg, op->inc_ptr.as<int32_t>(), N, op->scanws.ptr, s)) return bail(e);
-  he = hipMemcpyAsync(deg, op->inc_ptr.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
-  if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
-  if (C > 0) {
-    k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>(), priority);
+  if (sorted_rows) {
+    int32_t* tdeg = op->acnt.as<int32_t>();
+    int32_t* row_start = op->aptr.as<int32_t>();
+    he = hipMemcpyAsync(tdeg, deg, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // deg holds the target counts
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
+    k_inc_deg<<<grid_for(N), kBlock, 0, s>>>(N, tdeg, row_start, deg);
+    if (int e = exclusive_scan_i32(deg, op->inc_ptr.as<int32_t>(), N, op->scanws.ptr, s)) return bail(e);
+    he = hipMemsetAsync(deg, 0, (N + 1) * sizeof(int32_t), s);   // now the targets' cursors
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
     if (int e = op->sort_tmp.reserve((2 * C + 2) * sizeof(unsigned))) return bail(e);
-    if (int e = op->sort_list.reserve((N + 32) * sizeof(int32_t))) return bail(e);
-    if (int e = sort_segments_u32(N, op->inc_ptr.as<int32_t>(), op->inc.as<unsigned>(), op->sort_tmp.as<unsigned>(), 32,
-                                  op->sort_list.as<int32_t>(), s))
-      return bail(e);
-    if (priority) k_clear_class_bit<<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>());
+    k_inc_fill_sorted<<<grid_for(C), kBlock, 0, s>>>(C, p2, op->inc_ptr.as<int32_t>(), tdeg, deg, row_start,
+                                                    op->sort_tmp.as<unsigned>(), priority);
+    k_inc_arrange<<<grid_for(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), tdeg, op->sort_tmp.as<unsigned>(),
+                                                op->inc.as<int32_t>(), op->pos.as<unsigned char>());
+    pos_built = true;
+  } else {
+    if (int e = exclusive_scan_i32(deg, op->inc_ptr.as<int32_t>(), N, op->scanws.ptr, s)) return bail(e);
+    he = hipMemcpyAsync(deg, op->inc_ptr.ptr, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
+    if (C > 0) {
+      k_inc_fill<<<grid_for(C), kBlock, 0, s>>>(C, p2, deg, op->inc.as<int32_t>(), priority);
+      if (int e = op->sort_tmp.reserve((2 * C + 2) * sizeof(unsigned))) return bail(e);
+      if (int e = op->sort_list.reserve((N + 32) * sizeof(int32_t))) return bail(e);
+      if (int e = sort_segments_u32(N, op->inc_ptr.as<int32_t>(), op->inc.as<unsigned>(), op->sort_tmp.as<unsigned>(), 32,
+                                    op->sort_list.as<int32_t>(), s))
+        return bail(e);
+      if (priority) k_clear_class_bit<<<grid_for(2 * C), kBlock, 0, s>>>(2 * C, op->inc.as<int32_t>());
+    }
   }
   he = hipGetLastError();
   if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "incidence build failed: %s", hipGetErrorString(he)));
@@ -3174,9 +3291,7 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
                     op->half.as<double>(), op->vel.as<double>(), dt, 0, N, nullptr, arc_s, arc_t,
                     op->axis.as<double>(), op->omega.as<double>(), 0, 0, C, 0, 0, nullptr, nullptr,
                     nullptr, nullptr, nullptr, nullptr};
-  if (int e = op->body_mask.reserve((N + 2) * sizeof(unsigned long long))) return bail(e);
-  if (int e = op->pos.reserve(2 * C + 16)) return bail(e);
-  if (N > 0 && C > 0) {
+  if (N > 0 && C > 0 && !pos_built) {
     k_pos_build<<<grid_for(N), kBlock, 0, s>>>(N, op->inc_ptr.as<int32_t>(), op->inc.as<int32_t>(),
                                               op->pos.as<unsigned char>());
     he = hipGetLastError();
@@ -3466,6 +3581,14 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
       enqueued = op->host_state->iter;
     }
     if (op->host_state->done || enqueued >= config->max_iters) break;
+#if MHIP_SNAPSHOT_AT_INIT
+    // the masks of the INITIAL iterate exist (the init sweep wrote them): a first snapshot of the active lists at the
+    // first poll -- unless the problem was solved already -- so that iterations 1 ... 8 stream compact lists too instead
+    // of walking every body's mask (round 3: k_body at 130-196 us in those iterations against 110 with a snapshot); what
+    // becomes active since takes the per-body path
+    if (enqueued == 0)
+      if (int e = op_snapshot_active(op, s)) return e;
+#endif
     // cold tier: the drift bookkeeping starts with the first iteration, the first classification comes with the first
     // snapshot (short solves -- a relaxed packing needs ~100 iterations -- get their tiers early)
     const bool light = plan.light_poll();
