@@ -547,6 +547,9 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 #ifndef MHIP_KBODY_FLAT
 #define MHIP_KBODY_FLAT 2
 #endif
+#ifndef MHIP_KBODY_FLAT3_ABOVE   // share of a 2 x 256-entry chunk a workgroup's lists may fill before the chunk is 3 x 256
+#define MHIP_KBODY_FLAT3_ABOVE 0.9
+#endif
 // FLATP > 0 (packed solves with a snapshot of the active lists): the compact lists are not walked body by body --
 // the workgroup's 256 threads STREAM the entries of its 256 / G bodies flat, FLATP x 256 at a time (every lane has the
 // same work whatever its body's share of the list; entry, record and the gather of the iterate are FLATP independent
@@ -755,11 +758,20 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
 #pragma unroll
           for (int p = 0; p < FLATP; ++p)
             pit[p] = iterate_load<MODE, PACKED>(fe[p] >= 0 ? static_cast<size_t>(fe[p] >> 1) : 0, xt, gt);
+#ifdef MHIP_EXP_EXTRA_GATHER   // TIMING EXPERIMENT ONLY: a second gather of the same pattern (the other parity's pairs)
+          double2 pit2[FLATP];
+#pragma unroll
+          for (int p = 0; p < FLATP; ++p)
+            pit2[p] = iterate_load<MODE, PACKED>(fe[p] >= 0 ? static_cast<size_t>(fe[p] >> 1) : 0, (xt == X0) ? X1 : X0, gt);
+#endif
 #pragma unroll
           for (int p = 0; p < FLATP; ++p) {
             // (the iterate is USED unconditionally and the dead slot's value dropped by a select: with the use inside
             // `fe >= 0` the compiler sinks the gather into that branch and waits for it there with vmcnt(0))
-            const double lam_live = iterate_value<MODE>(pit[p], step, step_is_zero, sp);
+            double lam_live = iterate_value<MODE>(pit[p], step, step_is_zero, sp);
+#ifdef MHIP_EXP_EXTRA_GATHER
+            if (pit2[p].x == 1.2345e300) lam_live = 0.0;
+#endif
             const double lam = (fe[p] >= 0) ? lam_live : 0.0;
             // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472): the products the per-body chains form, formed
             // here by the lane that holds the record (the same multiplications: the same bits)
@@ -2280,7 +2292,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
     const int32_t known = op->host_state ? *reinterpret_cast<const int32_t*>(op->host_state + 1) : 0;
     const double entries = known > 0 ? static_cast<double>(known) : 2.0 * static_cast<double>(op->view.C);
     const double per_group = entries / static_cast<double>(op->view.body_count) * (kBlock / (double)G);
-    if (per_group > 0.9 * 2 * kBlock) flatp = 3;
+    if (per_group > MHIP_KBODY_FLAT3_ABOVE * 2 * kBlock) flatp = 3;
   }
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
