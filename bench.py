@@ -65,8 +65,10 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
                     edge incidence entry 4 + (n, s - 1/2) record 32 = 36 B; per ACTIVE contact its packed iterate 16 B
                     (gathered by both of its half edges, counted once); per body row pointer 4 + active-list pointer 4
                     + mask 8 + snapshot mask 8 + mobilities 16 + axis 24 + velocity row 48 = 112 B (the angular
-                    velocity, 24 B, is written once per solve, by a sweep of the final iterate).  `active_contacts` is
-                    measured in the run (state at the end of the solve); None = every contact (the pre-mask count).
+                    velocity, 24 B, is written once per solve, by a sweep of the final iterate); tiered iterations
+                    add 72 B per body: drift read + written 16, firing threshold 8, the row of the previous iterate
+                    48.  `active_contacts` is measured in the run (state at the end of the solve); None = every
+                    contact (the pre-mask count).
     SURVEY 8(d)'s own figure, 368 C + 96 N per iteration, charges a gathered row to every contact that reads it and
     assumes vector lever arms; this implementation streams scalar arclengths and serves the 48 MB row table from L2 /
     Infinity Cache, so that figure divided by the measured time exceeds the HBM peak (1.39 x at 10^6 rods) -- it is
@@ -75,7 +77,10 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
     # kin = "rigid" (mixed shapes: explicit lever arms): the constraint streams 48 B of arms instead of 16 B of
     # arclengths (120 B per constraint), a half-edge record is (n, r) 48 B instead of (n, s - 1/2) 32 B (entry + record
     # 52 B), a body has no axis (88 B) -- and in tiered iterations reads its longest arm (8 B) on top of the drift words
-    per_con, per_edge, per_body, tier_body = (88.0, 36.0, 112.0, 24.0) if kin == "rod" else (120.0, 52.0, 88.0, 32.0)
+    # tier_body (round 4): + 48 B -- the drift of a tiered sweep is the difference of the body's new row and its row of
+    # the previous iterate, which the sweep therefore reads (rounds 2-3 kept the force change in registers instead: 18
+    # VGPRs and a fourth LDS plane, which capped the vector-arm sweep at three workgroups per CU)
+    per_con, per_edge, per_body, tier_body = (88.0, 36.0, 112.0, 72.0) if kin == "rod" else (120.0, 52.0, 88.0, 80.0)
     con = per_con * contacts + 48.0 * bodies
     body = 2 * per_edge * act + 16.0 * act + per_body * bodies
     if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
