@@ -547,6 +547,9 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 #ifndef MHIP_KBODY_FLAT
 #define MHIP_KBODY_FLAT 2
 #endif
+#ifndef MHIP_KBODY_EARLY_FROM   // chunk size (x 256 entries) from which the sweep's last words are fetched at its top
+#define MHIP_KBODY_EARLY_FROM 3
+#endif
 #ifndef MHIP_KBODY_FLAT3_ABOVE   // share of a 2 x 256-entry chunk a workgroup's lists may fill before the chunk is 3 x 256
 #define MHIP_KBODY_FLAT3_ABOVE 0.9
 #endif
@@ -557,6 +560,9 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 // entry in LDS, and the G lanes of a body then add up their body's slice of that image -- the double-double sums see
 // the same terms (rounded once: any order gives the same bits).  What the snapshot does not cover (entries that became
 // active since, lists beyond 64 entries, steps outside [0, finite]) takes the per-body chains as before.
+#ifdef MHIP_EXP_COUNT_MM
+__device__ unsigned long long g_dbg[4];
+#endif
 template <int MODE, int KIN, int G, int U, bool PACKED, bool TRACK = false, int FLATP = 0>
 __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
@@ -623,8 +629,8 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   // the others, instead of costing one more memory round trip in the life of every workgroup (round 3, when the 36 KB
   // image capped the sweep at four workgroups per CU and 128 VGPRs were free; round 4: 24 KB image and 96 VGPRs -- five
   // workgroups -- with these words still in); with 2 x 256 entries they stay where they are used.
-  constexpr bool kEarlyTail = FLAT && FLATP >= 3 && track;
-  constexpr bool kEarlySnap = FLAT && FLATP >= 3;
+  constexpr bool kEarlyTail = FLAT && FLATP >= MHIP_KBODY_EARLY_FROM && track;
+  constexpr bool kEarlySnap = FLAT && FLATP >= MHIP_KBODY_EARLY_FROM;
   double drift_old = 0.0, fire_thr = 0.0;
   unsigned long long snap_early = 0ull;
   if (kEarlySnap) {
@@ -642,6 +648,8 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
                                                               : reinterpret_cast<const unsigned long long*>(op.vel);
     mask_early = src[b];
   }
+  // tracked sweeps: the row of the previous iterate (the drift is the difference of the two rows), with the early words
+  double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0;
   if (sub == 0) {
     mt = op.mt[b];
     if (KIN != KIN_TRANS) mr = op.mr[b];
@@ -649,6 +657,11 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     if (kEarlyTail) {
       drift_old = op.drift[b];
       if (op.fire_at != nullptr) fire_thr = op.fire_at[b];
+      const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
+      const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
+      o0 = vo[0];
+      o1 = vo[1];
+      o2 = vo[2];
     }
   }
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
@@ -827,6 +840,19 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     if (head < 64) mm &= (1ull << head) - 1ull;
     if (op.aptr != nullptr) mm &= ~(kEarlySnap ? snap_early : op.snap_mask[b]);
     if (FLAT && !has_body) mm = 0ull;
+#ifdef MHIP_EXP_COUNT_MM   // DIAGNOSTIC BUILD ONLY: how many waves / lanes / entries take the per-body chains behind a snapshot
+    if (op.aptr != nullptr && FLAT) {
+      const bool any_lane = __any(mm != 0ull);
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_dbg[2], 1ull);
+        if (any_lane) atomicAdd(&g_dbg[0], 1ull);
+      }
+      if (mm != 0ull) {
+        atomicAdd(&g_dbg[1], 1ull);
+        atomicAdd(&g_dbg[3], (unsigned long long)__popcll(mm));
+      }
+    }
+#endif
     int32_t kk[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) kk[u] = -1;
@@ -867,9 +893,8 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     }
   }
   if (sub != 0) return;
-  // tracked sweeps: the row of the previous iterate, asked for before the last arithmetic of the sweep
-  double2 o0 = make_double2(0.0, 0.0), o1 = o0, o2 = o0;
-  if (track) {
+  // (where it was not fetched at the top: asked for before the last arithmetic of the sweep)
+  if (track && !kEarlyTail) {
     const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
     const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
     o0 = vo[0];
@@ -3675,6 +3700,14 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   return MHIP_SUCCESS;
 }
 
+#ifdef MHIP_EXP_COUNT_MM
+int mhip_debug_counters(unsigned long long* out4) {
+  MHIP_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_dbg), 4 * sizeof(unsigned long long)));
+  const unsigned long long z[4] = {0, 0, 0, 0};
+  MHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)));
+  return MHIP_SUCCESS;
+}
+#endif
 /* cold-tier statistics of the last mhip_bbpgd_solve_contact on this operator (all zero when the solve did not tier) */
 int mhip_contact_op_tier_stats(mhip_contact_op_t op, size_t* tiered_iterations, double* mean_hot_fraction,
                                size_t* renumberings, size_t* wakeups) {
