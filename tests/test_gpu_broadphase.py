@@ -138,6 +138,35 @@ def test_crowded_cells_need_several_lds_tiles(ops, oracle):
             g.close()
 
 
+@pytest.mark.parametrize("periodic", [False, True])
+def test_grid_rows_beyond_the_slab_are_searched_again(ops, oracle, periodic):
+    # round 4: the cell grid's counting pass parks up to 32 partners per body in a slab and the filling pass copies the
+    # parked rows; a body with more partners walks the stencil again (its workgroup-mates only help staging the tiles).
+    # A dense cluster (rows of 40-200 partners) beside a dilute cloud (rows of 0-5) in ONE system, the grid forced, free
+    # and periodic cell (the periodic search is the per-lane kernel): the brute-force oracle's lists, pairs and order
+    from gpu_util import dev, host
+    rng = np.random.default_rng(19 + periodic)
+    box = np.array([24.0, 24.0, 24.0])
+    c = np.concatenate([rng.uniform(0, 3.0, (2500, 3)), rng.uniform(6, 24, (6000, 3))])
+    r = np.full(len(c), 0.3)
+    aabb = oracle.compute_aabb_spheres(c, r)
+    lo, hi, R = oracle.grow(aabb, r, 0.2)
+    for kind in (0, 1):
+        for symmetric in (False, True):
+            exp = oracle.search(kind, lo, hi, c, R, symmetric=symmetric, method="brute", box=box if periodic else None)
+            rows = np.bincount(exp[:, 0], minlength=len(c))
+            assert rows.max() > 64 and (rows > 32).sum() > 500 and (rows <= 32).sum() > 3000
+            g = (ops.GenNeighborLinks().set_search_kind(kind).set_search_buffer(0.2)
+                 .set_search_method(ops.SEARCH_METHOD_GRID).set_enforce_source_target_symmetry(symmetric))
+            if periodic:
+                g = g.set_periodic_box(box)
+            g = g.concretize()
+            g.generate(dev(aabb), dev(c), dev(r))
+            assert g.method_used() == ops.SEARCH_METHOD_GRID
+            np.testing.assert_array_equal(host(g.pairs), exp)
+            g.close()
+
+
 def test_rebuild_rule(ops):
     # GenNeighborLinkers.hpp:510-543, :603-615: generate() returns False until a centre moves > buffer/2
     from gpu_util import dev
