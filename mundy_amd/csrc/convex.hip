@@ -547,6 +547,12 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 #ifndef MHIP_KBODY_FLAT
 #define MHIP_KBODY_FLAT 2
 #endif
+// 1: the sweep's early-fetched last words wait in LDS instead of registers (rods: 110 -> 96 VGPRs, 24 + 8 KB of LDS: FIVE
+// workgroups per CU with the chain still four levels long).  Measured, same box, three runs each
+// (profiles/r04_ab_experiments.txt): 0.0807 ms against 0.0772 -- a fifth resident workgroup makes the sweep SLOWER.  Off.
+#ifndef MHIP_KBODY_STASH
+#define MHIP_KBODY_STASH 0
+#endif
 #ifndef MHIP_KBODY_EARLY_FROM   // chunk size (x 256 entries) from which the sweep's last words are fetched at its top
 #define MHIP_KBODY_EARLY_FROM 3
 #endif
@@ -664,6 +670,19 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
       o2 = vo[2];
     }
   }
+#if MHIP_KBODY_STASH
+  // (A/B only, see MHIP_KBODY_STASH) ... parked in LDS until the end of the sweep: 64 B per body, 8 KB per workgroup
+  // (not with vector arms: their 36 KB image plus the stash would leave three workgroups per CU where there are four)
+  constexpr bool kStash = kEarlyTail && KIN != KIN_RIGID;
+  __shared__ double2 stash[kStash ? 4 * (kBlock / G) : 1];
+  if (kStash && sub == 0) {
+    double2* mine = stash + 4 * (threadIdx.x / G);
+    mine[0] = o0;
+    mine[1] = o1;
+    mine[2] = o2;
+    mine[3] = make_double2(drift_old, fire_thr);
+  }
+#endif
   // The sweep is a chain of dependent accesses (row pointer -> incidence entry -> iterate of that contact -> record),
   // so what it waits on is latency, not bytes: each lane keeps U independent chains in flight, every level's U loads
   // issued back to back before the first use.  kk[u] = incidence slot or -1.
@@ -893,6 +912,16 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     }
   }
   if (sub != 0) return;
+#if MHIP_KBODY_STASH
+  if (kStash) {
+    const double2* mine = stash + 4 * (threadIdx.x / G);
+    o0 = mine[0];
+    o1 = mine[1];
+    o2 = mine[2];
+    drift_old = mine[3].x;
+    fire_thr = mine[3].y;
+  }
+#endif
   // (where it was not fetched at the top: asked for before the last arithmetic of the sweep)
   if (track && !kEarlyTail) {
     const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
@@ -1197,8 +1226,11 @@ __global__ void __launch_bounds__(kBlock, (KIN == KIN_RIGID ? 6 : 7))
       if (PACKED) {
         reinterpret_cast<double2*>(xn)[c] = make_double2(xc, g);
         if (op.body_mask != nullptr && sp.kind == MHIP_SPACE_LOWER_BOUND && sp.lo == 0.0) {
-          // masks start all-ones (every contact "active"); flip this contact's two bits when its state changes
-          const bool was = (MODE == X_INIT) ? true : !(x_old == 0.0 && g_old >= 0.0 && g_old <= 1.7976931348623157e308);
+          // the masks start all-ZERO and the init sweep sets the bits of the contacts that are active in the first
+          // iterate -- a third of them (rounds 1-3 started from all-ones and cleared the other two thirds: twice the
+          // atomics, 0.49 ms of every step's init sweep at 10^6 rods); from then on a contact flips its two bits when
+          // its state changes
+          const bool was = (MODE == X_INIT) ? false : !(x_old == 0.0 && g_old >= 0.0 && g_old <= 1.7976931348623157e308);
           const bool now = !(xc == 0.0 && g >= 0.0 && g <= 1.7976931348623157e308);
           if (was != now) {
             const unsigned pi = op.pos[2 * c], pj = op.pos[2 * c + 1];
@@ -3538,8 +3570,8 @@ int mhip_bbpgd_solve_contact(mhip_contact_op_t op, const double* q, const mhip_s
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   double* P0 = op->iterate.as<double>();
   double* P1 = P0 + 2 * C;
-  if (op->view.body_mask) MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), s));
-  op->view.aptr = nullptr;  // no snapshot of the active entries yet: the masks start all-ones
+  if (op->view.body_mask) MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0x00, op->view.N * sizeof(unsigned long long), s));
+  op->view.aptr = nullptr;  // no snapshot of the active entries yet (the init sweep writes the masks)
   // initialize: x_tmp = x ; g_tmp = A x_tmp + q ; residual ; step = 1/res   (the pair lands packed in P0)
   if (int e = op_launch_body(op, X_INIT, x, x, nullptr, nullptr, sp, s)) return e;
   if (int e = op_launch_constraint(op, X_INIT, P0, P1, x, nullptr, q, sp, rk, cgrid, s, true)) return e;
@@ -4005,7 +4037,7 @@ int mhip_bbpgd_stage_begin(mhip_contact_op_t op, const double* q, const mhip_spa
   op->stage.part_used = 0;
   op->view.aptr = nullptr;
   if (op->view.body_mask)
-    MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0xFF, op->view.N * sizeof(unsigned long long), as_stream(stream)));
+    MHIP_HIP(hipMemsetAsync(op->view.body_mask, 0x00, op->view.N * sizeof(unsigned long long), as_stream(stream)));
   if (int e = op->iterate.reserve(2 * (C + 1) * sizeof(double2))) return e;
   MHIP_HIP(hipMemsetAsync(op->state.ptr, 0, sizeof(SolverState), as_stream(stream)));
   // cold tier (see "Cold tier"): interior contacts only, one row buffer
