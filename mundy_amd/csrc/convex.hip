@@ -550,6 +550,9 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 // 1: the sweep's early-fetched last words wait in LDS instead of registers (rods: 110 -> 96 VGPRs, 24 + 8 KB of LDS: FIVE
 // workgroups per CU with the chain still four levels long).  Measured, same box, three runs each
 // (profiles/r04_ab_experiments.txt): 0.0807 ms against 0.0772 -- a fifth resident workgroup makes the sweep SLOWER.  Off.
+#ifndef MHIP_KBODY_DYN_LDS   // A/B only: unused dynamic LDS per workgroup of the flat sweep (caps the workgroups per CU)
+#define MHIP_KBODY_DYN_LDS 0
+#endif
 #ifndef MHIP_KBODY_STASH
 #define MHIP_KBODY_STASH 0
 #endif
@@ -2354,9 +2357,9 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
     if (flatp == 3 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
-      k_body<M, R, GG, UU, true, true, 3><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+      k_body<M, R, GG, UU, true, true, 3><<<grid, kBlock, MHIP_KBODY_DYN_LDS, s>>>(op->view, st, X0, X1, G0, G1, sp); \
     else if (flatp == 3 && packed && M == X_SOLVE && op->view.aptr != nullptr)                     \
-      k_body<M, R, GG, UU, true, false, 3><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+      k_body<M, R, GG, UU, true, false, 3><<<grid, kBlock, MHIP_KBODY_DYN_LDS, s>>>(op->view, st, X0, X1, G0, G1, sp); \
     else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
       k_body<M, R, GG, UU, true, true, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
     else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr)             \
