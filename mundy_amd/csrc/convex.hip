@@ -550,6 +550,9 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 // 1: the sweep's early-fetched last words wait in LDS instead of registers (rods: 110 -> 96 VGPRs, 24 + 8 KB of LDS: FIVE
 // workgroups per CU with the chain still four levels long).  Measured, same box, three runs each
 // (profiles/r04_ab_experiments.txt): 0.0807 ms against 0.0772 -- a fifth resident workgroup makes the sweep SLOWER.  Off.
+#ifndef MHIP_KCON_DYN_LDS    // A/B only: the same for the packed constraint sweep
+#define MHIP_KCON_DYN_LDS 0
+#endif
 #ifndef MHIP_KBODY_DYN_LDS   // A/B only: unused dynamic LDS per workgroup of the flat sweep (caps the workgroups per CU)
 #define MHIP_KBODY_DYN_LDS 0
 #endif
@@ -2400,7 +2403,7 @@ int op_launch_constraint(mhip_contact_op* op, int mode, double* X0, double* X1, 
 #define CON(M, R)                                                                                              \
   do {                                                                                                         \
     if (packed && M != X_APPLY)                                                                                \
-      k_constraint<M, R, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts); \
+      k_constraint<M, R, true><<<grid, kBlock, MHIP_KCON_DYN_LDS, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts); \
     else                                                                                                       \
       k_constraint<M, R, false><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, q, sp, resid_kind, parts); \
   } while (0)
@@ -3012,7 +3015,7 @@ int op_launch_constraint_tiered(mhip_contact_op* op, const TierPairs& cur, Space
   hot.c_first = 0; hot.c_end = t.H; hot.part_offset = 0; hot.part_stride = kStageStride;
   const TierCheck tc{t.H, t.I, m.wake[t.set], m.list, m.counters, m.fired, m.fire_at, gcheck};
 #define TIERED(K)                                                                                                 \
-  k_constraint<X_SOLVE, K, true><<<ghot + gcheck, kBlock, 0, s>>>(hot, st, cur.P0, cur.P1, nullptr, nullptr,     \
+  k_constraint<X_SOLVE, K, true><<<ghot + gcheck, kBlock, MHIP_KCON_DYN_LDS, s>>>(hot, st, cur.P0, cur.P1, nullptr, nullptr,     \
                                                                  cur.q, sp, resid_kind, parts, tc)
   if (ghot + gcheck) {
     if (op->kin == KIN_ROD) TIERED(KIN_ROD); else if (op->kin == KIN_RIGID) TIERED(KIN_RIGID); else TIERED(KIN_TRANS);
