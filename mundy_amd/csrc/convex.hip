@@ -1702,7 +1702,14 @@ __global__ void __launch_bounds__(kBlock)
       prev = pairs[c - 1].x;
       if (prev < 0 || (size_t)prev >= N) prev = ij.x;  // (that row is reported by its own thread)
     }
-    if (ij.x >= ij.y || prev > ij.x) flags[1] = 1;
+    // (a run of more than kMaxEmptyRows bodies without a row of their own -- a dilute system, where the build costs
+    // nothing either way -- is left to the general path rather than to one thread's loop)
+    constexpr int kMaxEmptyRows = 4096;
+    const bool tail_gap = (c + 1 == C) && N - (size_t)ij.x > (size_t)kMaxEmptyRows;
+    if (ij.x >= ij.y || prev > ij.x || ij.x - prev > kMaxEmptyRows || tail_gap) {
+      flags[1] = 1;
+      continue;
+    }
     atomicAdd(&tdeg[ij.y], 1);
     for (int b = prev + 1; b <= ij.x; ++b) row_start[b] = static_cast<int32_t>(c);  // first row of every body up to this one
     if (c + 1 == C)

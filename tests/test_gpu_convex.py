@@ -406,6 +406,53 @@ def test_state_vector_postconditions(ops, oracle):
     op.close()
 
 
+@pytest.mark.parametrize("maker,n", [(_sphere_problem, 6000), (_rod_problem, 4000)])
+def test_incidence_build_paths_give_the_same_solve(ops, oracle, maker, n):
+    # round 4: a pair list of the broad phase's form (rows sorted by the lower body, i < j) takes the fast incidence build
+    # -- only the transpose half counted / filled with atomics and sorted --, any other list the general one.  The same
+    # contacts through both: (a) as they are (fast path), (b) with every body index multiplied by 3 -- bodies without any
+    # contact between the rows, still the fast path --, (c) multiplied by 5000 -- runs of empty rows beyond the fast
+    # path's limit: the general path --, (d) rows in reversed order -- not sorted: the general path.  Every sum is
+    # rounded once, so all four give the same iteration count and the same multipliers, bit for bit.
+    from gpu_util import assert_bits_equal, dev, host
+    P = maker(oracle, n, seed=17)
+    C = len(P["pairs"])
+    cfg = ops.PGDConfig(max_iters=10000, tol=1e-6)
+
+    def spread(k):
+        Q = dict(P)
+        Q["N"] = P["N"] * k
+        Q["pairs"] = np.ascontiguousarray(P["pairs"] * k)
+        for key in ("mt", "mr"):
+            if P.get(key) is not None:
+                a = np.ones(Q["N"])
+                a[::k] = P[key]
+                Q[key] = a
+        return Q
+
+    def solve(Q, order=None):
+        if order is not None:
+            Q = dict(Q, **{key: np.ascontiguousarray(Q[key][order]) for key in ("pairs", "normal", "sep", "ra", "rb")
+                           if Q.get(key) is not None})
+        op = _gpu_op(ops, Q)
+        x, g, res = ops.solve_lcp(op, dev(Q["sep"]), dev(np.zeros(C)), cfg)
+        out = (host(x), host(g), res.num_iters, bool(res.converged))
+        op.close()
+        return out
+
+    ref = solve(P)
+    assert ref[3] and ref[2] > 20
+    for name, got in (("bodies x 3", solve(spread(3))), ("bodies x 5000", solve(spread(5000)))):
+        assert got[2:] == ref[2:], (name, got[2], ref[2])
+        assert_bits_equal(got[0], ref[0], "x, " + name)
+        assert_bits_equal(got[1], ref[1], "g, " + name)
+    rev = np.arange(C)[::-1].copy()
+    got = solve(P, rev)
+    assert got[2:] == ref[2:], ("reversed rows", got[2], ref[2])
+    assert_bits_equal(got[0][rev], ref[0], "x, reversed rows")
+    assert_bits_equal(got[1][rev], ref[1], "g, reversed rows")
+
+
 def test_empty_and_invalid(ops):
     import torch
     from gpu_util import dev
