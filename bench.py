@@ -53,7 +53,7 @@ METRIC = "timesteps/sec, 10^6 spherocylinders, frictionless LCP contact (BBPGD)"
 MIXED_PHI_DEFAULT = 0.40   # configs[4]'s box is derived "from phi" = 0.40, like configs[2]
 
 
-def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=None, kin="rod"):
+def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=None, kin="rod", drift_rows=True):
     """Algorithmic bytes per launch of the two sweeps of one fused BBPGD iteration (rod-compressed kinematics): every
     array the launch REQUIRES, counted once (a gathered table once per row, not once per reader) -- what HBM must move
     even with perfect caches.  This is what roofline.achieved divides.
@@ -80,7 +80,10 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
     # tier_body (round 4): + 48 B -- the drift of a tiered sweep is the difference of the body's new row and its row of
     # the previous iterate, which the sweep therefore reads (rounds 2-3 kept the force change in registers instead: 18
     # VGPRs and a fourth LDS plane, which capped the vector-arm sweep at three workgroups per CU)
+    # (systems beyond 1.75e6 bodies keep the force change in registers instead -- drift_rows False: no such read)
     per_con, per_edge, per_body, tier_body = (88.0, 36.0, 112.0, 72.0) if kin == "rod" else (120.0, 52.0, 88.0, 80.0)
+    if not drift_rows:
+        tier_body -= 48.0
     con = per_con * contacts + 48.0 * bodies
     body = 2 * per_edge * act + 16.0 * act + per_body * bodies
     if tier and tier.get("tiered_iterations", 0) > 0 and iterations:
@@ -95,8 +98,8 @@ def kernel_bytes(contacts, bodies, active_contacts=None, tier=None, iterations=N
 
 
 def roofline_entries(contacts, bodies, con_ms, body_ms, launches, label="", active_contacts=None, tier=None,
-                     iterations=None, kin="rod"):
-    kb = kernel_bytes(contacts, bodies, active_contacts, tier, iterations, kin)
+                     iterations=None, kin="rod", drift_rows=True):
+    kb = kernel_bytes(contacts, bodies, active_contacts, tier, iterations, kin, drift_rows)
     ms = {"k_constraint": con_ms, "k_body": body_ms}
     ent = {}
     for k in ms:
@@ -329,6 +332,7 @@ def main():
             prof["iters"] += k
             prof["tier"] = stepper.op.tier_stats()
             prof["solve_iters"] = st.num_iters
+            prof["drift_rows"] = stepper.op.drift_source() == 1
         return st
 
     def sync():
@@ -365,7 +369,8 @@ def main():
     if prof["iters"] > 0:
         roof, extra, dom, oth = roofline_entries(contacts, n, prof["con_ms"] / prof["iters"],
                                                  prof["body_ms"] / prof["iters"], prof["iters"], active_contacts=active,
-                                                 tier=prof.get("tier"), iterations=prof.get("solve_iters"))
+                                                 tier=prof.get("tier"), iterations=prof.get("solve_iters"),
+                                                 drift_rows=prof.get("drift_rows", True))
         attach_traffic(roof, extra, dom, oth, n, args.buffer)
         measured_ceiling(roof, extra)
 

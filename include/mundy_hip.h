@@ -375,6 +375,14 @@ int mhip_contact_op_sizes(mhip_contact_op_t handle, size_t* num_constraints, siz
  *   lanes_per_body  lanes that share one body's contact list in the body sweep: 2, 4, 8 or 16 (default by mean
  *                   degree); -1 keeps the current value */
 int mhip_contact_op_set_work_mapping(mhip_contact_op_t handle, int xcd_tile, int lanes_per_body);
+/* Cold tier, TIME ONLY (the iterates are the same bits): where the body sweep of a tiered solve takes its drift bound
+ * from -- 1: the difference of a body's new row and its row of the previous iterate (48 more bytes read per body: free
+ * while both row tables sit in the Infinity Cache); 2: the change of the force accumulated in registers beside the
+ * sums (no extra read; rods and spheres with the default lane layout only); 0 (default): by size -- rows up to
+ * 1.75 * 10^6 bodies, registers beyond. */
+int mhip_contact_op_set_drift_source(mhip_contact_op_t op, int source);
+/* *source [host] = the form a tiered solve on this operator would take now (1 or 2) */
+int mhip_contact_op_get_drift_source(mhip_contact_op_t op, int* source /*[host]*/);
 /* Cold tier of mhip_bbpgd_solve_contact (time only, never results).  Two thirds of the contacts of a packing are inactive
  * (x = 0, g > 0) for most of a solve; such a contact adds exact zeros to every sum of an iteration, and how far its
  * gradient can have moved is bounded by its two bodies' accumulated velocity changes.  From the first convergence poll on

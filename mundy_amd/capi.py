@@ -179,6 +179,8 @@ SIGNATURES = {
     "mhip_gather_rows": [_sz, _sz, _vp, _vp, _vp, _vp],
     "mhip_copy_strided": [_sz, _sz, _vp, _sz, _vp, _sz, _vp],
     "mhip_contact_op_sizes": [_vp, C.POINTER(_sz), C.POINTER(_sz)],
+    "mhip_contact_op_set_drift_source": [_vp, _i],
+    "mhip_contact_op_get_drift_source": [_vp, C.POINTER(_i)],
     "mhip_comm_unique_id": [C.c_char_p],
     "mhip_comm_create_rccl": [C.POINTER(_vp), C.c_char_p, _i, _i],
     "mhip_comm_create_host": [C.POINTER(_vp), _i, _i, EXCHANGE_FN, ALL_GATHER_FN, _vp],

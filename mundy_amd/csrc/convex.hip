@@ -575,7 +575,13 @@ __device__ inline double iterate_x(size_t c, const double* __restrict__ xt, cons
 #ifdef MHIP_EXP_COUNT_MM
 __device__ unsigned long long g_dbg[4];
 #endif
-template <int MODE, int KIN, int G, int U, bool PACKED, bool TRACK = false, int FLATP = 0>
+// TRACK (tiered solves): 0 = no drift bookkeeping; 1 = the drift is the difference of the body's new row and its row of
+// the previous iterate (an extra 48-byte read per body: free while the row tables live in the Infinity Cache, i.e. up
+// to ~1.7 * 10^6 bodies); 2 = the change of the force is accumulated beside the sums from +/-(lam - x_old) n of the
+// entries walked (rounds 2-3: no extra read, but 18 VGPRs and a (n, coef, +/-lam, +/-dlam) image of 48 B per entry) --
+// what systems whose row tables outgrow the cache take: 4 * 10^6 / 16 * 10^6 rods 0.329 / 1.303 ms with 1, 0.30 / 1.17
+// with 2 (profiles/r04_large_sizes.txt).  Chosen by op_drift_source().
+template <int MODE, int KIN, int G, int U, bool PACKED, int TRACK = 0, int FLATP = 0>
 __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     k_body(OpView op, const SolverState* __restrict__ st, const double* __restrict__ X0, const double* __restrict__ X1,
            const double* __restrict__ G0, const double* __restrict__ G1, Space sp) {
@@ -583,7 +589,8 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   // the image holds PRODUCTS: the entry's force f = +/-lambda n and, with it, what the torque sum takes -- the arclength
   // coefficient (rods: S += coef f) or r x f itself (vector arms): 32 / 48 bytes per entry (round 3 stored (n, arm,
   // +/-lambda, +/-dlambda): 48 / 64), i.e. 24 / 36 KB per workgroup at 3 x 256 entries
-  constexpr int kFlatPlanes = (KIN == KIN_RIGID) ? 3 : 2;
+  constexpr bool kRegTrack = TRACK == 2 && MODE == X_SOLVE && PACKED;   // (image of rounds 2-3: see TRACK)
+  constexpr int kFlatPlanes = kRegTrack ? ((KIN == KIN_RIGID) ? 4 : 3) : ((KIN == KIN_RIGID) ? 3 : 2);
   __shared__ double2 flat_img[FLAT ? kFlatPlanes * FLATP * kBlock : 1];
   // one tile = one workgroup's worth of bodies (see xcd_tile), the grid covers them once
   const size_t tile = xcd_tile(blockIdx.x, gridDim.x, op.xcd_aware);
@@ -636,7 +643,10 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   // F_new - F_old = sum +/- (lam - x_old) n beside the sums, which cost the sweep 18 VGPRs, a fourth LDS plane and the
   // cross products of phase B.  A bound only: its value never reaches an iterate.
   // (a template parameter: carried as a run-time flag the bookkeeping cost the untracked sweep 6 % in registers)
-  constexpr bool track = TRACK && MODE == X_SOLVE && PACKED;
+  constexpr bool track = TRACK != 0 && MODE == X_SOLVE && PACKED;
+  constexpr bool track_regs = kRegTrack;             // TRACK == 2
+  constexpr bool track_rows = track && !track_regs;  // TRACK == 1
+  V3 dF{0.0, 0.0, 0.0}, dS{0.0, 0.0, 0.0};           // (TRACK == 2) F_new - F_old, S_new - S_old: plain sums, a bound only
   // With 3 x 256 entries per chunk the words the END of the sweep needs (drift, firing threshold) are fetched now, beside
   // the others, instead of costing one more memory round trip in the life of every workgroup (round 3, when the 36 KB
   // image capped the sweep at four workgroups per CU and 128 VGPRs were free; round 4: 24 KB image and 96 VGPRs -- five
@@ -669,17 +679,19 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     if (kEarlyTail) {
       drift_old = op.drift[b];
       if (op.fire_at != nullptr) fire_thr = op.fire_at[b];
-      const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
-      const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
-      o0 = vo[0];
-      o1 = vo[1];
-      o2 = vo[2];
+      if (track_rows) {
+        const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
+        const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
+        o0 = vo[0];
+        o1 = vo[1];
+        o2 = vo[2];
+      }
     }
   }
 #if MHIP_KBODY_STASH
   // (A/B only, see MHIP_KBODY_STASH) ... parked in LDS until the end of the sweep: 64 B per body, 8 KB per workgroup
   // (not with vector arms: their 36 KB image plus the stash would leave three workgroups per CU where there are four)
-  constexpr bool kStash = kEarlyTail && KIN != KIN_RIGID;
+  constexpr bool kStash = kEarlyTail && track_rows && KIN != KIN_RIGID;
   __shared__ double2 stash[kStash ? 4 * (kBlock / G) : 1];
   if (kStash && sub == 0) {
     double2* mine = stash + 4 * (threadIdx.x / G);
@@ -698,7 +710,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   auto process = [&](const int32_t* __restrict__ ent, const double* __restrict__ rec, const int32_t* kk,
                      const bool eager) {
     int32_t e[U];
-    double lam[U];
+    double lam[U], xo[U];
     double2 h0[U], h1[U], h2[U];
     auto fetch = [&](int u) {
       const size_t k = static_cast<size_t>(kk[u]);
@@ -726,18 +738,30 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
     for (int u = 0; u < U; ++u)
       pit[u] = iterate_load<MODE, PACKED>(e[u] >= 0 ? static_cast<size_t>(e[u] >> 1) : 0, xt, gt);
 #pragma unroll
-    for (int u = 0; u < U; ++u) lam[u] = (e[u] >= 0) ? iterate_value<MODE>(pit[u], step, step_is_zero, sp) : 0.0;
+    for (int u = 0; u < U; ++u) {
+      xo[u] = (track_regs && e[u] >= 0) ? pit[u].x : 0.0;
+      lam[u] = (e[u] >= 0) ? iterate_value<MODE>(pit[u], step, step_is_zero, sp) : 0.0;
+    }
     // an inactive contact (lam == 0) adds +/-0 to the sums, which leaves them bit for bit unchanged -- so (when the
-    // records are not fetched eagerly) its record is never fetched
+    // records are not fetched eagerly) its record is never fetched (TRACK == 2: unless its multiplier just dropped to
+    // zero and the drift bookkeeping wants the change)
     if (!eager) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (lam[u] != 0.0) fetch(u);
+        if (lam[u] != 0.0 || (track_regs && xo[u] != 0.0)) fetch(u);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (lam[u] == 0.0) continue;
+      if (lam[u] == 0.0 && !(track_regs && xo[u] != 0.0)) continue;
       const V3 n{h0[u].x, h0[u].y, h1[u].x};
+      if (track_regs) {  // change of this body's force (and of S) against the previous iterate
+        const double dl = (e[u] & 1) ? lam[u] - xo[u] : xo[u] - lam[u];
+        const V3 df{dl * n.x, dl * n.y, dl * n.z};
+        dF = dF + df;
+        if (KIN == KIN_ROD) dS = dS + h1[u].y * df;
+        if (KIN == KIN_RIGID) dS = dS + cross(V3{h1[u].y, h2[u].x, h2[u].y}, df);  // change of the torque
+      }
+      if (lam[u] == 0.0) continue;
       V3 f{lam[u] * n.x, lam[u] * n.y, lam[u] * n.z};
       if (!(e[u] & 1)) f = V3{-f.x, -f.y, -f.z};  // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472)
       dd_add(Fdd, f);
@@ -814,8 +838,16 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
             // F_src += -lam n, F_tgt += +lam n  (NgpLcp.cpp:467-472): the products the per-body chains form, formed
             // here by the lane that holds the record (the same multiplications: the same bits)
             const double sl = (fe[p] & 1) ? lam : -lam;
-            const V3 f{sl * r0[p].x, sl * r0[p].y, sl * r1[p].x};
             const int slot = p * kBlock + static_cast<int>(threadIdx.x);
+            if constexpr (track_regs) {  // the image of rounds 2-3: (n, arm, +/-lam, +/-dlam)
+              const double xo = (fe[p] >= 0) ? pit[p].x : 0.0;
+              pl0[slot] = r0[p];
+              pl1[slot] = r1[p];
+              if (KIN == KIN_RIGID) flat_img[2 * kChunk + slot] = r2[p];
+              pl2[slot] = make_double2(sl, (fe[p] & 1) ? lam - xo : xo - lam);
+              continue;
+            }
+            const V3 f{sl * r0[p].x, sl * r0[p].y, sl * r1[p].x};
             pl0[slot] = make_double2(f.x, f.y);
             if (KIN == KIN_RIGID) {
               const V3 tq = cross(V3{r1[p].y, r2[p].x, r2[p].y}, f);  // torque r x (+/- lam n)
@@ -834,6 +866,27 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
             for (int32_t k = lo + sub; k < hi; k += G) {
               const int slot = k - base;
               const double2 a0 = pl0[slot], a1 = pl1[slot];
+              if constexpr (track_regs) {
+                const double2 a3 = pl2[slot];   // (+/-lam, +/-dlam)
+                const V3 n{a0.x, a0.y, a1.x};
+                V3 arm{0.0, 0.0, 0.0};
+                if (KIN == KIN_RIGID) {
+                  const double2 a2 = flat_img[2 * kChunk + slot];
+                  arm = V3{a1.y, a2.x, a2.y};
+                }
+                if (a3.y != 0.0) {
+                  const V3 df{a3.y * n.x, a3.y * n.y, a3.y * n.z};
+                  dF = dF + df;
+                  if (KIN == KIN_ROD) dS = dS + a1.y * df;
+                  if (KIN == KIN_RIGID) dS = dS + cross(arm, df);
+                }
+                if (a3.x == 0.0) continue;
+                const V3 fr{a3.x * n.x, a3.x * n.y, a3.x * n.z};
+                dd_add(Fdd, fr);
+                if (KIN == KIN_RIGID) dd_add(Tdd, cross(arm, fr));
+                if (KIN == KIN_ROD) dd_add(Tdd, a1.y * fr);
+                continue;
+              }
               const V3 f{a0.x, a0.y, a1.x};
 #ifdef MHIP_EXP_PLAIN_SUMS   // TIMING EXPERIMENT ONLY (what the double-double sums of phase B cost): plain sums
               Fdd.x.hi += f.x; Fdd.y.hi += f.y; Fdd.z.hi += f.z;
@@ -917,6 +970,13 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
       dd_add(Tdd.z, dd_shfl_xor(Tdd.z, off));
     }
   }
+  if (track_regs) {
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      dF = dF + V3{__shfl_xor(dF.x, off, 64), __shfl_xor(dF.y, off, 64), __shfl_xor(dF.z, off, 64)};
+      if (KIN != KIN_TRANS) dS = dS + V3{__shfl_xor(dS.x, off, 64), __shfl_xor(dS.y, off, 64), __shfl_xor(dS.z, off, 64)};
+    }
+  }
   if (sub != 0) return;
 #if MHIP_KBODY_STASH
   if (kStash) {
@@ -929,7 +989,7 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   }
 #endif
   // (where it was not fetched at the top: asked for before the last arithmetic of the sweep)
-  if (track && !kEarlyTail) {
+  if (track_rows && !kEarlyTail) {
     const double* vel_old = op.vel_alt ? ((vel_new == op.vel) ? op.vel_alt : op.vel) : op.vel;
     const double2* vo = reinterpret_cast<const double2*>(vel_old + 6 * b);
     o0 = vo[0];
@@ -955,11 +1015,22 @@ __global__ void __launch_bounds__(kBlock, MHIP_KBODY_WAVES)
   if (track) {
     // |change of n . (U + coef Z)| <= |dU|_1 + |coef| |dZ|_1 with |coef| <= 1/2 (rods; spheres carry no Z): what any
     // contact of this body can have moved by, times dt as the gradient sees it.  The row holds (U, Z) resp. (U, W).
-    double d = fabs(Ub.x - o0.x) + fabs(Ub.y - o0.y) + fabs(Ub.z - o1.x);
-    const double dw = fabs(W.x - o1.y) + fabs(W.y - o2.x) + fabs(W.z - o2.y);
-    if (KIN == KIN_ROD) d += 0.5 * dw;
-    // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|
-    if (KIN == KIN_RIGID) d += op.arm_max[b] * dw;
+    double d;
+    if constexpr (track_regs) {  // dU = mt dF, dZ = (mr (u x dS)) x u; vector arms: dW = mr dT
+      d = mt * (fabs(dF.x) + fabs(dF.y) + fabs(dF.z));
+      if (KIN == KIN_ROD) {
+        const V3 tq = cross(axis, dS);
+        const V3 dZ = cross(V3{mr * tq.x, mr * tq.y, mr * tq.z}, axis);
+        d += 0.5 * (fabs(dZ.x) + fabs(dZ.y) + fabs(dZ.z));
+      }
+      if (KIN == KIN_RIGID) d += op.arm_max[b] * mr * (fabs(dS.x) + fabs(dS.y) + fabs(dS.z));
+    } else {
+      d = fabs(Ub.x - o0.x) + fabs(Ub.y - o0.y) + fabs(Ub.z - o1.x);
+      const double dw = fabs(W.x - o1.y) + fabs(W.y - o2.x) + fabs(W.z - o2.y);
+      if (KIN == KIN_ROD) d += 0.5 * dw;
+      // vector arms: the contact point at arm r moves by dU + dW x r, |dW x r| <= |dW|_1 |r|
+      if (KIN == KIN_RIGID) d += op.arm_max[b] * dw;
+    }
     const double D = (kEarlyTail ? drift_old : op.drift[b]) + op.dt * d;
     op.drift[b] = D;
     if (op.fire_at != nullptr && !(D < (kEarlyTail ? fire_thr : op.fire_at[b])))  // one of its sleeping contacts has used up its share of slack
@@ -2296,6 +2367,7 @@ struct mhip_contact_op {
   DeviceBuffer aptr, aent, arec, snap_mask, acnt;  // active lists (see OpView)
   int device = -1;  // the device current at create: where every buffer of this operator lives
   int tiering = 1;         // the fused solve may use the cold tier (mhip_contact_op_set_tiering); 2: test hook
+  int drift_source = 0;    // tiered solves: 0 = by size (op_drift_source), 1 = rows, 2 = registers (time only)
   int lanes_per_body = 2;  // k_body's G (2, 4, 8 or 16), each lane keeping 4 (2 and 16 lanes: 2) half-edge chains in flight
   SolverState* host_state = nullptr;  // pinned
   // staged (multi-rank) solve context, set by mhip_bbpgd_stage_begin
@@ -2343,6 +2415,16 @@ struct mhip_contact_op {
 
 namespace {
 
+// Source of the body sweep's drift in tiered solves: 1 = difference of the two rows, 2 = accumulated in registers (see
+// k_body).  Auto (0): the row form while both row tables (96 B per body) stay well inside the 256 MiB Infinity Cache,
+// where its extra read is free and its smaller LDS image and register count pay; the register form beyond, and never
+// for vector arms or a non-default lane layout.
+constexpr size_t kRowDriftMaxBodies = 1750000;
+static int op_drift_source(const mhip_contact_op* op) {
+  if (op->kin == KIN_RIGID || op->lanes_per_body != 2) return 1;
+  if (op->drift_source == 1 || op->drift_source == 2) return op->drift_source;
+  return op->view.N > kRowDriftMaxBodies ? 2 : 1;
+}
 int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double* X1, const double* G0,
                    const double* G1, Space sp, hipStream_t s, bool packed = false) {
   if (op->view.N == 0) return MHIP_SUCCESS;
@@ -2364,18 +2446,28 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
     const double per_group = entries / static_cast<double>(op->view.body_count) * (kBlock / (double)G);
     if (per_group > MHIP_KBODY_FLAT3_ABOVE * 2 * kBlock) flatp = 3;
   }
+  // tracked sweeps: where the drift comes from (see k_body's TRACK) -- the register form exists for the default lane
+  // layout of rods and spheres only (the vector-arm sweep needs the smaller image of the row form for its occupancy)
+  const bool regs = op_drift_source(op) == 2;
+#define BODY_TRACKED(M, R, GG, UU, FP, LDS)                                                                    \
+  do {                                                                                                         \
+    if constexpr (GG == 2 && R != KIN_RIGID) {                                                                 \
+      if (regs) { k_body<M, R, GG, UU, true, 2, FP><<<grid, kBlock, LDS, s>>>(op->view, st, X0, X1, G0, G1, sp); break; } \
+    }                                                                                                          \
+    k_body<M, R, GG, UU, true, 1, FP><<<grid, kBlock, LDS, s>>>(op->view, st, X0, X1, G0, G1, sp);            \
+  } while (0)
 #define BODY4(M, R, GG, UU)                                                                        \
   do {                                                                                             \
     if (flatp == 3 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
-      k_body<M, R, GG, UU, true, true, 3><<<grid, kBlock, MHIP_KBODY_DYN_LDS, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+      BODY_TRACKED(M, R, GG, UU, 3, MHIP_KBODY_DYN_LDS);                                           \
     else if (flatp == 3 && packed && M == X_SOLVE && op->view.aptr != nullptr)                     \
-      k_body<M, R, GG, UU, true, false, 3><<<grid, kBlock, MHIP_KBODY_DYN_LDS, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+      k_body<M, R, GG, UU, true, 0, 3><<<grid, kBlock, MHIP_KBODY_DYN_LDS, s>>>(op->view, st, X0, X1, G0, G1, sp); \
     else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr && op->view.drift != nullptr) \
-      k_body<M, R, GG, UU, true, true, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+      BODY_TRACKED(M, R, GG, UU, MHIP_KBODY_FLAT, 0);                                              \
     else if (MHIP_KBODY_FLAT > 0 && packed && M == X_SOLVE && op->view.aptr != nullptr)             \
-      k_body<M, R, GG, UU, true, false, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
+      k_body<M, R, GG, UU, true, 0, MHIP_KBODY_FLAT><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp); \
     else if (packed && M == X_SOLVE && op->view.drift != nullptr)                                  \
-      k_body<M, R, GG, UU, true, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);  \
+      BODY_TRACKED(M, R, GG, UU, 0, 0);                                                            \
     else if (packed && M == X_SOLVE)                                                               \
       k_body<M, R, GG, UU, true><<<grid, kBlock, 0, s>>>(op->view, st, X0, X1, G0, G1, sp);        \
     else                                                                                           \
@@ -2396,6 +2488,7 @@ int op_launch_body(mhip_contact_op* op, int mode, const double* X0, const double
   else BODYK(KIN_TRANS);
 #undef BODYK
 #undef BODY4
+#undef BODY_TRACKED
 #undef BODY
   MHIP_LAUNCH_CHECK();
   return MHIP_SUCCESS;
@@ -3521,6 +3614,19 @@ int mhip_contact_op_set_work_mapping(mhip_contact_op_t op, int xcd_tile, int lan
   MHIP_REQUIRE(!op->stage.active, MHIP_ERR_RUNTIME, "a staged solve is in progress");
   if (xcd_tile >= 0) op->view.xcd_aware = xcd_tile;
   if (lanes_per_body > 0) op->lanes_per_body = lanes_per_body;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_set_drift_source(mhip_contact_op_t op, int source) {
+  MHIP_REQUIRE(op != nullptr, MHIP_ERR_INVALID_ARGUMENT, "operator handle is null");
+  MHIP_REQUIRE(source >= 0 && source <= 2, MHIP_ERR_INVALID_ARGUMENT, "drift source must be 0 (by size), 1 (rows) or 2 (registers), got %d", source);
+  op->drift_source = source;
+  return MHIP_SUCCESS;
+}
+
+int mhip_contact_op_get_drift_source(mhip_contact_op_t op, int* source) {
+  MHIP_REQUIRE(op != nullptr && source != nullptr, MHIP_ERR_INVALID_ARGUMENT, "null argument");
+  *source = op_drift_source(op);
   return MHIP_SUCCESS;
 }
 

@@ -613,6 +613,17 @@ class ContactOperator:
         """cold tier of the fused solve: 0 off, 1 on (default), 2 test hook (time only; results do not depend on it)"""
         capi.check(capi.load().mhip_contact_op_set_tiering(self._h, int(mode)))
 
+    def set_drift_source(self, source=0):
+        """tiered solves, time only: 0 by size, 1 drift from the difference of the two body rows, 2 from the change of
+        the force kept in registers (mhip_contact_op_set_drift_source)"""
+        capi.check(capi.load().mhip_contact_op_set_drift_source(self._h, int(source)))
+
+    def drift_source(self):
+        """the form a tiered solve on this operator takes: 1 rows, 2 registers"""
+        v = C.c_int(0)
+        capi.check(capi.load().mhip_contact_op_get_drift_source(self._h, C.byref(v)))
+        return int(v.value)
+
     def tier_stats(self):
         """(tiered iterations, mean hot share, renumberings, wake-ups) of the last solve_lcp on this operator"""
         it, rn, wk, hot = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_double(0.0)

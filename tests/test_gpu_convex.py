@@ -585,13 +585,16 @@ def test_fill_and_deep_copy(ops):
         assert torch.equal(u[1:n + 1], t[1:n + 1]) and float(u[0]) == 0.0 and float(u[-1]) == 0.0
 
 
+@pytest.mark.parametrize("drift_source", [1, 2])
 @pytest.mark.parametrize("maker,n", [(_sphere_problem, 60000), (_rod_problem_arclength, 12000), (_rod_problem, 12000)])
-def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
+def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n, drift_source):
     # the fused solve keeps inactive contacts in a cold tier from the first convergence poll on (renumbered hot-first,
     # the tail swept only through drift bounds): x, g and the previous iterate, the iteration count and the body
     # velocities equal the untiered solve bit for bit -- for a run to convergence, for iteration caps (61, 62) that end
     # the solve inside the tiers at either parity, and when the solve is made to leave the tiers mid-way (what it does
-    # before a BB step outside [0, finite]); afterwards the operator is back in the caller's numbering
+    # before a BB step outside [0, finite]); afterwards the operator is back in the caller's numbering.  Both sources
+    # of the drift bound (round 4: the difference of a body's two rows, the default up to 1.75e6 bodies; rounds 2-3: the
+    # change of the force kept in registers, what larger systems take) -- it decides who sleeps, never a bit of an iterate
     import torch
     from gpu_util import dev
     P = maker(oracle, n, seed=41)
@@ -602,6 +605,7 @@ def test_cold_tier_leaves_every_bit_where_it_was(ops, oracle, maker, n):
     for mode in (0, 3, 2):
         op = _gpu_op(ops, P)
         op.set_tiering(mode)
+        op.set_drift_source(drift_source)
         out = []
         for max_iters in (10000, 61, 62):
             st = tuple(dev(np.zeros(C)) for _ in range(4))
