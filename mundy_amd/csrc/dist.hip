@@ -1248,6 +1248,7 @@ int mhip_bbpgd_solve_contact_distributed(mhip_contact_op_t op, mhip_comm_t c, co
                MHIP_ERR_INVALID_ARGUMENT, "null argument");
   MHIP_REQUIRE(halo->num_send_peers >= 0 && halo->num_recv_peers >= 0, MHIP_ERR_INVALID_ARGUMENT,
                "negative peer count");
+  *result = mhip_solve_result{};  // (read on every exit path, also those that come before the first poll)
   if (poll_every == 0) poll_every = 64;  // (as the fused driver; 32 cost 2-3 % of a step at 1.25e5 ... 1e6 rods per rank)
   hipStream_t s = as_stream(stream);
   if (c->in_flight)  // an earlier solve ended in an error between start and finish: close that exchange first
