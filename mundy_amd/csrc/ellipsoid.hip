@@ -129,7 +129,10 @@ int launch_ellipsoid_lockstep(size_t n, const EEInput& in, const EEOutput& out, 
   const lockstep::StartBoard board{es.board.as<double>(), reinterpret_cast<unsigned*>(es.board.as<double>() + rec_doubles)};
   MHIP_HIP(hipMemsetAsync(board.arrived, 0, n * sizeof(unsigned), s));
   const size_t waves = ((9 / lockstep::starts_per_unit(n)) * n + 63) / 64;
-  const unsigned grid = static_cast<unsigned>(waves < 2048 ? waves : 2048);  // 256 CUs x 4 SIMDs x 2 waves: all resident
+#ifndef MHIP_ELL_GRID
+#define MHIP_ELL_GRID 2048   // 256 CUs x 4 SIMDs x 2 waves: all resident (A/B: 1024 = one wave per SIMD)
+#endif
+  const unsigned grid = static_cast<unsigned>(waves < MHIP_ELL_GRID ? waves : MHIP_ELL_GRID);
   if (in.point)
     k_ellipsoid_pairs_lockstep<true><<<grid, kEllBlock, 0, s>>>(n, in, out, es.counter.as<unsigned long long>(), board);
   else
