@@ -12,8 +12,8 @@ win = rows[a + 1:b]
 t0, t1 = int(rows[a]["End_Timestamp"]), int(rows[b]["Start_Timestamp"])
 tot = defaultdict(lambda: [0, 0])
 for r in win:
-    k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mhip::", "")
-    k = k.split("<")[0] if k.startswith("k_") or k.startswith("at::") is False else k[:60]
+    k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("mhip::", "").split("(")[0]
+    k = k.split("<")[0] if not k.startswith("at::") else k[:60]
     tot[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     tot[k][1] += 1
 busy = sum(v[0] for v in tot.values())
