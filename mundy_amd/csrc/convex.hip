@@ -1787,10 +1787,17 @@ __global__ void __launch_bounds__(kBlock)
       for (size_t b = (size_t)ij.x + 1; b <= N; ++b) row_start[b] = static_cast<int32_t>(C);
   }
 }
+// (flags[2] = the longest list: k_inc_arrange sorts a body's targets in one thread, so a list of thousands -- a large
+//  body among small ones -- goes to the general path and its workgroup radix sort)
+constexpr int kArrangeMaxList = 1024;
 __global__ void __launch_bounds__(kBlock) k_inc_deg(size_t N, const int32_t* __restrict__ tdeg,
-                                                   const int32_t* __restrict__ row_start, int32_t* __restrict__ deg) {
-  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x)
-    deg[b] = tdeg[b] + (row_start[b + 1] - row_start[b]);
+                                                   const int32_t* __restrict__ row_start, int32_t* __restrict__ deg,
+                                                   int* __restrict__ flags) {
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N; b += (size_t)gridDim.x * blockDim.x) {
+    const int32_t d = tdeg[b] + (row_start[b + 1] - row_start[b]);
+    deg[b] = d;
+    if (d > kArrangeMaxList) flags[2] = 1;
+  }
 }
 // staged lists: [targets, in the order their atomics arrived][sources, ascending]; the class bit as in k_inc_fill
 __global__ void __launch_bounds__(kBlock)
@@ -3386,26 +3393,28 @@ static int create_contact_op(mhip_contact_op_t* handle, int kin, size_t num_cons
     if (int e = op->aptr.reserve((N + 2) * sizeof(int32_t))) return bail(e);
     int32_t* row_start = op->aptr.as<int32_t>();   // (both free until the first snapshot of the active lists)
     k_inc_count_sorted<<<grid_for(C), kBlock, 0, s>>>(C, N, p2, deg, row_start, bad);
-    int hflags[2] = {0, 0};
-    he = hipMemcpyAsync(hflags, bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+    // (the degrees too before the one host read: deg -> tdeg, deg = tdeg + rows; meaningless if the list is of another
+    //  form, and then not used)
+    he = hipMemcpyAsync(op->acnt.ptr, deg, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
+    k_inc_deg<<<grid_for(N), kBlock, 0, s>>>(N, op->acnt.as<int32_t>(), row_start, deg, bad);
+    int hflags[3] = {0, 0, 0};
+    he = hipMemcpyAsync(hflags, bad, 3 * sizeof(int), hipMemcpyDeviceToHost, s);
     if (he == hipSuccess) he = hipStreamSynchronize(s);
     if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "pair validation failed: %s", hipGetErrorString(he)));
     if (hflags[0])
       return bail(fail(MHIP_ERR_INVALID_ARGUMENT, "pairs contain an index outside [0, %zu) or a self pair", N));
-    sorted_rows = hflags[1] == 0;
+    sorted_rows = hflags[1] == 0 && hflags[2] == 0;
     if (!sorted_rows) {
       he = hipMemsetAsync(deg, 0, (N + 1) * sizeof(int32_t), s);
-      if (he == hipSuccess) he = hipMemsetAsync(bad, 0, 2 * sizeof(int), s);
+      if (he == hipSuccess) he = hipMemsetAsync(bad, 0, 3 * sizeof(int), s);
       if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));
       k_inc_count<<<grid_for(C), kBlock, 0, s>>>(C, N, p2, deg, bad);
     }
   }
   if (sorted_rows) {
-    int32_t* tdeg = op->acnt.as<int32_t>();
+    int32_t* tdeg = op->acnt.as<int32_t>();      // (the target counts; deg holds the lists' lengths: see above)
     int32_t* row_start = op->aptr.as<int32_t>();
-    he = hipMemcpyAsync(tdeg, deg, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s);   // deg holds the target counts
-    if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(he)));
-    k_inc_deg<<<grid_for(N), kBlock, 0, s>>>(N, tdeg, row_start, deg);
     if (int e = exclusive_scan_i32(deg, op->inc_ptr.as<int32_t>(), N, op->scanws.ptr, s)) return bail(e);
     he = hipMemsetAsync(deg, 0, (N + 1) * sizeof(int32_t), s);   // now the targets' cursors
     if (he != hipSuccess) return bail(fail(MHIP_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(he)));

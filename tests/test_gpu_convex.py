@@ -536,6 +536,43 @@ def test_high_degree_bodies_beyond_the_activity_mask(ops, oracle, rigid):
     op.close()
 
 
+def test_hub_bodies_with_thousands_of_contacts(ops, oracle):
+    # round 4: the fast incidence build sorts a body's targets in one thread; a list of thousands (here two hubs touched by
+    # 2 500 small spheres each, one hub with the LOWEST index -- all sources --, one with the HIGHEST -- all targets) must
+    # take the general path with its workgroup radix sort instead.  Same checks as for the ~150-contact bodies above.
+    from gpu_util import dev, host
+    from mundy_amd import synth
+    rng = np.random.default_rng(9)
+    hubs = np.array([[0.0, 0.0, 0.0], [60.0, 0.0, 0.0]])
+    small = []
+    for b in hubs:
+        d = rng.normal(size=(2500, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        small.append(b + d * (20.0 + 0.3 - rng.uniform(0.0, 0.05, (2500, 1))))
+    c = np.concatenate([hubs[:1], small[0], small[1], hubs[1:]])
+    r = np.concatenate([[20.0], np.full(5000, 0.3), [20.0]])
+    n = len(c)
+    lo, hi, R = oracle.grow(oracle.compute_aabb_spheres(c, r), r, 0.1)
+    pairs = oracle.search(0, lo, hi, c, R)
+    deg = np.bincount(pairs.ravel(), minlength=n)
+    assert deg[0] > 2000 and deg[-1] > 2000 and np.median(deg) < 20
+    sep, nrm = oracle.contact_spheres(pairs, c, r)
+    mt, _ = synth.dry_mobility(r)
+    C = len(pairs)
+    tol = 1e-7
+    op = ops.ContactOperator(dev(pairs), dev(nrm), dev(mt), 5e-3, priority=dev(sep))
+    x, g, res = ops.solve_lcp(op, dev(sep), dev(np.zeros(C)), ops.PGDConfig(max_iters=20000, tol=tol))
+    with oracle.compensated_sums():
+        xo, go, ro = oracle.solve_cqpp_contact(pairs, nrm, None, None, mt, None, 5e-3, sep, np.zeros(C), max_iters=20000,
+                                               tol=tol, threads=False)
+    assert res.converged and ro["converged"] and abs(res.num_iters - ro["num_iters"]) <= 2
+    np.testing.assert_allclose(host(g), go, atol=20 * tol)
+    x = host(x)
+    assert x.min() >= 0 and np.abs(np.minimum(x, host(g))).max() <= 10 * tol
+    np.testing.assert_allclose(host(op.apply(dev(x))) + sep, host(g), atol=1e-10)
+    op.close()
+
+
 def test_staged_api_whole_range_equals_fused_solve(ops, oracle):
     # the staged entry points driven by hand on one rank, with the whole-range mhip_bbpgd_stage_constraint wrapper:
     # same kernels in the same order as the fused driver -> identical iterates
