@@ -52,3 +52,41 @@ def test_gpus_2_without_a_launcher_starts_two_ranks_or_fails_loudly():
                        timeout=600, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert p.returncode == 2 and "--gpus 2 but the launcher started WORLD_SIZE=1" in p.stderr
     assert not p.stdout.strip()
+
+
+def test_traffic_figure_is_refused_when_the_sweep_kernels_changed(bench, monkeypatch):
+    # roofline.traffic comes from committed PMC passes (profiles/traffic.json); the file carries a stamp of the sweep
+    # kernels it was measured on, and a running library with another stamp gets `traffic: null` and the reason instead of
+    # a figure measured on other kernels (round-3 review: "silently goes stale with the next kernel edit")
+    import json
+    from mundy_amd import build as hip_build
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert "_kernel_stamp" in tj and tj["k_body"]["hbm_bytes_per_launch"] > 0
+
+    def entries():
+        return {"traffic": None, "traffic_source": None}, {"k_constraint": {"traffic": None, "traffic_source": None}}
+
+    roof, extra = entries()
+    monkeypatch.setattr(hip_build, "sweep_kernels_stamp", lambda: tj["_kernel_stamp"])
+    bench.attach_traffic(roof, extra, "k_body", "k_constraint", 1_000_000, 0.1)
+    assert roof["traffic"] == tj["k_body"]["hbm_bytes_per_launch"]
+    assert extra["k_constraint"]["traffic"] == tj["k_constraint"]["hbm_bytes_per_launch"]
+    roof, extra = entries()
+    monkeypatch.setattr(hip_build, "sweep_kernels_stamp", lambda: "0000000000000000")
+    bench.attach_traffic(roof, extra, "k_body", "k_constraint", 1_000_000, 0.1)
+    assert roof["traffic"] is None and "dropped" in roof["traffic_source"]
+    assert extra["k_constraint"]["traffic"] is None
+    # another workload than the one the passes were taken on: no figure either way
+    roof, extra = entries()
+    bench.attach_traffic(roof, extra, "k_body", "k_constraint", 500_000, 0.1)
+    assert roof["traffic"] is None and roof["traffic_source"] is None
+
+
+def test_committed_traffic_matches_the_committed_kernels():
+    # the stamp in profiles/traffic*.json must be the stamp of the sources in this tree: a kernel edit without a new
+    # profile run shows up here, on the CPU, before the GPU line prints `traffic: null`
+    import json
+    from mundy_amd import build as hip_build
+    for name in ("traffic.json", "traffic_mixed.json"):
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert tj.get("_kernel_stamp") == hip_build.sweep_kernels_stamp(), name
